@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by EXECUTING the reference's own Python files.
+
+Run in the build container only (needs /root/reference, which never travels to the GPU box):
+
+    python tests/golden/make_golden.py
+
+What runs verbatim from the reference (imported from /root/reference, not copied):
+    cdvslam/projective_ops.py, cdvslam/ba.py, cdvslam/lietorch/{groups,group_ops,broadcasting}.py
+What is injected so those files import on this CPU-only image (ordinary ModuleNotFoundError
+otherwise -- no permission was denied):
+    torch_scatter      -> scatter_sum via index_add_ (used at ba.py:42,46,51,56)
+    cuda_ba, cuda_corr -> empty placeholders (imported by cdvslam/fastba, cdvslam/altcorr at import time only)
+    lietorch_backends  -> forward group ops backed by THIS repo's CPU oracle (oracle/lie_impl.h)
+So the fixtures pin the reference's Python-level algorithm (pops.transform, jacobians, ba.BA
+control flow, gates, scatter layout, broadcasting) -- the Lie arithmetic inside is our restatement,
+which is pinned separately by the reference's property tests (tests/test_oracle_lie.py).
+
+Fixtures are DATA ONLY: seeded inputs + the outputs the reference code produced.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+
+from oracle import oracle as O  # noqa: E402
+from cdv_slam_amd import synth  # noqa: E402
+
+
+def _install_shims():
+    ts = types.ModuleType("torch_scatter")
+
+    def scatter_sum(src, index, dim=-1, out=None, dim_size=None):
+        dim = dim % src.dim()
+        if dim_size is None:
+            dim_size = int(index.max()) + 1 if index.numel() else 0
+        shape = list(src.shape)
+        shape[dim] = dim_size
+        res = torch.zeros(shape, dtype=src.dtype, device=src.device)
+        return res.index_add_(dim, index.to(src.device).long(), src)
+
+    ts.scatter_sum = scatter_sum
+    ts.scatter_mean = None
+    sys.modules["torch_scatter"] = ts
+    sys.modules["cuda_ba"] = types.ModuleType("cuda_ba")
+    sys.modules["cuda_ba"].neighbors = None
+    sys.modules["cuda_ba"].reproject = None
+    sys.modules["cuda_corr"] = types.ModuleType("cuda_corr")
+
+    lb = types.ModuleType("lietorch_backends")
+
+    def _np(t):
+        return t.detach().cpu().numpy()
+
+    def _mk(op, nin):
+        def f(group_id, *inputs):
+            dt = np.float64 if inputs[0].dtype == torch.float64 else np.float32
+            arrs = [_np(x).astype(dt) for x in inputs[:nin]]
+            out = O.lie(group_id, op, *arrs, dtype=dt)
+            return torch.from_numpy(out).to(inputs[0].dtype)
+        return f
+
+    for name, op, nin in (("expm", "exp", 1), ("logm", "log", 1), ("inv", "inv", 1), ("mul", "mul", 2),
+                          ("adj", "adj", 2), ("adjT", "adjT", 2), ("act", "act", 2), ("act4", "act4", 2),
+                          ("as_matrix", "matrix", 1)):
+        setattr(lb, name, _mk(op, nin))
+    for name in ("expm_backward", "logm_backward", "inv_backward", "mul_backward", "adj_backward",
+                 "adjT_backward", "act_backward", "act4_backward", "projector", "Jinv"):
+        setattr(lb, name, None)
+    sys.modules["lietorch_backends"] = lb
+
+
+def main():
+    _install_shims()
+    sys.path.insert(0, REF)
+    from cdvslam import projective_ops as pops
+    from cdvslam.lietorch import SE3
+    from cdvslam import ba as refba
+
+    out = {}
+
+    # ---- pops.transform / jacobian / valid / tonly / flow_mag / point_cloud (tiny graph) ----
+    for dt, tdt in (("f32", torch.float32), ("f64", torch.float64)):
+        st = synth.make_state("tiny", features=False)
+        poses = torch.from_numpy(st.poses).to(tdt)[None]
+        patches = torch.from_numpy(st.patches).to(tdt)[None]
+        intr = torch.from_numpy(st.intrinsics).to(tdt)[None]
+        # per-frame intrinsics differ slightly so that the ii / jj intrinsics roles are pinned
+        intr = intr * (1 + 0.01 * torch.arange(intr.shape[1], dtype=tdt)[None, :, None])
+        ii, jj, kk = (torch.from_numpy(x) for x in (st.ii, st.jj, st.kk))
+        with torch.no_grad():
+            x1 = pops.transform(SE3(poses), patches, intr, ii, jj, kk)
+            x1j, v, (Ji, Jj, Jz) = pops.transform(SE3(poses), patches, intr, ii, jj, kk, jacobian=True)
+            x1v, val = pops.transform(SE3(poses), patches, intr, ii, jj, kk, valid=True)
+            x1t = pops.transform(SE3(poses), patches, intr, ii, jj, kk, tonly=True)
+            fm, fv = pops.flow_mag(SE3(poses), patches, intr, ii, jj, kk, beta=0.5)
+            m = st.n * st.cfg.M
+            ix = torch.arange(m) // st.cfg.M
+            pc = pops.point_cloud(SE3(poses), patches[:, :m], intr, ix)
+        np.savez_compressed(
+            os.path.join(HERE, "pops_transform_%s.npz" % dt),
+            poses=poses[0].numpy(), patches=patches[0].numpy(), intrinsics=intr[0].numpy(),
+            ii=st.ii, jj=st.jj, kk=st.kk, coords=x1[0].numpy(), coords_jac=x1j[0].numpy(), valid=v[0].numpy(),
+            Ji=Ji[0].numpy(), Jj=Jj[0].numpy(), Jz=Jz[0].numpy(), coords_valid=x1v[0].numpy(),
+            validpx=val[0].numpy(), coords_tonly=x1t[0].numpy(), flow_mag=fm[0].numpy(),
+            flow_valid=fv[0].numpy(), point_cloud=pc[0].numpy(), point_cloud_ix=ix.numpy())
+        out["pops_" + dt] = x1.shape
+
+    # ---- reference ba.BA on the tiny graph (fully connected variant + sliding-window variant) ----
+    for tag, kw in (("fc", dict(frames=5, M=6, fully_connected=True)), ("win", dict())):
+        st = synth.make_state("tiny", features=False, **kw)
+        tdt = torch.float32
+        poses = torch.from_numpy(st.poses).to(tdt)[None]
+        patches = torch.from_numpy(st.patches).to(tdt)[None]
+        intr = torch.from_numpy(st.intrinsics).to(tdt)[None]
+        ii, jj, kk = (torch.from_numpy(x) for x in (st.ii, st.jj, st.kk))
+        target = torch.from_numpy(st.target)[None]
+        weight = torch.from_numpy(st.weight)[None]
+        h, w = st.cfg.ht // st.cfg.res, st.cfg.wd // st.cfg.res
+        bounds = [-64, -64, w + 64, h + 64]
+        res = {}
+        for ep in (1.0, 100.0):
+            with torch.no_grad():
+                P2, X2 = refba.BA(SE3(poses.clone()), patches.clone(), intr, target, weight,
+                                  torch.as_tensor([1e-4]), ii, jj, kk, bounds, ep=ep, fixedp=1)
+                # second iteration feeds the first one's output, as the training loop does
+                P3, X3 = refba.BA(P2, X2, intr, target, weight, torch.as_tensor([1e-4]), ii, jj, kk, bounds,
+                                  ep=ep, fixedp=1)
+            res["poses_ep%g" % ep] = P2.data[0].numpy()
+            res["patches_ep%g" % ep] = X2[0].numpy()
+            res["poses2_ep%g" % ep] = P3.data[0].numpy()
+            res["patches2_ep%g" % ep] = X3[0].numpy()
+        with torch.no_grad():
+            Ps, Xs = refba.BA(SE3(poses.clone()), patches.clone(), intr, target, weight, torch.as_tensor([1e-4]),
+                              ii, jj, kk, bounds, ep=1.0, fixedp=1, structure_only=True)
+        res["patches_structure_only"] = Xs[0].numpy()
+        np.savez_compressed(os.path.join(HERE, "ba_py_%s.npz" % tag), poses=st.poses, patches=st.patches,
+                            intrinsics=st.intrinsics, target=st.target, weight=st.weight, ii=st.ii, jj=st.jj,
+                            kk=st.kk, bounds=np.array(bounds, np.float32), **res)
+        out["ba_" + tag] = len(st.ii)
+
+    # ---- lietorch python layer: broadcasting + op wiring (groups.py) ----
+    g = torch.Generator().manual_seed(1234)
+    a = 0.3 * torch.randn(3, 4, 6, generator=g, dtype=torch.float64)
+    b = 0.3 * torch.randn(3, 1, 6, generator=g, dtype=torch.float64)
+    p4 = torch.randn(3, 4, 5, 4, generator=g, dtype=torch.float64)
+    X, Y = SE3.exp(a), SE3.exp(b)
+    np.savez_compressed(
+        os.path.join(HERE, "lietorch_py.npz"), a=a.numpy(), b=b.numpy(), p4=p4.numpy(),
+        X=X.data.numpy(), Y=Y.data.numpy(), XY=(X * Y).data.numpy(), Xinv=X.inv().data.numpy(),
+        logX=X.log().numpy(), act4=(X[:, :, None] * p4).numpy(), matrix=X.matrix().numpy(),
+        adjT=X.adjT(a).numpy(), adj=X.adj(a).numpy(), retr=X.retr(a).data.numpy())
+    out["lietorch_py"] = tuple(X.data.shape)
+    print("golden fixtures written:", out)
+
+
+if __name__ == "__main__":
+    main()
