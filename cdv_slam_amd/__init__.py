@@ -1,0 +1,26 @@
+"""cdv_slam_amd -- MI355X (gfx950) implementation of CDV-SLAM's per-frame update hot path.
+
+Layout (only what the path needs):
+  csrc/                hand-written HIP kernels + the C ABI (include/cdvslam_hip.h) -> libcdvslam_hip.so
+  ops.py               torch plumbing over the C ABI (device pointers + current HIP stream)
+  altcorr/ fastba/ lietorch/ projective_ops.py
+                       host-side mirror of the reference operator surface
+                       (cdvslam/altcorr, cdvslam/fastba, cdvslam/lietorch, cdvslam/projective_ops.py)
+  dropin/              modules named cuda_corr / cuda_ba / lietorch_backends with the reference's pybind
+                       signatures, so cdvslam/slam.py and net_cdv.py run unchanged
+  update.py            the fused per-frame update path used by bench.py (reproject -> corr -> neighbors -> BA)
+  synth.py             seeded synthetic patch-graph states
+"""
+
+__all__ = ["ops", "altcorr", "fastba", "lietorch", "projective_ops", "synth", "install_dropin"]
+
+
+def install_dropin():
+    """Register cuda_corr, cuda_ba and lietorch_backends in sys.modules (reference import names:
+    cdvslam/altcorr/correlation.py:2, cdvslam/fastba/ba.py:2, cdvslam/lietorch/group_ops.py:1)."""
+    import sys
+    from .dropin import cuda_ba, cuda_corr, lietorch_backends
+    sys.modules.setdefault("cuda_corr", cuda_corr)
+    sys.modules.setdefault("cuda_ba", cuda_ba)
+    sys.modules.setdefault("lietorch_backends", lietorch_backends)
+    return cuda_corr, cuda_ba, lietorch_backends

@@ -1,0 +1,65 @@
+"""ctypes loader for libcdvslam_hip.so (the C-ABI HIP library, include/cdvslam_hip.h).
+
+There is NO CPU fallback: if the shared library is missing or a call fails, this raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcdvslam_hip.so")
+
+_vp, _i32, _i64, _sz, _f32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t, ctypes.c_float
+
+# name -> (restype, argtypes); mirrors include/cdvslam_hip.h one to one
+SIGNATURES = {
+    "cdv_last_error": (ctypes.c_char_p, []),
+    "cdv_version": (ctypes.c_char_p, []),
+    "cdv_corr_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "cdv_fmap_to_nhwc": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i64, _i64, _vp]),
+    "cdv_fmap_ingest": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "cdv_corr_fused": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32,
+                              _f32, _f32, _i32, _i64, _i64, _vp]),
+    "cdv_patchify_fwd": (_i32, [_vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "cdv_transform": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cdv_fastba_reproject": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
+    "cdv_graph_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "cdv_graph_build": (_i32, [_vp, _vp, _i64, _vp, _sz, _i64, _i64, _vp]),
+    "cdv_graph_read_meta_host": (_i32, [_vp, _vp, _vp]),
+    "cdv_graph_get_unique": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp]),
+    "cdv_graph_pair_order": (_vp, [_vp]),
+    "cdv_neighbors": (_i32, [_vp, _i64, _vp, _vp, _vp]),
+    "cdv_ba_workspace_bytes": (_sz, [_i64, _i64, _i32]),
+    "cdv_ba_forward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _sz,
+                              _i64, _vp, _vp]),
+    "cdv_lie_op": (_i32, [_i32, _i32, _i32, _i64, _vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+class CdvError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library (once).  Raises ImportError with build instructions if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "cdv_slam_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C cdv_slam_amd/csrc`). There is no CPU fallback for the HIP path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().cdv_last_error()
+        raise CdvError("%s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else "?"))

@@ -1,0 +1,406 @@
+"""torch-level entry points over the C ABI (include/cdvslam_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the current HIP stream; every function below
+only passes raw device pointers and sizes to libcdvslam_hip.so.  No CPU fallback exists -- a missing
+library or a non-CUDA(ROCm) tensor raises.
+"""
+import ctypes
+import os
+
+import torch
+
+from . import _lib
+
+F16, F32, F64 = 0, 1, 2
+_DT = {torch.float16: F16, torch.float32: F32, torch.float64: F64}
+LIE_OPS = {"exp": 0, "log": 1, "inv": 2, "mul": 3, "adj": 4, "adjT": 5, "act": 6, "act4": 7, "matrix": 8}
+
+# default index-range capacities of the graph workspace (reference buffers: BUFFER_SIZE = 4096 frames
+# x 96 patches, cdvslam/config.py, patchgraph.py:25-29)
+DEFAULT_K_RANGE = 4096 * 96
+DEFAULT_F_RANGE = 4096
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("cdv_slam_amd: tensors must live on the GPU (HIP path only, no CPU fallback)")
+
+
+def _sync_check():
+    return os.environ.get("CDV_CHECK", "0") == "1"
+
+
+def version():
+    return _lib.load().cdv_version().decode()
+
+
+# ---------------------------------------------------------------------------------------------------
+# patch-graph index
+# ---------------------------------------------------------------------------------------------------
+
+class GraphIndex:
+    """Device workspace holding unique(kk), the patch CSR and the target-frame edge order."""
+
+    def __init__(self, device, E_cap=1 << 16, k_range=DEFAULT_K_RANGE, f_range=DEFAULT_F_RANGE):
+        self.lib = _lib.load()
+        self.device = device
+        self.E_cap, self.k_range, self.f_range = 0, k_range, f_range
+        self.ws = None
+        self._key = None
+        self.E = 0
+        self._reserve(E_cap)
+
+    def _reserve(self, E):
+        if self.ws is not None and E <= self.E_cap:
+            return
+        self.E_cap = max(E, int(self.E_cap * 1.5), 1024)
+        nbytes = self.lib.cdv_graph_workspace_bytes(self.E_cap, self.k_range, self.f_range)
+        self.ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        self.ws_bytes = nbytes
+        self._key = None
+
+    def build(self, jj, kk, force=False):
+        """Enqueue the index build for (jj, kk).  Re-used when called again with the same, unmodified
+        tensor objects (neighbors() and BA() of one update share one build)."""
+        _need_cuda(jj, kk)
+        if jj.dtype != torch.int64 or kk.dtype != torch.int64:
+            raise TypeError("index tensors must be int64")
+        jj, kk = jj.contiguous(), kk.contiguous()
+        key = (jj, kk, jj._version, kk._version)
+        if (not force and self._key is not None and self._key[0] is jj and self._key[1] is kk
+                and self._key[2] == jj._version and self._key[3] == kk._version):
+            return self
+        E = kk.numel()
+        if jj.numel() != E:
+            raise ValueError("jj and kk must have the same length")
+        self._reserve(E)
+        rc = self.lib.cdv_graph_build(_p(jj), _p(kk), E, _p(self.ws), self.ws_bytes, self.k_range, self.f_range,
+                                      _stream())
+        _lib.check(rc, "cdv_graph_build")
+        self._key = key  # strong refs pin the tensors so that identity implies content
+        self.E = E
+        if _sync_check():
+            self.meta()
+        return self
+
+    def meta(self):
+        """(U, n_targets, kmin, kmax, jmin, jmax, error, E) -- synchronises the stream."""
+        m = (ctypes.c_int64 * 8)()
+        _lib.check(self.lib.cdv_graph_read_meta_host(_p(self.ws), m, _stream()), "cdv_graph_read_meta_host")
+        m = list(m)
+        if m[6]:
+            raise _lib.CdvError("patch-graph index: id range exceeds the workspace capacity "
+                                "(k_range=%d, f_range=%d; got k in [%d,%d], j in [%d,%d])"
+                                % (self.k_range, self.f_range, m[2], m[3], m[4], m[5]))
+        return m
+
+    def neighbors(self):
+        ix = torch.empty(self.E, dtype=torch.int64, device=self.device)
+        jx = torch.empty(self.E, dtype=torch.int64, device=self.device)
+        _lib.check(self.lib.cdv_neighbors(_p(self.ws), self.E, _p(ix), _p(jx), _stream()), "cdv_neighbors")
+        return ix, jx
+
+    def unique(self):
+        """(kx, ku) == torch._unique(kk, sorted=True, return_inverse=True); one host sync for U."""
+        U = self.meta()[0] if self.E else 0
+        kx = torch.empty(U, dtype=torch.int64, device=self.device)
+        ku = torch.empty(self.E, dtype=torch.int64, device=self.device)
+        _lib.check(self.lib.cdv_graph_get_unique(_p(self.ws), _p(kx), U, _p(ku), self.E, _stream()),
+                   "cdv_graph_get_unique")
+        return kx, ku
+
+    def order_ptr(self):
+        return ctypes.c_void_p(self.lib.cdv_graph_pair_order(_p(self.ws)))
+
+    def order(self):
+        """[E] int32 view of the target-grouped edge order inside the workspace."""
+        off = self.lib.cdv_graph_pair_order(_p(self.ws)) - self.ws.data_ptr()
+        return self.ws[off:off + 4 * self.E].view(torch.int32)
+
+
+_graphs = {}
+
+
+def graph_for(jj, kk, **kw):
+    """Per-device shared GraphIndex, (re)built for (jj, kk)."""
+    dev = kk.device
+    g = _graphs.get(dev)
+    if g is None:
+        g = _graphs[dev] = GraphIndex(dev, **kw)
+    return g.build(jj, kk)
+
+
+def neighbors(kk, jj):
+    """cuda_ba.neighbors(ii=kk, jj) (cdvslam/fastba/ba.cpp:59-97), fully on device."""
+    if kk.numel() == 0:
+        e = torch.empty(0, dtype=torch.int64, device=kk.device)
+        return e, e.clone()
+    return graph_for(jj, kk).neighbors()
+
+
+# ---------------------------------------------------------------------------------------------------
+# projective ops
+# ---------------------------------------------------------------------------------------------------
+
+def transform(poses, patches, intrinsics, ii, jj, kk, layout_e2pp=False, valid=False, jacobian=False, tonly=False):
+    """Fused pops.transform (cdvslam/projective_ops.py:53-113).  poses [1,n,7] (tensor), patches
+    [1,m,3,P,P], intrinsics [1,n,4] float32 -> coords [1,E,P,P,2] (or [1,E,2,P,P] if layout_e2pp)."""
+    lib = _lib.load()
+    _need_cuda(poses, patches, intrinsics, ii, jj, kk)
+    if poses.dtype != torch.float32:
+        raise TypeError("cdv_transform is float32 (the reference state buffers are float32, patchgraph.py:28-32)")
+    poses, patches, intrinsics = poses.contiguous(), patches.contiguous(), intrinsics.contiguous()
+    ii, jj, kk = ii.contiguous(), jj.contiguous(), kk.contiguous()
+    E, P = ii.numel(), patches.shape[-1]
+    dev = poses.device
+    shape = (1, E, 2, P, P) if layout_e2pp else (1, E, P, P, 2)
+    coords = torch.empty(shape, dtype=torch.float32, device=dev)
+    vpx = torch.empty((1, E, P, P), dtype=torch.float32, device=dev) if valid else None
+    v = Ji = Jj = Jz = None
+    if jacobian:
+        v = torch.empty((1, E), dtype=torch.float32, device=dev)
+        Ji = torch.empty((1, E, 2, 6), dtype=torch.float32, device=dev)
+        Jj = torch.empty((1, E, 2, 6), dtype=torch.float32, device=dev)
+        Jz = torch.empty((1, E, 2, 1), dtype=torch.float32, device=dev)
+    flags = (1 if layout_e2pp else 0) | (2 if tonly else 0)
+    rc = lib.cdv_transform(_p(poses), _p(patches), _p(intrinsics), _p(ii), _p(jj), _p(kk), E, P, flags, _p(coords),
+                           _p(vpx), _p(v), _p(Ji), _p(Jj), _p(Jz), _stream())
+    _lib.check(rc, "cdv_transform")
+    if jacobian:
+        return coords, v, (Ji, Jj, Jz)
+    if valid:
+        return coords, vpx
+    return coords
+
+
+def fastba_reproject(poses, patches, intrinsics, ii, jj, kk):
+    """cuda_ba.reproject (ba_cuda.cu:408-458, 614-646) -> [1,E,2,P,P]."""
+    lib = _lib.load()
+    _need_cuda(poses, patches, intrinsics, ii, jj, kk)
+    poses, patches, intrinsics = poses.contiguous(), patches.contiguous(), intrinsics.contiguous()
+    E, P = ii.numel(), patches.shape[-1]
+    coords = torch.empty((1, E, 2, P, P), dtype=torch.float32, device=poses.device)
+    rc = lib.cdv_fastba_reproject(_p(poses), _p(patches), _p(intrinsics), _p(ii.contiguous()), _p(jj.contiguous()),
+                                  _p(kk.contiguous()), E, P, _p(coords), _stream())
+    _lib.check(rc, "cdv_fastba_reproject")
+    return coords
+
+
+# ---------------------------------------------------------------------------------------------------
+# altcorr
+# ---------------------------------------------------------------------------------------------------
+
+class NhwcCache:
+    """channels-last shadows of planar feature rings, refreshed when the source tensor's version moves."""
+
+    def __init__(self, max_entries=4):
+        self.entries = []
+        self.max_entries = max_entries
+
+    def get(self, fmap):
+        for ent in self.entries:
+            if ent[0] is fmap:
+                if ent[1] != fmap._version:
+                    self._convert(fmap, ent[2])
+                    ent[1] = fmap._version
+                return ent[2]
+        shadow = torch.empty(fmap.shape[:-3] + (fmap.shape[-2], fmap.shape[-1], fmap.shape[-3]),
+                             dtype=fmap.dtype, device=fmap.device)
+        self._convert(fmap, shadow)
+        self.entries.append([fmap, fmap._version, shadow])
+        if len(self.entries) > self.max_entries:
+            self.entries.pop(0)
+        return shadow
+
+    @staticmethod
+    def _convert(fmap, shadow):
+        lib = _lib.load()
+        C, H, W = fmap.shape[-3:]
+        N = fmap.numel() // (C * H * W)
+        _lib.check(lib.cdv_fmap_to_nhwc(_p(fmap), _p(shadow), N, C, H, W, 0, N, _stream()), "cdv_fmap_to_nhwc")
+
+
+_nhwc = NhwcCache()
+
+
+def fmap_ingest(fmap_chw, fmap1_nhwc, fmap2_nhwc, slot, fmap1_nchw=None, fmap2_nchw=None):
+    """One new frame [C,H,W] f16 -> ring slot `slot` of the channels-last level-0 ring and its 4x4
+    average pool into the level-1 ring (slam.py:681-682)."""
+    lib = _lib.load()
+    _need_cuda(fmap_chw, fmap1_nhwc, fmap2_nhwc)
+    C, H, W = fmap_chw.shape[-3:]
+    fmap_chw = fmap_chw.contiguous()
+    rc = lib.cdv_fmap_ingest(_p(fmap_chw), _p(fmap1_nhwc), _p(fmap2_nhwc), _p(fmap1_nchw), _p(fmap2_nchw), int(slot),
+                             C, H, W, _stream())
+    _lib.check(rc, "cdv_fmap_ingest")
+
+
+def corr_fused(gmap, fmap0_nhwc, fmap1_nhwc, coords, kk, jj, kmod=0, jmod=0, scales=(1.0, 4.0), order_ptr=None,
+               out=None):
+    """SLAM.corr (slam.py:316-323) in one launch.  gmap [Ng,C,3,3] f16 planar, fmapL_nhwc
+    [slots,H,W,C] f16, coords [1,E,2,3,3] f32 -> [1,E,882] f16 (fmap1_nhwc None -> one level, [1,E,441])."""
+    lib = _lib.load()
+    _need_cuda(gmap, fmap0_nhwc, coords, kk, jj)
+    if gmap.dtype != torch.float16 or fmap0_nhwc.dtype != torch.float16 or coords.dtype != torch.float32:
+        raise TypeError("corr_fused: gmap/fmap must be float16 and coords float32")
+    nlev = 1 if fmap1_nhwc is None else 2
+    E = kk.numel()
+    C = gmap.shape[-3]
+    gmap, coords = gmap.contiguous(), coords.contiguous()
+    Ng = gmap.numel() // (C * 9)
+    slots, H0, W0 = fmap0_nhwc.shape[-4], fmap0_nhwc.shape[-3], fmap0_nhwc.shape[-2]
+    H1, W1 = (fmap1_nhwc.shape[-3], fmap1_nhwc.shape[-2]) if nlev == 2 else (0, 0)
+    if out is None:
+        out = torch.empty((1, E, 441 * nlev), dtype=torch.float16, device=gmap.device)
+    rc = lib.cdv_corr_fused(_p(gmap), _p(fmap0_nhwc), _p(fmap1_nhwc), _p(coords), _p(kk.contiguous()),
+                            _p(jj.contiguous()), order_ptr, _p(out), E, Ng, slots, C, H0, W0, H1, W1, float(scales[0]),
+                            float(scales[1]), nlev, int(kmod), int(jmod), _stream())
+    _lib.check(rc, "cdv_corr_fused")
+    return out
+
+
+def corr_forward(fmap1, fmap2, coords, ii, jj, radius):
+    """cuda_corr.forward (cdvslam/altcorr/correlation.cpp:35-42): fmap1 [B,N1,C,P,P], fmap2
+    [B,N2,C,H2,W2], coords [B,M,2,P,P] f32 -> [B,M,2r+1 (x),2r+1 (y),P,P]."""
+    lib = _lib.load()
+    _need_cuda(fmap1, fmap2, coords, ii, jj)
+    if fmap1.dtype != fmap2.dtype or fmap1.dtype not in (torch.float16, torch.float32):
+        raise TypeError("corr: feature maps must both be float16 or float32")
+    if coords.dtype != torch.float32:
+        raise TypeError("corr: coords must be float32 (correlation_kernel.cu:86)")
+    B, N1, C, P = fmap1.shape[0], fmap1.shape[1], fmap1.shape[2], fmap1.shape[3]
+    N2, H2, W2 = fmap2.shape[1], fmap2.shape[3], fmap2.shape[4]
+    M = coords.shape[1]
+    D1 = 2 * radius + 1
+    coords = coords.contiguous()
+    ii, jj = ii.contiguous(), jj.contiguous()
+    fast = (fmap1.dtype == torch.float16 and radius == 3 and P == 3 and C % 8 == 0 and C <= 128
+            and fmap2.is_contiguous())
+    if fast:
+        shadow = _nhwc.get(fmap2)
+        outs = []
+        for b in range(B):
+            o = corr_fused(fmap1[b], shadow[b], None, coords[b:b + 1], ii, jj)
+            outs.append(o.view(1, M, D1, D1, P, P))
+        return outs[0] if B == 1 else torch.cat(outs, 0)
+    fmap1, fmap2 = fmap1.contiguous(), fmap2.contiguous()
+    out = torch.empty((B, M, D1, D1, P, P), dtype=fmap1.dtype, device=fmap1.device)
+    for b in range(B):
+        rc = lib.cdv_corr_fwd(_p(fmap1[b]), _p(fmap2[b]), _p(coords[b]), _p(ii), _p(jj), _p(out[b]), M, N1, N2, C, P,
+                              H2, W2, radius, _DT[fmap1.dtype], _stream())
+        _lib.check(rc, "cdv_corr_fwd")
+    return out
+
+
+def patchify_forward(net, coords, radius):
+    """cuda_corr.patchify_forward (correlation.cpp:49-52): net [B,C,H,W], coords [B,M,2] -> [B,M,C,D,D]."""
+    lib = _lib.load()
+    _need_cuda(net, coords)
+    if net.dtype not in (torch.float16, torch.float32):
+        raise TypeError("patchify: net must be float16 or float32")
+    net, coords = net.contiguous(), coords.contiguous().float()
+    B, C, H, W = net.shape
+    M, D = coords.shape[1], 2 * radius + 2
+    out = torch.empty((B, M, C, D, D), dtype=net.dtype, device=net.device)
+    rc = lib.cdv_patchify_fwd(_p(net), _p(coords), _p(out), B, M, C, H, W, radius, _DT[net.dtype], _stream())
+    _lib.check(rc, "cdv_patchify_fwd")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# fastba
+# ---------------------------------------------------------------------------------------------------
+
+_ba_ws = {}
+
+
+def _ba_workspace(dev, E, U_max, N):
+    lib = _lib.load()
+    need = lib.cdv_ba_workspace_bytes(E, U_max, max(N, 1))
+    ws = _ba_ws.get(dev)
+    if ws is None or ws.numel() < need:
+        ws = _ba_ws[dev] = torch.empty(int(need * 1.25) + 4096, dtype=torch.uint8, device=dev)
+    return ws
+
+
+def ba_forward(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, PPF, t0, t1, iterations,
+               eff_impl=False, debug=False, U_max=None, graph=None):
+    """cuda_ba.forward (cdvslam/fastba/ba.cpp:31-45): in place on poses / patches, returns []."""
+    lib = _lib.load()
+    _need_cuda(poses, patches, intrinsics, target, weight, ii, jj, kk)
+    for t in (poses, patches, intrinsics):
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise TypeError("BA: poses / patches / intrinsics must be contiguous float32 (updated in place)")
+    N = int(t1) - int(t0)
+    if N > 32 or eff_impl:
+        raise NotImplementedError("global BA (eff_impl / more than 32 free poses) is not built yet")
+    E, P = kk.numel(), patches.shape[-1]
+    dev = poses.device
+    if E == 0:
+        return []
+    target = target.reshape(-1, 2).float().contiguous()
+    weight = weight.reshape(-1, 2).float().contiguous()
+    if not torch.is_tensor(lmbda):
+        lmbda = torch.tensor([float(lmbda)], dtype=torch.float32, device=dev)
+    lmbda = lmbda.reshape(-1).float().contiguous().to(dev)
+    ii, jj, kk = ii.contiguous(), jj.contiguous(), kk.contiguous()
+    g = graph.build(jj, kk) if graph is not None else graph_for(jj, kk)
+    if U_max is None:
+        U_max = min(E, patches.numel() // (3 * P * P))
+    ws = _ba_workspace(dev, E, U_max, N)
+    dbg = None
+    if debug:
+        n6, Us = 6 * N, (U_max + 31) // 32 * 32
+        dbg = torch.zeros(n6 * n6 + 2 * n6 + 3 * Us + n6 * Us + 64, dtype=torch.float32, device=dev)
+    rc = lib.cdv_ba_forward(_p(poses), _p(patches), _p(intrinsics), _p(target), _p(weight), _p(lmbda), _p(ii), _p(jj),
+                            _p(kk), E, P, int(t0), int(t1), int(iterations), _p(g.ws), _p(ws), ws.numel(), U_max,
+                            _p(dbg), _stream())
+    _lib.check(rc, "cdv_ba_forward")
+    if _sync_check():
+        g.meta()
+    if debug:
+        n6, Us = 6 * N, (U_max + 31) // 32 * 32
+        o = 0
+        out = {}
+        for name, size, shape in (("S", n6 * n6, (n6, n6)), ("y", n6, (n6,)), ("dX", n6, (N, 6)), ("dZ", Us, (Us,)),
+                                  ("C", Us, (Us,)), ("u", Us, (Us,)), ("E", n6 * Us, (n6, Us))):
+            out[name] = dbg[o:o + size].view(shape)
+            o += size
+        return out
+    return []
+
+
+# ---------------------------------------------------------------------------------------------------
+# lietorch
+# ---------------------------------------------------------------------------------------------------
+
+_LIE_OUT = {"exp": "N", "log": "K", "inv": "N", "mul": "N", "adj": "K", "adjT": "K", "act": 3, "act4": 4, "matrix": 16}
+
+
+def lie_op(group_id, op, x, y=None):
+    """lietorch_backends.<op>(group_id, x[, y]) forward on flat contiguous [n, dim] rows."""
+    lib = _lib.load()
+    _need_cuda(x, y)
+    if x.dtype not in (torch.float32, torch.float64):
+        raise TypeError("lietorch ops: float32 or float64")
+    if not x.is_contiguous() or (y is not None and not y.is_contiguous()):
+        raise RuntimeError("lietorch ops: inputs must be contiguous (lietorch.cpp:7)")
+    if group_id not in (1, 3):
+        raise NotImplementedError("only SO3 (1) and SE3 (3) are on the update path")
+    N, K = (7, 6) if group_id == 3 else (4, 3)
+    n = x.shape[0]
+    od = _LIE_OUT[op]
+    od = N if od == "N" else K if od == "K" else od
+    z = torch.empty((n, od), dtype=x.dtype, device=x.device)
+    rc = lib.cdv_lie_op(group_id, LIE_OPS[op], _DT[x.dtype], n, _p(x), _p(y), _p(z), _stream())
+    _lib.check(rc, "cdv_lie_op")
+    return z.view(n, 4, 4) if op == "matrix" else z

@@ -1,0 +1,78 @@
+"""The per-frame update hot path as one object: reproject -> 2-level correlation -> neighbors -> BA.
+
+Mirrors the sequence of SLAM.update (cdvslam/slam.py:480-526) with the Update network replaced by
+fixed `delta` / `weight` tensors: what bench.py times and what smoke() checks.
+
+HBM-resident state (DESIGN.md "Data layout"):
+  poses [N,7] f32, patches [N*M,3,3,3] f32, intrinsics [N,4] f32         (reference layouts)
+  ii/jj/kk [E] int64, target/weight [E,2] f32
+  gmap  [pmem*M, C, 3, 3] f16                                            (reference layout)
+  fmap1 [mem, H, W, C] f16, fmap2 [mem, H/4, W/4, C] f16                 CHANNELS-LAST rings
+"""
+import torch
+
+from . import ops
+
+
+class UpdatePath:
+    def __init__(self, st, device, sort_corr=True):
+        """st: synth.SynthState (numpy).  Uploads the state once; step() then runs entirely on device."""
+        self.cfg = st.cfg
+        self.dev = device
+        t = lambda a, dt=None: torch.as_tensor(a, device=device) if dt is None else torch.as_tensor(a, dtype=dt, device=device)
+        self.poses = t(st.poses).contiguous()
+        self.patches = t(st.patches).contiguous()
+        self.intrinsics = t(st.intrinsics).contiguous()
+        self.ii, self.jj, self.kk = t(st.ii), t(st.jj), t(st.kk)
+        self.target, self.weight = t(st.target).contiguous(), t(st.weight).contiguous()
+        self.lmbda = torch.tensor([st.lmbda], dtype=torch.float32, device=device)
+        self.t0, self.n = st.t0, st.n
+        self.M = st.cfg.M
+        self.E = st.E
+        self.sort_corr = sort_corr
+        self._poses0, self._patches0 = self.poses.clone(), self.patches.clone()
+        self.graph = ops.GraphIndex(device, E_cap=self.E, k_range=st.cfg.buffer_size * st.cfg.M,
+                                    f_range=st.cfg.buffer_size)
+        self.U_max = min(self.E, (st.cfg.removal_window + 2) * st.cfg.M) if not st.cfg.fully_connected \
+            else st.cfg.frames * st.cfg.M
+        self.has_features = st.fmap1 is not None
+        if self.has_features:
+            self.gmap = t(st.gmap).contiguous()
+            mem, C, h, w = st.fmap1.shape
+            self.fmap1 = torch.empty((mem, h, w, C), dtype=torch.float16, device=device)
+            self.fmap2 = torch.empty((mem, h // 4, w // 4, C), dtype=torch.float16, device=device)
+            planar = t(st.fmap1)
+            for slot in range(mem):  # fill the rings exactly as the per-frame ingest does
+                ops.fmap_ingest(planar[slot], self.fmap1, self.fmap2, slot)
+            # the newest frame's planar features, re-ingested every step (slam.py:679-682)
+            self.new_frame = planar[(st.n - 1) % mem].clone()
+            self.new_slot = (st.n - 1) % mem
+            self.kmod, self.jmod = st.cfg.M * st.cfg.pmem, st.cfg.mem
+            self.corr_out = torch.empty((1, self.E, 882), dtype=torch.float16, device=device)
+
+    def reset(self):
+        self.poses.copy_(self._poses0)
+        self.patches.copy_(self._patches0)
+
+    def step(self, ingest=True, rebuild_graph=True, iterations=2):
+        """One update.  Everything is enqueued on the current stream; no host synchronisation."""
+        out = {}
+        if self.has_features and ingest:
+            ops.fmap_ingest(self.new_frame, self.fmap1, self.fmap2, self.new_slot)
+        # 1. reproject (slam.py:325-329)
+        coords = ops.transform(self.poses[None], self.patches[None], self.intrinsics[None], self.ii, self.jj, self.kk,
+                               layout_e2pp=True)
+        out["coords"] = coords
+        # patch-graph index: shared by the correlation order, neighbors and BA
+        self.graph.build(self.jj, self.kk, force=rebuild_graph)
+        # 2. correlation, both levels (slam.py:316-323)
+        if self.has_features:
+            out["corr"] = ops.corr_fused(self.gmap, self.fmap1, self.fmap2, coords, self.kk, self.jj, kmod=self.kmod,
+                                         jmod=self.jmod, order_ptr=self.graph.order_ptr() if self.sort_corr else None,
+                                         out=self.corr_out)
+        # 3. neighbors (net_cdv.py:102 -> ba.cpp:59-97)
+        out["ix"], out["jx"] = self.graph.neighbors()
+        # 4. bundle adjustment (slam.py:512-515)
+        ops.ba_forward(self.poses, self.patches, self.intrinsics, self.target, self.weight, self.lmbda, self.ii,
+                       self.jj, self.kk, self.M, self.t0, self.n, iterations, False, U_max=self.U_max, graph=self.graph)
+        return out

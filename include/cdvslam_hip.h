@@ -1,0 +1,201 @@
+/*
+ * cdvslam_hip.h -- C ABI of libcdvslam_hip.so: the MI355X (gfx950) implementation of CDV-SLAM's
+ * per-frame update hot path (altcorr -> projective_ops -> fastba).
+ *
+ * Drop-in boundary: these entry points are what the reference's three pybind11 torch extensions
+ * would bind for this path (reference paths relative to the reference root):
+ *   cuda_corr          cdvslam/altcorr/correlation.cpp:57-63   (forward / patchify_forward)
+ *   cuda_ba            cdvslam/fastba/ba.cpp:183-188           (forward / neighbors / reproject)
+ *   lietorch_backends  cdvslam/lietorch/src/lietorch.cpp:286-316 (expm, logm, inv, mul, adj, adjT,
+ *                                                                act, act4, as_matrix)
+ * plus fused forms the reference composes in Python (SLAM.corr, slam.py:316-323; pops.transform,
+ * projective_ops.py:53-113).  See INTEGRATION.md for the reference-side binding.
+ *
+ * Conventions
+ *   - plain C: raw DEVICE pointers + sizes; no torch types.  All pointers are device memory of the
+ *     current HIP device unless the parameter name ends in _host.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Every call only ENQUEUES
+ *     work on that stream; no call synchronises or allocates (hipGraph-capturable), except
+ *     cdv_graph_read_meta_host which is an explicit device->host read-back.
+ *   - return value: 0 = success, < 0 = error (CDV_ERR_*); cdv_last_error() gives the message.
+ *     Never calls exit() (the reference does, block_e.cu:20-27, ba.cpp:151-152).
+ *   - index tensors are int64 (torch.long) exactly as the reference passes them.
+ *   - float layouts are the reference's contiguous torch layouts unless stated otherwise.
+ */
+#ifndef CDVSLAM_HIP_H
+#define CDVSLAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CDV_OK 0
+#define CDV_ERR_HIP (-1)         /* a HIP runtime call failed */
+#define CDV_ERR_ARG (-2)         /* invalid argument / unsupported shape */
+#define CDV_ERR_WORKSPACE (-3)   /* workspace too small */
+#define CDV_ERR_UNSUPPORTED (-4) /* group / dtype / configuration not implemented */
+
+#define CDV_F16 0
+#define CDV_F32 1
+#define CDV_F64 2
+
+const char* cdv_last_error(void);
+/* "gfx950" + build info; also a cheap symbol to probe that the library loaded */
+const char* cdv_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * altcorr  (replaces cuda_corr.forward / patchify_forward)
+ * ---------------------------------------------------------------------------------------------- */
+
+/*
+ * cuda_corr.forward(fmap1, fmap2, coords, ii, jj, radius)  -- correlation.cpp:35-42,
+ * correlation_kernel.cu:82-136 (kernel) + :213-232 (bilinear blend + permute), one pyramid level.
+ *   fmap1  [N1][C][P][P]     patch feature tiles, channel-planar (reference layout)
+ *   fmap2  [N2][C][H2][W2]   frame feature maps, channel-planar (reference layout)
+ *   coords [M][2][P][P] f32 ; us[M] index into fmap1 ; vs[M] index into fmap2
+ *   out    [M][D-1 (x)][D-1 (y)][P][P], D = 2*radius+2 -- the logical layout of the tensor the
+ *          reference returns (its permute(0,1,3,2,4,5)), stored contiguously.
+ * dtype CDV_F16: f16 in/out, f32 accumulate (the reference accumulates in f16; tolerance in
+ * DESIGN.md).  dtype CDV_F32: f32 throughout.  Any C, P, radius.  Generic (non-MFMA) kernel.
+ */
+int cdv_corr_fwd(const void* fmap1, const void* fmap2, const float* coords, const int64_t* us,
+                 const int64_t* vs, void* out, int64_t M, int64_t N1, int64_t N2, int C, int P, int H2, int W2,
+                 int radius, int dtype, void* stream);
+
+/*
+ * Channel-planar [N][C][H][W] f16 -> channels-last [N][H][W][C] f16 (the HBM layout the fast
+ * correlation kernel gathers from: one pixel = C contiguous halves).  `first`/`count` select a slot
+ * range so a ring buffer can be refreshed one frame at a time (slam.py:679-682 writes one slot).
+ */
+int cdv_fmap_to_nhwc(const void* src_nchw, void* dst_nhwc, int64_t N, int C, int H, int W, int64_t first,
+                     int64_t count, void* stream);
+
+/*
+ * Per-frame ingest of one new feature frame (slam.py:681-682): fmap [C][H][W] f16 (planar) is
+ * written channels-last into ring slot `slot` of fmap1_nhwc [mem][H][W][C] and its 4x4 average
+ * pool into fmap2_nhwc [mem][H/4][W/4][C]; optionally also into the planar rings the reference
+ * keeps (fmap1_nchw / fmap2_nchw may be NULL).
+ */
+int cdv_fmap_ingest(const void* fmap_chw, void* fmap1_nhwc, void* fmap2_nhwc, void* fmap1_nchw, void* fmap2_nchw,
+                    int slot, int C, int H, int W, void* stream);
+
+/*
+ * Fused multi-level correlation: SLAM.corr (slam.py:316-323) = two cuda_corr.forward calls +
+ * torch.stack(..., -1).view(1, E, -1), in ONE launch on MFMA.
+ *   gmap        [Ng][C][3][3] f16 planar (view of gmap_, slam.py:250-251)
+ *   fmapL_nhwc  [slots][H_L][W_L][C] f16 channels-last, L = 0 .. nlev-1 ; coords are divided by
+ *               scale[L] (1 and 4 in SLAM.corr)
+ *   coords      [E][2][3][3] f32
+ *   kk, jj      raw graph indices; the kernel applies ii1 = kk % kmod, jj1 = jj % jmod
+ *               (slam.py:319-320; pass kmod = jmod = 0 for "no modulus")
+ *   order       optional [E] int32 processing order (e.g. graph pair-sorted order for L2 locality),
+ *               NULL = natural order.  Output rows are always indexed by edge id.
+ *   out         [E][7 (x)][7 (y)][3][3][nlev] f16  == corr.view(E, 882) for nlev = 2
+ * Requirements: radius 3, P 3, C % 8 == 0, C <= 128, nlev in {1,2}.
+ */
+int cdv_corr_fused(const void* gmap, const void* fmap0_nhwc, const void* fmap1_nhwc, const float* coords,
+                   const int64_t* kk, const int64_t* jj, const int32_t* order, void* out, int64_t E, int64_t Ng,
+                   int64_t slots, int C, int H0, int W0, int H1, int W1, float scale0, float scale1, int nlev,
+                   int64_t kmod, int64_t jmod, void* stream);
+
+/* cuda_corr.patchify_forward(net, coords, radius) -- correlation.cpp:49-52, kernel :16-47.
+ *   net [B][C][H][W] (f16 or f32), coords [B][M][2] f32 -> patches [B][M][C][D][D], zero when OOB */
+int cdv_patchify_fwd(const void* net, const float* coords, void* patches, int B, int64_t M, int C, int H, int W,
+                     int radius, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * projective ops  (replaces the ~15 launches of pops.transform, projective_ops.py:53-113)
+ * ---------------------------------------------------------------------------------------------- */
+
+#define CDV_TF_LAYOUT_EPP2 0 /* coords [E][P][P][2]  (what pops.transform returns)            */
+#define CDV_TF_LAYOUT_E2PP 1 /* coords [E][2][P][P]  (SLAM.reproject's permute+contiguous)    */
+#define CDV_TF_TONLY 2       /* flag: rotation of Gij replaced by identity (projective_ops.py:62) */
+
+/*
+ * pops.transform(poses, patches, intrinsics, ii, jj, kk[, valid][, jacobian][, tonly]) in f32,
+ * lietorch semantics (quaternions re-normalised on every load, so3.h:30-37; d = 1/max(Z, 0.1)).
+ *   poses [n][7], patches [m][3][P][P], intrinsics [n][4] (per-frame), ii/jj/kk [E]
+ *   coords out (layout by flags) ; optional (NULL to skip):
+ *     validpx [E][P][P]  (X1.z > 0.2)                      projective_ops.py:110-111
+ *     valid [E], Ji [E][2][6], Jj [E][2][6], Jz [E][2]     projective_ops.py:71-108
+ */
+int cdv_transform(const float* poses, const float* patches, const float* intrinsics, const int64_t* ii,
+                  const int64_t* jj, const int64_t* kk, int64_t E, int P, int flags, float* coords, float* validpx,
+                  float* valid, float* Ji, float* Jj, float* Jz, void* stream);
+
+/* cuda_ba.reproject (ba.cpp:50-57, ba_cuda.cu:408-458): intrinsics row 0, no depth clamp, no
+ * quaternion normalisation -> coords [E][2][P][P] */
+int cdv_fastba_reproject(const float* poses, const float* patches, const float* intrinsics, const int64_t* ii,
+                         const int64_t* jj, const int64_t* kk, int64_t E, int P, float* coords, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * patch-graph index (device-side replacement of torch::_unique + the CPU loops of
+ * fastba.neighbors, ba.cpp:59-97; shared by neighbors, BA and the correlation order)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* bytes of device workspace for a graph of up to E_max edges whose patch ids span at most
+ * k_range values and whose target frame ids span at most f_range values */
+size_t cdv_graph_workspace_bytes(int64_t E_max, int64_t k_range, int64_t f_range);
+
+/*
+ * Build the index for edge lists (jj = target frame, kk = patch id), [E] int64 -- the arguments of
+ * cuda_ba.neighbors(kk, jj).  Contents (device side, addressed through the accessors below):
+ *   kx [U] sorted unique patch ids, ku [E] inverse index  == torch::_unique(kk, true, true)
+ *   patch CSR: for each unique patch its edges ordered by (jj, edge id)
+ *   target order: edge ids sorted by (jj, edge id)
+ * Ranges that exceed the workspace set an error word readable via cdv_graph_read_meta_host.
+ */
+int cdv_graph_build(const int64_t* jj, const int64_t* kk, int64_t E, void* ws, size_t ws_bytes, int64_t k_range,
+                    int64_t f_range, void* stream);
+
+/* meta_host[8] <- {U, n_targets, kmin, kmax, jmin, jmax, error, E}; synchronises `stream`. */
+int cdv_graph_read_meta_host(const void* ws, int64_t* meta_host, void* stream);
+
+/* copy out torch::_unique results (kx needs U from cdv_graph_read_meta_host to size it) */
+int cdv_graph_get_unique(const void* ws, int64_t* kx, int64_t kx_capacity, int64_t* ku, int64_t E, void* stream);
+
+/* device pointer to the [E] int32 (jj, edge id)-sorted edge order (valid until the next build) */
+const int32_t* cdv_graph_pair_order(const void* ws);
+
+/* cuda_ba.neighbors(kk, jj) (ba.cpp:59-97) from a built graph: ix/jx [E] int64, -1 = none */
+int cdv_neighbors(const void* ws, int64_t E, int64_t* ix, int64_t* jx, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * fastba  (replaces cuda_ba.forward, ba.cpp:31-45, ba_cuda.cu:462-611)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* bytes of device workspace for up to U_max unique patches and N_max <= 32 free poses */
+size_t cdv_ba_workspace_bytes(int64_t E_max, int64_t U_max, int N_max);
+
+/*
+ * In-place bundle adjustment: `iterations` Gauss-Newton steps with Schur complement over patch
+ * inverse depths; poses[t0:t1] and patches[kx] are updated in place, nothing is returned
+ * (ba_cuda.cu:462-611, dense-E path; t1 == t0 is the structure-only branch :550-560).
+ *   poses [*][7] f32, patches [*][3][P][P] f32, intrinsics [*][4] (only row 0 is read, :253-259),
+ *   target/weight [E][2] f32, lmbda: DEVICE pointer to 1 float, ii/jj/kk [E] int64.
+ *   graph_ws: a workspace on which cdv_graph_build(jj, kk, E) has been enqueued on `stream`.
+ *   ba_ws / U_max: workspace of cdv_ba_workspace_bytes(E, U_max, N) bytes; U_max bounds the number of
+ *             unique patches (exceeding it sets info word 1 and skips the update).
+ *   dbg (optional, NULL): receives iteration-0 values, with n = 6N and Us = round_up(U_max, 32):
+ *             [S n*n (damped) | y n | dX n | dZ Us | C Us | u Us | E n*Us]
+ * Supports N = t1 - t0 <= 32 (single-workgroup LDS Cholesky).
+ */
+int cdv_ba_forward(float* poses, float* patches, const float* intrinsics, const float* target, const float* weight,
+                   const float* lmbda, const int64_t* ii, const int64_t* jj, const int64_t* kk, int64_t E, int P,
+                   int t0, int t1, int iterations, const void* graph_ws, void* ba_ws, size_t ba_ws_bytes,
+                   int64_t U_max, float* dbg, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * lietorch forward ops  (replaces lietorch_backends.{expm,logm,inv,mul,adj,adjT,act,act4,as_matrix})
+ * group ids as the reference: SO3 = 1, SE3 = 3 (lietorch.cpp:286-316, groups.py:236-290).
+ * op: 0 exp, 1 log, 2 inv, 3 mul, 4 adj, 5 adjT, 6 act, 7 act4, 8 as_matrix.  Flat [n][dim] rows.
+ * ---------------------------------------------------------------------------------------------- */
+int cdv_lie_op(int group, int op, int dtype, int64_t n, const void* x, const void* y, void* z, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CDVSLAM_HIP_H */

@@ -1,0 +1,97 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol that
+include/cdvslam_hip.h declares, argument validation returns error codes (no exit()), and the Python
+operator surface has the reference's names.  No GPU compute is launched here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    src = open(os.path.join(ROOT, "include", "cdvslam_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(cdv_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from cdv_slam_amd import _lib
+    lib = _lib.load()
+    names = _declared_functions()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), "missing export: " + n
+    assert set(names) == set(_lib.SIGNATURES), "ctypes table and header disagree"
+    assert b"gfx950" in lib.cdv_version()
+
+
+def test_argument_errors_are_codes_not_exits():
+    from cdv_slam_amd import _lib
+    lib = _lib.load()
+    # unsupported group id -> CDV_ERR_UNSUPPORTED before anything touches the GPU
+    rc = lib.cdv_lie_op(2, 0, 1, 4, None, None, None, None)
+    assert rc == -4 and b"SO3" in lib.cdv_last_error()
+    rc = lib.cdv_corr_fused(None, None, None, None, None, None, None, None, 10, 1, 1, 24, 8, 8, 2, 2, 1.0, 4.0, 3, 0,
+                            0, None)
+    assert rc == -2
+    rc = lib.cdv_graph_build(None, None, 10, None, 0, 16, 16, None)
+    assert rc == -2
+    assert lib.cdv_graph_workspace_bytes(1000, 100, 10) > 1000 * 4 * 4
+    assert lib.cdv_ba_workspace_bytes(1000, 100, 10) > 8 * 3660 * 4
+    # more than 32 free poses is a clean error
+    rc = lib.cdv_ba_forward(None, None, None, None, None, None, None, None, None, 10, 3, 0, 40, 2, None, None, 0, 10,
+                            None, None)
+    assert rc == -4
+
+
+def test_operator_surface_names():
+    import cdv_slam_amd
+    from cdv_slam_amd import altcorr, fastba, lietorch, projective_ops
+    assert callable(altcorr.corr) and callable(altcorr.patchify)
+    assert callable(fastba.BA) and callable(fastba.neighbors) and callable(fastba.reproject)
+    for n in ("SE3", "SO3", "cat", "stack"):
+        assert hasattr(lietorch, n)
+    for n in ("transform", "iproj", "proj", "point_cloud", "flow_mag", "coords_grid"):
+        assert hasattr(projective_ops, n)
+    cc, cb, lb = cdv_slam_amd.install_dropin()
+    for n in ("forward", "backward", "patchify_forward", "patchify_backward"):
+        assert hasattr(cc, n)
+    for n in ("forward", "neighbors", "reproject", "solve_system"):
+        assert hasattr(cb, n)
+    for n in ("expm", "logm", "inv", "mul", "adj", "adjT", "act", "act4", "as_matrix", "projector", "Jinv",
+              "expm_backward", "act4_backward"):
+        assert hasattr(lb, n)
+    assert lietorch.SE3.group_id == 3 and lietorch.SO3.group_id == 1
+
+
+def test_hip_path_refuses_cpu_tensors():
+    import torch
+    from cdv_slam_amd import ops
+    with pytest.raises(RuntimeError):
+        ops.lie_op(3, "exp", torch.zeros(2, 6))
+    with pytest.raises(RuntimeError):
+        ops.neighbors(torch.zeros(4, dtype=torch.long), torch.zeros(4, dtype=torch.long))
+
+
+def test_product_never_imports_oracle():
+    """the oracle is test infrastructure: nothing under cdv_slam_amd/ may reference it"""
+    pkg = os.path.join(ROOT, "cdv_slam_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
+                assert "libcdv_oracle" not in txt, f
+
+
+def test_synth_graph_sizes():
+    from cdv_slam_amd import synth
+    import numpy as np
+    for name, E, U, N in (("default", 47712, 2208, 10), ("stress", 97412, 4508, 22), ("init", 6144, 768, 7),
+                          ("pr1", 9600, 960, 9)):
+        ii, jj, kk = synth.replay_edges(synth.CONFIGS[name])
+        assert len(ii) == E and len(np.unique(kk)) == U
+    st = synth.make_state("default", features=False)
+    assert st.n - st.t0 == 10

@@ -1,0 +1,395 @@
+"""GPU parity tests: every HIP entry point (through the C ABI) against the CPU oracle on the same
+seeded inputs, plus the golden fixtures captured from the reference's Python files.
+
+Tolerances: reprojected coords atol 1e-3 px; corr f16 path
+|d| <= 2^-8 max|corr| + 2^-10 vs the float64 truth; S/y/C/u/E rtol 1e-4 (of the matrix scale);
+poses after 2 GN iterations atol 1e-5 (t) / 1e-6 (q) vs the float64 oracle on well-conditioned
+graphs; inverse depth rtol 1e-4; BIT-EXACT for kx, ku, neighbors.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from cdv_slam_amd import ops, synth
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _check_mode():
+    os.environ["CDV_CHECK"] = "1"
+    yield
+    os.environ["CDV_CHECK"] = "0"
+
+
+def T(a, dtype=None):
+    return torch.as_tensor(np.ascontiguousarray(a), device=DEV) if dtype is None else \
+        torch.as_tensor(np.ascontiguousarray(a), dtype=dtype, device=DEV)
+
+
+# ---------------------------------------------------------------------------------------------------
+# lietorch ops
+# ---------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("group", [O.SO3, O.SE3])
+@pytest.mark.parametrize("dtype,tol", [(np.float32, 2e-6), (np.float64, 1e-13)])
+def test_lie_ops(group, dtype, tol):
+    rng = np.random.default_rng(7)
+    K, N = (6, 7) if group == O.SE3 else (3, 4)
+    n = 1000
+    a = (0.5 * rng.standard_normal((n, K))).astype(dtype)
+    a[0] = 0
+    a[1, -3:] = 1e-8  # Taylor branches
+    b = rng.standard_normal((n, K)).astype(dtype)
+    p3 = rng.standard_normal((n, 3)).astype(dtype)
+    p4 = rng.standard_normal((n, 4)).astype(dtype)
+    X = O.lie(group, "exp", a, dtype=dtype)
+    Y = O.lie(group, "exp", b, dtype=dtype)
+    Xg = ops.lie_op(group, "exp", T(a))
+    assert np.allclose(Xg.cpu().numpy(), X, atol=tol)
+    Xt, Yt = T(X), T(Y)
+    cases = [("log", (Xt,), (X,)), ("inv", (Xt,), (X,)), ("mul", (Xt, Yt), (X, Y)), ("adj", (Xt, T(b)), (X, b)),
+             ("adjT", (Xt, T(b)), (X, b)), ("act", (Xt, T(p3)), (X, p3)), ("act4", (Xt, T(p4)), (X, p4)),
+             ("matrix", (Xt,), (X,))]
+    for op, gargs, oargs in cases:
+        got = ops.lie_op(group, op, *gargs).cpu().numpy()
+        want = O.lie(group, op, *oargs, dtype=dtype)
+        scale = max(1.0, np.abs(want).max())
+        assert np.allclose(got, want, atol=tol * scale * 8), op
+
+
+def test_lietorch_classes_golden(golden_dir):
+    """the SE3 class surface reproduces the reference Python layer's outputs (groups.py broadcasting)"""
+    from cdv_slam_amd.lietorch import SE3
+    g = np.load(os.path.join(golden_dir, "lietorch_py.npz"))
+    a, b, p4 = T(g["a"]), T(g["b"]), T(g["p4"])
+    X, Y = SE3.exp(a), SE3.exp(b)
+    tol = 1e-12
+    assert np.allclose(X.data.cpu().numpy(), g["X"], atol=tol)
+    assert np.allclose((X * Y).data.cpu().numpy(), g["XY"], atol=tol)
+    assert np.allclose(X.inv().data.cpu().numpy(), g["Xinv"], atol=tol)
+    assert np.allclose(X.log().cpu().numpy(), g["logX"], atol=tol)
+    assert np.allclose((X[:, :, None] * p4).cpu().numpy(), g["act4"], atol=tol)
+    assert np.allclose(X.matrix().cpu().numpy(), g["matrix"], atol=tol)
+    assert np.allclose(X.adjT(a).cpu().numpy(), g["adjT"], atol=tol)
+    assert np.allclose(X.adj(a).cpu().numpy(), g["adj"], atol=tol)
+    assert np.allclose(X.retr(a).data.cpu().numpy(), g["retr"], atol=tol)
+
+
+# ---------------------------------------------------------------------------------------------------
+# projective ops
+# ---------------------------------------------------------------------------------------------------
+
+def test_transform_golden(golden_dir):
+    """fused cdv_transform vs outputs of the reference's own projective_ops.py"""
+    from cdv_slam_amd import projective_ops as pops
+    from cdv_slam_amd.lietorch import SE3
+    g = np.load(os.path.join(golden_dir, "pops_transform_f32.npz"))
+    poses, patches, intr = T(g["poses"])[None], T(g["patches"])[None], T(g["intrinsics"])[None]
+    ii, jj, kk = T(g["ii"]), T(g["jj"]), T(g["kk"])
+    x1 = pops.transform(SE3(poses), patches, intr, ii, jj, kk)
+    assert x1.shape == (1,) + g["coords"].shape
+    assert np.abs(x1[0].cpu().numpy() - g["coords"]).max() < 1e-3
+    x1j, v, (Ji, Jj, Jz) = pops.transform(SE3(poses), patches, intr, ii, jj, kk, jacobian=True)
+    assert np.array_equal(v[0].cpu().numpy(), g["valid"])
+    for a, b in ((Ji, g["Ji"]), (Jj, g["Jj"]), (Jz, g["Jz"])):
+        assert a.shape == (1,) + b.shape
+        assert np.allclose(a[0].cpu().numpy(), b, rtol=1e-4, atol=1e-4 * np.abs(b).max())
+    x1v, val = pops.transform(SE3(poses), patches, intr, ii, jj, kk, valid=True)
+    assert np.array_equal(val[0].cpu().numpy(), g["validpx"])
+    x1t = pops.transform(SE3(poses), patches, intr, ii, jj, kk, tonly=True)
+    assert np.abs(x1t[0].cpu().numpy() - g["coords_tonly"]).max() < 1e-3
+    fm, fv = pops.flow_mag(SE3(poses), patches, intr, ii, jj, kk, beta=0.5)
+    assert np.allclose(fm[0].cpu().numpy(), g["flow_mag"], atol=2e-3)
+    assert np.array_equal(fv[0].cpu().numpy(), g["flow_valid"])
+    ix = T(g["point_cloud_ix"])
+    pc = pops.point_cloud(SE3(poses), patches[:, :len(ix)], intr, ix)
+    assert np.allclose(pc[0].cpu().numpy(), g["point_cloud"], rtol=1e-4, atol=1e-4)
+    # SLAM.reproject layout
+    rp = pops.reproject(SE3(poses), patches, intr, ii, jj, kk)
+    assert torch.equal(rp, x1.permute(0, 1, 4, 2, 3).contiguous())
+
+
+@pytest.mark.parametrize("name", ["small", "default"])
+def test_transform_vs_oracle(name):
+    st = synth.make_state(name, features=False)
+    coords = ops.transform(T(st.poses)[None], T(st.patches)[None], T(st.intrinsics)[None], T(st.ii), T(st.jj),
+                           T(st.kk), layout_e2pp=True)
+    want = O.transform(st.poses, st.patches, st.intrinsics, st.ii, st.jj, st.kk, dtype=np.float64)
+    assert np.abs(coords[0].cpu().numpy() - want.transpose(0, 3, 1, 2)).max() < 1e-3
+    fr = ops.fastba_reproject(T(st.poses), T(st.patches), T(st.intrinsics), T(st.ii), T(st.jj), T(st.kk))
+    want = O.fastba_reproject(st.poses, st.patches, st.intrinsics[0], st.ii, st.jj, st.kk, dtype=np.float64)
+    assert np.abs(fr[0].cpu().numpy() - want).max() < 1e-3
+
+
+# ---------------------------------------------------------------------------------------------------
+# patch-graph index: bit-exact
+# ---------------------------------------------------------------------------------------------------
+
+def _check_graph(kk, jj, k_range, f_range):
+    g = ops.GraphIndex(torch.device(DEV), E_cap=len(kk), k_range=k_range, f_range=f_range)
+    g.build(T(jj), T(kk))
+    kx, ku = g.unique()
+    kx_o, ku_o = O.unique(kk)
+    assert np.array_equal(kx.cpu().numpy(), kx_o)
+    assert np.array_equal(ku.cpu().numpy(), ku_o)
+    ix, jx = g.neighbors()
+    ix_o, jx_o = O.neighbors(kk, jj)
+    assert np.array_equal(ix.cpu().numpy(), ix_o)
+    assert np.array_equal(jx.cpu().numpy(), jx_o)
+    m = g.meta()
+    assert m[0] == len(kx_o) and m[7] == len(kk)
+    # the target order is a permutation grouped by jj
+    o = g.order().cpu().numpy()
+    assert np.array_equal(np.sort(o), np.arange(len(kk)))
+    assert np.all(np.diff(jj[o]) >= 0)
+
+
+@pytest.mark.parametrize("name", ["tiny", "small", "pr1", "default", "stress"])
+def test_graph_index_bit_exact(name):
+    cfg = synth.CONFIGS[name]
+    ii, jj, kk = synth.replay_edges(cfg)
+    _check_graph(kk, jj, cfg.buffer_size * cfg.M, cfg.buffer_size)
+
+
+def test_graph_index_irregular():
+    """random multigraph: duplicate (k, j) edges, gaps in the id ranges, shuffled order"""
+    rng = np.random.default_rng(11)
+    E = 20000
+    kk = rng.choice(np.arange(100, 9000, 3), size=E).astype(np.int64)
+    jj = rng.integers(5, 300, size=E).astype(np.int64)
+    _check_graph(kk, jj, 9000, 300)
+    # single edge / single patch
+    _check_graph(np.array([7], np.int64), np.array([3], np.int64), 64, 64)
+    _check_graph(np.full(500, 42, np.int64), rng.integers(0, 20, 500).astype(np.int64), 64, 64)
+
+
+def test_graph_range_overflow_is_reported():
+    g = ops.GraphIndex(torch.device(DEV), E_cap=16, k_range=8, f_range=8)
+    os.environ["CDV_CHECK"] = "0"
+    try:
+        g.build(T(np.array([0, 1, 2], np.int64)), T(np.array([0, 100, 5], np.int64)))
+        with pytest.raises(Exception):
+            g.meta()
+    finally:
+        os.environ["CDV_CHECK"] = "1"
+
+
+def test_neighbors_dropin_signature():
+    import cdv_slam_amd
+    _, cuda_ba, _ = cdv_slam_amd.install_dropin()
+    st = synth.make_state("small", features=False)
+    ix, jx = cuda_ba.neighbors(T(st.kk), T(st.jj))
+    ix_o, jx_o = O.neighbors(st.kk, st.jj)
+    assert ix.dtype == torch.int64 and ix.is_cuda
+    assert np.array_equal(ix.cpu().numpy(), ix_o) and np.array_equal(jx.cpu().numpy(), jx_o)
+
+
+# ---------------------------------------------------------------------------------------------------
+# altcorr
+# ---------------------------------------------------------------------------------------------------
+
+def _corr_tol(truth):
+    return 2.0 ** -8 * np.abs(truth).max() + 2.0 ** -10
+
+
+def _gpu_coords(st):
+    return ops.transform(T(st.poses)[None], T(st.patches)[None], T(st.intrinsics)[None], T(st.ii), T(st.jj),
+                         T(st.kk), layout_e2pp=True)
+
+
+@pytest.mark.parametrize("name", ["tiny", "small"])
+def test_corr_fused_vs_oracle(name):
+    from cdv_slam_amd.update import UpdatePath
+    st = synth.make_state(name)
+    up = UpdatePath(st, torch.device(DEV))
+    # the channels-last rings hold exactly the reference-layout maps
+    assert torch.equal(up.fmap1.permute(0, 3, 1, 2).cpu(), torch.as_tensor(st.fmap1))
+    f2 = up.fmap2.permute(0, 3, 1, 2).float().cpu().numpy()
+    assert np.abs(f2 - st.fmap2.astype(np.float32)).max() <= 2.0 ** -11 * np.abs(f2).max() + 1e-7
+    coords = _gpu_coords(st)
+    for order in (None, "graph"):
+        up.graph.build(up.jj, up.kk, force=True)
+        out = ops.corr_fused(up.gmap, up.fmap1, up.fmap2, coords, up.kk, up.jj, kmod=up.kmod, jmod=up.jmod,
+                             order_ptr=up.graph.order_ptr() if order else None)
+        got = out[0].float().cpu().numpy()
+        c = coords[0].cpu().numpy()
+        fmap2 = up.fmap2.permute(0, 3, 1, 2).contiguous().cpu().numpy()  # what the kernel actually reads
+        truth = O.slam_corr(st.gmap, st.fmap1, fmap2, c, st.ii1, st.jj1, 3, "truth")
+        assert got.shape == truth.shape == (st.E, 882)
+        assert np.abs(got - truth).max() <= _corr_tol(truth)
+        # and the reference-faithful half-precision emulation sits inside the same envelope
+        ref = O.slam_corr(st.gmap, st.fmap1, fmap2, c, st.ii1, st.jj1, 3, "ref").astype(np.float64)
+        assert np.abs(ref - truth).max() <= 4 * _corr_tol(truth)
+        assert np.abs(got - ref).max() <= 4 * _corr_tol(truth)
+
+
+def test_corr_edge_cases():
+    """out-of-bounds windows, windows straddling the border, wide footprints (per-pixel path), exact
+    integer coordinates, and the per-level drop-in signature (planar inputs, f16 and f32)."""
+    from cdv_slam_amd import altcorr
+    rng = np.random.default_rng(5)
+    N2, C, H, W, Ng = 3, 24, 20, 28, 10
+    fmap2 = (rng.standard_normal((1, N2, C, H, W)) / 4).astype(np.float16)
+    gmap = (rng.standard_normal((1, Ng, C, 3, 3)) / 4).astype(np.float16)
+    cases = []
+    base = np.stack(np.meshgrid(np.arange(3.0), np.arange(3.0), indexing="xy"))  # [2,3,3] x then y offsets
+    for cx, cy, s in [(10.3, 8.7, 1.0), (-20.0, 5.0, 1.0), (0.2, 0.4, 1.0), (27.9, 19.9, 1.0), (40.0, 40.0, 1.0),
+                      (12.0, 9.0, 1.0), (12.5, 9.5, 6.0), (5.0, 5.0, 12.0), (-1.0, -1.0, 3.3), (13.999, 7.001, 0.2)]:
+        cases.append(np.stack([cx + s * (base[0] - 1), cy + s * (base[1] - 1)]))
+    coords = np.stack(cases)[None].astype(np.float32)  # [1,M,2,3,3]
+    M = coords.shape[1]
+    us = rng.integers(0, Ng, M).astype(np.int64)
+    vs = rng.integers(0, N2, M).astype(np.int64)
+    truth = O.corr(gmap[0], fmap2[0], coords[0], us, vs, 3, "truth")
+    got = altcorr.corr(T(gmap), T(fmap2), T(coords), T(us), T(vs), 3)  # fast MFMA path via the NHWC shadow
+    assert got.shape == (1, M, 7, 7, 3, 3) and got.dtype == torch.float16
+    assert np.abs(got[0].float().cpu().numpy() - truth).max() <= _corr_tol(truth)
+    # fully out-of-bounds edges are exactly zero
+    assert float(got[0, 1].abs().max()) == 0.0 and float(got[0, 4].abs().max()) == 0.0
+    # generic kernel: f32 maps, radius 1 and 3
+    f2_32, g_32 = fmap2.astype(np.float32), gmap.astype(np.float32)
+    for r in (1, 3):
+        got32 = altcorr.corr(T(g_32), T(f2_32), T(coords), T(us), T(vs), r)
+        want = O.corr(g_32[0], f2_32[0], coords[0], us, vs, r, "truth")
+        assert got32.dtype == torch.float32
+        assert np.allclose(got32[0].cpu().numpy(), want, rtol=1e-5, atol=1e-5)
+        ref32 = O.corr(g_32[0], f2_32[0], coords[0], us, vs, r, "f32")
+        assert np.allclose(got32[0].cpu().numpy(), ref32, rtol=1e-5, atol=2e-5)
+    # generic kernel, f16, radius 1 (not the MFMA shape)
+    got16 = altcorr.corr(T(gmap), T(fmap2), T(coords), T(us), T(vs), 1)
+    want = O.corr(gmap[0], fmap2[0], coords[0], us, vs, 1, "truth")
+    assert np.abs(got16[0].float().cpu().numpy() - want).max() <= _corr_tol(want)
+
+
+def test_corr_c128():
+    """DPVO feature width (DIMF = 128, net_dpv.py:99): four MFMA k-steps"""
+    rng = np.random.default_rng(9)
+    N2, C, H, W, Ng, M = 2, 128, 16, 20, 6, 40
+    fmap2 = (rng.standard_normal((1, N2, C, H, W)) / 8).astype(np.float16)
+    gmap = (rng.standard_normal((1, Ng, C, 3, 3)) / 8).astype(np.float16)
+    coords = np.empty((1, M, 2, 3, 3), np.float32)
+    cx, cy = rng.uniform(-2, W + 2, M), rng.uniform(-2, H + 2, M)
+    off = np.arange(3.0) - 1
+    coords[0, :, 0] = cx[:, None, None] + off[None, None, :]
+    coords[0, :, 1] = cy[:, None, None] + off[None, :, None]
+    us, vs = rng.integers(0, Ng, M).astype(np.int64), rng.integers(0, N2, M).astype(np.int64)
+    from cdv_slam_amd import altcorr
+    got = altcorr.corr(T(gmap), T(fmap2), T(coords), T(us), T(vs), 3)
+    truth = O.corr(gmap[0], fmap2[0], coords[0], us, vs, 3, "truth")
+    assert np.abs(got[0].float().cpu().numpy() - truth).max() <= _corr_tol(truth)
+
+
+def test_patchify_vs_oracle():
+    from cdv_slam_amd import altcorr
+    rng = np.random.default_rng(3)
+    C, H, W, M = 24, 24, 32, 50
+    net = rng.standard_normal((1, C, H, W)).astype(np.float16)
+    coords = np.stack([rng.uniform(-3, W + 3, M), rng.uniform(-3, H + 3, M)], -1)[None].astype(np.float32)
+    for r in (0, 1, 3):
+        raw = altcorr.patchify(T(net), T(coords), r, mode="raw")
+        assert torch.equal(raw[0].cpu(), torch.as_tensor(O.patchify_raw(net[0], coords[0], r)))
+    bl = altcorr.patchify(T(net), T(coords), 1)
+    want = O.patchify(net[0], coords[0], 1)
+    assert bl.dtype == torch.float32 and np.allclose(bl[0].cpu().numpy(), want, atol=1e-6)
+    ul = altcorr.patchify(T(net), T(coords), 0, mode="upperleft")
+    assert ul.shape == (1, M, C, 1, 1)
+
+
+# ---------------------------------------------------------------------------------------------------
+# fastba
+# ---------------------------------------------------------------------------------------------------
+
+def _run_ba(st, iterations=2, debug=False, t0=None, t1=None):
+    poses, patches = T(st.poses).clone(), T(st.patches).clone()
+    t0 = st.t0 if t0 is None else t0
+    t1 = st.n if t1 is None else t1
+    res = ops.ba_forward(poses, patches, T(st.intrinsics), T(st.target), T(st.weight),
+                         torch.tensor([st.lmbda], device=DEV), T(st.ii), T(st.jj), T(st.kk), st.cfg.M, t0, t1,
+                         iterations, False, debug=debug)
+    torch.cuda.synchronize()
+    return poses.cpu().numpy(), patches.cpu().numpy(), res
+
+
+@pytest.mark.parametrize("name", ["small", "init", "pr1", "default"])
+def test_ba_intermediates_vs_oracle(name):
+    """iteration-0 S, y, C, u, E, dX, dZ against the float64 oracle"""
+    st = synth.make_state(name, features=False)
+    _, _, dbg = _run_ba(st, iterations=1, debug=True)
+    _, _, info, o = O.fastba(st.poses, st.patches, st.intrinsics[0], st.target, st.weight, st.lmbda, st.ii, st.jj,
+                             st.kk, st.t0, st.n, 1, np.float64, debug=True)
+    assert info == 0
+    U = len(o["kx"])
+    for key, got, want in (("S", dbg["S"], o["S"]), ("y", dbg["y"], o["y"]), ("C", dbg["C"][:U], o["C"]),
+                           ("u", dbg["u"][:U], o["u"]), ("E", dbg["E"][:, :U], o["E"])):
+        got = got.cpu().numpy()
+        assert np.abs(got - want).max() <= 1e-4 * np.abs(want).max(), key
+    assert np.abs(dbg["dX"].cpu().numpy() - o["dX"]).max() <= 2e-3 * max(1e-3, np.abs(o["dX"]).max())
+    assert np.abs(dbg["dZ"][:U].cpu().numpy() - o["dZ"]).max() <= 2e-3 * max(1e-3, np.abs(o["dZ"]).max())
+
+
+@pytest.mark.parametrize("name", ["small", "init", "pr1", "default", "stress"])
+def test_ba_two_iterations_vs_oracle(name):
+    st = synth.make_state(name, features=False)
+    poses, patches, _ = _run_ba(st, iterations=2)
+    p64, x64, info = O.fastba(st.poses, st.patches, st.intrinsics[0], st.target, st.weight, st.lmbda, st.ii, st.jj,
+                              st.kk, st.t0, st.n, 2, np.float64)
+    assert info == 0
+    # the float32 oracle bounds how much of the difference is float32 conditioning, not the kernel
+    p32, x32, _ = O.fastba(st.poses, st.patches, st.intrinsics[0], st.target, st.weight, st.lmbda, st.ii, st.jj,
+                           st.kk, st.t0, st.n, 2, np.float32)
+    slack = max(1.0, np.abs(p32 - p64).max() / 1e-6)
+    assert np.abs(poses[:, :3] - p64[:, :3]).max() <= 1e-5 * slack * 3
+    assert np.abs(poses[:, 3:] - p64[:, 3:]).max() <= 1e-6 * slack * 3
+    d, d64 = patches[:, 2, 0, 0], x64[:, 2, 0, 0]
+    assert np.abs(d - d64).max() <= 1e-4 * slack * np.maximum(np.abs(d64), 1e-2).max()
+    # fixed poses and untouched patches are bit-identical to the input
+    assert np.array_equal(poses[:st.t0], st.poses[:st.t0])
+    untouched = np.setdiff1d(np.arange(len(st.patches)), np.unique(st.kk))
+    assert np.array_equal(patches[untouched], st.patches[untouched])
+    # all P*P depth pixels of an updated patch are equal (ba_cuda.cu:223-227)
+    k0 = np.unique(st.kk)
+    assert np.all(patches[k0, 2] == patches[k0, 2, :1, :1])
+
+
+def test_ba_structure_only_and_gates():
+    """t1 == t0 branch (ba_cuda.cu:550-560, caller long_term.py:124-125) and the depth clamps"""
+    st = synth.make_state("small", features=False)
+    # make some updates run into the gates: huge residuals (masked), very small depth
+    st.target[::7] += 500.0
+    st.patches[np.unique(st.kk)[::5], 2] = 1e-5
+    poses, patches, _ = _run_ba(st, iterations=3, t0=st.n, t1=st.n)
+    p64, x64, _ = O.fastba(st.poses, st.patches, st.intrinsics[0], st.target, st.weight, st.lmbda, st.ii, st.jj,
+                           st.kk, st.n, st.n, 3, np.float64)
+    assert np.array_equal(poses, st.poses)
+    d, d64 = patches[:, 2, 0, 0], x64[:, 2, 0, 0]
+    assert np.abs(d - d64).max() <= 2e-4 * np.maximum(np.abs(d64), 1e-2).max()
+    assert d.min() >= 1e-4
+
+
+def test_ba_dropin_inplace_contract():
+    """fastba.BA(poses view of the state buffer, ...) mutates the buffers in place and returns []"""
+    from cdv_slam_amd import fastba
+    from cdv_slam_amd.lietorch import SE3
+    st = synth.make_state("small", features=False)
+    poses_ = T(st.poses).clone()
+    patches_ = T(st.patches).clone()
+    N, M = st.cfg.buffer_size, st.cfg.M
+    res = fastba.BA(SE3(poses_.view(1, N, 7)), patches_.view(1, N * M, 3, 3, 3), T(st.intrinsics).view(1, N, 4),
+                    T(st.target)[None], T(st.weight)[None], torch.as_tensor([1e-4], device=DEV), T(st.ii), T(st.jj),
+                    T(st.kk), st.t0, st.n, M=M, iterations=2, eff_impl=False)
+    assert res == []
+    torch.cuda.synchronize()
+    assert not torch.equal(poses_, T(st.poses))
+    p64, _, _ = O.fastba(st.poses, st.patches, st.intrinsics[0], st.target, st.weight, st.lmbda, st.ii, st.jj, st.kk,
+                         st.t0, st.n, 2, np.float64)
+    assert np.abs(poses_.cpu().numpy() - p64).max() < 1e-4
+
+
+def test_update_path_end_to_end():
+    import __graft_entry__ as ge
+    ge.smoke()
