@@ -63,6 +63,7 @@ class UpdatePath:
         coords = ops.transform(self.poses[None], self.patches[None], self.intrinsics[None], self.ii, self.jj, self.kk,
                                layout_e2pp=True)
         out["coords"] = coords
+        self.last_coords = coords
         # patch-graph index: shared by the correlation order, neighbors and BA
         self.graph.build(self.jj, self.kk, force=rebuild_graph)
         # 2. correlation, both levels (slam.py:316-323)
@@ -76,3 +77,41 @@ class UpdatePath:
         ops.ba_forward(self.poses, self.patches, self.intrinsics, self.target, self.weight, self.lmbda, self.ii,
                        self.jj, self.kk, self.M, self.t0, self.n, iterations, False, U_max=self.U_max, graph=self.graph)
         return out
+
+    # -- measurement helpers (bench.py) --------------------------------------------------------------
+    def corr_only(self, coords):
+        """just the fused correlation launch (dominant kernel) on the current stream"""
+        return ops.corr_fused(self.gmap, self.fmap1, self.fmap2, coords, self.kk, self.jj, kmod=self.kmod,
+                              jmod=self.jmod, order_ptr=self.graph.order_ptr() if self.sort_corr else None,
+                              out=self.corr_out)
+
+    def stage_times(self, reps=20):
+        """median microseconds per stage, each timed with HIP events on the current stream"""
+        import numpy as np
+
+        def timed(fn):
+            ts = []
+            for _ in range(reps):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                fn()
+                e1.record()
+                e1.synchronize()
+                ts.append(e0.elapsed_time(e1) * 1e3)
+            return float(np.median(ts))
+
+        coords = self.last_coords if hasattr(self, "last_coords") else self.step()["coords"]
+        res = {}
+        if self.has_features:
+            res["ingest"] = timed(lambda: ops.fmap_ingest(self.new_frame, self.fmap1, self.fmap2, self.new_slot))
+        res["reproject"] = timed(lambda: ops.transform(self.poses[None], self.patches[None], self.intrinsics[None],
+                                                       self.ii, self.jj, self.kk, layout_e2pp=True))
+        res["graph_build"] = timed(lambda: self.graph.build(self.jj, self.kk, force=True))
+        if self.has_features:
+            res["corr"] = timed(lambda: self.corr_only(coords))
+        res["neighbors"] = timed(lambda: self.graph.neighbors())
+        res["ba_2it"] = timed(lambda: ops.ba_forward(self.poses, self.patches, self.intrinsics, self.target,
+                                                     self.weight, self.lmbda, self.ii, self.jj, self.kk, self.M,
+                                                     self.t0, self.n, 2, False, U_max=self.U_max, graph=self.graph))
+        res["step"] = timed(lambda: self.step())
+        return res

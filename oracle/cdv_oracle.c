@@ -25,6 +25,9 @@
  */
 
 #include <math.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -89,6 +92,15 @@ static inline uint16_t f2h(float f) {
 
 /* round a float to the nearest half and back (one c10::Half arithmetic result) */
 static inline float rh(float f) { return h2f(f2h(f)); }
+
+/* threads the edge-parallel loops (corr, transform) use; 1 without OpenMP */
+int orc_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
 
 void orc_f2h(long n, const float *x, uint16_t *y) { for (long i = 0; i < n; i++) y[i] = f2h(x[i]); }
 void orc_h2f(long n, const uint16_t *x, float *y) { for (long i = 0; i < n; i++) y[i] = h2f(x[i]); }
@@ -264,7 +276,14 @@ void orc_neighbors(long n, const long *ii, const long *jj, long *ix, long *jx) {
 void orc_corr(int mode, const void *fmap1_, const void *fmap2_, const float *coords, const long *us,
               const long *vs, long M, int C, int H, int W, int H2, int W2, int R, void *out_) {
   const int D = 2 * R + 2, D1 = D - 1;
+#ifdef _OPENMP
+#pragma omp parallel
+#endif
+  {
   double *raw = (double *)malloc(sizeof(double) * (size_t)(D * D));
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 16)
+#endif
   for (long m = 0; m < M; m++) {
     const long ix = us[m], jx = vs[m];
     for (int i0 = 0; i0 < H; i0++)
@@ -338,6 +357,7 @@ void orc_corr(int mode, const void *fmap1_, const void *fmap2_, const float *coo
       }
   }
   free(raw);
+  }
 }
 
 /*

@@ -377,6 +377,9 @@ static int SUF(fb_ba)(REAL *poses, REAL *patches, const REAL *intr, const REAL *
 static void SUF(pops_transform)(const REAL *poses, const REAL *patches, const REAL *intr, const long *ii,
                                 const long *jj, const long *kk, long E_, int P, int tonly, REAL *coords,
                                 REAL *validpx, REAL *valid, REAL *Ji, REAL *Jj, REAL *Jz) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
   for (long n = 0; n < E_; n++) {
     const REAL *Ki = intr + 4 * ii[n], *Kj = intr + 4 * jj[n];
     const REAL *pk = patches + kk[n] * 3 * P * P;

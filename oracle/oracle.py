@@ -42,6 +42,11 @@ def lib():
     return _lib
 
 
+def num_threads():
+    """threads used by the edge-parallel oracle loops (corr, transform); BA assembly/solve are serial"""
+    return int(lib().orc_num_threads())
+
+
 def _p(a):
     return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
 
