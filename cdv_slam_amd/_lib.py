@@ -6,7 +6,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcdvslam_hip.so")
+# CDV_LIB selects another build of the same library (the diagnostic in-kernel-stamp build); default = product
+LIB_PATH = os.environ.get("CDV_LIB") or os.path.join(_HERE, "libcdvslam_hip.so")
 
 _vp, _i32, _i64, _sz, _f32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t, ctypes.c_float
 
@@ -22,11 +23,10 @@ SIGNATURES = {
     "cdv_patchify_fwd": (_i32, [_vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
     "cdv_transform": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cdv_fastba_reproject": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
-    "cdv_graph_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "cdv_graph_workspace_bytes": (_sz, [_i64, _i64]),
     "cdv_graph_build": (_i32, [_vp, _vp, _i64, _vp, _sz, _i64, _i64, _vp]),
     "cdv_graph_read_meta_host": (_i32, [_vp, _vp, _vp]),
     "cdv_graph_get_unique": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp]),
-    "cdv_graph_pair_order": (_vp, [_vp]),
     "cdv_neighbors": (_i32, [_vp, _i64, _vp, _vp, _vp]),
     "cdv_ba_workspace_bytes": (_sz, [_i64, _i64, _i32]),
     "cdv_ba_forward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _sz,

@@ -5,18 +5,22 @@
 // ATen's matmul / cholesky_ex / cholesky_solve launches (ba_cuda.cu:583-592).
 //
 // Per Gauss-Newton iteration, three launches:
-//  1. ba_assemble_kernel, two roles in one grid:
-//     - pair role   : wave = (64 unique patches, target slot t) through the patch CSR; every wave holds
-//                     edges of (almost always) one frame pair, so the 6x6 blocks of B and the 6-vectors of v are
-//                     ONE 13x13 Gram matrix of the wave's 128 residual rows: 32 f32 MFMAs
-//                     (v_mfma_f32_16x16x4_f32), then one atomic per matrix entry per wave.
-//     - patch role  : 32 unique patches per workgroup through the patch CSR; the E columns, C and u of
-//                     those patches are complete inside the workgroup (LDS), so the Schur products
-//                     E Q E^T and E Q u are formed in LDS and only the 6N x 6N partial leaves the CU.
-//     Both add into R replicas of [S | y] (S = B - E Q E^T, y = v - E Q u) to keep the number of
-//     same-address memory-side atomics per replica low.
-//  2. ba_solve_kernel (one workgroup): sums the replicas into LDS, damping (ba_cuda.cu:589), Cholesky,
-//     forward/back substitution, pose retraction (ba_cuda.cu:178-206), re-zeroes the replicas.
+//  1. ba_assemble_kernel: one workgroup per chunk of 64 unique patches (through the patch CSR).
+//     A wave (8 per workgroup) works on one "target slot" t at a time: lane = patch, edge = t-th edge of that patch in
+//     (jj, edge id) order.  Patches of one source frame share their target list, so the 64 edges of a
+//     wave belong to (almost always) ONE frame pair (i, j):
+//       - B blocks and v: the 13x13 Gram matrix of the wave's 128 residual rows [Ji | Jj | r], weighted
+//         by w, is ONE 16x16 f32 MFMA tile with K = 128 (32 x v_mfma_f32_16x16x4_f32); one atomic per
+//         entry per wave then adds it into [S | y].
+//       - E columns, C, u of a patch only receive contributions from that patch's own edges: the lane
+//         accumulates them in registers (E_i, C, u) or owns the LDS slot (E_j): no conflicts.
+//     After the slot loop the chunk's E (6N x 64) is complete in LDS, and the Schur products
+//     E Q E^T, E Q u are again MFMA tiles ([Ed; u] diag(q) [Ed; u]^T, K = 64).
+//     Everything is added into R replicas of [S | y] (S = B - E Q E^T, y = v - E Q u) to bound the
+//     number of same-address memory-side atomics.
+//  2. ba_solve_kernel (one workgroup): sums the replicas into LDS, damping (ba_cuda.cu:589), 6x6-block
+//     Cholesky with the right-hand side carried as an extra row (so the forward substitution is free),
+//     block back-substitution, pose retraction (ba_cuda.cu:178-206); re-zeroes the replicas.
 //  3. ba_retract_kernel: dZ = Q (u - E^T dX) and the inverse-depth update (ba_cuda.cu:209-229, 592).
 #include "cdv_common.h"
 #include "cdv_graph.h"
@@ -24,12 +28,18 @@
 
 using namespace cdv;
 
+CDV_STAMP_TU(ba)
+
 namespace {
 
 constexpr int BA_REPLICAS = 8;
-constexpr int BA_CHUNK = 32;      // unique patches per patch-role workgroup
+constexpr int BA_CHUNK = 64;      // unique patches per workgroup (= lanes of a wave)
 constexpr int BA_NMAX = 32;       // free poses supported by the single-workgroup solver
-constexpr int PAIR_TSY = 8;       // pair-role workgroups per 64-patch chunk (4 target slots each per pass)
+constexpr int XLD = 17;           // floats per residual row in the Gram staging buffer (16 + 1 pad)
+constexpr int PAIR_LDS_FLOATS = 128 * XLD + 64;  // per wave: [128][XLD] rows + 64 per-edge pair keys
+constexpr int ELD = BA_CHUNK + 4; // row stride of the chunk's E block in LDS (2-way bank conflicts at most)
+constexpr int ASM_WAVES = 8;      // waves per assemble workgroup: target slots are dealt round-robin to them
+constexpr int ASM_THREADS = 64 * ASM_WAVES;
 
 struct BaLayout {
   size_t sy, dX, C, u, q, Ed, info, total;
@@ -40,7 +50,7 @@ struct BaLayout {
 inline BaLayout ba_layout(int64_t U_max, int N_max) {
   BaLayout L;
   L.U_max = U_max; L.N_max = N_max;
-  L.U_stride = (U_max + 31) / 32 * 32;
+  L.U_stride = (U_max + BA_CHUNK - 1) / BA_CHUNK * BA_CHUNK;
   const size_t n6 = 6 * (size_t)N_max;
   size_t o = 0;
   L.sy = o;   o = align256(o + sizeof(float) * BA_REPLICAS * (n6 * n6 + n6));
@@ -58,37 +68,66 @@ struct EdgeJ {
   float r[2], w[2], Jz[2], Ji[12], Jj[12];
 };
 
+// Inputs of one edge, fetched ahead of use (the slot loop is software-pipelined: indices two slots
+// ahead, inputs one slot ahead, so the global-load round trips overlap the Gram / E work).
+struct EdgeIdx {
+  int e;
+  int ix, jx;
+  int64_t kx;
+};
+struct EdgeIn {
+  float pi[7], pj[7], px, py, pd, tx, ty, wx, wy;
+};
+
+__device__ __forceinline__ EdgeIdx load_idx(const int32_t* __restrict__ pcsr, const int64_t* __restrict__ ii,
+                                            const int64_t* __restrict__ jj, const int64_t* __restrict__ kk, int p) {
+  EdgeIdx o;
+  o.e = pcsr[p];
+  o.ix = (int)ii[o.e];
+  o.jx = (int)jj[o.e];
+  o.kx = kk[o.e];
+  return o;
+}
+
+__device__ __forceinline__ EdgeIn load_in(const float* __restrict__ poses, const float* __restrict__ patches,
+                                          const float* __restrict__ target, const float* __restrict__ weight,
+                                          const EdgeIdx& x, int PP, int centre) {
+  EdgeIn o;
+#pragma unroll
+  for (int a = 0; a < 7; a++) { o.pi[a] = poses[7 * (int64_t)x.ix + a]; o.pj[a] = poses[7 * (int64_t)x.jx + a]; }
+  const float* pk = patches + x.kx * 3 * PP;
+  o.px = pk[centre];
+  o.py = pk[PP + centre];
+  o.pd = pk[2 * PP + centre];
+  o.tx = target[2 * (int64_t)x.e + 0];
+  o.ty = target[2 * (int64_t)x.e + 1];
+  o.wx = weight[2 * (int64_t)x.e + 0];
+  o.wy = weight[2 * (int64_t)x.e + 1];
+  return o;
+}
+
 // ba_cuda.cu:261-342: residual, validity mask and the two Jacobian rows of one edge
-__device__ __forceinline__ void ba_edge(const float* __restrict__ poses, const float* __restrict__ patches,
-                                        float fx, float fy, float cx, float cy, const float* __restrict__ target,
-                                        const float* __restrict__ weight, int64_t ix, int64_t jx, int64_t kx, int PP,
-                                        int centre, int64_t n, EdgeJ& o) {
-  float ti[3], tj[3], qi[4], qj[4];
-#pragma unroll
-  for (int a = 0; a < 3; a++) { ti[a] = poses[7 * ix + a]; tj[a] = poses[7 * jx + a]; }
-#pragma unroll
-  for (int a = 0; a < 4; a++) { qi[a] = poses[7 * ix + 3 + a]; qj[a] = poses[7 * jx + 3 + a]; }
-  const float* pk = patches + kx * 3 * PP;
+__device__ __forceinline__ void ba_edge(const EdgeIn& in, float fx, float fy, float cx, float cy, EdgeJ& o) {
   float Xi[4], Xj[4];
-  Xi[0] = (pk[centre] - cx) / fx;
-  Xi[1] = (pk[PP + centre] - cy) / fy;
+  Xi[0] = (in.px - cx) / fx;
+  Xi[1] = (in.py - cy) / fy;
   Xi[2] = 1.0f;
-  Xi[3] = pk[2 * PP + centre];
+  Xi[3] = in.pd;
   float tij[3], qij[4];
-  fb_relSE3(ti, qi, tj, qj, tij, qij);
+  fb_relSE3(in.pi, in.pi + 3, in.pj, in.pj + 3, tij, qij);
   fb_actSE3(tij, qij, Xi, Xj);
   const float X = Xj[0], Y = Xj[1], Z = Xj[2], W = Xj[3];
   const float d = (Z >= 0.2f) ? 1.0f / Z : 0.0f;
   const float d2 = d * d;
   const float x1 = fx * (X / Z) + cx;
   const float y1 = fy * (Y / Z) + cy;
-  const float rx = target[2 * n + 0] - x1;
-  const float ry = target[2 * n + 1] - y1;
+  const float rx = in.tx - x1;
+  const float ry = in.ty - y1;
   const bool in_bounds = (sqrtf(rx * rx + ry * ry) < 128.f) && (Z > 0.2f) && (x1 > -64.f) && (y1 > -64.f) &&
                          (x1 < 2 * cx + 64.f) && (y1 < 2 * cy + 64.f);
   const float mask = in_bounds ? 1.0f : 0.0f;
   o.r[0] = rx;
-  o.w[0] = mask * weight[2 * n + 0];
+  o.w[0] = mask * in.wx;
   o.Jz[0] = fx * (tij[0] * d - tij[2] * X * d2);
   o.Jj[0] = fx * W * d;
   o.Jj[1] = 0.0f;
@@ -97,7 +136,7 @@ __device__ __forceinline__ void ba_edge(const float* __restrict__ poses, const f
   o.Jj[4] = fx * (1.0f + X * X * d2);
   o.Jj[5] = -fx * Y * d;
   o.r[1] = ry;
-  o.w[1] = mask * weight[2 * n + 1];
+  o.w[1] = mask * in.wy;
   o.Jz[1] = fy * (tij[1] * d - tij[2] * Y * d2);
   o.Jj[6] = 0.0f;
   o.Jj[7] = fy * W * d;
@@ -109,16 +148,13 @@ __device__ __forceinline__ void ba_edge(const float* __restrict__ poses, const f
   fb_adjSE3(tij, qij, o.Jj + 6, o.Ji + 6);
 }
 
-// Pair-role reduction on the matrix cores.  For the 64 edges (128 residual rows) of a wave, with
-// X[k] = [Ji(6) | Jj(6) | r | 0 0 | w] per residual row k, the 13x13 Gram matrix
-//      G = sum_k w_k X[k] X[k]^T  =  [ Aii  Aij  vi ]      Aii = sum w Ji Ji^T, Aij = sum w Ji Jj^T,
-//                                    [ Aji  Ajj  vj ]      vi = sum w r Ji, vj = sum w r Jj
-//                                    [ vi^T vj^T rr ]
-// is one 16x16 f32 MFMA tile with K = 128: 32 x v_mfma_f32_16x16x4_f32 (exact f32 fma chains).
-// The rows are transposed from lane-per-edge to the MFMA operand layout through LDS.
-constexpr int XLD = 17;                       // floats per residual row in LDS (16 + 1 pad)
-constexpr int PAIR_LDS_FLOATS = 128 * XLD + 64;  // + 64 ints of per-edge pair keys
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
 
+// one entry (row, col) of the 13x13 Gram matrix G = sum_k w_k X[k] X[k]^T, X[k] = [Ji | Jj | r]
 __device__ __forceinline__ void pair_emit(float val, int row, int col, int ixf, int jxf, int n6,
                                           float* __restrict__ S, float* __restrict__ y) {
   if (row >= 12 || col >= 13 || val == 0.0f) return;  // row 12 duplicates column 12; (12,12) = sum w r^2
@@ -127,8 +163,7 @@ __device__ __forceinline__ void pair_emit(float val, int row, int col, int ixf, 
   if (rb < 0) return;
   const int r = 6 * rb + (ri ? row : row - 6);
   if (col == 12) {
-    // v[i] -= w r Ji ; v[j] += w r Jj      (ba_cuda.cu:393-398)
-    atomicAdd(&y[r], ri ? -val : val);
+    atomicAdd(&y[r], ri ? -val : val);  // v[i] -= w r Ji ; v[j] += w r Jj      (ba_cuda.cu:393-398)
     return;
   }
   const bool ci = col < 6;
@@ -139,189 +174,262 @@ __device__ __forceinline__ void pair_emit(float val, int row, int col, int ixf, 
   atomicAdd(&S[r * n6 + c], (ri == ci) ? val : -val);
 }
 
-__global__ __launch_bounds__(256) void ba_assemble_kernel(
+__global__ __launch_bounds__(ASM_THREADS) void ba_assemble_kernel(
     const float* __restrict__ poses, const float* __restrict__ patches, const float* __restrict__ intr,
     const float* __restrict__ target, const float* __restrict__ weight, const float* __restrict__ lmbda,
-    const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, const int64_t* __restrict__ kk, int E, int P,
-    int t0, int N, const int32_t* __restrict__ gmeta, const int32_t* __restrict__ pperm,
-    const int32_t* __restrict__ pcsr, const int32_t* __restrict__ koff_u, const int32_t* __restrict__ ku,
+    const int64_t* __restrict__ ii, const int64_t* __restrict__ jj, const int64_t* __restrict__ kk, int P, int t0,
+    int N, const int32_t* __restrict__ gmeta, const int32_t* __restrict__ pcsr, const int32_t* __restrict__ koff_u,
     float* __restrict__ sy, float* __restrict__ Cg, float* __restrict__ ug, float* __restrict__ qg,
-    float* __restrict__ Edg, int U_stride, int U_max, int n_pair_blocks, int32_t* __restrict__ info) {
+    float* __restrict__ Edg, int U_stride, int U_max, int32_t* __restrict__ info) {
   if (gmeta[GM_ERROR]) return;
+  const int U = gmeta[GM_U];
+  if (U > U_max) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) info[1] = 1;  // workspace too small: BA is skipped
+    return;
+  }
+  const int r0 = blockIdx.x * BA_CHUNK;
+  if (r0 >= U) return;
   const int n6 = 6 * N;
   const int PP = P * P;
   const int centre = (P > 1) ? (P + 1) : 0;
   const float fx = intr[0], fy = intr[1], cx = intr[2], cy = intr[3];  // ba_cuda.cu:253-259
   const size_t rep_stride = (size_t)n6 * n6 + n6;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* S = sy + (size_t)(blockIdx.x % BA_REPLICAS) * rep_stride;
+  float* y = S + (size_t)n6 * n6;
 
-  if ((int)blockIdx.x < n_pair_blocks) {
-    // ------------------------------ pair role: B and v ------------------------------------------
-    if (N == 0) return;
-    // wave (chunk c of 64 unique patches, target slot t): lane = patch, edge = t-th edge of the patch
-    // in (jj, edge id) order.  Patches of one source frame share their target list, so a wave holds
-    // one (i, j) frame pair unless the chunk straddles frames or the graph is irregular (handled by
-    // the distinct-key loop below).
-    const int U = gmeta[GM_U];
-    const int chunk64 = blockIdx.x / PAIR_TSY, ty = blockIdx.x % PAIR_TSY;
-    const int r = chunk64 * 64 + lane;
-    if (chunk64 * 64 >= U || U > U_max) return;
-    const int plo = (r < U) ? koff_u[r] : 0;
-    const int deg = (r < U) ? koff_u[r + 1] - plo : 0;
-    int maxdeg = deg;
+  CDV_IF_STAMPS(const int sslot = blockIdx.x * ASM_WAVES + wave; unsigned long long t_edge = 0, t_gram = 0, t_x;)
+  CDV_STAMP(ba, sslot, 0);
+  extern __shared__ float smem[];
+  const int nrow = n6 + 1;                      // E rows + one row holding u
+  float* Ed = smem;                             // [nrow][ELD]
+  float* Cs = Ed + (size_t)nrow * ELD;          // [64]
+  float* qs = Cs + BA_CHUNK;                    // [64]
+  float* X = qs + BA_CHUNK + (size_t)wave * PAIR_LDS_FLOATS;  // per wave [128][XLD]
+  int* keys = reinterpret_cast<int*>(X + 128 * XLD);          // per wave [64]
+  for (int t = threadIdx.x; t < nrow * ELD + 2 * BA_CHUNK; t += blockDim.x) smem[t] = 0.f;
+  __syncthreads();
+
+  CDV_STAMP(ba, sslot, 1);
+  // ---- slot loop: lane = patch r0 + lane, this wave takes target slots t = wave, wave + 4, ... ----
+  const int r = r0 + lane;
+  const int plo = (r < U) ? koff_u[r] : 0;
+  const int deg = (r < U) ? koff_u[r + 1] - plo : 0;
+  int maxdeg = deg;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, o));
-    maxdeg = __builtin_amdgcn_readfirstlane(maxdeg);
-    float* S = sy + (size_t)(blockIdx.x % BA_REPLICAS) * rep_stride;
-    float* y = S + (size_t)n6 * n6;
-    extern __shared__ float smem_pair[];
-    float* X = smem_pair + (size_t)wave * PAIR_LDS_FLOATS;  // [128][XLD]
-    int* keys = reinterpret_cast<int*>(X + 128 * XLD);      // [64]
-    const int c16 = lane & 15, g4 = lane >> 4;
-    for (int t = ty * 4 + wave; t < maxdeg; t += 4 * PAIR_TSY) {
+  for (int o = 32; o > 0; o >>= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, o));
+  maxdeg = __builtin_amdgcn_readfirstlane(maxdeg);
+  const int c16 = lane & 15, g4 = lane >> 4;
+  float Ei[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float Cacc = 0.f, uacc = 0.f;
+  int my_ixf = -1;  // free-pose index of this patch's source frame (same for all its edges)
+  // software pipeline: idx two slots ahead, inputs one slot ahead (inactive lanes re-read slot 0 / edge 0)
+  const int pdef = (deg > 0) ? plo : 0;
+  EdgeIdx idx0 = load_idx(pcsr, ii, jj, kk, (wave < deg) ? plo + wave : pdef);
+  EdgeIdx idx1 = load_idx(pcsr, ii, jj, kk, (wave + ASM_WAVES < deg) ? plo + wave + ASM_WAVES : pdef);
+  EdgeIn in0 = load_in(poses, patches, target, weight, idx0, PP, centre);
+  for (int t = wave; t < maxdeg; t += ASM_WAVES) {
     const bool active = t < deg;
+    const int t2 = t + 2 * ASM_WAVES;
+    const EdgeIdx idx2 = load_idx(pcsr, ii, jj, kk, (t2 < deg) ? plo + t2 : pdef);
+    const EdgeIn in1 = load_in(poses, patches, target, weight, idx1, PP, centre);
     EdgeJ J;
     int ixf = -1, jxf = -1;
+    CDV_IF_STAMPS(t_x = cdv_now();)
+    ba_edge(in0, fx, fy, cx, cy, J);
     if (active) {
-      const int e = pcsr[plo + t];
-      const int64_t ix = ii[e], jx = jj[e];
-      ba_edge(poses, patches, fx, fy, cx, cy, target, weight, ix, jx, kk[e], PP, centre, e, J);
-      const int64_t a = ix - t0, b = jx - t0;
-      ixf = (a >= 0 && a < N) ? (int)a : -1;
-      jxf = (b >= 0 && b < N) ? (int)b : -1;
-    }
-    const int key = (ixf + 1) * (N + 1) + (jxf + 1);
-    keys[lane] = active ? key : 0;
+      const int a = idx0.ix - t0, b = idx0.jx - t0;
+      ixf = (a >= 0 && a < N) ? a : -1;
+      jxf = (b >= 0 && b < N) ? b : -1;
+      // E, C, u of this lane's patch (ba_cuda.cu:380-390, 401-402)
 #pragma unroll
-    for (int row = 0; row < 2; row++) {
-      float* xr = X + (2 * lane + row) * XLD;
+      for (int row = 0; row < 2; row++) {
+        const float w = J.w[row];
+        const float wr = w * J.r[row], wz = w * J.Jz[row];
+        Cacc += wz * J.Jz[row];
+        uacc += wr * J.Jz[row];
+        if (ixf >= 0) {
+          if (my_ixf >= 0 && my_ixf != ixf) {
+            // irregular graph: edges of one patch disagree on the source frame; flush the register block
 #pragma unroll
-      for (int c = 0; c < 6; c++) {
-        xr[c] = active ? J.Ji[6 * row + c] : 0.f;
-        xr[6 + c] = active ? J.Jj[6 * row + c] : 0.f;
+            for (int c = 0; c < 6; c++) { atomicAdd(&Ed[(6 * my_ixf + c) * ELD + lane], Ei[c]); Ei[c] = 0.f; }
+          }
+          my_ixf = ixf;
+#pragma unroll
+          for (int c = 0; c < 6; c++) Ei[c] += -wz * J.Ji[6 * row + c];
+        }
+        if (jxf >= 0 && w != 0.f) {
+#pragma unroll
+          for (int c = 0; c < 6; c++) atomicAdd(&Ed[(6 * jxf + c) * ELD + lane], wz * J.Jj[6 * row + c]);
+        }
       }
-      xr[12] = active ? J.r[row] : 0.f;
-      xr[13] = 0.f;
-      xr[14] = 0.f;
-      xr[15] = active ? J.w[row] : 0.f;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    unsigned long long todo = __ballot(active && key != 0);
-    while (todo) {
-      const int leader = __ffsll((long long)todo) - 1;
-      const int kcur = __shfl(key, leader);
-      const int ci = __shfl(ixf, leader), cj = __shfl(jxf, leader);
-      cdv_float4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-      for (int st = 0; st < 32; st++) {
-        const int k = 4 * st + g4;
-        const float a = X[k * XLD + c16];
-        const float wk = (keys[k >> 1] == kcur) ? X[k * XLD + 15] : 0.f;
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wk * a, acc, 0, 0, 0);
-      }
-      // D layout: col = lane & 15, row = 4 * (lane >> 4) + reg
+    CDV_IF_STAMPS({ const unsigned long long t_y = cdv_now(); t_edge += t_y - t_x; t_x = t_y; })
+    if (N > 0) {
+      // ---- B and v of this wave's frame pair(s): Gram matrix on the matrix cores --------------------
+      const int key = (ixf + 1) * (N + 1) + (jxf + 1);
+      keys[lane] = active ? key : 0;
 #pragma unroll
-      for (int q = 0; q < 4; q++) pair_emit(acc[q], 4 * g4 + q, c16, ci, cj, n6, S, y);
-      todo &= ~__ballot(active && key == kcur);
-    }
-    // the next slot overwrites X: all lanes must be done reading it
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    }
-    return;
-  }
-
-  // -------------------------------- patch role: E, C, u, Schur ----------------------------------
-  const int U = gmeta[GM_U];
-  if (U > U_max) {
-    if (threadIdx.x == 0 && blockIdx.x == (unsigned)n_pair_blocks) info[1] = 1;  // workspace too small
-    return;
-  }
-  const int chunk = blockIdx.x - n_pair_blocks;
-  const int r0 = chunk * BA_CHUNK;
-  if (r0 >= U) return;
-  const int r1 = min(r0 + BA_CHUNK, U);
-  extern __shared__ float smem[];
-  constexpr int LD = BA_CHUNK + 1;
-  float* Ed = smem;                 // [n6][LD]
-  float* Cs = Ed + (size_t)n6 * LD; // [32]
-  float* us = Cs + BA_CHUNK;
-  float* qs = us + BA_CHUNK;
-  for (int t = threadIdx.x; t < n6 * LD + 3 * BA_CHUNK; t += blockDim.x) smem[t] = 0.f;
-  __syncthreads();
-  const int p0 = koff_u[r0], p1 = koff_u[r1];
-  for (int p = p0 + threadIdx.x; p < p1; p += blockDim.x) {
-    const int e = pcsr[p];
-    const int kl = ku[e] - r0;
-    const int64_t ix = ii[e], jx = jj[e];
-    EdgeJ J;
-    ba_edge(poses, patches, fx, fy, cx, cy, target, weight, ix, jx, kk[e], PP, centre, e, J);
-    const int64_t a = ix - t0, b = jx - t0;
-    const bool fi = (a >= 0 && a < N), fj = (b >= 0 && b < N);
-#pragma unroll
-    for (int row = 0; row < 2; row++) {
-      const float w = J.w[row];
-      const float wr = w * J.r[row], wz = w * J.Jz[row];
-      if (w != 0.f) {
+      for (int row = 0; row < 2; row++) {
+        float* xr = X + (2 * lane + row) * XLD;
 #pragma unroll
         for (int c = 0; c < 6; c++) {
-          if (fi) atomicAdd(&Ed[(6 * (int)a + c) * LD + kl], -wz * J.Ji[6 * row + c]);  // ba_cuda.cu:380-390
-          if (fj) atomicAdd(&Ed[(6 * (int)b + c) * LD + kl], wz * J.Jj[6 * row + c]);
+          xr[c] = active ? J.Ji[6 * row + c] : 0.f;
+          xr[6 + c] = active ? J.Jj[6 * row + c] : 0.f;
         }
-        atomicAdd(&Cs[kl], wz * J.Jz[row]);  // ba_cuda.cu:401-402
-        atomicAdd(&us[kl], wr * J.Jz[row]);
+        xr[12] = active ? J.r[row] : 0.f;
+        xr[13] = 0.f;
+        xr[14] = 0.f;
+        xr[15] = active ? J.w[row] : 0.f;
       }
+      wave_lds_sync();
+      unsigned long long todo = __ballot(active && key != 0);
+      while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int kcur = __shfl(key, leader);
+        const int ci = __shfl(ixf, leader), cj = __shfl(jxf, leader);
+        cdv_float4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+        for (int st = 0; st < 32; st++) {
+          const int k = 4 * st + g4;
+          const float a = X[k * XLD + c16];
+          const float wk = (keys[k >> 1] == kcur) ? X[k * XLD + 15] : 0.f;
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wk * a, acc, 0, 0, 0);
+        }
+        // D layout: col = lane & 15, row = 4 * (lane >> 4) + reg
+#pragma unroll
+        for (int q = 0; q < 4; q++) pair_emit(acc[q], 4 * g4 + q, c16, ci, cj, n6, S, y);
+        todo &= ~__ballot(active && key == kcur);
+      }
+      wave_lds_sync();  // the next slot overwrites X
     }
+    CDV_IF_STAMPS(t_gram += cdv_now() - t_x;)
+    idx0 = idx1; idx1 = idx2; in0 = in1;
   }
+  CDV_STAMP(ba, sslot, 2);
+  CDV_STAMP_VAL(ba, sslot, 6, t_edge);
+  CDV_STAMP_VAL(ba, sslot, 7, t_gram);
+  // per-wave register partials of (E_i, C, u) -> LDS (4 waves add into the same 64 columns)
+  if (my_ixf >= 0) {
+#pragma unroll
+    for (int c = 0; c < 6; c++) atomicAdd(&Ed[(6 * my_ixf + c) * ELD + lane], Ei[c]);
+  }
+  atomicAdd(&Cs[lane], Cacc);
+  atomicAdd(&Ed[n6 * ELD + lane], uacc);  // row n6 = u
   __syncthreads();
+
+  CDV_STAMP(ba, sslot, 3);
   const float lm = lmbda[0];
   if (threadIdx.x < BA_CHUNK) {
-    const int r = r0 + threadIdx.x;
+    const int rr = r0 + threadIdx.x;
     const float q = 1.0f / (Cs[threadIdx.x] + lm);  // ba_cuda.cu:548
-    qs[threadIdx.x] = (r < r1) ? q : 0.f;
-    if (r < r1) { Cg[r] = Cs[threadIdx.x]; ug[r] = us[threadIdx.x]; qg[r] = q; }
+    qs[threadIdx.x] = (rr < U) ? q : 0.f;
+    if (rr < U) { Cg[rr] = Cs[threadIdx.x]; ug[rr] = Ed[n6 * ELD + threadIdx.x]; qg[rr] = q; }
   }
-  __syncthreads();
   // E columns of this chunk -> global (read back by ba_retract_kernel)
   for (int t = threadIdx.x; t < n6 * BA_CHUNK; t += blockDim.x) {
     const int row = t / BA_CHUNK, kl = t % BA_CHUNK;
-    if (r0 + kl < r1) Edg[(size_t)row * U_stride + r0 + kl] = Ed[row * LD + kl];
+    if (r0 + kl < U) Edg[(size_t)row * U_stride + r0 + kl] = Ed[row * ELD + kl];
   }
+  __syncthreads();
+  CDV_STAMP(ba, sslot, 4);
   if (N == 0) return;
-  // Schur partial: S -= Ed diag(q) Ed^T, y -= Ed (q .* u)      (ba_cuda.cu:583-587)
-  float* S = sy + (size_t)(chunk % BA_REPLICAS) * rep_stride;
-  float* y = S + (size_t)n6 * n6;
-  for (int idx = threadIdx.x; idx < n6 * n6 + n6; idx += blockDim.x) {
-    float acc = 0.f;
-    if (idx < n6 * n6) {
-      const int a = idx / n6, b = idx - a * n6;
-#pragma unroll 8
-      for (int k = 0; k < BA_CHUNK; k++) acc += Ed[a * LD + k] * qs[k] * Ed[b * LD + k];
-    } else {
-      const int a = idx - n6 * n6;
-#pragma unroll 8
-      for (int k = 0; k < BA_CHUNK; k++) acc += Ed[a * LD + k] * qs[k] * us[k];
+
+  // ---- Schur partial on the matrix cores: [Ed; u] diag(q) [Ed; u]^T, K = 64 patches ---------------
+  //      S -= Ed Q Ed^T, y -= Ed Q u      (ba_cuda.cu:583-587)
+  const int T16 = (nrow + 15) / 16;
+  const int npairs = T16 * (T16 + 1) / 2;
+  for (int pidx = wave; pidx < npairs; pidx += ASM_WAVES) {
+    // lower-triangular tile pair (ti >= tj)
+    int ti = 0, acc_rows = 0;
+    while (acc_rows + ti + 1 <= pidx) { acc_rows += ti + 1; ti++; }
+    const int tj = pidx - acc_rows;
+    const int ra = 16 * ti + c16, rbw = 16 * tj + c16;
+    const float* pa = Ed + (size_t)min(ra, nrow - 1) * ELD;
+    const float* pb = Ed + (size_t)min(rbw, nrow - 1) * ELD;
+    const bool va = ra < nrow, vb = rbw < nrow;
+    cdv_float4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int st = 0; st < BA_CHUNK / 4; st++) {
+      const int k = 4 * st + g4;
+      const float a = va ? pa[k] : 0.f;
+      const float b = vb ? qs[k] * pb[k] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
     }
-    if (acc != 0.f) atomicAdd((idx < n6 * n6) ? &S[idx] : &y[idx - n6 * n6], -acc);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int R = 16 * ti + 4 * g4 + q, Cc = 16 * tj + c16;
+      const float v = acc[q];
+      if (v == 0.f || R >= nrow || Cc >= n6) continue;  // column n6 (u) only duplicates row n6
+      if (R == n6) {
+        atomicAdd(&y[Cc], -v);
+      } else {
+        atomicAdd(&S[R * n6 + Cc], -v);
+        if (ti != tj) atomicAdd(&S[Cc * n6 + R], -v);
+      }
+    }
   }
+  CDV_STAMP(ba, sslot, 5);
 }
 
-// One workgroup: S = sum of replicas, damping, Cholesky, solve, pose retraction.
+// ---------------------------------------------------------------------------------------------------------
+// 6x6-block Cholesky in LDS.  The matrix is [S | y]: the right-hand side is carried as block row N (height
+// 1), so the forward substitution happens inside the factorisation.  One thread owns one block pair per step.
+// ---------------------------------------------------------------------------------------------------------
+
+// inverse of the lower Cholesky factor of a 6x6 block (row-major input, lower part used).
+// Li = L^-1 is all the solver needs: panel = A L^-T, x = L^-T z.
+__device__ __forceinline__ bool chol6_inv(const float* a, float* Li) {
+  float Lm[36];
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    float s = a[j * 6 + j];
+#pragma unroll
+    for (int k = 0; k < j; k++) s -= Lm[j * 6 + k] * Lm[j * 6 + k];
+    ok = ok && (s > 0.f);
+    const float inv = 1.0f / sqrtf(s);
+    Lm[j * 6 + j] = inv;  // the diagonal is kept inverted
+#pragma unroll
+    for (int i = j + 1; i < 6; i++) {
+      float tt = a[i * 6 + j];
+#pragma unroll
+      for (int k = 0; k < j; k++) tt -= Lm[i * 6 + k] * Lm[j * 6 + k];
+      Lm[i * 6 + j] = tt * inv;
+    }
+  }
+  // forward substitution on the identity, column by column
+#pragma unroll
+  for (int c = 0; c < 6; c++) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      if (i < c) { Li[i * 6 + c] = 0.f; continue; }
+      float s = (i == c) ? 1.0f : 0.0f;
+#pragma unroll
+      for (int k = c; k < i; k++) s -= Lm[i * 6 + k] * Li[k * 6 + c];
+      Li[i * 6 + c] = s * Lm[i * 6 + i];
+    }
+  }
+  return ok;
+}
+
+// One workgroup (256 threads).  Per block step: (1)+(2) one thread per matrix row below the diagonal block
+// factors the 6x6 block redundantly in registers and forms its panel row; (3) the trailing update is split
+// element-wise over all threads (6 MACs per element, operands read as 8-byte LDS loads).
 __global__ __launch_bounds__(256) void ba_solve_kernel(float* __restrict__ poses, float* __restrict__ sy,
                                                        float* __restrict__ dXg, int t0, int N,
                                                        const int32_t* __restrict__ gmeta, float* __restrict__ dbg,
                                                        int32_t* __restrict__ info) {
   if (gmeta[GM_ERROR] || info[1]) return;
-  extern __shared__ float smem[];
+  extern __shared__ __attribute__((aligned(16))) float smem[];
   const int n = 6 * N;
-  const int LD = n + 1;
-  float* A = smem;            // [n][LD]
-  float* yv = A + (size_t)n * LD;
+  const int LD = n + 2;                 // even: 6-float block rows stay 8-byte aligned
+  float* A = smem;                      // [n + 1][LD]: rows 0..n-1 = S (lower part used), row n = y^T
+  float* Dinv = A + (size_t)(n + 1) * LD;  // [N][36] inverses of the diagonal factors
   const size_t rep_stride = (size_t)n * n + n;
   const int T = blockDim.x, t = threadIdx.x;
+  CDV_IF_STAMPS(const int sslot = 4096 + (t >> 6); unsigned long long t_pan = 0, t_tr = 0, t_x;)
+  CDV_STAMP(ba, sslot, 0);
   for (int idx = t; idx < n * n + n; idx += T) {
     float s = 0.f;
 #pragma unroll
@@ -329,53 +437,101 @@ __global__ __launch_bounds__(256) void ba_solve_kernel(float* __restrict__ poses
       s += sy[r * rep_stride + idx];
       sy[r * rep_stride + idx] = 0.f;  // ready for the next iteration / call
     }
-    if (idx < n * n) {
-      const int a = idx / n, b = idx - a * n;
-      if (a == b) s += 1e-4f * s + 1.0f;  // S += I * (1e-4 * S + 1.0)   ba_cuda.cu:589
-      A[a * LD + b] = s;
-      if (dbg) dbg[idx] = s;
-    } else {
-      yv[idx - n * n] = s;
-      if (dbg) dbg[idx] = s;
-    }
+    const int a = idx / n, b = idx - a * n;   // a == n: the y row
+    if (a == b) s += 1e-4f * s + 1.0f;        // S += I * (1e-4 * S + 1.0)   ba_cuda.cu:589
+    A[a * LD + b] = s;
+    if (dbg) dbg[idx] = s;
   }
-  __syncthreads();
-  // left-looking Cholesky, lower triangle in place (info ignored by the reference, ba_cuda.cu:590)
-  __shared__ float s_diag;
   __shared__ int s_bad;
   if (t == 0) s_bad = 0;
-  for (int j = 0; j < n; j++) {
-    float s = 0.f;
-    const int i = j + t;
-    if (i < n) {
-      s = A[i * LD + j];
-      for (int k = 0; k < j; k++) s -= A[i * LD + k] * A[j * LD + k];
+  __syncthreads();
+
+  CDV_STAMP(ba, sslot, 1);
+  for (int kb = 0; kb < N; kb++) {
+    CDV_IF_STAMPS(t_x = cdv_now();)
+    const int R0 = 6 * (kb + 1);      // first matrix row below the diagonal block
+    const int nrows = n + 1 - R0;     // rows R0 .. n (row n = y)
+    if (t < nrows || t == 0) {
+      float a[36], Li[36];
+#pragma unroll
+      for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = 0; j < 6; j += 2) {
+          const float2 v = *reinterpret_cast<const float2*>(&A[(6 * kb + i) * LD + 6 * kb + j]);
+          a[i * 6 + j] = v.x; a[i * 6 + j + 1] = v.y;
+        }
+      const bool ok = chol6_inv(a, Li);
+      if (t == 0) {
+        if (!ok && s_bad == 0) s_bad = kb + 1;
+#pragma unroll
+        for (int i = 0; i < 36; i++) Dinv[kb * 36 + i] = Li[i];
+      }
+      if (t < nrows) {  // panel row: P = A[row][kb-block] * L^-T
+        float* rp = &A[(R0 + t) * LD + 6 * kb];
+        float row[6], o[6];
+#pragma unroll
+        for (int j = 0; j < 6; j += 2) {
+          const float2 v = *reinterpret_cast<const float2*>(rp + j);
+          row[j] = v.x; row[j + 1] = v.y;
+        }
+#pragma unroll
+        for (int c = 0; c < 6; c++) {  // o[c] = sum_{j <= c} row[j] * Li[c][j]
+          float s = 0.f;
+#pragma unroll
+          for (int j = 0; j <= c; j++) s += row[j] * Li[c * 6 + j];
+          o[c] = s;
+        }
+#pragma unroll
+        for (int j = 0; j < 6; j += 2) *reinterpret_cast<float2*>(rp + j) = make_float2(o[j], o[j + 1]);
+      }
     }
-    if (t == 0) {
-      if (!(s > 0.f)) s_bad = j + 1;
-      s_diag = sqrtf(s);
+    __syncthreads();
+    CDV_IF_STAMPS({ const unsigned long long t_y = cdv_now(); t_pan += t_y - t_x; t_x = t_y; })
+    // trailing update over the rectangle rows R0..n x cols R0..n-1, lower part (cc <= rr) only
+    const int ncols = n - R0;
+    for (int idx = t; idx < nrows * ncols; idx += T) {
+      const int rr = idx / ncols, cc = idx - rr * ncols;
+      if (cc > rr) continue;
+      const float* pr = &A[(R0 + rr) * LD + 6 * kb];
+      const float* pc = &A[(R0 + cc) * LD + 6 * kb];
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 6; j += 2) {
+        const float2 x = *reinterpret_cast<const float2*>(pr + j);
+        const float2 yv = *reinterpret_cast<const float2*>(pc + j);
+        s += x.x * yv.x + x.y * yv.y;
+      }
+      A[(R0 + rr) * LD + R0 + cc] -= s;
     }
     __syncthreads();
-    if (i < n) A[i * LD + j] = (t == 0) ? s_diag : s / s_diag;
+    CDV_IF_STAMPS(t_tr += cdv_now() - t_x;)
+  }
+  CDV_STAMP(ba, sslot, 2);
+  CDV_STAMP_VAL(ba, sslot, 5, t_pan);
+  CDV_STAMP_VAL(ba, sslot, 6, t_tr);
+  // row n of A now holds z = L^-1 y.  Back substitution L^T x = z, block by block from the bottom.
+  float* z = A + (size_t)n * LD;
+  for (int kb = N - 1; kb >= 0; kb--) {
+    float xs = 0.f;
+    if (t < 6) {  // x_k = L_kk^-T z_k : x[c] = sum_{j >= c} Li[j][c] z[j]
+      for (int j = t; j < 6; j++) xs += Dinv[kb * 36 + j * 6 + t] * z[6 * kb + j];
+    }
+    __syncthreads();
+    if (t < 6) z[6 * kb + t] = xs;
+    __syncthreads();
+    // z_cb -= L[kb][cb]^T x_k for cb < kb  (one thread per component)
+    for (int idx = t; idx < 6 * kb; idx += T) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 6; j++) s += A[(6 * kb + j) * LD + idx] * z[6 * kb + j];
+      z[idx] -= s;
+    }
     __syncthreads();
   }
-  // forward substitution L z = y, then L^T x = z (one wave is plenty: n <= 192)
-  for (int j = 0; j < n; j++) {
-    if (t == 0) yv[j] = yv[j] / A[j * LD + j];
-    __syncthreads();
-    const int i = j + 1 + t;
-    if (i < n) yv[i] -= A[i * LD + j] * yv[j];
-    __syncthreads();
-  }
-  for (int j = n - 1; j >= 0; j--) {
-    if (t == 0) yv[j] = yv[j] / A[j * LD + j];
-    __syncthreads();
-    if (t < j) yv[t] -= A[j * LD + t] * yv[j];
-    __syncthreads();
-  }
+  CDV_STAMP(ba, sslot, 3);
   if (t < n) {
-    dXg[t] = yv[t];
-    if (dbg) dbg[n * n + n + t] = yv[t];
+    dXg[t] = z[t];
+    if (dbg) dbg[n * n + n + t] = z[t];
   }
   if (t == 0) info[0] = s_bad;
   // pose_retr_kernel (ba_cuda.cu:178-206)
@@ -383,27 +539,32 @@ __global__ __launch_bounds__(256) void ba_solve_kernel(float* __restrict__ poses
     float* p = poses + 7 * (size_t)(t0 + t);
     float tt[3] = {p[0], p[1], p[2]}, qq[4] = {p[3], p[4], p[5], p[6]}, tn[3], qn[4], xi[6];
 #pragma unroll
-    for (int c = 0; c < 6; c++) xi[c] = yv[6 * t + c];
+    for (int c = 0; c < 6; c++) xi[c] = z[6 * t + c];
     fb_retrSE3(xi, tt, qq, tn, qn);
     p[0] = tn[0]; p[1] = tn[1]; p[2] = tn[2];
     p[3] = qn[0]; p[4] = qn[1]; p[5] = qn[2]; p[6] = qn[3];
   }
+  CDV_STAMP(ba, sslot, 4);
 }
 
-__global__ __launch_bounds__(256) void ba_retract_kernel(float* __restrict__ patches, int P, int N,
-                                                         const int32_t* __restrict__ gmeta,
-                                                         const int64_t* __restrict__ kx,
-                                                         const float* __restrict__ ug, const float* __restrict__ qg,
-                                                         const float* __restrict__ Edg, int U_stride,
-                                                         const float* __restrict__ dXg, float* __restrict__ dZdbg,
-                                                         const int32_t* __restrict__ info) {
+__global__ __launch_bounds__(64) void ba_retract_kernel(float* __restrict__ patches, int P, int N,
+                                                        const int32_t* __restrict__ gmeta,
+                                                        const int64_t* __restrict__ kx,
+                                                        const float* __restrict__ ug, const float* __restrict__ qg,
+                                                        const float* __restrict__ Edg, int U_stride,
+                                                        const float* __restrict__ dXg, float* __restrict__ dZdbg,
+                                                        const int32_t* __restrict__ info) {
   if (gmeta[GM_ERROR] || info[1]) return;
   const int U = gmeta[GM_U];
-  const int n6 = 6 * N, PP = P * P;
+  const int PP = P * P;
   for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < U; r += gridDim.x * blockDim.x) {
-    float s = ug[r];
-    for (int a = 0; a < n6; a++) s -= Edg[(size_t)a * U_stride + r] * dXg[a];  // u - E^T dX  (ba_cuda.cu:592)
-    const float dz = qg[r] * s;
+    // u - E^T dX  (ba_cuda.cu:592); six independent partial sums keep six loads in flight
+    float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < N; b++) {
+#pragma unroll
+      for (int c = 0; c < 6; c++) s[c] += Edg[(size_t)(6 * b + c) * U_stride + r] * dXg[6 * b + c];
+    }
+    const float dz = qg[r] * (ug[r] - (((s[0] + s[1]) + (s[2] + s[3])) + (s[4] + s[5])));
     if (dZdbg) dZdbg[r] = dz;
     float* pk = patches + kx[r] * 3 * PP + 2 * PP;
     float d = pk[0];                 // patch_retr_kernel reads pixel [0][0]   ba_cuda.cu:218
@@ -458,21 +619,22 @@ extern "C" int cdv_ba_forward(float* poses, float* patches, const float* intrins
   if (sy_bytes) CDV_HIP_CHECK(hipMemsetAsync(sy, 0, sy_bytes, s));
   CDV_HIP_CHECK(hipMemsetAsync(info, 0, sizeof(int32_t) * 16, s));
 
-  const int n_pair_blocks = (N > 0) ? cdv_div_up(L.U_max, 64) * PAIR_TSY : 0;
-  const int n_chunk_blocks = cdv_div_up(L.U_max, BA_CHUNK);
-  size_t smem_asm = sizeof(float) * ((size_t)n6i * (BA_CHUNK + 1) + 3 * BA_CHUNK);
-  if (N > 0 && smem_asm < sizeof(float) * 4 * PAIR_LDS_FLOATS) smem_asm = sizeof(float) * 4 * PAIR_LDS_FLOATS;
-  const size_t smem_sol = sizeof(float) * ((size_t)n6i * (n6i + 1) + n6i + 8);
-  const int rb = cdv_div_up(L.U_max, 256);
+  const int n_chunks = cdv_div_up(L.U_max, BA_CHUNK);
+  const size_t smem_asm =
+      sizeof(float) * ((size_t)(n6i + 1) * ELD + 2 * BA_CHUNK + ASM_WAVES * (size_t)PAIR_LDS_FLOATS);
+  const size_t smem_sol = sizeof(float) * ((size_t)(n6i + 1) * (n6i + 2) + 36 * (size_t)(N > 0 ? N : 1) + 8);
+  if (smem_asm > 48 * 1024)
+    CDV_HIP_CHECK(hipFuncSetAttribute((const void*)ba_assemble_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)smem_asm));
   if (smem_sol > 48 * 1024)
     CDV_HIP_CHECK(hipFuncSetAttribute((const void*)ba_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       (int)smem_sol));
+  const int rb = cdv_div_up(L.U_max, 64);
   for (int itr = 0; itr < iterations; itr++) {
     float* d = (dbg && itr == 0) ? dbg : nullptr;
-    hipLaunchKernelGGL(ba_assemble_kernel, dim3(n_pair_blocks + n_chunk_blocks), dim3(256), smem_asm, s, poses,
-                       patches, intrinsics, target, weight, lmbda, ii, jj, kk, (int)E, P, t0, N, gv.meta, gv.pperm,
-                       gv.pcsr, gv.koff_u, gv.ku, sy, Cg, ug, qg, Edg, (int)L.U_stride, (int)L.U_max, n_pair_blocks,
-                       info);
+    hipLaunchKernelGGL(ba_assemble_kernel, dim3(n_chunks), dim3(ASM_THREADS), smem_asm, s, poses, patches, intrinsics, target,
+                       weight, lmbda, ii, jj, kk, P, t0, N, gv.meta, gv.pcsr, gv.koff_u, sy, Cg, ug, qg, Edg,
+                       (int)L.U_stride, (int)L.U_max, info);
     if (N > 0)
       hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(256), smem_sol, s, poses, sy, dXg, t0, N, gv.meta, d, info);
     // dbg layout: [S n6^2 | y n6 | dX n6 | dZ U_stride | C U_stride | u U_stride | E n6*U_stride]
@@ -484,7 +646,7 @@ extern "C" int cdv_ba_forward(float* poses, float* patches, const float* intrins
       CDV_HIP_CHECK(hipMemcpyAsync(q + 2 * L.U_stride, Edg, sizeof(float) * (size_t)n6i * L.U_stride,
                                    hipMemcpyDeviceToDevice, s));
     }
-    hipLaunchKernelGGL(ba_retract_kernel, dim3(rb), dim3(256), 0, s, patches, P, N, gv.meta, gv.kx, ug, qg, Edg,
+    hipLaunchKernelGGL(ba_retract_kernel, dim3(rb), dim3(64), 0, s, patches, P, N, gv.meta, gv.kx, ug, qg, Edg,
                        (int)L.U_stride, dXg, dZdbg, info);
     CDV_LAUNCH_CHECK();
   }

@@ -7,52 +7,46 @@ namespace cdv {
 
 // meta words (int32), written on device
 enum {
-  GM_U = 0,       // number of unique patches
-  GM_NPAIRS = 1,  // number of distinct target frames
-  GM_KMIN = 2,
+  GM_U = 0,        // number of unique patches
+  GM_KMIN = 2,     // published by the scan kernel
   GM_KMAX = 3,
-  GM_FMIN = 4,    // min over jj
-  GM_FMAX = 5,
-  GM_ERROR = 6,   // != 0: a range exceeded the workspace capacity (index contents undefined)
+  GM_JMIN = 4,
+  GM_JMAX = 5,
+  GM_ERROR = 6,    // != 0: the patch-id range exceeded the workspace capacity (index contents undefined)
   GM_E = 7,
-  GM_KRANGE = 8,  // kmax - kmin + 1
-  GM_FRANGE = 9,  // fmax - fmin + 1
+  GM_KRANGE = 8,   // kmax - kmin + 1 of the LAST successful build (0 if none): the range to re-zero
+  GM_STAGE = 16,   // [16..19] staging of min/max for the build in flight: kmin, kmax, jmin, jmax
   GM_WORDS = 64
 };
 
 struct GraphLayout {
-  int64_t E_max, k_range, f_range;
-  size_t meta, kcount, kcursor, krank, koff_u, kx, ku, pcsr_tmp, pcsr, pcount, pcursor, pperm, total;
+  int64_t E_max, k_range;
+  size_t meta, kcount, kcursor, krank, koff_u, kx, ku, pcsr_tmp, pcsr, total;
 };
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-static inline GraphLayout graph_layout(int64_t E_max, int64_t k_range, int64_t f_range) {
+static inline GraphLayout graph_layout(int64_t E_max, int64_t k_range) {
   GraphLayout L;
-  L.E_max = E_max; L.k_range = k_range; L.f_range = f_range;
+  L.E_max = E_max; L.k_range = k_range;
   const int64_t U_max = k_range < E_max ? k_range : E_max;
   size_t o = 0;
   L.meta = o;     o = align256(o + sizeof(int32_t) * GM_WORDS);
   L.kcount = o;   o = align256(o + sizeof(int32_t) * (size_t)(k_range + 1));   // histogram -> dense offsets
-  L.kcursor = o;  o = align256(o + sizeof(int32_t) * (size_t)k_range);
+  L.kcursor = o;  o = align256(o + sizeof(int32_t) * (size_t)(k_range + 1));
   L.krank = o;    o = align256(o + sizeof(int32_t) * (size_t)k_range);
   L.koff_u = o;   o = align256(o + sizeof(int32_t) * (size_t)(U_max + 1));
   L.kx = o;       o = align256(o + sizeof(int64_t) * (size_t)U_max);
   L.ku = o;       o = align256(o + sizeof(int32_t) * (size_t)E_max);
   L.pcsr_tmp = o; o = align256(o + sizeof(int32_t) * (size_t)E_max);
   L.pcsr = o;     o = align256(o + sizeof(int32_t) * (size_t)E_max);
-  L.pcount = o;   o = align256(o + sizeof(int32_t) * (size_t)(f_range + 1));
-  L.pcursor = o;  o = align256(o + sizeof(int32_t) * (size_t)f_range);
-  L.pperm = o;    o = align256(o + sizeof(int32_t) * (size_t)E_max);
   L.total = o;
   return L;
 }
 
-// The capacities are stored in the first bytes after meta's used words so that consumers that only
-// get the workspace pointer can recover the layout: meta[16..21] = E_max, k_range, f_range (int64 x3)
 struct GraphView {
   int32_t* meta;
-  int32_t *kcount, *kcursor, *krank, *koff_u, *ku, *pcsr_tmp, *pcsr, *pcount, *pcursor, *pperm;
+  int32_t *kcount, *kcursor, *krank, *koff_u, *ku, *pcsr_tmp, *pcsr;
   int64_t* kx;
 };
 
@@ -68,9 +62,6 @@ static inline GraphView graph_view(void* ws, const GraphLayout& L) {
   v.ku = (int32_t*)(b + L.ku);
   v.pcsr_tmp = (int32_t*)(b + L.pcsr_tmp);
   v.pcsr = (int32_t*)(b + L.pcsr);
-  v.pcount = (int32_t*)(b + L.pcount);
-  v.pcursor = (int32_t*)(b + L.pcursor);
-  v.pperm = (int32_t*)(b + L.pperm);
   return v;
 }
 

@@ -9,20 +9,30 @@
 //   * the union window of the 9 patch pixels (<= 16x16 feature pixels, typically 10x10) is the B
 //     operand, loaded straight from a CHANNELS-LAST feature ring (one pixel = C contiguous halves, so
 //     a lane's 8 k-values are one 16-byte load -- no LDS staging of the inputs at all);
-//   * v_mfma_f32_16x16x32_f16 produces, per window row, the 9 x 16 correlations in f32;
-//   * the raw volume lives only in LDS (9.2 KB per wave); the 8x8 -> 7x7 bilinear blend of every
-//     patch pixel reads it back with its own sub-pixel offset, separably (16 LDS reads per lane);
+//   * v_mfma_f32_16x16x32_f16 produces, per window row, the 16 x 9 correlations (f32 accumulate);
+//   * all window rows of BOTH levels are requested before the first MFMA (two dependent memory round
+//     trips per edge in total: indices+coordinates, then patch tile + windows);
+//   * the raw volume lives only in LDS (f16 like the reference's, 3.6 KB per wave); the 8x8 -> 7x7
+//     bilinear blend of every patch pixel reads it back with its own sub-pixel offset, separably;
 //   * the [882]-half row of the edge is staged in LDS and leaves as 256-byte coalesced stores.
 // Algorithmic HBM bytes per edge: 1764 out + 72 coords + 16 idx (+ the feature maps once): DESIGN.md.
+#include <stdlib.h>
+
 #include "cdv_common.h"
+
+CDV_STAMP_TU(corr)
 
 namespace {
 
-constexpr int RAW_ROWS = 16;                    // window rows held per patch pixel
-constexpr int RAW_MS = RAW_ROWS * 16 + 4;       // floats per patch pixel (+4: spreads the 4 row-groups over banks)
-constexpr int RAW_FLOATS = 9 * RAW_MS;          // 2340
+// Per-wave LDS: the raw correlation volume of ONE level in f16 (the reference's raw volume is f16 too,
+// correlation_kernel.cu:207) + the staged output row of the edge.
+constexpr int RAW_ROWS = 12;                    // window rows the fast path holds (typical: 10-11 / 8-9)
+constexpr int RAW_MSH = RAW_ROWS * 16 + 8;      // halfs per patch pixel (+8: 16-byte skew between pixels)
+constexpr int RAW_HALFS = 9 * RAW_MSH;          // 1800
 constexpr int OUT_HALFS = 896;                  // 882 rounded up to a multiple of 64 bytes
-constexpr int WAVE_LDS_BYTES = RAW_FLOATS * 4 + OUT_HALFS * 2;  // 11,152 B per wave
+constexpr int WAVE_LDS_BYTES = RAW_HALFS * 2 + OUT_HALFS * 2;  // 5,392 B per wave
+
+typedef _Float16 cdv_half4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void wave_lds_sync() {
   // LDS operations of one wave execute in order; this only has to stop the compiler from moving the
@@ -32,14 +42,15 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-__device__ __forceinline__ int wave_min_i(int v) {
+// min / max over lanes 0..15 (lanes >= 9 mirror lane 0), result valid in every lane of the group
+__device__ __forceinline__ int min16(int v) {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+  for (int o = 8; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
   return v;
 }
-__device__ __forceinline__ int wave_max_i(int v) {
+__device__ __forceinline__ int max16(int v) {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+  for (int o = 8; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
   return v;
 }
 
@@ -49,6 +60,110 @@ struct LevelParams {
   float scale;
 };
 
+// per-level window geometry of one edge (wave-uniform parts live in SGPRs)
+struct Box {
+  int x0, y0, Wb, Hb;   // union window of the 9 patch pixels: origin and extent
+  int ixm, iym;         // per lane (patch pixel m = lane, lanes >= 9 mirror pixel 0): floor of the coordinate
+  float dx, dy;         // per lane: sub-pixel offset, rounded to f16 as the reference does before blending
+  bool fast;
+};
+
+__device__ __forceinline__ Box make_box(float cxm, float cym, float scale) {
+  Box b;
+  const float x = cxm / scale, y = cym / scale;  // slam.py:321-322 (coords / 1, coords / 4)
+  const float fxf = floorf(x), fyf = floorf(y);
+  b.dx = (float)(_Float16)(x - fxf);              // correlation_kernel.cu:223-224
+  b.dy = (float)(_Float16)(y - fyf);
+  b.ixm = (int)fminf(fmaxf(fxf, -1.0e6f), 1.0e6f);
+  b.iym = (int)fminf(fmaxf(fyf, -1.0e6f), 1.0e6f);
+  b.x0 = __builtin_amdgcn_readfirstlane(min16(b.ixm) - 3);
+  b.y0 = __builtin_amdgcn_readfirstlane(min16(b.iym) - 3);
+  b.Wb = __builtin_amdgcn_readfirstlane(max16(b.ixm) + 4 - b.x0 + 1);
+  b.Hb = __builtin_amdgcn_readfirstlane(max16(b.iym) + 4 - b.y0 + 1);
+  b.fast = (b.Wb <= 16) && (b.Hb <= RAW_ROWS);
+  return b;
+}
+
+// one window row (16 pixels x 8 channels per lane group) of the channels-last map -> MFMA A fragment
+template <int KS>
+__device__ __forceinline__ void load_row(const _Float16* __restrict__ fbase, const LevelParams& LP, const Box& b,
+                                         int t, int n, int g, int C, bool idx_ok, cdv_half8 (&v)[KS]) {
+  const int py = b.y0 + t, px = b.x0 + n;
+  const bool ok = idx_ok && t < b.Hb && n < b.Wb && py >= 0 && py < LP.H && px >= 0 && px < LP.W;
+#pragma unroll
+  for (int s = 0; s < KS; s++) {
+    cdv_half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (ok && (32 * s + 8 * g) < C)
+      z = *reinterpret_cast<const cdv_half8*>(fbase + ((size_t)py * LP.W + px) * C + 32 * s + 8 * g);
+    v[s] = z;
+  }
+}
+
+// D[window pixel n][patch pixel m] = sum_c window[n][c] * patch[m][c]; lane (m = lane & 15, g = lane >> 4)
+// receives the 4 consecutive window pixels n = 4g .. 4g+3 of row t: one 8-byte LDS store of 4 halfs.
+template <int KS>
+__device__ __forceinline__ void mfma_row_store(const cdv_half8 (&win)[KS], const cdv_half8 (&pat)[KS],
+                                               _Float16* __restrict__ raw, int t, int lane) {
+  cdv_float4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < KS; s++) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(win[s], pat[s], acc, 0, 0, 0);
+  const int m = lane & 15, g = lane >> 4;
+  if (m < 9) {
+    cdv_half4 h = {(_Float16)acc[0], (_Float16)acc[1], (_Float16)acc[2], (_Float16)acc[3]};
+    *reinterpret_cast<cdv_half4*>(raw + m * RAW_MSH + t * 16 + 4 * g) = h;
+  }
+}
+
+// 8x8 -> 7x7 bilinear blend of patch pixel m at x offset xo (lane = 7 m + xo), separable; res[yo]
+__device__ __forceinline__ void blend_level(const _Float16* __restrict__ raw, const Box& b, int lane,
+                                            float (&res)[7]) {
+  const int m = lane / 7, xo = lane - 7 * m;
+  const int msrc = m < 9 ? m : 0;
+  const int bx = b.fast ? (__shfl(b.ixm, msrc) - 3 - b.x0) : 0;
+  const int by = b.fast ? (__shfl(b.iym, msrc) - 3 - b.y0) : 0;
+  const float dxm = __shfl(b.dx, msrc), dym = __shfl(b.dy, msrc);
+  const _Float16* rp = raw + msrc * RAW_MSH + by * 16 + bx + xo;
+  float h[8];
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    const float c0 = (float)rp[r * 16], c1 = (float)rp[r * 16 + 1];
+    h[r] = (1.f - dxm) * c0 + dxm * c1;
+  }
+#pragma unroll
+  for (int yo = 0; yo < 7; yo++) res[yo] = (1.f - dym) * h[yo] + dym * h[yo + 1];
+}
+
+// wide reprojection footprint (strong zoom / rotation): every patch pixel gets its own 8x8 window; two
+// window rows share one MFMA (pixels 0-7 | 8-15), only column m of D is kept.  Loads are not prefetched.
+template <int KS>
+__device__ __forceinline__ void slow_level(const _Float16* __restrict__ fbase, const LevelParams& LP, const Box& b,
+                                           const cdv_half8 (&pat)[KS], _Float16* __restrict__ raw, int lane, int C,
+                                           bool idx_ok) {
+  const int n = lane & 15, g = lane >> 4;
+  for (int m = 0; m < 9; m++) {
+    const int xm = __shfl(b.ixm, m) - 3, ym = __shfl(b.iym, m) - 3;
+#pragma unroll
+    for (int t2 = 0; t2 < 4; t2++) {
+      const int py = ym + 2 * t2 + (n >> 3), px = xm + (n & 7);
+      const bool ok = idx_ok && py >= 0 && py < LP.H && px >= 0 && px < LP.W;
+      cdv_float4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < KS; s++) {
+        cdv_half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (ok && (32 * s + 8 * g) < C)
+          v = *reinterpret_cast<const cdv_half8*>(fbase + ((size_t)py * LP.W + px) * C + 32 * s + 8 * g);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(v, pat[s], acc, 0, 0, 0);
+      }
+      // lane (col = lane & 15 = patch pixel, g): window pixels 4g .. 4g+3 of the 16 (two rows of 8)
+      if (n == m) {
+        const int row = 2 * t2 + (g >> 1), col = 4 * (g & 1);
+        cdv_half4 h = {(_Float16)acc[0], (_Float16)acc[1], (_Float16)acc[2], (_Float16)acc[3]};
+        *reinterpret_cast<cdv_half4*>(raw + m * RAW_MSH + row * 16 + col) = h;
+      }
+    }
+  }
+}
+
 template <int KS>
 __global__ __launch_bounds__(256) void corr_fused_kernel(const _Float16* __restrict__ gmap, LevelParams L0,
                                                          LevelParams L1, const float* __restrict__ coords,
@@ -56,141 +171,129 @@ __global__ __launch_bounds__(256) void corr_fused_kernel(const _Float16* __restr
                                                          const int64_t* __restrict__ jj,
                                                          const int32_t* __restrict__ order,
                                                          _Float16* __restrict__ out, int E, int64_t Ng, int64_t slots,
-                                                         int C, int nlev, int64_t kmod, int64_t jmod) {
+                                                         int C, int nlev, int64_t kmod, int64_t jmod, int exp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int p = blockIdx.x * 4 + wave;
   if (p >= E) return;  // no block-wide barriers below: waves are independent
   const int e = order ? order[p] : p;
-  float* raw = reinterpret_cast<float*>(smem_raw + (size_t)wave * WAVE_LDS_BYTES);
-  _Float16* outT = reinterpret_cast<_Float16*>(raw + RAW_FLOATS);
+  CDV_STAMP(corr, p, 0);
+  _Float16* raw = reinterpret_cast<_Float16*>(smem_raw + (size_t)wave * WAVE_LDS_BYTES);
+  _Float16* outT = raw + RAW_HALFS;
 
+  // ---- round trip 1: indices and the 18 coordinates ------------------------------------------------
   int64_t kpatch = kk[e], jslot = jj[e];
+  const int mm = lane < 9 ? lane : 0;  // lanes 0..8 own patch pixel m = lane; the others mirror pixel 0
+  const float cxm = coords[(int64_t)e * 18 + mm];
+  const float cym = coords[(int64_t)e * 18 + 9 + mm];
   if (kmod > 0) kpatch %= kmod;
   if (jmod > 0) jslot %= jmod;
-  const bool idx_ok = kpatch >= 0 && kpatch < Ng && jslot >= 0 && jslot < slots;
-
+  const bool idx_ok0 = kpatch >= 0 && kpatch < Ng && jslot >= 0 && jslot < slots;
+  const bool idx_ok = idx_ok0 && !(exp & 1);   // experiment bit 0: no window loads
   const int n = lane & 15, g = lane >> 4;
 
-  // ---- A operand: patch tile, rows = patch pixels (i0*3+j0), k = channels -----------------------
-  cdv_half8 afrag[KS];
+  const Box b0 = make_box(cxm, cym, L0.scale);
+  const Box b1 = make_box(cxm, cym, nlev == 2 ? L1.scale : L0.scale);
+  CDV_STAMP(corr, p, 1);
+  const _Float16* f0 = L0.fmap + (size_t)(idx_ok ? jslot : 0) * L0.H * L0.W * C;
+  const _Float16* f1 = nlev == 2 ? L1.fmap + (size_t)(idx_ok ? jslot : 0) * L1.H * L1.W * C : f0;
+
+  // ---- round trip 2: patch tile (MFMA B operand) and, in the common case, EVERY window row of both
+  //      levels -- all loads are in flight before the first MFMA -----------------------------------------
+  cdv_half8 pat[KS];
 #pragma unroll
   for (int s = 0; s < KS; s++) {
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       const int ch = 32 * s + 8 * g + j;
       _Float16 v = (_Float16)0.f;
-      if (idx_ok && n < 9 && ch < C) v = gmap[(kpatch * C + ch) * 9 + n];
-      afrag[s][j] = v;
+      if (idx_ok0 && !(exp & 8) && n < 9 && ch < C) v = gmap[(kpatch * C + ch) * 9 + n];
+      pat[s][j] = v;
     }
   }
 
-  // ---- per patch pixel coordinates (lanes 0..8 own pixel m = lane; others mirror pixel 0) -------
-  const int mm = lane < 9 ? lane : 0;
-  const float cxm = coords[(int64_t)e * 18 + mm];
-  const float cym = coords[(int64_t)e * 18 + 9 + mm];
-
-  for (int lev = 0; lev < nlev; lev++) {
-    const LevelParams LP = lev == 0 ? L0 : L1;
-    const float x = cxm / LP.scale, y = cym / LP.scale;  // slam.py:321-322 (coords / 1, coords / 4)
-    const float fxf = floorf(x), fyf = floorf(y);
-    // dx, dy are cast to the feature dtype before the blend (correlation_kernel.cu:223-224)
-    const float dx = (float)(_Float16)(x - fxf), dy = (float)(_Float16)(y - fyf);
-    const int ixm = (int)fminf(fmaxf(fxf, -1.0e6f), 1.0e6f);
-    const int iym = (int)fminf(fmaxf(fyf, -1.0e6f), 1.0e6f);
-    // wave-uniform window box, forced into SGPRs so that the row loop is a scalar loop
-    const int x0 = __builtin_amdgcn_readfirstlane(wave_min_i(ixm) - 3);
-    const int y0 = __builtin_amdgcn_readfirstlane(wave_min_i(iym) - 3);
-    const int Wb = __builtin_amdgcn_readfirstlane(wave_max_i(ixm) + 4 - x0 + 1);
-    const int Hb = __builtin_amdgcn_readfirstlane(wave_max_i(iym) + 4 - y0 + 1);
-    const bool fast = (Wb <= 16) && (Hb <= RAW_ROWS);
-    const _Float16* fbase = LP.fmap + (size_t)jslot * LP.H * LP.W * C;
-
-    if (fast) {
-      // one MFMA per window row: 16 columns x 9 patch pixels x C channels
-      constexpr int RB = (KS == 1) ? 8 : 2;  // rows in flight (register budget)
-      for (int tb = 0; tb < Hb; tb += RB) {
-        cdv_half8 bfrag[RB][KS];
+  float res0[7], res1[7];
+  if constexpr (KS == 1) {
+    cdv_half8 w0[RAW_ROWS][1], w1[RAW_ROWS][1];
+    if (b0.fast) {
 #pragma unroll
-        for (int r = 0; r < RB; r++) {
-          const int py = y0 + tb + r, px = x0 + n;
-          const bool ok = idx_ok && (tb + r) < Hb && n < Wb && py >= 0 && py < LP.H && px >= 0 && px < LP.W;
+      for (int t = 0; t < RAW_ROWS; t++) load_row<1>(f0, L0, b0, t, n, g, C, idx_ok, w0[t]);
+    }
+    if (nlev == 2 && b1.fast) {
 #pragma unroll
-          for (int s = 0; s < KS; s++) {
-            cdv_half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (ok && (32 * s + 8 * g) < C)
-              v = *reinterpret_cast<const cdv_half8*>(fbase + ((size_t)py * LP.W + px) * C + 32 * s + 8 * g);
-            bfrag[r][s] = v;
-          }
-        }
+      for (int t = 0; t < RAW_ROWS; t++) load_row<1>(f1, L1, b1, t, n, g, C, idx_ok, w1[t]);
+    }
+    CDV_STAMP(corr, p, 2);
+    // level 0
+    if (b0.fast) {
 #pragma unroll
-        for (int r = 0; r < RB; r++) {
-          if (tb + r < Hb) {
-            cdv_float4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < KS; s++) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag[s], bfrag[r][s], acc, 0, 0, 0);
-            // D layout: col = lane & 15 (window column), row = 4 * (lane >> 4) + reg (patch pixel)
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-              const int m = 4 * g + q;
-              if (m < 9) raw[m * RAW_MS + (tb + r) * 16 + n] = acc[q];
-            }
-          }
-        }
-      }
+      for (int t = 0; t < RAW_ROWS; t++)
+        if (t < b0.Hb) mfma_row_store<1>(w0[t], pat, raw, t, lane);
     } else {
-      // wide reprojection footprint (strong zoom / rotation): every patch pixel gets its own 8x8
-      // window; two window rows share one MFMA (columns 0-7 | 8-15), only row m of D is kept.
-      for (int m = 0; m < 9; m++) {
-        const int xm = __shfl(ixm, m) - 3, ym = __shfl(iym, m) - 3;
-#pragma unroll
-        for (int t2 = 0; t2 < 4; t2++) {
-          const int py = ym + 2 * t2 + (n >> 3), px = xm + (n & 7);
-          const bool ok = idx_ok && py >= 0 && py < LP.H && px >= 0 && px < LP.W;
-          cdv_float4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int s = 0; s < KS; s++) {
-            cdv_half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (ok && (32 * s + 8 * g) < C)
-              v = *reinterpret_cast<const cdv_half8*>(fbase + ((size_t)py * LP.W + px) * C + 32 * s + 8 * g);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(afrag[s], v, acc, 0, 0, 0);
-          }
-          if (g == (m >> 2)) {
-            const int q = m & 3;
-            const float val = q == 0 ? acc[0] : q == 1 ? acc[1] : q == 2 ? acc[2] : acc[3];
-            raw[m * RAW_MS + (2 * t2 + (n >> 3)) * 16 + (n & 7)] = val;
-          }
-        }
-      }
+      slow_level<1>(f0, L0, b0, pat, raw, lane, C, idx_ok);
     }
     wave_lds_sync();
-
-    // ---- bilinear blend 8x8 -> 7x7, lane = (patch pixel m, x offset xo) ---------------------------
-    {
-      const int m = lane / 7, xo = lane - 7 * m;
-      const int msrc = m < 9 ? m : 0;
-      const int bx = fast ? (__shfl(ixm, msrc) - 3 - x0) : 0;
-      const int by = fast ? (__shfl(iym, msrc) - 3 - y0) : 0;
-      const float dxm = __shfl(dx, msrc), dym = __shfl(dy, msrc);
-      if (lane < 63) {
-        const float* rp = raw + m * RAW_MS + by * 16 + bx + xo;
-        float h[8];
+    CDV_STAMP(corr, p, 3);
+    blend_level(raw, b0, lane, res0);
+    CDV_STAMP(corr, p, 4);
+    if (nlev == 2) {
+      wave_lds_sync();
+      if (b1.fast) {
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-          const float c0 = rp[r * 16], c1 = rp[r * 16 + 1];
-          h[r] = (1.f - dxm) * c0 + dxm * c1;
+        for (int t = 0; t < RAW_ROWS; t++)
+          if (t < b1.Hb) mfma_row_store<1>(w1[t], pat, raw, t, lane);
+      } else {
+        slow_level<1>(f1, L1, b1, pat, raw, lane, C, idx_ok);
+      }
+      wave_lds_sync();
+      CDV_STAMP(corr, p, 5);
+      blend_level(raw, b1, lane, res1);
+      CDV_STAMP(corr, p, 6);
+    }
+  } else {
+    // wide feature vectors (DPVO, C = 128): rows in batches of 2 to stay inside the register file
+    for (int lev = 0; lev < nlev; lev++) {
+      const LevelParams& LP = lev == 0 ? L0 : L1;
+      const Box& b = lev == 0 ? b0 : b1;
+      const _Float16* fb = lev == 0 ? f0 : f1;
+      if (lev == 1) wave_lds_sync();
+      if (b.fast) {
+        for (int tb = 0; tb < b.Hb; tb += 2) {
+          cdv_half8 wa[KS], wb[KS];
+          load_row<KS>(fb, LP, b, tb, n, g, C, idx_ok, wa);
+          load_row<KS>(fb, LP, b, tb + 1, n, g, C, idx_ok, wb);
+          mfma_row_store<KS>(wa, pat, raw, tb, lane);
+          if (tb + 1 < b.Hb) mfma_row_store<KS>(wb, pat, raw, tb + 1, lane);
         }
+      } else {
+        slow_level<KS>(fb, LP, b, pat, raw, lane, C, idx_ok);
+      }
+      wave_lds_sync();
+      if (lev == 0) blend_level(raw, b, lane, res0); else blend_level(raw, b, lane, res1);
+    }
+  }
+
+  // ---- stage the edge's output row [x][y][m][lev] in LDS, then 256-byte coalesced stores ------------
+  {
+    const int m = lane / 7, xo = lane - 7 * m;
+    if (lane < 63) {
+      if (nlev == 2) {
+        uint32_t* o32 = reinterpret_cast<uint32_t*>(outT);
 #pragma unroll
         for (int yo = 0; yo < 7; yo++) {
-          const float v = (1.f - dym) * h[yo] + dym * h[yo + 1];
-          outT[((xo * 7 + yo) * 9 + m) * nlev + lev] = (_Float16)v;
+          const _Float16 h0 = (_Float16)res0[yo], h1 = (_Float16)res1[yo];
+          const uint32_t lo = __builtin_bit_cast(unsigned short, h0), hi = __builtin_bit_cast(unsigned short, h1);
+          o32[(xo * 7 + yo) * 9 + m] = lo | (hi << 16);
         }
+      } else {
+#pragma unroll
+        for (int yo = 0; yo < 7; yo++) outT[(xo * 7 + yo) * 9 + m] = (_Float16)res0[yo];
       }
     }
-    wave_lds_sync();
   }
-
-  // ---- coalesced store of the edge's row ---------------------------------------------------------
+  wave_lds_sync();
+  CDV_STAMP(corr, p, 7);
+  if (exp & 2) return;                          // experiment bit 1: no global store
   if (nlev == 2) {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(outT);
     uint32_t* dst = reinterpret_cast<uint32_t*>(out) + (size_t)e * 441;
@@ -207,6 +310,7 @@ __global__ __launch_bounds__(256) void corr_fused_kernel(const _Float16* __restr
       if (t < 441) dst[t] = outT[t];
     }
   }
+  CDV_STAMP(corr, p, 8);
 }
 
 // ---- generic per-level kernel: planar layouts, any C / P / radius, f16 or f32 ----------------------
@@ -406,13 +510,14 @@ extern "C" int cdv_corr_fused(const void* gmap, const void* fmap0_nhwc, const vo
   LevelParams L1{(const _Float16*)fmap1_nhwc, H1, W1, scale1};
   const int blocks = cdv_div_up(E, 4);
   const size_t smem = 4 * (size_t)WAVE_LDS_BYTES;
+  static const int exp = getenv("CDV_CORR_EXP") ? atoi(getenv("CDV_CORR_EXP")) : 0;  // diagnostics only
   hipStream_t s = (hipStream_t)stream;
   if (C <= 32)
     hipLaunchKernelGGL(corr_fused_kernel<1>, dim3(blocks), dim3(256), smem, s, (const _Float16*)gmap, L0, L1, coords,
-                       kk, jj, order, (_Float16*)out, (int)E, Ng, slots, C, nlev, kmod, jmod);
+                       kk, jj, order, (_Float16*)out, (int)E, Ng, slots, C, nlev, kmod, jmod, exp);
   else
     hipLaunchKernelGGL(corr_fused_kernel<4>, dim3(blocks), dim3(256), smem, s, (const _Float16*)gmap, L0, L1, coords,
-                       kk, jj, order, (_Float16*)out, (int)E, Ng, slots, C, nlev, kmod, jmod);
+                       kk, jj, order, (_Float16*)out, (int)E, Ng, slots, C, nlev, kmod, jmod, exp);
   CDV_LAUNCH_CHECK();
   return CDV_OK;
 }

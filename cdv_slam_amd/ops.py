@@ -18,7 +18,6 @@ LIE_OPS = {"exp": 0, "log": 1, "inv": 2, "mul": 3, "adj": 4, "adjT": 5, "act": 6
 # default index-range capacities of the graph workspace (reference buffers: BUFFER_SIZE = 4096 frames
 # x 96 patches, cdvslam/config.py, patchgraph.py:25-29)
 DEFAULT_K_RANGE = 4096 * 96
-DEFAULT_F_RANGE = 4096
 
 
 def _stream():
@@ -48,12 +47,12 @@ def version():
 # ---------------------------------------------------------------------------------------------------
 
 class GraphIndex:
-    """Device workspace holding unique(kk), the patch CSR and the target-frame edge order."""
+    """Device workspace holding unique(kk) and the patch CSR (edges of every patch in (jj, id) order)."""
 
-    def __init__(self, device, E_cap=1 << 16, k_range=DEFAULT_K_RANGE, f_range=DEFAULT_F_RANGE):
+    def __init__(self, device, E_cap=1 << 16, k_range=DEFAULT_K_RANGE):
         self.lib = _lib.load()
         self.device = device
-        self.E_cap, self.k_range, self.f_range = 0, k_range, f_range
+        self.E_cap, self.k_range = 0, k_range
         self.ws = None
         self._key = None
         self.E = 0
@@ -63,7 +62,7 @@ class GraphIndex:
         if self.ws is not None and E <= self.E_cap:
             return
         self.E_cap = max(E, int(self.E_cap * 1.5), 1024)
-        nbytes = self.lib.cdv_graph_workspace_bytes(self.E_cap, self.k_range, self.f_range)
+        nbytes = self.lib.cdv_graph_workspace_bytes(self.E_cap, self.k_range)
         self.ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         self.ws_bytes = nbytes
         self._key = None
@@ -83,7 +82,7 @@ class GraphIndex:
         if jj.numel() != E:
             raise ValueError("jj and kk must have the same length")
         self._reserve(E)
-        rc = self.lib.cdv_graph_build(_p(jj), _p(kk), E, _p(self.ws), self.ws_bytes, self.k_range, self.f_range,
+        rc = self.lib.cdv_graph_build(_p(jj), _p(kk), E, _p(self.ws), self.ws_bytes, self.E_cap, self.k_range,
                                       _stream())
         _lib.check(rc, "cdv_graph_build")
         self._key = key  # strong refs pin the tensors so that identity implies content
@@ -93,14 +92,13 @@ class GraphIndex:
         return self
 
     def meta(self):
-        """(U, n_targets, kmin, kmax, jmin, jmax, error, E) -- synchronises the stream."""
+        """(U, 0, kmin, kmax, jmin, jmax, error, E) -- synchronises the stream."""
         m = (ctypes.c_int64 * 8)()
         _lib.check(self.lib.cdv_graph_read_meta_host(_p(self.ws), m, _stream()), "cdv_graph_read_meta_host")
         m = list(m)
         if m[6]:
-            raise _lib.CdvError("patch-graph index: id range exceeds the workspace capacity "
-                                "(k_range=%d, f_range=%d; got k in [%d,%d], j in [%d,%d])"
-                                % (self.k_range, self.f_range, m[2], m[3], m[4], m[5]))
+            raise _lib.CdvError("patch-graph index: patch-id range exceeds the workspace capacity "
+                                "(k_range=%d; got k in [%d,%d])" % (self.k_range, m[2], m[3]))
         return m
 
     def neighbors(self):
@@ -117,14 +115,6 @@ class GraphIndex:
         _lib.check(self.lib.cdv_graph_get_unique(_p(self.ws), _p(kx), U, _p(ku), self.E, _stream()),
                    "cdv_graph_get_unique")
         return kx, ku
-
-    def order_ptr(self):
-        return ctypes.c_void_p(self.lib.cdv_graph_pair_order(_p(self.ws)))
-
-    def order(self):
-        """[E] int32 view of the target-grouped edge order inside the workspace."""
-        off = self.lib.cdv_graph_pair_order(_p(self.ws)) - self.ws.data_ptr()
-        return self.ws[off:off + 4 * self.E].view(torch.int32)
 
 
 _graphs = {}
@@ -359,7 +349,7 @@ def ba_forward(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, PP
     ws = _ba_workspace(dev, E, U_max, N)
     dbg = None
     if debug:
-        n6, Us = 6 * N, (U_max + 31) // 32 * 32
+        n6, Us = 6 * N, (U_max + 63) // 64 * 64
         dbg = torch.zeros(n6 * n6 + 2 * n6 + 3 * Us + n6 * Us + 64, dtype=torch.float32, device=dev)
     rc = lib.cdv_ba_forward(_p(poses), _p(patches), _p(intrinsics), _p(target), _p(weight), _p(lmbda), _p(ii), _p(jj),
                             _p(kk), E, P, int(t0), int(t1), int(iterations), _p(g.ws), _p(ws), ws.numel(), U_max,
@@ -368,7 +358,7 @@ def ba_forward(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, PP
     if _sync_check():
         g.meta()
     if debug:
-        n6, Us = 6 * N, (U_max + 31) // 32 * 32
+        n6, Us = 6 * N, (U_max + 63) // 64 * 64
         o = 0
         out = {}
         for name, size, shape in (("S", n6 * n6, (n6, n6)), ("y", n6, (n6,)), ("dX", n6, (N, 6)), ("dZ", Us, (Us,)),

@@ -91,8 +91,8 @@ int cdv_fmap_ingest(const void* fmap_chw, void* fmap1_nhwc, void* fmap2_nhwc, vo
  *   coords      [E][2][3][3] f32
  *   kk, jj      raw graph indices; the kernel applies ii1 = kk % kmod, jj1 = jj % jmod
  *               (slam.py:319-320; pass kmod = jmod = 0 for "no modulus")
- *   order       optional [E] int32 processing order (e.g. graph pair-sorted order for L2 locality),
- *               NULL = natural order.  Output rows are always indexed by edge id.
+ *   order       optional [E] int32 processing order (a permutation of the edge ids), NULL = natural
+ *               order.  Output rows are always indexed by edge id.
  *   out         [E][7 (x)][7 (y)][3][3][nlev] f16  == corr.view(E, 882) for nlev = 2
  * Requirements: radius 3, P 3, C % 8 == 0, C <= 128, nlev in {1,2}.
  */
@@ -136,29 +136,26 @@ int cdv_fastba_reproject(const float* poses, const float* patches, const float* 
  * fastba.neighbors, ba.cpp:59-97; shared by neighbors, BA and the correlation order)
  * ---------------------------------------------------------------------------------------------- */
 
-/* bytes of device workspace for a graph of up to E_max edges whose patch ids span at most
- * k_range values and whose target frame ids span at most f_range values */
-size_t cdv_graph_workspace_bytes(int64_t E_max, int64_t k_range, int64_t f_range);
+/* bytes of device workspace for a graph of up to E_max edges whose patch ids span at most k_range
+ * values (kmax - kmin + 1 <= k_range) */
+size_t cdv_graph_workspace_bytes(int64_t E_max, int64_t k_range);
 
 /*
  * Build the index for edge lists (jj = target frame, kk = patch id), [E] int64 -- the arguments of
- * cuda_ba.neighbors(kk, jj).  Contents (device side, addressed through the accessors below):
+ * cuda_ba.neighbors(kk, jj).  Contents (device side, used by cdv_neighbors / cdv_ba_forward):
  *   kx [U] sorted unique patch ids, ku [E] inverse index  == torch::_unique(kk, true, true)
  *   patch CSR: for each unique patch its edges ordered by (jj, edge id)
- *   target order: edge ids sorted by (jj, edge id)
- * Ranges that exceed the workspace set an error word readable via cdv_graph_read_meta_host.
+ * (E_max, k_range) must be the values the workspace was sized with.  A patch-id range larger than
+ * k_range sets an error word readable via cdv_graph_read_meta_host (consumers then do nothing).
  */
-int cdv_graph_build(const int64_t* jj, const int64_t* kk, int64_t E, void* ws, size_t ws_bytes, int64_t k_range,
-                    int64_t f_range, void* stream);
+int cdv_graph_build(const int64_t* jj, const int64_t* kk, int64_t E, void* ws, size_t ws_bytes, int64_t E_max,
+                    int64_t k_range, void* stream);
 
-/* meta_host[8] <- {U, n_targets, kmin, kmax, jmin, jmax, error, E}; synchronises `stream`. */
+/* meta_host[8] <- {U, 0, kmin, kmax, jmin, jmax, error, E}; synchronises `stream`. */
 int cdv_graph_read_meta_host(const void* ws, int64_t* meta_host, void* stream);
 
 /* copy out torch::_unique results (kx needs U from cdv_graph_read_meta_host to size it) */
 int cdv_graph_get_unique(const void* ws, int64_t* kx, int64_t kx_capacity, int64_t* ku, int64_t E, void* stream);
-
-/* device pointer to the [E] int32 (jj, edge id)-sorted edge order (valid until the next build) */
-const int32_t* cdv_graph_pair_order(const void* ws);
 
 /* cuda_ba.neighbors(kk, jj) (ba.cpp:59-97) from a built graph: ix/jx [E] int64, -1 = none */
 int cdv_neighbors(const void* ws, int64_t E, int64_t* ix, int64_t* jx, void* stream);
@@ -179,7 +176,7 @@ size_t cdv_ba_workspace_bytes(int64_t E_max, int64_t U_max, int N_max);
  *   graph_ws: a workspace on which cdv_graph_build(jj, kk, E) has been enqueued on `stream`.
  *   ba_ws / U_max: workspace of cdv_ba_workspace_bytes(E, U_max, N) bytes; U_max bounds the number of
  *             unique patches (exceeding it sets info word 1 and skips the update).
- *   dbg (optional, NULL): receives iteration-0 values, with n = 6N and Us = round_up(U_max, 32):
+ *   dbg (optional, NULL): receives iteration-0 values, with n = 6N and Us = round_up(U_max, 64):
  *             [S n*n (damped) | y n | dX n | dZ Us | C Us | u Us | E n*Us]
  * Supports N = t1 - t0 <= 32 (single-workgroup LDS Cholesky).
  */

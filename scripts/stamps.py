@@ -1,0 +1,44 @@
+"""Diagnostic: where the cycles go inside the big kernels (needs `make -C cdv_slam_amd/csrc STAMPS=1`).
+Run on the GPU box:  CDV_LIB=cdv_slam_amd/libcdvslam_hip_stamps.so python scripts/stamps.py"""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from cdv_slam_amd import synth, _lib
+from cdv_slam_amd.update import UpdatePath
+
+lib = _lib.load()
+dev = torch.device("cuda:0")
+cfg = sys.argv[1] if len(sys.argv) > 1 else "default"
+st = synth.make_state(cfg)
+up = UpdatePath(st, dev)
+for _ in range(5):
+    up.step()
+torch.cuda.synchronize()
+nslot = max(st.E, 8192)
+buf_c = torch.zeros((nslot, 16), dtype=torch.int64, device=dev)
+buf_b = torch.zeros((8192, 16), dtype=torch.int64, device=dev)
+for name, b in (("corr", buf_c), ("ba", buf_b)):
+    fn = getattr(lib, "cdv_set_stamps_" + name)
+    fn.argtypes = [ctypes.c_void_p]
+    assert fn(ctypes.c_void_p(b.data_ptr())) == 0
+up.step()
+torch.cuda.synchronize()
+c = buf_c.cpu().numpy()[: st.E].astype(np.float64)
+d = np.diff(c[:, :9], axis=1)
+names = ["idx+coords+box", "issue loads", "L0 wait+mfma+store", "blend0", "L1 mfma+store", "blend1", "stage out", "store"]
+print("corr: per-wave cycles (median / mean) per phase, total %.0f" % np.median(c[:, 8] - c[:, 0]))
+for i, nme in enumerate(names):
+    print("  %-22s %8.0f %8.0f" % (nme, np.median(d[:, i]), d[:, i].mean()))
+print("  kernel span (first start -> last end): %.0f cycles" % (c[:, 8].max() - c[:, 0].min()))
+b = buf_b.cpu().numpy().astype(np.float64)
+asm = b[:4096]
+asm = asm[asm[:, 0] > 0]
+print("assemble: waves %d" % len(asm))
+for i, nme in enumerate(["zero-init+sync", "slot loop", "flush+sync", "q/E-write+sync", "schur"]):
+    print("  %-22s %8.0f" % (nme, np.median(asm[:, i + 1] - asm[:, i])))
+print("  edge math (sum)        %8.0f   gram (sum) %8.0f" % (np.median(asm[:, 6]), np.median(asm[:, 7])))
+print("  kernel span %.0f" % (asm[:, 5].max() - asm[:, 0].min()))
+sol = b[4096:4100]
+for i, nme in enumerate(["load replicas", "factor loop", "back-subst", "write+retr"]):
+    print("solve %-22s %8.0f" % (nme, np.median(sol[:, i + 1] - sol[:, i])))
+print("solve panel(sum) %8.0f trailing(sum) %8.0f" % (np.median(sol[:, 5]), np.median(sol[:, 6])))

@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     from cdv_slam_amd import _lib
     lib = _lib.load()
     names = _declared_functions()
-    assert len(names) >= 18
+    assert len(names) >= 17
     for n in names:
         assert hasattr(lib, n), "missing export: " + n
     assert set(names) == set(_lib.SIGNATURES), "ctypes table and header disagree"
@@ -38,7 +38,7 @@ def test_argument_errors_are_codes_not_exits():
     assert rc == -2
     rc = lib.cdv_graph_build(None, None, 10, None, 0, 16, 16, None)
     assert rc == -2
-    assert lib.cdv_graph_workspace_bytes(1000, 100, 10) > 1000 * 4 * 4
+    assert lib.cdv_graph_workspace_bytes(1000, 100) > 1000 * 4 * 3
     assert lib.cdv_ba_workspace_bytes(1000, 100, 10) > 8 * 3660 * 4
     # more than 32 free poses is a clean error
     rc = lib.cdv_ba_forward(None, None, None, None, None, None, None, None, None, 10, 3, 0, 40, 2, None, None, 0, 10,
