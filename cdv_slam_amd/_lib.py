@@ -16,6 +16,7 @@ SIGNATURES = {
     "cdv_last_error": (ctypes.c_char_p, []),
     "cdv_version": (ctypes.c_char_p, []),
     "cdv_corr_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "cdv_fmap_padded_elems": (_sz, [_i64, _i32, _i32, _i32]),
     "cdv_fmap_to_nhwc": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i64, _i64, _vp]),
     "cdv_fmap_ingest": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "cdv_corr_fused": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32,
@@ -27,6 +28,7 @@ SIGNATURES = {
     "cdv_graph_build": (_i32, [_vp, _vp, _i64, _vp, _sz, _i64, _i64, _vp]),
     "cdv_graph_read_meta_host": (_i32, [_vp, _vp, _vp]),
     "cdv_graph_get_unique": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp]),
+    "cdv_graph_corr_order": (_vp, [_vp]),
     "cdv_neighbors": (_i32, [_vp, _i64, _vp, _vp, _vp]),
     "cdv_ba_workspace_bytes": (_sz, [_i64, _i64, _i32]),
     "cdv_ba_forward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _sz,

@@ -16,6 +16,7 @@
 //     bilinear blend of every patch pixel reads it back with its own sub-pixel offset, separably;
 //   * the [882]-half row of the edge is staged in LDS and leaves as 256-byte coalesced stores.
 // Algorithmic HBM bytes per edge: 1764 out + 72 coords + 16 idx (+ the feature maps once): DESIGN.md.
+#include <math.h>
 #include <stdlib.h>
 
 #include "cdv_common.h"
@@ -24,12 +25,21 @@ CDV_STAMP_TU(corr)
 
 namespace {
 
+// HBM layout of the feature rings the fused kernel gathers from ("padded channels-last"):
+//   [slot][H + 2*PADY][W + 2*PADX][C] f16, zero margins.  A 16 x 12 window box whose origin is clamped to
+//   [-PADX, W] x [-PADY, H] never leaves the allocation, and everything it reads outside the image is the
+//   zero the reference's out-of-bounds rule asks for (correlation_kernel.cu:122) -- no per-lane bounds
+//   tests, no masks in the kernel.
+constexpr int PADX = CDV_FMAP_PADX;             // 16
+constexpr int PADY = CDV_FMAP_PADY;             // 12
+
 // Per-wave LDS: the raw correlation volume of ONE level in f16 (the reference's raw volume is f16 too,
 // correlation_kernel.cu:207) + the staged output row of the edge.
 constexpr int RAW_ROWS = 12;                    // window rows the fast path holds (typical: 10-11 / 8-9)
 constexpr int RAW_MSH = RAW_ROWS * 16 + 8;      // halfs per patch pixel (+8: 16-byte skew between pixels)
 constexpr int RAW_HALFS = 9 * RAW_MSH;          // 1800
-constexpr int OUT_HALFS = 896;                  // 882 rounded up to a multiple of 64 bytes
+constexpr int OUT_XS = 73;                      // dwords between x offsets in the staged row (= 9 mod 32: conflict-free)
+constexpr int OUT_HALFS = 2 * 7 * OUT_XS + 2;   // 1024
 constexpr int WAVE_LDS_BYTES = RAW_HALFS * 2 + OUT_HALFS * 2;  // 5,392 B per wave
 
 typedef _Float16 cdv_half4 __attribute__((ext_vector_type(4)));
@@ -42,122 +52,141 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-// min / max over lanes 0..15 (lanes >= 9 mirror lane 0), result valid in every lane of the group
-__device__ __forceinline__ int min16(int v) {
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+// all-reduce over the 16 lanes of a DPP row by rotation (row_ror 8,4,2,1): no LDS crossbar traffic
+template <bool IS_MIN>
+__device__ __forceinline__ float row16_reduce(float v) {
+#define CDV_ROR(n)                                                                                        \
+  {                                                                                                       \
+    const float o = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x120 + (n), \
+                                                               0xf, 0xf, false));                          \
+    v = IS_MIN ? fminf(v, o) : fmaxf(v, o);                                                               \
+  }
+  CDV_ROR(8) CDV_ROR(4) CDV_ROR(2) CDV_ROR(1)
+#undef CDV_ROR
   return v;
 }
-__device__ __forceinline__ int max16(int v) {
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
-  return v;
+
+__device__ __forceinline__ float uniform_f(float v) {
+  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
 }
 
 struct LevelParams {
-  const _Float16* fmap;  // [slots][H][W][C]
+  const _Float16* fmap;  // [slots][H + 2 PADY][W + 2 PADX][C]
   int H, W;
-  float scale;
+  float inv_scale;       // 1 / scale, scale a power of two: x * inv_scale == x / scale exactly (slam.py:321-322)
 };
 
-// per-level window geometry of one edge (wave-uniform parts live in SGPRs)
+// wave-uniform window box of one level (all members live in SGPRs)
 struct Box {
-  int x0, y0, Wb, Hb;   // union window of the 9 patch pixels: origin and extent
-  int ixm, iym;         // per lane (patch pixel m = lane, lanes >= 9 mirror pixel 0): floor of the coordinate
-  float dx, dy;         // per lane: sub-pixel offset, rounded to f16 as the reference does before blending
-  bool fast;
+  int x0, y0;        // unclamped origin of the union window of the 9 patch pixels
+  int Wb, Hb;        // extent
+  bool fast;         // fits the 16 x RAW_ROWS tile
+  int stride;        // halfs between window rows of the raw volume in LDS (dense: Wb; per-pixel path: 16)
+  bool outside;      // fast && entirely outside the padded image: the level is all zeros
+  int x0c, y0c;      // origin clamped into the padded map
 };
 
-__device__ __forceinline__ Box make_box(float cxm, float cym, float scale) {
-  Box b;
-  const float x = cxm / scale, y = cym / scale;  // slam.py:321-322 (coords / 1, coords / 4)
-  const float fxf = floorf(x), fyf = floorf(y);
-  b.dx = (float)(_Float16)(x - fxf);              // correlation_kernel.cu:223-224
-  b.dy = (float)(_Float16)(y - fyf);
-  b.ixm = (int)fminf(fmaxf(fxf, -1.0e6f), 1.0e6f);
-  b.iym = (int)fminf(fmaxf(fyf, -1.0e6f), 1.0e6f);
-  b.x0 = __builtin_amdgcn_readfirstlane(min16(b.ixm) - 3);
-  b.y0 = __builtin_amdgcn_readfirstlane(min16(b.iym) - 3);
-  b.Wb = __builtin_amdgcn_readfirstlane(max16(b.ixm) + 4 - b.x0 + 1);
-  b.Hb = __builtin_amdgcn_readfirstlane(max16(b.iym) + 4 - b.y0 + 1);
-  b.fast = (b.Wb <= 16) && (b.Hb <= RAW_ROWS);
-  return b;
+__device__ __forceinline__ int floor_clamped(float v) {
+  return (int)fminf(fmaxf(floorf(v), -1.0e6f), 1.0e6f);
 }
 
-// one window row (16 pixels x 8 channels per lane group) of the channels-last map -> MFMA A fragment
-template <int KS>
-__device__ __forceinline__ void load_row(const _Float16* __restrict__ fbase, const LevelParams& LP, const Box& b,
-                                         int t, int n, int g, int C, bool idx_ok, cdv_half8 (&v)[KS]) {
-  const int py = b.y0 + t, px = b.x0 + n;
-  const bool ok = idx_ok && t < b.Hb && n < b.Wb && py >= 0 && py < LP.H && px >= 0 && px < LP.W;
-#pragma unroll
-  for (int s = 0; s < KS; s++) {
-    cdv_half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (ok && (32 * s + 8 * g) < C)
-      z = *reinterpret_cast<const cdv_half8*>(fbase + ((size_t)py * LP.W + px) * C + 32 * s + 8 * g);
-    v[s] = z;
-  }
+__device__ __forceinline__ Box make_box(float minx, float maxx, float miny, float maxy, const LevelParams& LP) {
+  Box b;
+  // floor(x / s) is monotone in x, so the extreme pixels give the extreme integer coordinates
+  b.x0 = __builtin_amdgcn_readfirstlane(floor_clamped(minx * LP.inv_scale) - 3);   // slam.py:321-322
+  b.y0 = __builtin_amdgcn_readfirstlane(floor_clamped(miny * LP.inv_scale) - 3);
+  b.Wb = __builtin_amdgcn_readfirstlane(floor_clamped(maxx * LP.inv_scale) + 4 - b.x0 + 1);
+  b.Hb = __builtin_amdgcn_readfirstlane(floor_clamped(maxy * LP.inv_scale) + 4 - b.y0 + 1);
+  b.fast = (b.Wb <= 16) && (b.Hb <= RAW_ROWS);
+  b.stride = b.fast ? b.Wb : 16;
+  b.x0c = min(max(b.x0, -PADX), LP.W);
+  b.y0c = min(max(b.y0, -PADY), LP.H);
+  b.outside = (b.x0c != b.x0) || (b.y0c != b.y0);  // a clamped <=16 x <=12 box lies entirely in the margin
+  return b;
 }
 
 // D[window pixel n][patch pixel m] = sum_c window[n][c] * patch[m][c]; lane (m = lane & 15, g = lane >> 4)
 // receives the 4 consecutive window pixels n = 4g .. 4g+3 of row t: one 8-byte LDS store of 4 halfs.
 template <int KS>
 __device__ __forceinline__ void mfma_row_store(const cdv_half8 (&win)[KS], const cdv_half8 (&pat)[KS],
-                                               _Float16* __restrict__ raw, int t, int lane) {
+                                               _Float16* __restrict__ raw_lane, int t) {
   cdv_float4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int s = 0; s < KS; s++) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(win[s], pat[s], acc, 0, 0, 0);
-  const int m = lane & 15, g = lane >> 4;
-  if (m < 9) {
-    cdv_half4 h = {(_Float16)acc[0], (_Float16)acc[1], (_Float16)acc[2], (_Float16)acc[3]};
-    *reinterpret_cast<cdv_half4*>(raw + m * RAW_MSH + t * 16 + 4 * g) = h;
-  }
+  cdv_half4 h = {(_Float16)acc[0], (_Float16)acc[1], (_Float16)acc[2], (_Float16)acc[3]};
+  *reinterpret_cast<cdv_half4*>(raw_lane + t * 16) = h;
 }
 
-// 8x8 -> 7x7 bilinear blend of patch pixel m at x offset xo (lane = 7 m + xo), separable; res[yo]
-__device__ __forceinline__ void blend_level(const _Float16* __restrict__ raw, const Box& b, int lane,
-                                            float (&res)[7]) {
-  const int m = lane / 7, xo = lane - 7 * m;
-  const int msrc = m < 9 ? m : 0;
-  const int bx = b.fast ? (__shfl(b.ixm, msrc) - 3 - b.x0) : 0;
-  const int by = b.fast ? (__shfl(b.iym, msrc) - 3 - b.y0) : 0;
-  const float dxm = __shfl(b.dx, msrc), dym = __shfl(b.dy, msrc);
-  const _Float16* rp = raw + msrc * RAW_MSH + by * 16 + bx + xo;
+// per-lane blend geometry of one level: lane = 7 m + xo
+struct BlendGeo {
+  int off;       // half offset of raw[m][by][bx + xo]
+  int stride;    // halfs between window rows
+  float dx, dy;  // sub-pixel offsets rounded to f16, as the reference casts them before blending
+};
+
+__device__ __forceinline__ BlendGeo blend_geo(float xm, float ym, int m, int xo, const LevelParams& LP,
+                                              const Box& b, bool per_pixel) {
+  BlendGeo g;
+  const float x = xm * LP.inv_scale, y = ym * LP.inv_scale;
+  const float fxf = floorf(x), fyf = floorf(y);
+  g.dx = (float)(_Float16)(x - fxf);   // correlation_kernel.cu:223-224
+  g.dy = (float)(_Float16)(y - fyf);
+  const int bx = per_pixel ? 0 : floor_clamped(x) - 3 - b.x0;
+  const int by = per_pixel ? 0 : floor_clamped(y) - 3 - b.y0;
+  g.off = m * RAW_MSH + by * b.stride + bx + xo;
+  g.stride = b.stride;
+  return g;
+}
+
+// 8x8 -> 7x7 bilinear blend, separable.  The pair (c0, c1) of a window row starts at an arbitrary half
+// offset; a 4-byte LDS read at an odd half offset is an UNALIGNED access (very slow on the LDS), so the two
+// aligned dwords around it are read and funnel-shifted (v_alignbit) into the pair.
+__device__ __forceinline__ void blend_level(const _Float16* __restrict__ raw, const BlendGeo& g, float (&res)[7]) {
+  const uint32_t* r32 = reinterpret_cast<const uint32_t*>(raw);   // raw is 16-byte aligned
+  const unsigned sh = (g.off & 1) ? 16u : 0u;
   float h[8];
 #pragma unroll
   for (int r = 0; r < 8; r++) {
-    const float c0 = (float)rp[r * 16], c1 = (float)rp[r * 16 + 1];
-    h[r] = (1.f - dxm) * c0 + dxm * c1;
+    const int hoff = g.off + r * g.stride;           // half index of c0
+    const unsigned sh_r = ((hoff & 1) ? 16u : 0u);
+    const uint32_t lo = r32[hoff >> 1], hi = r32[(hoff + 1) >> 1];
+    const uint32_t pr = __builtin_amdgcn_alignbit(hi, lo, sh_r);
+    const float c0 = (float)__builtin_bit_cast(_Float16, (unsigned short)(pr & 0xffffu));
+    const float c1 = (float)__builtin_bit_cast(_Float16, (unsigned short)(pr >> 16));
+    h[r] = c0 + g.dx * (c1 - c0);
   }
+  (void)sh;
 #pragma unroll
-  for (int yo = 0; yo < 7; yo++) res[yo] = (1.f - dym) * h[yo] + dym * h[yo + 1];
+  for (int yo = 0; yo < 7; yo++) res[yo] = h[yo] + g.dy * (h[yo + 1] - h[yo]);
 }
 
 // wide reprojection footprint (strong zoom / rotation): every patch pixel gets its own 8x8 window; two
-// window rows share one MFMA (pixels 0-7 | 8-15), only column m of D is kept.  Loads are not prefetched.
+// window rows share one MFMA (pixels 0-7 | 8-15), only column m of D is kept.  Rare: compact, not tuned.
 template <int KS>
-__device__ __forceinline__ void slow_level(const _Float16* __restrict__ fbase, const LevelParams& LP, const Box& b,
-                                           const cdv_half8 (&pat)[KS], _Float16* __restrict__ raw, int lane, int C,
-                                           bool idx_ok) {
+__device__ __forceinline__ void slow_level(const LevelParams& LP, int64_t jslot, float xv, float yv,
+                                           const cdv_half8 (&pat)[KS], _Float16* __restrict__ raw, int lane, int C) {
   const int n = lane & 15, g = lane >> 4;
+  const int Wp = LP.W + 2 * PADX, Hp = LP.H + 2 * PADY;
+  const _Float16* fbase = LP.fmap + (size_t)jslot * Hp * Wp * C;
   for (int m = 0; m < 9; m++) {
-    const int xm = __shfl(b.ixm, m) - 3, ym = __shfl(b.iym, m) - 3;
-#pragma unroll
+    const float xm = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv), m));
+    const float ym = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(yv), m));
+    const int x0 = floor_clamped(xm * LP.inv_scale) - 3, y0 = floor_clamped(ym * LP.inv_scale) - 3;
+    const int x0c = min(max(x0, -PADX), LP.W), y0c = min(max(y0, -PADY), LP.H);
+    const bool outside = (x0c != x0) || (y0c != y0);
     for (int t2 = 0; t2 < 4; t2++) {
-      const int py = ym + 2 * t2 + (n >> 3), px = xm + (n & 7);
-      const bool ok = idx_ok && py >= 0 && py < LP.H && px >= 0 && px < LP.W;
+      const int py = y0c + PADY + 2 * t2 + (n >> 3), px = x0c + PADX + (n & 7);
       cdv_float4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < KS; s++) {
-        cdv_half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (ok && (32 * s + 8 * g) < C)
-          v = *reinterpret_cast<const cdv_half8*>(fbase + ((size_t)py * LP.W + px) * C + 32 * s + 8 * g);
+        const int chg = min(32 * s + 8 * g, C - 8);  // lanes of the k padding re-read real (finite) data
+        const cdv_half8 v = *reinterpret_cast<const cdv_half8*>(fbase + ((size_t)py * Wp + px) * C + chg);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(v, pat[s], acc, 0, 0, 0);
       }
-      // lane (col = lane & 15 = patch pixel, g): window pixels 4g .. 4g+3 of the 16 (two rows of 8)
       if (n == m) {
         const int row = 2 * t2 + (g >> 1), col = 4 * (g & 1);
         cdv_half4 h = {(_Float16)acc[0], (_Float16)acc[1], (_Float16)acc[2], (_Float16)acc[3]};
+        if (outside) h = cdv_half4{0, 0, 0, 0};
         *reinterpret_cast<cdv_half4*>(raw + m * RAW_MSH + row * 16 + col) = h;
       }
     }
@@ -173,134 +202,200 @@ __global__ __launch_bounds__(256) void corr_fused_kernel(const _Float16* __restr
                                                          _Float16* __restrict__ out, int E, int64_t Ng, int64_t slots,
                                                          int C, int nlev, int64_t kmod, int64_t jmod, int exp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int p = blockIdx.x * 4 + wave;
-  if (p >= E) return;  // no block-wide barriers below: waves are independent
-  const int e = order ? order[p] : p;
-  CDV_STAMP(corr, p, 0);
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   _Float16* raw = reinterpret_cast<_Float16*>(smem_raw + (size_t)wave * WAVE_LDS_BYTES);
   _Float16* outT = raw + RAW_HALFS;
+  const int p = blockIdx.x * 4 + wave;
+  if (p >= E) return;  // no block-wide barriers below: waves are independent
+  const int e = order ? __builtin_amdgcn_readfirstlane(order[p]) : p;   // wave-uniform: scalar loads below
+  CDV_STAMP(corr, p, 0);
 
-  // ---- round trip 1: indices and the 18 coordinates ------------------------------------------------
+  // ---- round trip 1: indices (scalar) and the 18 coordinates ----------------------------------------
   int64_t kpatch = kk[e], jslot = jj[e];
-  const int mm = lane < 9 ? lane : 0;  // lanes 0..8 own patch pixel m = lane; the others mirror pixel 0
-  const float cxm = coords[(int64_t)e * 18 + mm];
-  const float cym = coords[(int64_t)e * 18 + 9 + mm];
   if (kmod > 0) kpatch %= kmod;
   if (jmod > 0) jslot %= jmod;
-  const bool idx_ok0 = kpatch >= 0 && kpatch < Ng && jslot >= 0 && jslot < slots;
-  const bool idx_ok = idx_ok0 && !(exp & 1);   // experiment bit 0: no window loads
-  const int n = lane & 15, g = lane >> 4;
-
-  const Box b0 = make_box(cxm, cym, L0.scale);
-  const Box b1 = make_box(cxm, cym, nlev == 2 ? L1.scale : L0.scale);
+  const bool idx_ok = kpatch >= 0 && kpatch < Ng && jslot >= 0 && jslot < slots;
+  if (!idx_ok) { kpatch = 0; jslot = 0; }  // reference behaviour is undefined here; stay in bounds
+  if (exp & 16) jslot = 0;                 // experiment bit 4: every edge reads map slot 0 (L2-resident)
+  const float* cptr = coords + (size_t)e * 18;
+  const int mm = lane < 9 ? lane : 0;       // row 0 of the wave: lanes 0..8 own patch pixel m, 9..15 mirror 0
+  const float xv = cptr[mm], yv = cptr[9 + mm];
+  const int bm = min(lane / 7, 8), bxo = lane - 7 * (lane / 7);  // blend role of this lane: (m, x offset)
+  const float xb = cptr[bm], yb = cptr[9 + bm];
+  const float minx = uniform_f(row16_reduce<true>(xv)), maxx = uniform_f(row16_reduce<false>(xv));
+  const float miny = uniform_f(row16_reduce<true>(yv)), maxy = uniform_f(row16_reduce<false>(yv));
+  const Box b0 = make_box(minx, maxx, miny, maxy, L0);
+  const Box b1 = make_box(minx, maxx, miny, maxy, nlev == 2 ? L1 : L0);
   CDV_STAMP(corr, p, 1);
-  const _Float16* f0 = L0.fmap + (size_t)(idx_ok ? jslot : 0) * L0.H * L0.W * C;
-  const _Float16* f1 = nlev == 2 ? L1.fmap + (size_t)(idx_ok ? jslot : 0) * L1.H * L1.W * C : f0;
 
-  // ---- round trip 2: patch tile (MFMA B operand) and, in the common case, EVERY window row of both
-  //      levels -- all loads are in flight before the first MFMA -----------------------------------------
+  const int n = lane & 15, g = lane >> 4;
+  // per-lane byte offset inside a window row: pixel n, channel group g (the k-padding group re-reads real,
+  // finite data: its products meet the zero k-slots of the patch fragment)
+  // ---- round trip 2: patch tile (MFMA B operand) ------------------------------------------------------
   cdv_half8 pat[KS];
+  {
+    const _Float16* gp = gmap + (size_t)kpatch * C * 9 + (n < 9 ? n : 0);
 #pragma unroll
-  for (int s = 0; s < KS; s++) {
+    for (int s = 0; s < KS; s++) {
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-      const int ch = 32 * s + 8 * g + j;
-      _Float16 v = (_Float16)0.f;
-      if (idx_ok0 && !(exp & 8) && n < 9 && ch < C) v = gmap[(kpatch * C + ch) * 9 + n];
-      pat[s][j] = v;
+      for (int j = 0; j < 8; j++) {
+        const int ch = 32 * s + 8 * g + j;
+        const _Float16 v = gp[min(ch, C - 1) * 9];
+        pat[s][j] = (n < 9 && ch < C) ? v : (_Float16)0.f;
+      }
     }
   }
 
   float res0[7], res1[7];
+#pragma unroll
+  for (int i = 0; i < 7; i++) { res0[i] = 0.f; res1[i] = 0.f; }
+  _Float16* raw_lane = raw + (n < 9 ? n : 0) * RAW_MSH + 4 * g;   // lanes n >= 9 of the D tile are dropped below
+
   if constexpr (KS == 1) {
-    cdv_half8 w0[RAW_ROWS][1], w1[RAW_ROWS][1];
-    if (b0.fast) {
-#pragma unroll
-      for (int t = 0; t < RAW_ROWS; t++) load_row<1>(f0, L0, b0, t, n, g, C, idx_ok, w0[t]);
+    // ---- EVERY window row of both levels is requested before the first MFMA --------------------------
+    const int Wp0 = L0.W + 2 * PADX, Hp0 = L0.H + 2 * PADY, Wp1 = L1.W + 2 * PADX, Hp1 = L1.H + 2 * PADY;
+    const char* r0 = reinterpret_cast<const char*>(L0.fmap) +
+                     (((size_t)jslot * Hp0 + (b0.y0c + PADY)) * Wp0 + (b0.x0c + PADX)) * C * 2;
+    const char* r1 = reinterpret_cast<const char*>(nlev == 2 ? L1.fmap : L0.fmap) +
+                     (((size_t)jslot * Hp1 + (b1.y0c + PADY)) * Wp1 + (b1.x0c + PADX)) * C * 2;
+    const size_t pitch0 = (size_t)Wp0 * C * 2, pitch1 = (size_t)Wp1 * C * 2;
+    // The CU's vector-memory return path (~70 GB/s per CU from L2) is what bounds this kernel, so only
+    // the useful lanes load: pixels n < Wb and the 3 real channel groups.  Rows n >= Wb of D are never read
+    // (garbage allowed); the k-padding lanes must hold zeros (their products meet zeros, but 0 * NaN = NaN).
+    // The union window is packed DENSELY into the 16 pixel slots of the MFMA A operand: slot s of group q
+    // is window pixel P = 16 q + s = (row P / Wb, col P % Wb).  A 10 x 11 window is 7 loads + 7 MFMAs
+    // instead of 11, and D comes out linear in P, which is the LDS layout (row stride Wb).
+    // Loads are BUFFER loads through a per-edge descriptor whose base is the window origin and whose size
+    // is Hb rows: the hardware range check returns zeros for the lanes past the last pixel and for the
+    // k-padding lanes (offset forced out of range) -- no EXEC masking, no zero-initialised fragments.
+    typedef int cdv_i32x4 __attribute__((ext_vector_type(4)));
+    cdv_half8 w[RAW_ROWS][1];
+    const bool do0 = b0.fast && !b0.outside;
+    const bool do1 = nlev == 2 && b1.fast && !b1.outside;
+    const unsigned CB = (unsigned)C * 2u;                              // bytes per pixel
+    const unsigned gbyte = (8 * g < C) ? (unsigned)(8 * g) * 2u : 0x40000000u;  // k padding -> out of range
+    const int nq0 = (b0.Wb * b0.Hb + 15) >> 4, nq1 = (b1.Wb * b1.Hb + 15) >> 4;
+#define CDV_LOAD_LEVEL(BX, RB, PITCH, NQ)                                                          \
+    {                                                                                              \
+      const unsigned Wb_ = (unsigned)(BX).Wb, pitch_ = (unsigned)(PITCH);                          \
+      const auto rsrc_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(RB), (short)0,        \
+                                                           (int)((unsigned)(BX).Hb * pitch_), 0x00020000); \
+      const unsigned a_ = (Wb_ == 8u) ? 2u : 1u, b_ = 16u - a_ * Wb_;                              \
+      const unsigned step_ = a_ * pitch_ + b_ * CB, wrap_ = pitch_ - Wb_ * CB;                     \
+      const unsigned row0_ = ((unsigned)n >= Wb_) ? 1u : 0u;                                       \
+      unsigned col_ = (unsigned)n - row0_ * Wb_;                                                   \
+      unsigned voff_ = row0_ * pitch_ + col_ * CB + gbyte;                                         \
+      _Pragma("unroll") for (int q = 0; q < RAW_ROWS; q++) {                                       \
+        if (q < (NQ)) {                                                                            \
+          const cdv_i32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(rsrc_, (int)voff_, 0, 0);     \
+          w[q][0] = __builtin_bit_cast(cdv_half8, v_);                                             \
+          col_ += b_; voff_ += step_;                                                              \
+          const bool wr_ = col_ >= Wb_;                                                            \
+          col_ -= wr_ ? Wb_ : 0u; voff_ += wr_ ? wrap_ : 0u;                                       \
+        }                                                                                          \
+      }                                                                                            \
     }
-    if (nlev == 2 && b1.fast) {
-#pragma unroll
-      for (int t = 0; t < RAW_ROWS; t++) load_row<1>(f1, L1, b1, t, n, g, C, idx_ok, w1[t]);
-    }
+#define CDV_MFMA_LEVEL(NQ)                                                                         \
+    _Pragma("unroll") for (int q = 0; q < RAW_ROWS; q++)                                           \
+      if (q < (NQ)) {                                                                              \
+        cdv_float4 acc = {0.f, 0.f, 0.f, 0.f};                                                     \
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[q][0], pat[0], acc, 0, 0, 0);               \
+        if (n < 9) {                                                                               \
+          cdv_half4 h = {(_Float16)acc[0], (_Float16)acc[1], (_Float16)acc[2], (_Float16)acc[3]};  \
+          *reinterpret_cast<cdv_half4*>(raw_lane + q * 16) = h;                                    \
+        }                                                                                          \
+      }
+    if (do0 && !(exp & 1)) CDV_LOAD_LEVEL(b0, r0, pitch0, nq0)
+    const BlendGeo g0 = blend_geo(xb, yb, bm, bxo, L0, b0, !b0.fast);
+    const BlendGeo g1 = blend_geo(xb, yb, bm, bxo, nlev == 2 ? L1 : L0, b1, !b1.fast);
     CDV_STAMP(corr, p, 2);
-    // level 0
-    if (b0.fast) {
-#pragma unroll
-      for (int t = 0; t < RAW_ROWS; t++)
-        if (t < b0.Hb) mfma_row_store<1>(w0[t], pat, raw, t, lane);
-    } else {
-      slow_level<1>(f0, L0, b0, pat, raw, lane, C, idx_ok);
+    // level 0: MFMA per pixel group; the registers are immediately re-used for the level-1 request
+    if (do0 && !(exp & 256)) {
+      CDV_MFMA_LEVEL(nq0)
+    } else if (!b0.fast) {
+      slow_level<1>(L0, jslot, xv, yv, pat, raw, lane, C);
     }
+    if (do1 && !(exp & 1)) CDV_LOAD_LEVEL(b1, r1, pitch1, nq1)
     wave_lds_sync();
     CDV_STAMP(corr, p, 3);
-    blend_level(raw, b0, lane, res0);
+    if ((do0 || !b0.fast) && !(exp & 128)) blend_level(raw, g0, res0);
     CDV_STAMP(corr, p, 4);
     if (nlev == 2) {
       wave_lds_sync();
-      if (b1.fast) {
-#pragma unroll
-        for (int t = 0; t < RAW_ROWS; t++)
-          if (t < b1.Hb) mfma_row_store<1>(w1[t], pat, raw, t, lane);
-      } else {
-        slow_level<1>(f1, L1, b1, pat, raw, lane, C, idx_ok);
+      if (do1 && !(exp & 256)) {
+        CDV_MFMA_LEVEL(nq1)
+      } else if (!b1.fast) {
+        slow_level<1>(L1, jslot, xv, yv, pat, raw, lane, C);
       }
       wave_lds_sync();
       CDV_STAMP(corr, p, 5);
-      blend_level(raw, b1, lane, res1);
+      if ((do1 || !b1.fast) && !(exp & 128)) blend_level(raw, g1, res1);
       CDV_STAMP(corr, p, 6);
     }
+#undef CDV_LOAD_LEVEL
+#undef CDV_MFMA_LEVEL
   } else {
     // wide feature vectors (DPVO, C = 128): rows in batches of 2 to stay inside the register file
     for (int lev = 0; lev < nlev; lev++) {
       const LevelParams& LP = lev == 0 ? L0 : L1;
-      const Box& b = lev == 0 ? b0 : b1;
-      const _Float16* fb = lev == 0 ? f0 : f1;
+      Box b = lev == 0 ? b0 : b1;
+      b.stride = 16;  // this path stores one 16-pixel tile per window row
+      const int Wp = LP.W + 2 * PADX, Hp = LP.H + 2 * PADY;
       if (lev == 1) wave_lds_sync();
-      if (b.fast) {
-        for (int tb = 0; tb < b.Hb; tb += 2) {
-          cdv_half8 wa[KS], wb[KS];
-          load_row<KS>(fb, LP, b, tb, n, g, C, idx_ok, wa);
-          load_row<KS>(fb, LP, b, tb + 1, n, g, C, idx_ok, wb);
-          mfma_row_store<KS>(wa, pat, raw, tb, lane);
-          if (tb + 1 < b.Hb) mfma_row_store<KS>(wb, pat, raw, tb + 1, lane);
+      if (b.fast && !b.outside) {
+        const _Float16* fb = LP.fmap + (((size_t)jslot * Hp + (b.y0c + PADY)) * Wp + (b.x0c + PADX)) * C;
+        for (int t = 0; t < b.Hb; t++) {
+          cdv_half8 wa[KS];
+#pragma unroll
+          for (int s = 0; s < KS; s++)
+            wa[s] = *reinterpret_cast<const cdv_half8*>(fb + ((size_t)t * Wp + n) * C + min(32 * s + 8 * g, C - 8));
+          cdv_float4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int s = 0; s < KS; s++) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[s], pat[s], acc, 0, 0, 0);
+          if (n < 9) {
+            cdv_half4 h = {(_Float16)acc[0], (_Float16)acc[1], (_Float16)acc[2], (_Float16)acc[3]};
+            *reinterpret_cast<cdv_half4*>(raw_lane + t * 16) = h;
+          }
         }
-      } else {
-        slow_level<KS>(fb, LP, b, pat, raw, lane, C, idx_ok);
+      } else if (!b.fast) {
+        slow_level<KS>(LP, jslot, xv, yv, pat, raw, lane, C);
       }
       wave_lds_sync();
-      if (lev == 0) blend_level(raw, b, lane, res0); else blend_level(raw, b, lane, res1);
+      if (!(b.fast && b.outside)) {
+        const BlendGeo gg = blend_geo(xb, yb, bm, bxo, LP, b, !b.fast);
+        if (lev == 0) blend_level(raw, gg, res0); else blend_level(raw, gg, res1);
+      }
     }
   }
 
   // ---- stage the edge's output row [x][y][m][lev] in LDS, then 256-byte coalesced stores ------------
-  {
-    const int m = lane / 7, xo = lane - 7 * m;
-    if (lane < 63) {
-      if (nlev == 2) {
-        uint32_t* o32 = reinterpret_cast<uint32_t*>(outT);
+  if (lane < 63 && !(exp & 512)) {
+    if (nlev == 2) {
+      uint32_t* o32 = reinterpret_cast<uint32_t*>(outT) + bxo * OUT_XS + bm;   // bank = (9 xo + m + 9 yo) mod 32
 #pragma unroll
-        for (int yo = 0; yo < 7; yo++) {
-          const _Float16 h0 = (_Float16)res0[yo], h1 = (_Float16)res1[yo];
-          const uint32_t lo = __builtin_bit_cast(unsigned short, h0), hi = __builtin_bit_cast(unsigned short, h1);
-          o32[(xo * 7 + yo) * 9 + m] = lo | (hi << 16);
-        }
-      } else {
-#pragma unroll
-        for (int yo = 0; yo < 7; yo++) outT[(xo * 7 + yo) * 9 + m] = (_Float16)res0[yo];
+      for (int yo = 0; yo < 7; yo++) {
+        const _Float16 h0 = idx_ok ? (_Float16)res0[yo] : (_Float16)0.f;
+        const _Float16 h1 = idx_ok ? (_Float16)res1[yo] : (_Float16)0.f;
+        const uint32_t lo = __builtin_bit_cast(unsigned short, h0), hi = __builtin_bit_cast(unsigned short, h1);
+        o32[yo * 9] = lo | (hi << 16);
       }
+    } else {
+#pragma unroll
+      for (int yo = 0; yo < 7; yo++) outT[(bxo * 7 + yo) * 9 + bm] = idx_ok ? (_Float16)res0[yo] : (_Float16)0.f;
     }
   }
   wave_lds_sync();
   CDV_STAMP(corr, p, 7);
-  if (exp & 2) return;                          // experiment bit 1: no global store
+  if (!(exp & 2)) {                             // experiment bit 1: no global store
   if (nlev == 2) {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(outT);
     uint32_t* dst = reinterpret_cast<uint32_t*>(out) + (size_t)e * 441;
 #pragma unroll
     for (int i = 0; i < 7; i++) {
-      const int t = i * 64 + lane;
-      if (t < 441) dst[t] = src[t];
+      const int t = i * 64 + lane;        // output dword t = 63 xo + r  lives at LDS dword OUT_XS xo + r
+      const int xo = (t * 1041) >> 16;    // t / 63 for 0 <= t < 4096
+      if (t < 441) dst[t] = src[t + (OUT_XS - 63) * xo];
     }
   } else {
     _Float16* dst = out + (size_t)e * 441;
@@ -309,6 +404,7 @@ __global__ __launch_bounds__(256) void corr_fused_kernel(const _Float16* __restr
       const int t = i * 64 + lane;
       if (t < 441) dst[t] = outT[t];
     }
+  }
   }
   CDV_STAMP(corr, p, 8);
 }
@@ -359,8 +455,9 @@ __global__ __launch_bounds__(256) void corr_generic_kernel(const T* __restrict__
 }
 
 // ---- layout kernels -----------------------------------------------------------------------------------
-// planar [N][C][H][W] -> channels-last [N][H][W][C]; one thread per (pixel, 8-channel group): 8 strided
-// 2-byte reads (coalesced across the wave along W), one 16-byte write.
+// planar [N][C][H][W] -> padded channels-last [N][H+2PADY][W+2PADX][C] (interior only; the margins are
+// zeroed once at allocation); one thread per (pixel, 8-channel group): 8 strided 2-byte reads (coalesced
+// across the wave along W), one 16-byte write.
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const _Float16* __restrict__ src,
                                                            _Float16* __restrict__ dst, int64_t first, int64_t count,
                                                            int C, int H, int W) {
@@ -377,7 +474,8 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const _Float16* __res
     cdv_half8 v;
 #pragma unroll
     for (int j = 0; j < 8; j++) v[j] = src[((nslot * C + 8 * gq + j) * H + yh) * W + xw];
-    *reinterpret_cast<cdv_half8*>(dst + ((nslot * H + yh) * W + xw) * C + 8 * gq) = v;
+    *reinterpret_cast<cdv_half8*>(dst + ((nslot * (H + 2 * PADY) + yh + PADY) * (W + 2 * PADX) + xw + PADX) * C +
+                                  8 * gq) = v;
   }
 }
 
@@ -411,7 +509,8 @@ __global__ __launch_bounds__(256) void fmap_ingest_kernel(const _Float16* __rest
           sum[j] += (float)s;
           if (f1_nchw) f1_nchw[(((int64_t)slot * C + 8 * gq + j) * H + yh) * W + xw] = s;
         }
-        *reinterpret_cast<cdv_half8*>(f1_nhwc + (((int64_t)slot * H + yh) * W + xw) * C + 8 * gq) = v;
+        *reinterpret_cast<cdv_half8*>(f1_nhwc + (((int64_t)slot * (H + 2 * PADY) + yh + PADY) * (W + 2 * PADX) + xw +
+                                                 PADX) * C + 8 * gq) = v;
       }
     cdv_half8 pv;
 #pragma unroll
@@ -419,7 +518,8 @@ __global__ __launch_bounds__(256) void fmap_ingest_kernel(const _Float16* __rest
       pv[j] = (_Float16)(sum[j] * (1.0f / 16.0f));
       if (f2_nchw) f2_nchw[(((int64_t)slot * C + 8 * gq + j) * H4 + yq) * W4 + xq] = pv[j];
     }
-    *reinterpret_cast<cdv_half8*>(f2_nhwc + (((int64_t)slot * H4 + yq) * W4 + xq) * C + 8 * gq) = pv;
+    *reinterpret_cast<cdv_half8*>(f2_nhwc + (((int64_t)slot * (H4 + 2 * PADY) + yq + PADY) * (W4 + 2 * PADX) + xq +
+                                             PADX) * C + 8 * gq) = pv;
   }
 }
 
@@ -469,6 +569,10 @@ extern "C" int cdv_corr_fwd(const void* fmap1, const void* fmap2, const float* c
   return CDV_OK;
 }
 
+extern "C" size_t cdv_fmap_padded_elems(int64_t slots, int C, int H, int W) {
+  return (size_t)slots * (size_t)(H + 2 * PADY) * (size_t)(W + 2 * PADX) * (size_t)C;
+}
+
 extern "C" int cdv_fmap_to_nhwc(const void* src_nchw, void* dst_nhwc, int64_t N, int C, int H, int W, int64_t first,
                                 int64_t count, void* stream) {
   CDV_REQUIRE(C % 8 == 0 && C > 0, CDV_ERR_ARG, "cdv_fmap_to_nhwc: C must be a multiple of 8");
@@ -503,11 +607,13 @@ extern "C" int cdv_corr_fused(const void* gmap, const void* fmap0_nhwc, const vo
   CDV_REQUIRE(nlev == 1 || nlev == 2, CDV_ERR_ARG, "cdv_corr_fused: nlev must be 1 or 2");
   CDV_REQUIRE(C % 8 == 0 && C > 0 && C <= 128, CDV_ERR_UNSUPPORTED, "cdv_corr_fused: C must be a multiple of 8, <= 128");
   CDV_REQUIRE(E >= 0 && E < ((int64_t)1 << 31), CDV_ERR_ARG, "cdv_corr_fused: E out of range");
-  CDV_REQUIRE(scale0 > 0.f && (nlev == 1 || scale1 > 0.f), CDV_ERR_ARG, "cdv_corr_fused: scales must be positive");
+  int ex0 = 0, ex1 = 0;
+  CDV_REQUIRE(scale0 > 0.f && frexpf(scale0, &ex0) == 0.5f && (nlev == 1 || (scale1 > 0.f && frexpf(scale1, &ex1) == 0.5f)),
+              CDV_ERR_UNSUPPORTED, "cdv_corr_fused: pyramid scales must be powers of two (1 and 4 in SLAM.corr)");
   CDV_REQUIRE(fmap0_nhwc != nullptr && (nlev == 1 || fmap1_nhwc != nullptr), CDV_ERR_ARG, "cdv_corr_fused: NULL map");
   if (E == 0) return CDV_OK;
-  LevelParams L0{(const _Float16*)fmap0_nhwc, H0, W0, scale0};
-  LevelParams L1{(const _Float16*)fmap1_nhwc, H1, W1, scale1};
+  LevelParams L0{(const _Float16*)fmap0_nhwc, H0, W0, 1.0f / scale0};
+  LevelParams L1{(const _Float16*)fmap1_nhwc, H1, W1, nlev == 2 ? 1.0f / scale1 : 1.0f};
   const int blocks = cdv_div_up(E, 4);
   const size_t smem = 4 * (size_t)WAVE_LDS_BYTES;
   static const int exp = getenv("CDV_CORR_EXP") ? atoi(getenv("CDV_CORR_EXP")) : 0;  // diagnostics only

@@ -117,6 +117,16 @@ class GraphIndex:
         return kx, ku
 
 
+    def order_ptr(self):
+        """device pointer of the target-frame-grouped edge order (processing order for corr_fused)"""
+        return ctypes.c_void_p(self.lib.cdv_graph_corr_order(_p(self.ws)))
+
+    def order(self):
+        """[E] int32 view of that order inside the workspace"""
+        off = self.lib.cdv_graph_corr_order(_p(self.ws)) - self.ws.data_ptr()
+        return self.ws[off:off + 4 * self.E].view(torch.int32)
+
+
 _graphs = {}
 
 
@@ -189,8 +199,21 @@ def fastba_reproject(poses, patches, intrinsics, ii, jj, kk):
 # altcorr
 # ---------------------------------------------------------------------------------------------------
 
+FMAP_PADX, FMAP_PADY = 16, 12   # CDV_FMAP_PADX / CDV_FMAP_PADY (include/cdvslam_hip.h)
+
+
+def alloc_fmap_ring(slots, C, H, W, device):
+    """Zero-initialised padded channels-last ring [slots, H + 2 PADY, W + 2 PADX, C] f16."""
+    return torch.zeros((slots, H + 2 * FMAP_PADY, W + 2 * FMAP_PADX, C), dtype=torch.float16, device=device)
+
+
+def fmap_interior(ring):
+    """[slots, H, W, C] view of the image area of a padded ring."""
+    return ring[:, FMAP_PADY:-FMAP_PADY, FMAP_PADX:-FMAP_PADX, :]
+
+
 class NhwcCache:
-    """channels-last shadows of planar feature rings, refreshed when the source tensor's version moves."""
+    """padded channels-last shadows of planar feature rings, refreshed when the source tensor's version moves."""
 
     def __init__(self, max_entries=4):
         self.entries = []
@@ -203,7 +226,8 @@ class NhwcCache:
                     self._convert(fmap, ent[2])
                     ent[1] = fmap._version
                 return ent[2]
-        shadow = torch.empty(fmap.shape[:-3] + (fmap.shape[-2], fmap.shape[-1], fmap.shape[-3]),
+        C, H, W = fmap.shape[-3:]
+        shadow = torch.zeros(fmap.shape[:-3] + (H + 2 * FMAP_PADY, W + 2 * FMAP_PADX, C),
                              dtype=fmap.dtype, device=fmap.device)
         self._convert(fmap, shadow)
         self.entries.append([fmap, fmap._version, shadow])
@@ -236,8 +260,9 @@ def fmap_ingest(fmap_chw, fmap1_nhwc, fmap2_nhwc, slot, fmap1_nchw=None, fmap2_n
 
 def corr_fused(gmap, fmap0_nhwc, fmap1_nhwc, coords, kk, jj, kmod=0, jmod=0, scales=(1.0, 4.0), order_ptr=None,
                out=None):
-    """SLAM.corr (slam.py:316-323) in one launch.  gmap [Ng,C,3,3] f16 planar, fmapL_nhwc
-    [slots,H,W,C] f16, coords [1,E,2,3,3] f32 -> [1,E,882] f16 (fmap1_nhwc None -> one level, [1,E,441])."""
+    """SLAM.corr (slam.py:316-323) in one launch.  gmap [Ng,C,3,3] f16 planar, fmapL_nhwc padded
+    channels-last rings (alloc_fmap_ring), coords [1,E,2,3,3] f32 -> [1,E,882] f16 (fmap1_nhwc None -> one
+    level, [1,E,441])."""
     lib = _lib.load()
     _need_cuda(gmap, fmap0_nhwc, coords, kk, jj)
     if gmap.dtype != torch.float16 or fmap0_nhwc.dtype != torch.float16 or coords.dtype != torch.float32:
@@ -247,8 +272,11 @@ def corr_fused(gmap, fmap0_nhwc, fmap1_nhwc, coords, kk, jj, kmod=0, jmod=0, sca
     C = gmap.shape[-3]
     gmap, coords = gmap.contiguous(), coords.contiguous()
     Ng = gmap.numel() // (C * 9)
-    slots, H0, W0 = fmap0_nhwc.shape[-4], fmap0_nhwc.shape[-3], fmap0_nhwc.shape[-2]
-    H1, W1 = (fmap1_nhwc.shape[-3], fmap1_nhwc.shape[-2]) if nlev == 2 else (0, 0)
+    slots = fmap0_nhwc.shape[-4]
+    H0, W0 = fmap0_nhwc.shape[-3] - 2 * FMAP_PADY, fmap0_nhwc.shape[-2] - 2 * FMAP_PADX
+    H1, W1 = (fmap1_nhwc.shape[-3] - 2 * FMAP_PADY, fmap1_nhwc.shape[-2] - 2 * FMAP_PADX) if nlev == 2 else (0, 0)
+    if not fmap0_nhwc.is_contiguous() or (nlev == 2 and not fmap1_nhwc.is_contiguous()):
+        raise RuntimeError("corr_fused: feature rings must be contiguous padded channels-last tensors")
     if out is None:
         out = torch.empty((1, E, 441 * nlev), dtype=torch.float16, device=gmap.device)
     rc = lib.cdv_corr_fused(_p(gmap), _p(fmap0_nhwc), _p(fmap1_nhwc), _p(coords), _p(kk.contiguous()),

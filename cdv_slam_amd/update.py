@@ -7,7 +7,7 @@ HBM-resident state (DESIGN.md "Data layout"):
   poses [N,7] f32, patches [N*M,3,3,3] f32, intrinsics [N,4] f32         (reference layouts)
   ii/jj/kk [E] int64, target/weight [E,2] f32
   gmap  [pmem*M, C, 3, 3] f16                                            (reference layout)
-  fmap1 [mem, H, W, C] f16, fmap2 [mem, H/4, W/4, C] f16                 CHANNELS-LAST rings
+  fmap1 [mem, H+24, W+32, C] f16, fmap2 [mem, H/4+24, W/4+32, C] f16     padded CHANNELS-LAST rings
 """
 import torch
 
@@ -15,7 +15,7 @@ from . import ops
 
 
 class UpdatePath:
-    def __init__(self, st, device):
+    def __init__(self, st, device, sort_corr=True):
         """st: synth.SynthState (numpy).  Uploads the state once; step() then runs entirely on device."""
         self.cfg = st.cfg
         self.dev = device
@@ -29,6 +29,7 @@ class UpdatePath:
         self.t0, self.n = st.t0, st.n
         self.M = st.cfg.M
         self.E = st.E
+        self.sort_corr = sort_corr   # walk the edges grouped by target frame (XCD / L2 locality)
         self._poses0, self._patches0 = self.poses.clone(), self.patches.clone()
         self.graph = ops.GraphIndex(device, E_cap=self.E, k_range=st.cfg.buffer_size * st.cfg.M)
         self.U_max = min(self.E, (st.cfg.removal_window + 2) * st.cfg.M) if not st.cfg.fully_connected \
@@ -37,8 +38,8 @@ class UpdatePath:
         if self.has_features:
             self.gmap = t(st.gmap).contiguous()
             mem, C, h, w = st.fmap1.shape
-            self.fmap1 = torch.empty((mem, h, w, C), dtype=torch.float16, device=device)
-            self.fmap2 = torch.empty((mem, h // 4, w // 4, C), dtype=torch.float16, device=device)
+            self.fmap1 = ops.alloc_fmap_ring(mem, C, h, w, device)
+            self.fmap2 = ops.alloc_fmap_ring(mem, C, h // 4, w // 4, device)
             planar = t(st.fmap1)
             for slot in range(mem):  # fill the rings exactly as the per-frame ingest does
                 ops.fmap_ingest(planar[slot], self.fmap1, self.fmap2, slot)
@@ -62,12 +63,11 @@ class UpdatePath:
                                layout_e2pp=True)
         out["coords"] = coords
         self.last_coords = coords
-        # patch-graph index: shared by neighbors and BA
+        # patch-graph index: shared by the correlation order, neighbors and BA
         self.graph.build(self.jj, self.kk, force=rebuild_graph)
         # 2. correlation, both levels (slam.py:316-323)
         if self.has_features:
-            out["corr"] = ops.corr_fused(self.gmap, self.fmap1, self.fmap2, coords, self.kk, self.jj, kmod=self.kmod,
-                                         jmod=self.jmod, out=self.corr_out)
+            out["corr"] = self.corr_only(coords)
         # 3. neighbors (net_cdv.py:102 -> ba.cpp:59-97)
         out["ix"], out["jx"] = self.graph.neighbors()
         # 4. bundle adjustment (slam.py:512-515)
@@ -79,7 +79,8 @@ class UpdatePath:
     def corr_only(self, coords):
         """just the fused correlation launch (dominant kernel) on the current stream"""
         return ops.corr_fused(self.gmap, self.fmap1, self.fmap2, coords, self.kk, self.jj, kmod=self.kmod,
-                              jmod=self.jmod, out=self.corr_out)
+                              jmod=self.jmod, order_ptr=self.graph.order_ptr() if self.sort_corr else None,
+                              out=self.corr_out)
 
     def stage_times(self, reps=20):
         """median microseconds per stage, each timed with HIP events on the current stream"""

@@ -66,18 +66,28 @@ int cdv_corr_fwd(const void* fmap1, const void* fmap2, const float* coords, cons
                  int radius, int dtype, void* stream);
 
 /*
- * Channel-planar [N][C][H][W] f16 -> channels-last [N][H][W][C] f16 (the HBM layout the fast
- * correlation kernel gathers from: one pixel = C contiguous halves).  `first`/`count` select a slot
- * range so a ring buffer can be refreshed one frame at a time (slam.py:679-682 writes one slot).
+ * HBM layout of the feature rings the fused correlation gathers from -- "padded channels-last":
+ *     [slot][H + 2*CDV_FMAP_PADY][W + 2*CDV_FMAP_PADX][C] f16, zero margins
+ * (one pixel = C contiguous halves; the margins make every window load in-bounds and supply the zeros of
+ * the reference's out-of-bounds rule, correlation_kernel.cu:122).  The buffer must be zero-initialised
+ * once (cdv_fmap_padded_elems() halves); the kernels below only write the interior.
+ */
+#define CDV_FMAP_PADX 16
+#define CDV_FMAP_PADY 12
+size_t cdv_fmap_padded_elems(int64_t slots, int C, int H, int W);
+
+/*
+ * Channel-planar [N][C][H][W] f16 -> padded channels-last.  `first`/`count` select a slot range so a
+ * ring buffer can be refreshed one frame at a time (slam.py:679-682 writes one slot).
  */
 int cdv_fmap_to_nhwc(const void* src_nchw, void* dst_nhwc, int64_t N, int C, int H, int W, int64_t first,
                      int64_t count, void* stream);
 
 /*
  * Per-frame ingest of one new feature frame (slam.py:681-682): fmap [C][H][W] f16 (planar) is
- * written channels-last into ring slot `slot` of fmap1_nhwc [mem][H][W][C] and its 4x4 average
- * pool into fmap2_nhwc [mem][H/4][W/4][C]; optionally also into the planar rings the reference
- * keeps (fmap1_nchw / fmap2_nchw may be NULL).
+ * written into ring slot `slot` of the padded channels-last ring fmap1_nhwc (H x W interior) and its
+ * 4x4 average pool into fmap2_nhwc (H/4 x W/4 interior); optionally also into the planar rings the
+ * reference keeps (fmap1_nchw / fmap2_nchw may be NULL).
  */
 int cdv_fmap_ingest(const void* fmap_chw, void* fmap1_nhwc, void* fmap2_nhwc, void* fmap1_nchw, void* fmap2_nchw,
                     int slot, int C, int H, int W, void* stream);
@@ -86,8 +96,8 @@ int cdv_fmap_ingest(const void* fmap_chw, void* fmap1_nhwc, void* fmap2_nhwc, vo
  * Fused multi-level correlation: SLAM.corr (slam.py:316-323) = two cuda_corr.forward calls +
  * torch.stack(..., -1).view(1, E, -1), in ONE launch on MFMA.
  *   gmap        [Ng][C][3][3] f16 planar (view of gmap_, slam.py:250-251)
- *   fmapL_nhwc  [slots][H_L][W_L][C] f16 channels-last, L = 0 .. nlev-1 ; coords are divided by
- *               scale[L] (1 and 4 in SLAM.corr)
+ *   fmapL_nhwc  padded channels-last rings (layout above) with interior H_L x W_L, L = 0 .. nlev-1 ;
+ *               coords are divided by scale[L] (1 and 4 in SLAM.corr)
  *   coords      [E][2][3][3] f32
  *   kk, jj      raw graph indices; the kernel applies ii1 = kk % kmod, jj1 = jj % jmod
  *               (slam.py:319-320; pass kmod = jmod = 0 for "no modulus")
@@ -145,6 +155,7 @@ size_t cdv_graph_workspace_bytes(int64_t E_max, int64_t k_range);
  * cuda_ba.neighbors(kk, jj).  Contents (device side, used by cdv_neighbors / cdv_ba_forward):
  *   kx [U] sorted unique patch ids, ku [E] inverse index  == torch::_unique(kk, true, true)
  *   patch CSR: for each unique patch its edges ordered by (jj, edge id)
+ *   order [E]: edge ids grouped by target frame (cdv_graph_corr_order)
  * (E_max, k_range) must be the values the workspace was sized with.  A patch-id range larger than
  * k_range sets an error word readable via cdv_graph_read_meta_host (consumers then do nothing).
  */
@@ -156,6 +167,10 @@ int cdv_graph_read_meta_host(const void* ws, int64_t* meta_host, void* stream);
 
 /* copy out torch::_unique results (kx needs U from cdv_graph_read_meta_host to size it) */
 int cdv_graph_get_unique(const void* ws, int64_t* kx, int64_t kx_capacity, int64_t* ku, int64_t E, void* stream);
+
+/* device pointer to `order` [E] int32: the edge ids grouped by target frame jj (valid until the next build);
+ * pass it to cdv_corr_fused so that every XCD's L2 only has to hold the few feature maps its edges read */
+const int32_t* cdv_graph_corr_order(const void* ws);
 
 /* cuda_ba.neighbors(kk, jj) (ba.cpp:59-97) from a built graph: ix/jx [E] int64, -1 = none */
 int cdv_neighbors(const void* ws, int64_t E, int64_t* ix, int64_t* jx, void* stream);

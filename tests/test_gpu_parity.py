@@ -143,6 +143,10 @@ def _check_graph(kk, jj, k_range):
     assert np.array_equal(jx.cpu().numpy(), jx_o)
     m = g.meta()
     assert m[0] == len(kx_o) and m[7] == len(kk)
+    # the correlation order is a permutation grouped by target frame
+    o = g.order().cpu().numpy()
+    assert np.array_equal(np.sort(o), np.arange(len(kk)))
+    assert np.all(np.diff(jj[o]) >= 0)
     # a rebuild on the same workspace (stale histogram range re-zeroed in-kernel) gives the same answer
     g.build(T(jj), T(kk), force=True)
     ix2, jx2 = g.neighbors()
@@ -225,18 +229,23 @@ def test_corr_fused_vs_oracle(name):
     st = synth.make_state(name)
     up = UpdatePath(st, torch.device(DEV))
     # the channels-last rings hold exactly the reference-layout maps
-    assert torch.equal(up.fmap1.permute(0, 3, 1, 2).cpu(), torch.as_tensor(st.fmap1))
-    f2 = up.fmap2.permute(0, 3, 1, 2).float().cpu().numpy()
+    assert torch.equal(ops.fmap_interior(up.fmap1).permute(0, 3, 1, 2).cpu(), torch.as_tensor(st.fmap1))
+    # the zero margins stay zero
+    assert float(up.fmap1.float().abs().sum()) == float(ops.fmap_interior(up.fmap1).float().abs().sum())
+    f2 = ops.fmap_interior(up.fmap2).permute(0, 3, 1, 2).float().cpu().numpy()
     assert np.abs(f2 - st.fmap2.astype(np.float32)).max() <= 2.0 ** -11 * np.abs(f2).max() + 1e-7
     coords = _gpu_coords(st)
     import ctypes
     perm = torch.randperm(st.E, device=DEV).to(torch.int32)
-    for order in (None, perm):
+    up.graph.build(up.jj, up.kk, force=True)
+    for order in (None, perm, "graph"):
+        optr = None if order is None else up.graph.order_ptr() if isinstance(order, str) else \
+            ctypes.c_void_p(order.data_ptr())
         out = ops.corr_fused(up.gmap, up.fmap1, up.fmap2, coords, up.kk, up.jj, kmod=up.kmod, jmod=up.jmod,
-                             order_ptr=None if order is None else ctypes.c_void_p(order.data_ptr()))
+                             order_ptr=optr)
         got = out[0].float().cpu().numpy()
         c = coords[0].cpu().numpy()
-        fmap2 = up.fmap2.permute(0, 3, 1, 2).contiguous().cpu().numpy()  # what the kernel actually reads
+        fmap2 = ops.fmap_interior(up.fmap2).permute(0, 3, 1, 2).contiguous().cpu().numpy()  # what the kernel reads
         truth = O.slam_corr(st.gmap, st.fmap1, fmap2, c, st.ii1, st.jj1, 3, "truth")
         assert got.shape == truth.shape == (st.E, 882)
         assert np.abs(got - truth).max() <= _corr_tol(truth)
