@@ -15,16 +15,13 @@ enum {
   GM_ERROR = 6,    // != 0: the patch-id range exceeded the workspace capacity (index contents undefined)
   GM_E = 7,
   GM_KRANGE = 8,   // kmax - kmin + 1 of the LAST successful build (0 if none): the range to re-zero
-  GM_JSORTED = 10, // 1: `order` holds the edges grouped by target frame jj; 0: identity (jj range > J_CAP)
   GM_STAGE = 16,   // [16..19] staging of min/max for the build in flight: kmin, kmax, jmin, jmax
   GM_WORDS = 64
 };
 
-constexpr int J_CAP = 4096;  // target-frame ids spanning more than this are not grouped (order = identity)
-
 struct GraphLayout {
   int64_t E_max, k_range;
-  size_t meta, kcount, kcursor, krank, koff_u, kx, ku, pcsr_tmp, pcsr, jcount, jcursor, order, total;
+  size_t meta, kcount, kcursor, krank, koff_u, kx, ku, pcsr_tmp, pcsr, total;
 };
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -43,16 +40,13 @@ static inline GraphLayout graph_layout(int64_t E_max, int64_t k_range) {
   L.ku = o;       o = align256(o + sizeof(int32_t) * (size_t)E_max);
   L.pcsr_tmp = o; o = align256(o + sizeof(int32_t) * (size_t)E_max);
   L.pcsr = o;     o = align256(o + sizeof(int32_t) * (size_t)E_max);
-  L.jcount = o;   o = align256(o + sizeof(int32_t) * (size_t)(J_CAP + 1));
-  L.jcursor = o;  o = align256(o + sizeof(int32_t) * (size_t)(J_CAP + 1));
-  L.order = o;    o = align256(o + sizeof(int32_t) * (size_t)E_max);
   L.total = o;
   return L;
 }
 
 struct GraphView {
   int32_t* meta;
-  int32_t *kcount, *kcursor, *krank, *koff_u, *ku, *pcsr_tmp, *pcsr, *jcount, *jcursor, *order;
+  int32_t *kcount, *kcursor, *krank, *koff_u, *ku, *pcsr_tmp, *pcsr;
   int64_t* kx;
 };
 
@@ -68,9 +62,6 @@ static inline GraphView graph_view(void* ws, const GraphLayout& L) {
   v.ku = (int32_t*)(b + L.ku);
   v.pcsr_tmp = (int32_t*)(b + L.pcsr_tmp);
   v.pcsr = (int32_t*)(b + L.pcsr);
-  v.jcount = (int32_t*)(b + L.jcount);
-  v.jcursor = (int32_t*)(b + L.jcursor);
-  v.order = (int32_t*)(b + L.order);
   return v;
 }
 

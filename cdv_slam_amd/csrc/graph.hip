@@ -7,9 +7,9 @@
 //   kx [U]   sorted unique patch ids           ku [E] inverse index
 //   patch CSR (koff_u [U+1], pcsr [E]): the edges of every unique patch ordered by (jj, edge id),
 //   i.e. the order std::stable_sort by jj gives on an ascending index list.
-// plus `order` [E]: the edge ids grouped by target frame jj (order inside a group unspecified) -- the
-// processing order of the fused correlation kernel, which gives every XCD a contiguous eighth of it so
-// that an XCD's L2 only has to hold the 3-4 feature maps its edges read.
+// (An edge order grouped by target frame was tried as the correlation kernel's processing order, with and
+// without giving every XCD a contiguous share: no measurable gain -- that kernel is not bound by L2 misses --
+// so it is not built.)
 //
 // Pipeline, 5 small launches, no host sync:
 //   1 minmax+clear : min/max of kk, jj (one atomic per block) and re-zeroing of the histogram range the
@@ -54,17 +54,12 @@ __global__ __launch_bounds__(256) void graph_init_kernel(int32_t* meta, int32_t*
 
 __global__ __launch_bounds__(256) void graph_minmax_clear_kernel(const int64_t* __restrict__ jj,
                                                                  const int64_t* __restrict__ kk, int32_t E,
-                                                                 int32_t* meta, int32_t* kcount, int32_t* kcursor,
-                                                                 int32_t* jcount, int32_t* jcursor) {
+                                                                 int32_t* meta, int32_t* kcount, int32_t* kcursor) {
   // re-zero what the previous build left in the histogram / cursor arrays
   const int old = meta[GM_KRANGE];
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t <= old; t += gridDim.x * blockDim.x) {
     kcount[t] = 0;
     kcursor[t] = 0;
-  }
-  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t <= J_CAP; t += gridDim.x * blockDim.x) {
-    jcount[t] = 0;
-    jcursor[t] = 0;
   }
   int kmin = IMAX, kmax = IMIN, jmin = IMAX, jmax = IMIN;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) {
@@ -93,35 +88,19 @@ __global__ __launch_bounds__(256) void graph_minmax_clear_kernel(const int64_t* 
   }
 }
 
-__global__ __launch_bounds__(1024) void graph_hist_kernel(const int64_t* __restrict__ jj,
-                                                          const int64_t* __restrict__ kk, int32_t E,
-                                                          const int32_t* __restrict__ meta, int32_t* kcount,
-                                                          int32_t* jcount, int64_t k_cap) {
+__global__ __launch_bounds__(256) void graph_hist_kernel(const int64_t* __restrict__ kk, int32_t E,
+                                                         const int32_t* __restrict__ meta, int32_t* kcount,
+                                                         int64_t k_cap) {
   const int kmin = meta[GM_STAGE + 0], kmax = meta[GM_STAGE + 1];
   if (kmin < 0 || (int64_t)kmax - kmin + 1 > k_cap) return;  // reported by the scan kernel
-  // target-frame histogram: few bins, thousands of edges each -> aggregate per workgroup in LDS first
-  __shared__ int32_t s_j[J_CAP];
-  const int jmin = meta[GM_STAGE + 2], jrange = meta[GM_STAGE + 3] - jmin + 1;
-  const bool jsort = jrange <= J_CAP;
-  if (jsort) {
-    for (int t = threadIdx.x; t < jrange; t += blockDim.x) s_j[t] = 0;
-    __syncthreads();
-  }
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) {
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x)
     atomicAdd(&kcount[(int)kk[e] - kmin], 1);
-    if (jsort) atomicAdd(&s_j[(int)jj[e] - jmin], 1);
-  }
-  if (jsort) {
-    __syncthreads();
-    for (int t = threadIdx.x; t < jrange; t += blockDim.x)
-      if (s_j[t]) atomicAdd(&jcount[t], s_j[t]);
-  }
 }
 
 // One workgroup of 1024 threads: publish meta, exclusive scan of the histogram in place
 // (kcount -> dense CSR offsets), krank[d] = number of non-empty bins before d.
 __global__ __launch_bounds__(1024) void graph_scan_kernel(int32_t* meta, int32_t* kcount, int32_t* krank,
-                                                          int32_t* jcount, int32_t E, int64_t k_cap) {
+                                                          int32_t E, int64_t k_cap) {
   __shared__ int32_t s_sum[1024];
   __shared__ int32_t s_cnt[1024];
   const int T = blockDim.x, t = threadIdx.x;
@@ -137,32 +116,9 @@ __global__ __launch_bounds__(1024) void graph_scan_kernel(int32_t* meta, int32_t
     meta[GM_E] = E;
     meta[GM_ERROR] = bad ? 1 : 0;
     meta[GM_KRANGE] = bad ? 0 : (int32_t)krange;  // hist was skipped when bad: the arrays are still zero
-    meta[GM_JSORTED] = (!bad && E > 0 && (int64_t)jmax - jmin + 1 <= J_CAP) ? 1 : 0;
     if (bad || E == 0) meta[GM_U] = 0;
   }
   if (bad || E == 0) return;
-  // target-frame offsets: jrange <= 4096 bins, 4 per thread, same Hillis-Steele pass
-  {
-    const int jrange = jmax - jmin + 1;
-    if (jrange <= J_CAP) {
-      int32_t v4[4], s4 = 0;
-#pragma unroll
-      for (int i = 0; i < 4; i++) { const int d = 4 * t + i; v4[i] = d < jrange ? jcount[d] : 0; s4 += v4[i]; }
-      s_sum[t] = s4;
-      __syncthreads();
-      for (int o = 1; o < T; o <<= 1) {
-        int32_t a1 = 0;
-        if (t >= o) a1 = s_sum[t - o];
-        __syncthreads();
-        s_sum[t] += a1;
-        __syncthreads();
-      }
-      int32_t run = s_sum[t] - s4;
-#pragma unroll
-      for (int i = 0; i < 4; i++) { const int d = 4 * t + i; if (d < jrange) jcount[d] = run; run += v4[i]; }
-      __syncthreads();
-    }
-  }
   const int64_t n = krange;
   const int64_t per = (n + T - 1) / T;
   const int64_t lo = min((int64_t)t * per, n), hi = min(lo + per, n);
@@ -187,45 +143,15 @@ __global__ __launch_bounds__(1024) void graph_scan_kernel(int32_t* meta, int32_t
   if (t == T - 1) { kcount[n] = s_sum[t]; meta[GM_U] = s_cnt[t]; }
 }
 
-__global__ __launch_bounds__(1024) void graph_fill_kernel(const int64_t* __restrict__ jj,
-                                                          const int64_t* __restrict__ kk, int32_t E,
-                                                          const int32_t* __restrict__ meta,
-                                                          const int32_t* __restrict__ kcount, int32_t* kcursor,
-                                                          const int32_t* __restrict__ krank,
-                                                          int32_t* __restrict__ koff_u, int64_t* __restrict__ kx,
-                                                          int32_t* __restrict__ ku, int32_t* __restrict__ pcsr_tmp,
-                                                          const int32_t* __restrict__ jcount, int32_t* jcursor,
-                                                          int32_t* __restrict__ order) {
+__global__ __launch_bounds__(256) void graph_fill_kernel(const int64_t* __restrict__ kk, int32_t E,
+                                                         const int32_t* __restrict__ meta,
+                                                         const int32_t* __restrict__ kcount, int32_t* kcursor,
+                                                         const int32_t* __restrict__ krank,
+                                                         int32_t* __restrict__ koff_u, int64_t* __restrict__ kx,
+                                                         int32_t* __restrict__ ku, int32_t* __restrict__ pcsr_tmp) {
   if (meta[GM_ERROR]) return;
   const int krange = meta[GM_KRANGE], kmin = meta[GM_KMIN];
   const int n = max(E, krange + 1);
-  // ---- `order`: edges grouped by target frame.  Every workgroup owns a contiguous slice of edges, counts
-  //      its bins in LDS, reserves one range per bin with ONE global atomic, then ranks inside the range.
-  {
-    __shared__ int32_t s_cnt[J_CAP];
-    __shared__ int32_t s_base[J_CAP];
-    const int jmin = meta[GM_JMIN], jrange = meta[GM_JMAX] - jmin + 1;
-    const int per = (E + gridDim.x - 1) / gridDim.x;
-    const int lo = blockIdx.x * per, hi = min(lo + per, E);
-    if (meta[GM_JSORTED]) {
-      for (int t = threadIdx.x; t < jrange; t += blockDim.x) s_cnt[t] = 0;
-      __syncthreads();
-      for (int e = lo + threadIdx.x; e < hi; e += blockDim.x) atomicAdd(&s_cnt[(int)jj[e] - jmin], 1);
-      __syncthreads();
-      for (int t = threadIdx.x; t < jrange; t += blockDim.x) {
-        const int c = s_cnt[t];
-        s_base[t] = c ? jcount[t] + atomicAdd(&jcursor[t], c) : 0;
-        s_cnt[t] = 0;
-      }
-      __syncthreads();
-      for (int e = lo + threadIdx.x; e < hi; e += blockDim.x) {
-        const int b = (int)jj[e] - jmin;
-        order[s_base[b] + atomicAdd(&s_cnt[b], 1)] = e;
-      }
-    } else {
-      for (int e = lo + threadIdx.x; e < hi; e += blockDim.x) order[e] = e;
-    }
-  }
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
     if (t <= krange) {  // dense bins -> unique ranks
       if (t == krange) {
@@ -345,16 +271,13 @@ extern "C" int cdv_graph_build(const int64_t* jj, const int64_t* kk, int64_t E, 
                        v.kcursor, k_range);
   // ~47 blocks for E = 47,712: few enough that one min/max atomic per block is free, enough to stream kk/jj
   const int eb = grid_for(E, 1024, 256);
-  hipLaunchKernelGGL(graph_minmax_clear_kernel, dim3(eb), dim3(tb), 0, s, jj, kk, En, v.meta, v.kcount, v.kcursor,
-                     v.jcount, v.jcursor);
+  hipLaunchKernelGGL(graph_minmax_clear_kernel, dim3(eb), dim3(tb), 0, s, jj, kk, En, v.meta, v.kcount, v.kcursor);
   const int fb = grid_for(E, tb, 1024);
-  const int hb = grid_for(E, 1024, 256);
-  if (E > 0)
-    hipLaunchKernelGGL(graph_hist_kernel, dim3(hb), dim3(1024), 0, s, jj, kk, En, v.meta, v.kcount, v.jcount, k_range);
-  hipLaunchKernelGGL(graph_scan_kernel, dim3(1), dim3(1024), 0, s, v.meta, v.kcount, v.krank, v.jcount, En, k_range);
+  if (E > 0) hipLaunchKernelGGL(graph_hist_kernel, dim3(fb), dim3(tb), 0, s, kk, En, v.meta, v.kcount, k_range);
+  hipLaunchKernelGGL(graph_scan_kernel, dim3(1), dim3(1024), 0, s, v.meta, v.kcount, v.krank, En, k_range);
   if (E > 0) {
-    hipLaunchKernelGGL(graph_fill_kernel, dim3(hb), dim3(1024), 0, s, jj, kk, En, v.meta, v.kcount, v.kcursor,
-                       v.krank, v.koff_u, v.kx, v.ku, v.pcsr_tmp, v.jcount, v.jcursor, v.order);
+    hipLaunchKernelGGL(graph_fill_kernel, dim3(fb), dim3(tb), 0, s, kk, En, v.meta, v.kcount, v.kcursor, v.krank,
+                       v.koff_u, v.kx, v.ku, v.pcsr_tmp);
     hipLaunchKernelGGL(graph_segsort_kernel, dim3(fb), dim3(tb), 0, s, jj, kk, En, v.meta, v.kcount, v.pcsr_tmp,
                        v.pcsr);
   }
@@ -384,12 +307,6 @@ extern "C" int cdv_graph_get_unique(const void* ws, int64_t* kx, int64_t kx_capa
                      v.kx, v.ku, kx, kx_capacity, ku, (int32_t)E);
   CDV_LAUNCH_CHECK();
   return CDV_OK;
-}
-
-extern "C" const int32_t* cdv_graph_corr_order(const void* ws) {
-  GraphLayout L;
-  if (!cdv_graph_lookup(ws, &L)) return nullptr;
-  return graph_view((void*)ws, L).order;
 }
 
 extern "C" int cdv_neighbors(const void* ws, int64_t E, int64_t* ix, int64_t* jx, void* stream) {

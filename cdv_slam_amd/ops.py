@@ -117,16 +117,6 @@ class GraphIndex:
         return kx, ku
 
 
-    def order_ptr(self):
-        """device pointer of the target-frame-grouped edge order (processing order for corr_fused)"""
-        return ctypes.c_void_p(self.lib.cdv_graph_corr_order(_p(self.ws)))
-
-    def order(self):
-        """[E] int32 view of that order inside the workspace"""
-        off = self.lib.cdv_graph_corr_order(_p(self.ws)) - self.ws.data_ptr()
-        return self.ws[off:off + 4 * self.E].view(torch.int32)
-
-
 _graphs = {}
 
 

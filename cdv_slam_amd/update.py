@@ -15,7 +15,7 @@ from . import ops
 
 
 class UpdatePath:
-    def __init__(self, st, device, sort_corr=True):
+    def __init__(self, st, device):
         """st: synth.SynthState (numpy).  Uploads the state once; step() then runs entirely on device."""
         self.cfg = st.cfg
         self.dev = device
@@ -29,7 +29,6 @@ class UpdatePath:
         self.t0, self.n = st.t0, st.n
         self.M = st.cfg.M
         self.E = st.E
-        self.sort_corr = sort_corr   # walk the edges grouped by target frame (XCD / L2 locality)
         self._poses0, self._patches0 = self.poses.clone(), self.patches.clone()
         self.graph = ops.GraphIndex(device, E_cap=self.E, k_range=st.cfg.buffer_size * st.cfg.M)
         self.U_max = min(self.E, (st.cfg.removal_window + 2) * st.cfg.M) if not st.cfg.fully_connected \
@@ -63,7 +62,7 @@ class UpdatePath:
                                layout_e2pp=True)
         out["coords"] = coords
         self.last_coords = coords
-        # patch-graph index: shared by the correlation order, neighbors and BA
+        # patch-graph index: shared by neighbors and BA
         self.graph.build(self.jj, self.kk, force=rebuild_graph)
         # 2. correlation, both levels (slam.py:316-323)
         if self.has_features:
@@ -79,8 +78,7 @@ class UpdatePath:
     def corr_only(self, coords):
         """just the fused correlation launch (dominant kernel) on the current stream"""
         return ops.corr_fused(self.gmap, self.fmap1, self.fmap2, coords, self.kk, self.jj, kmod=self.kmod,
-                              jmod=self.jmod, order_ptr=self.graph.order_ptr() if self.sort_corr else None,
-                              out=self.corr_out)
+                              jmod=self.jmod, out=self.corr_out)
 
     def stage_times(self, reps=20):
         """median microseconds per stage, each timed with HIP events on the current stream"""

@@ -155,7 +155,6 @@ size_t cdv_graph_workspace_bytes(int64_t E_max, int64_t k_range);
  * cuda_ba.neighbors(kk, jj).  Contents (device side, used by cdv_neighbors / cdv_ba_forward):
  *   kx [U] sorted unique patch ids, ku [E] inverse index  == torch::_unique(kk, true, true)
  *   patch CSR: for each unique patch its edges ordered by (jj, edge id)
- *   order [E]: edge ids grouped by target frame (cdv_graph_corr_order)
  * (E_max, k_range) must be the values the workspace was sized with.  A patch-id range larger than
  * k_range sets an error word readable via cdv_graph_read_meta_host (consumers then do nothing).
  */
@@ -167,10 +166,6 @@ int cdv_graph_read_meta_host(const void* ws, int64_t* meta_host, void* stream);
 
 /* copy out torch::_unique results (kx needs U from cdv_graph_read_meta_host to size it) */
 int cdv_graph_get_unique(const void* ws, int64_t* kx, int64_t kx_capacity, int64_t* ku, int64_t E, void* stream);
-
-/* device pointer to `order` [E] int32: the edge ids grouped by target frame jj (valid until the next build);
- * pass it to cdv_corr_fused so that every XCD's L2 only has to hold the few feature maps its edges read */
-const int32_t* cdv_graph_corr_order(const void* ws);
 
 /* cuda_ba.neighbors(kk, jj) (ba.cpp:59-97) from a built graph: ix/jx [E] int64, -1 = none */
 int cdv_neighbors(const void* ws, int64_t E, int64_t* ix, int64_t* jx, void* stream);
@@ -190,7 +185,9 @@ size_t cdv_ba_workspace_bytes(int64_t E_max, int64_t U_max, int N_max);
  *   target/weight [E][2] f32, lmbda: DEVICE pointer to 1 float, ii/jj/kk [E] int64.
  *   graph_ws: a workspace on which cdv_graph_build(jj, kk, E) has been enqueued on `stream`.
  *   ba_ws / U_max: workspace of cdv_ba_workspace_bytes(E, U_max, N) bytes; U_max bounds the number of
- *             unique patches (exceeding it sets info word 1 and skips the update).
+ *             unique patches (exceeding it sets info word 1 and skips the update).  The library zeroes
+ *             the accumulators inside it the first time it sees (ba_ws, U_max, N) and keeps them zero
+ *             between calls; do not write into it.
  *   dbg (optional, NULL): receives iteration-0 values, with n = 6N and Us = round_up(U_max, 64):
  *             [S n*n (damped) | y n | dX n | dZ Us | C Us | u Us | E n*Us]
  * Supports N = t1 - t0 <= 32 (single-workgroup LDS Cholesky).

@@ -6,7 +6,7 @@ from cdv_slam_amd import synth
 from cdv_slam_amd.update import UpdatePath
 dev = torch.device("cuda:0")
 st = synth.make_state(sys.argv[1] if len(sys.argv) > 1 else "default")
-up = UpdatePath(st, dev, sort_corr=os.environ.get("CDV_SORT", "1") == "1")
+up = UpdatePath(st, dev)
 coords = up.step()["coords"]
 ts = []
 for _ in range(40):

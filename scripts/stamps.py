@@ -34,10 +34,10 @@ b = buf_b.cpu().numpy().astype(np.float64)
 asm = b[:4096]
 asm = asm[asm[:, 0] > 0]
 print("assemble: waves %d" % len(asm))
-for i, nme in enumerate(["zero-init+sync", "slot loop", "flush+sync", "q/E-write+sync", "schur"]):
+for i, nme in enumerate(["(unused)", "slot"]):
     print("  %-22s %8.0f" % (nme, np.median(asm[:, i + 1] - asm[:, i])))
-print("  edge math (sum)        %8.0f   gram (sum) %8.0f" % (np.median(asm[:, 6]), np.median(asm[:, 7])))
-print("  kernel span %.0f" % (asm[:, 5].max() - asm[:, 0].min()))
+pass
+print("  assemble wave total %.0f" % np.median(asm[:, 2] - asm[:, 0]))
 sol = b[4096:4100]
 for i, nme in enumerate(["load replicas", "factor loop", "back-subst", "write+retr"]):
     print("solve %-22s %8.0f" % (nme, np.median(sol[:, i + 1] - sol[:, i])))
