@@ -79,6 +79,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="default", help="synthetic workload (default | stress | init | pr1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch the ~20 kernels of a step one by one instead of "
+                    "replaying a captured hipGraph")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     args = ap.parse_args()
 
@@ -110,12 +112,16 @@ def main():
             dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
+    use_graph = not args.no_graph
+    if use_graph:
+        up.capture()
+    run_step = up.step_graph if use_graph else up.step
     for _ in range(args.warmup):
-        up.step()
+        run_step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        up.step()
+        run_step()
     barrier()
     elapsed = time.perf_counter() - t0
 
@@ -180,6 +186,7 @@ def main():
                             "2-level corr+neighbors+BA(2 it); one independent sequence per GPU"
                             % (st.cfg.name, st.cfg.M, st.cfg.opt_window, st.E, st.n - st.t0),
                 "edges": st.E, "patches_per_frame": st.cfg.M, "window": st.cfg.opt_window,
+                "launch": "hipGraph replay" if use_graph else "eager launches",
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -213,6 +213,7 @@ __global__ __launch_bounds__(ASM_THREADS) void ba_assemble_kernel(
   float* y = S + (size_t)n6 * n6;
   CDV_IF_STAMPS(const int sslot = blockIdx.x * ASM_WAVES + wave;)
   CDV_STAMP(ba, sslot, 0);
+  CDV_STAMP_RT(ba, sslot, 8);
   extern __shared__ float smem[];
   float* X = smem + (size_t)wave * PAIR_LDS_FLOATS;    // per wave [128][XLD]
   int* keys = reinterpret_cast<int*>(X + 128 * XLD);   // per wave [64]
@@ -259,6 +260,7 @@ __global__ __launch_bounds__(ASM_THREADS) void ba_assemble_kernel(
         for (int c = 0; c < 6; c++) atomicAdd(&Edg[(size_t)(6 * jxf + c) * U_stride + r], ej[c]);
       }
     }
+    CDV_STAMP(ba, sslot, 3);
     if (N > 0) {
       // ---- B and v of this wave's frame pair(s): Gram matrix on the matrix cores --------------------
       const int key = (ixf + 1) * (N + 1) + (jxf + 1);
@@ -277,8 +279,11 @@ __global__ __launch_bounds__(ASM_THREADS) void ba_assemble_kernel(
         xr[15] = active ? J.w[row] : 0.f;
       }
       wave_lds_sync();
+      CDV_STAMP(ba, sslot, 4);
       unsigned long long todo = __ballot(active && key != 0);
+      CDV_IF_STAMPS(unsigned long long npass = 0;)
       while (todo) {
+        CDV_IF_STAMPS(npass++;)
         const int leader = __ffsll((long long)todo) - 1;
         const int kcur = __shfl(key, leader);
         const int ci = __shfl(ixf, leader), cj = __shfl(jxf, leader);
@@ -298,6 +303,8 @@ __global__ __launch_bounds__(ASM_THREADS) void ba_assemble_kernel(
         for (int q = 0; q < 4; q++) pair_emit(acc0[q] + acc1[q], 4 * g4 + q, c16, ci, cj, n6, S, y);
         todo &= ~__ballot(active && key == kcur);
       }
+      CDV_STAMP(ba, sslot, 5);
+      CDV_STAMP_VAL(ba, sslot, 6, npass);
       wave_lds_sync();  // the next slot overwrites X
     }
   }
@@ -306,6 +313,7 @@ __global__ __launch_bounds__(ASM_THREADS) void ba_assemble_kernel(
     atomicAdd(&ug[r], uacc);
   }
   CDV_STAMP(ba, sslot, 2);
+  CDV_STAMP_RT(ba, sslot, 9);
 }
 
 // Schur products of one chunk of 64 patches, after E, C, u are complete in global memory:
@@ -675,10 +683,13 @@ extern "C" int cdv_ba_forward(float* poses, float* patches, const float* intrins
   static std::once_flag attr_once;
   static hipError_t attr_err = hipSuccess;
   std::call_once(attr_once, [] {
-    const int cap = 160 * 1024;
-    hipError_t e1 = hipFuncSetAttribute((const void*)ba_assemble_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-    hipError_t e2 = hipFuncSetAttribute((const void*)ba_schur_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-    hipError_t e3 = hipFuncSetAttribute((const void*)ba_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+    // worst cases at N = 32: assemble 71 KB (fixed), schur 53 KB, solve 155 KB (+ a few static bytes)
+    hipError_t e1 = hipFuncSetAttribute((const void*)ba_assemble_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        96 * 1024);
+    hipError_t e2 = hipFuncSetAttribute((const void*)ba_schur_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        64 * 1024);
+    hipError_t e3 = hipFuncSetAttribute((const void*)ba_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        158 * 1024);
     attr_err = e1 != hipSuccess ? e1 : e2 != hipSuccess ? e2 : e3;
   });
   CDV_HIP_CHECK(attr_err);

@@ -57,6 +57,11 @@ __device__ __forceinline__ unsigned long long cdv_now() {
     const unsigned long long _t = cdv_now();                                                    \
     if (g_stamps_##name && (threadIdx.x & 63) == 0) g_stamps_##name[(size_t)(slot) * 16 + (id)] = _t; \
   } while (0)
+#define CDV_STAMP_RT(name, slot, id)                                                            \
+  do {                                                                                          \
+    const unsigned long long _t = __builtin_amdgcn_s_memrealtime();                             \
+    if (g_stamps_##name && (threadIdx.x & 63) == 0) g_stamps_##name[(size_t)(slot) * 16 + (id)] = _t; \
+  } while (0)
 #define CDV_STAMP_VAL(name, slot, id, val)                                                      \
   do {                                                                                          \
     if (g_stamps_##name && (threadIdx.x & 63) == 0) g_stamps_##name[(size_t)(slot) * 16 + (id)] = (val); \
@@ -66,5 +71,6 @@ __device__ __forceinline__ unsigned long long cdv_now() {
 #define CDV_STAMP_TU(name)
 #define CDV_STAMP(name, slot, id) do { } while (0)
 #define CDV_STAMP_VAL(name, slot, id, val) do { } while (0)
+#define CDV_STAMP_RT(name, slot, id) do { } while (0)
 #define CDV_IF_STAMPS(...)
 #endif

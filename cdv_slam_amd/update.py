@@ -52,6 +52,23 @@ class UpdatePath:
         self.poses.copy_(self._poses0)
         self.patches.copy_(self._patches0)
 
+    # -- hipGraph replay of the whole update ----------------------------------------------------------
+    def capture(self, warmup=3):
+        """Capture one step() -- ~20 dependent launches, all on one stream, no host sync, fixed buffers --
+        into a hipGraph (torch.cuda.CUDAGraph).  step_graph() then replays it with one host call."""
+        for _ in range(warmup):
+            self.step()
+        torch.cuda.synchronize()
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._graph_out = self.step()
+        torch.cuda.synchronize()
+        return self
+
+    def step_graph(self):
+        self._graph.replay()
+        return self._graph_out
+
     def step(self, ingest=True, rebuild_graph=True, iterations=2):
         """One update.  Everything is enqueued on the current stream; no host synchronisation."""
         out = {}

@@ -38,7 +38,33 @@ for i, nme in enumerate(["(unused)", "slot"]):
     print("  %-22s %8.0f" % (nme, np.median(asm[:, i + 1] - asm[:, i])))
 pass
 print("  assemble wave total %.0f" % np.median(asm[:, 2] - asm[:, 0]))
+rt = asm[:, 8:10] / 100.0  # s_memrealtime is 100 MHz -> microseconds
+print("  assemble realtime: first start 0, last start %.1f us, first end %.1f, last end %.1f; median wave span %.1f us" % (rt[:, 0].max() - rt[:, 0].min(), rt[:, 1].min() - rt[:, 0].min(), rt[:, 1].max() - rt[:, 0].min(), np.median(rt[:, 1] - rt[:, 0])))
 sol = b[4096:4100]
 for i, nme in enumerate(["load replicas", "factor loop", "back-subst", "write+retr"]):
     print("solve %-22s %8.0f" % (nme, np.median(sol[:, i + 1] - sol[:, i])))
 print("solve panel(sum) %8.0f trailing(sum) %8.0f" % (np.median(sol[:, 5]), np.median(sol[:, 6])))
+span = rt[:, 1] - rt[:, 0]
+order = np.argsort(-span)[:12]
+ids = np.nonzero(b[:4096, 0] > 0)[0]
+print("slowest assemble waves (slot -> chunk, sg, wave : span us):")
+for o in order:
+    sl = ids[o]
+    print("   ", sl, "->", sl // 8 // 4, (sl // 8) % 4, sl % 8, ": %.1f" % span[o])
+print("span percentiles", np.percentile(span, [50, 90, 99, 100]))
+cyc = asm[:, 2] - asm[:, 0]
+print("cycles of the slowest:", cyc[order][:6], " realtime start offsets:", (rt[order, 0] - rt[:, 0].min())[:6])
+# histogram of spans by slot group
+sgs = (ids // 8) % 4
+for g in range(4):
+    print("  sg", g, "median span %.1f max %.1f" % (np.median(span[sgs == g]), span[sgs == g].max()))
+chs = ids // 32
+slow = np.unique(chs[span > 10])
+print("chunks with slow waves:", slow)
+
+ph = np.stack([asm[:, 3] - asm[:, 0], asm[:, 4] - asm[:, 3], asm[:, 5] - asm[:, 4], asm[:, 2] - asm[:, 5]], 1)
+print("slow waves phases [edge+E atomics, X write, gram+emit, tail] and passes:")
+for o in order[:6]:
+    print("   ", ph[o], asm[o, 6])
+fast = np.argsort(span)[len(span) // 2]
+print("median wave phases:", ph[fast], asm[fast, 6])
