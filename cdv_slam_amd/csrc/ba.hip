@@ -39,13 +39,16 @@ constexpr int BA_NMAX = 32;       // free poses supported by the single-workgrou
 constexpr int XLD = 17;           // floats per residual row in the Gram staging buffer (16 + 1 pad)
 constexpr int PAIR_LDS_FLOATS = 128 * XLD + 64;  // per wave: [128][XLD] rows + 64 per-edge pair keys
 constexpr int ELD = BA_CHUNK + 4; // row stride of the chunk's E block in LDS (2-way bank conflicts at most)
-constexpr int ASM_WAVES = 8;      // waves per assemble workgroup, one target slot each
-constexpr int ASM_SG = 4;         // slot groups (workgroups) per chunk of 64 patches: 32 slots per pass
+constexpr int ASM_WAVES = 1;      // waves per assemble workgroup, one target slot each (the waves are independent;
+                                  // single-wave workgroups spread the atomics of the busy chunks over all CUs)
+constexpr int ASM_SG = 32;        // slot groups (workgroups) per chunk of 64 patches: 32 slots per pass
 constexpr int ASM_THREADS = 64 * ASM_WAVES;
+constexpr int BA_REPL = 4;        // copies of [S | y] the assemble / schur workgroups spread their atomics over
+                                  // (the memory-side atomic units serialise adds to one address); summed by the solve
 
 struct BaLayout {
   size_t sy, C, u, Ed, zero_bytes, q, dX, info, total;
-  int64_t U_max, U_stride;
+  int64_t U_max, U_stride, sy_stride;   // sy_stride: floats between two copies of [S | y]
   int N_max;
 };
 
@@ -56,7 +59,8 @@ inline BaLayout ba_layout(int64_t U_max, int N_max) {
   const size_t n6 = 6 * (size_t)N_max;
   size_t o = 0;
   // accumulators: zeroed once, then kept zero by their consumers
-  L.sy = o;   o = align256(o + sizeof(float) * (n6 * n6 + n6));
+  L.sy_stride = (int64_t)((n6 * n6 + n6 + 1023) / 1024 * 1024);   // 4 KB multiples: copies start on different channels
+  L.sy = o;   o = align256(o + sizeof(float) * (size_t)L.sy_stride * BA_REPL);
   L.C = o;    o = align256(o + sizeof(float) * (size_t)L.U_stride);
   L.u = o;    o = align256(o + sizeof(float) * (size_t)L.U_stride);
   L.Ed = o;   o = align256(o + sizeof(float) * n6 * (size_t)L.U_stride);
@@ -161,10 +165,12 @@ __device__ __forceinline__ void ba_edge(const EdgeIn& in, float fx, float fy, fl
   fb_adjSE3(tij, qij, o.Jj + 6, o.Ji + 6);
 }
 
+// LDS hand-off between the lanes of ONE wave: the LDS unit executes a wave's DS instructions in order, so only the
+// compiler has to be kept from moving accesses across this point.  (A workgroup-scope release fence would also drain
+// vmcnt, i.e. wait for the wave's outstanding global atomics: ~3000 cycles each time.)
 __device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
 // one entry (row, col) of the 13x13 Gram matrix G = sum_k w_k X[k] X[k]^T, X[k] = [Ji | Jj | r]
@@ -192,8 +198,8 @@ __global__ __launch_bounds__(ASM_THREADS) void ba_assemble_kernel(
     const float* __restrict__ target, const float* __restrict__ weight, const int64_t* __restrict__ ii,
     const int64_t* __restrict__ jj, const int64_t* __restrict__ kk, int P, int t0, int N,
     const int32_t* __restrict__ gmeta, const int32_t* __restrict__ pcsr, const int32_t* __restrict__ koff_u,
-    float* __restrict__ sy, float* __restrict__ Cg, float* __restrict__ ug, float* __restrict__ Edg, int U_stride,
-    int U_max, int32_t* __restrict__ info) {
+    float* __restrict__ sy, int sy_stride, float* __restrict__ Cg, float* __restrict__ ug, float* __restrict__ Edg,
+    int U_stride, int U_max, int32_t* __restrict__ info) {
   if (gmeta[GM_ERROR]) return;
   const int U = gmeta[GM_U];
   if (U > U_max) {
@@ -209,7 +215,7 @@ __global__ __launch_bounds__(ASM_THREADS) void ba_assemble_kernel(
   const int centre = (P > 1) ? (P + 1) : 0;
   const float fx = intr[0], fy = intr[1], cx = intr[2], cy = intr[3];  // ba_cuda.cu:253-259
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float* S = sy;
+  float* S = sy + (size_t)(blockIdx.x % BA_REPL) * sy_stride;
   float* y = S + (size_t)n6 * n6;
   CDV_IF_STAMPS(const int sslot = blockIdx.x * ASM_WAVES + wave;)
   CDV_STAMP(ba, sslot, 0);
@@ -281,30 +287,48 @@ __global__ __launch_bounds__(ASM_THREADS) void ba_assemble_kernel(
       wave_lds_sync();
       CDV_STAMP(ba, sslot, 4);
       unsigned long long todo = __ballot(active && key != 0);
-      CDV_IF_STAMPS(unsigned long long npass = 0;)
-      while (todo) {
-        CDV_IF_STAMPS(npass++;)
-        const int leader = __ffsll((long long)todo) - 1;
-        const int kcur = __shfl(key, leader);
-        const int ci = __shfl(ixf, leader), cj = __shfl(jxf, leader);
-        // two accumulators: consecutive f32 MFMAs do not wait on each other's result
-        cdv_float4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 8
-        for (int st = 0; st < 32; st += 2) {
-          const int k0 = 4 * st + g4, k1 = k0 + 4;
-          const float a0 = X[k0 * XLD + c16], a1 = X[k1 * XLD + c16];
-          const float w0 = (keys[k0 >> 1] == kcur) ? X[k0 * XLD + 15] : 0.f;
-          const float w1 = (keys[k1 >> 1] == kcur) ? X[k1 * XLD + 15] : 0.f;
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, w0 * a0, acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, w1 * a1, acc1, 0, 0, 0);
-        }
-        // D layout: col = lane & 15, row = 4 * (lane >> 4) + reg
+      CDV_IF_STAMPS(unsigned long long npass = 0, t_rd = 0, t_mf = 0, t_em = 0, t_x;)
+      if (todo) {
+        CDV_IF_STAMPS(t_x = cdv_now();)
+        // this lane's MFMA operands of all 32 k-steps, read once (unconditional, batched LDS reads): column c16 of
+        // row k = 4 st + g4, with the row's weight and its edge's pair key
+        float xa[32], xw[32];
+        int xk[32];
 #pragma unroll
-        for (int q = 0; q < 4; q++) pair_emit(acc0[q] + acc1[q], 4 * g4 + q, c16, ci, cj, n6, S, y);
-        todo &= ~__ballot(active && key == kcur);
+        for (int st = 0; st < 32; st++) {
+          const int k = 4 * st + g4;
+          xa[st] = X[k * XLD + c16];
+          xw[st] = X[k * XLD + 15];
+          xk[st] = keys[k >> 1];
+        }
+        CDV_IF_STAMPS(asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t_rd = cdv_now() - t_x;)
+        while (todo) {
+          CDV_IF_STAMPS(npass++; t_x = cdv_now();)
+          const int leader = __ffsll((long long)todo) - 1;
+          const int kcur = __shfl(key, leader);
+          const int ci = __shfl(ixf, leader), cj = __shfl(jxf, leader);
+          // two accumulators: consecutive f32 MFMAs do not wait on each other's result
+          cdv_float4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int st = 0; st < 32; st += 2) {
+            const float w0 = (xk[st] == kcur) ? xw[st] : 0.f;
+            const float w1 = (xk[st + 1] == kcur) ? xw[st + 1] : 0.f;
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[st], w0 * xa[st], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[st + 1], w1 * xa[st + 1], acc1, 0, 0, 0);
+          }
+          CDV_IF_STAMPS(asm volatile("v_nop" :: "v"(acc0[0] + acc1[0])); t_mf += cdv_now() - t_x; t_x = cdv_now();)
+          // D layout: col = lane & 15, row = 4 * (lane >> 4) + reg
+#pragma unroll
+          for (int q = 0; q < 4; q++) pair_emit(acc0[q] + acc1[q], 4 * g4 + q, c16, ci, cj, n6, S, y);
+          CDV_IF_STAMPS(t_em += cdv_now() - t_x;)
+          todo &= ~__ballot(active && key == kcur);
+        }
       }
       CDV_STAMP(ba, sslot, 5);
       CDV_STAMP_VAL(ba, sslot, 6, npass);
+      CDV_STAMP_VAL(ba, sslot, 10, t_rd);
+      CDV_STAMP_VAL(ba, sslot, 11, t_mf);
+      CDV_STAMP_VAL(ba, sslot, 12, t_em);
       wave_lds_sync();  // the next slot overwrites X
     }
   }
@@ -321,7 +345,8 @@ __global__ __launch_bounds__(ASM_THREADS) void ba_assemble_kernel(
 // as [Ed; u] diag(q) [Ed; u]^T on the matrix cores (K = 64 patches, v_mfma_f32_16x16x4_f32).
 __global__ __launch_bounds__(256) void ba_schur_kernel(const float* __restrict__ lmbda, int N,
                                                        const int32_t* __restrict__ gmeta, float* __restrict__ sy,
-                                                       const float* __restrict__ Cg, const float* __restrict__ ug,
+                                                       int sy_stride, const float* __restrict__ Cg,
+                                                       const float* __restrict__ ug,
                                                        float* __restrict__ qg, const float* __restrict__ Edg,
                                                        int U_stride, const int32_t* __restrict__ info) {
   if (gmeta[GM_ERROR] || info[1]) return;
@@ -331,9 +356,13 @@ __global__ __launch_bounds__(256) void ba_schur_kernel(const float* __restrict__
   const int n6 = 6 * N, nrow = n6 + 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c16 = lane & 15, g4 = lane >> 4;
+  CDV_IF_STAMPS(const int sslot = 5000 + blockIdx.x * 4 + wave;)
+  CDV_STAMP(ba, sslot, 0);
+  CDV_STAMP_RT(ba, sslot, 8);
   extern __shared__ float smem[];
-  float* Ed = smem;                     // [nrow][ELD], row n6 = u
-  float* qs = Ed + (size_t)nrow * ELD;  // [64]
+  const int T16 = (nrow + 15) / 16;
+  float* Ed = smem;                          // [16 T16][ELD], row n6 = u, rows beyond it zero
+  float* qs = Ed + (size_t)16 * T16 * ELD;   // [64]
   const float lm = lmbda[0];
   if (threadIdx.x < BA_CHUNK) {
     const int rr = r0 + threadIdx.x;
@@ -342,32 +371,52 @@ __global__ __launch_bounds__(256) void ba_schur_kernel(const float* __restrict__
     if (rr < U) qg[rr] = q;
     Ed[n6 * ELD + threadIdx.x] = (rr < U) ? ug[rr] : 0.f;
   }
-  for (int t = threadIdx.x; t < n6 * BA_CHUNK; t += blockDim.x) {
-    const int row = t >> 6, kl = t & 63;
-    Ed[row * ELD + kl] = (r0 + kl < U) ? Edg[(size_t)row * U_stride + r0 + kl] : 0.f;
+  // E rows of the chunk -> LDS: float4 loads, all of a thread's loads in flight together; rows nrow .. 16 T16 - 1
+  // are zero so that the tile reads below need no bounds checks
+  {
+    const int tot4 = n6 * (BA_CHUNK / 4), pad4 = 16 * T16 * (BA_CHUNK / 4);
+    const cdv_float4 z4 = {0.f, 0.f, 0.f, 0.f};
+    for (int base = 0; base < pad4; base += 4 * 256) {
+      cdv_float4 v[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int i4 = base + i * 256 + (int)threadIdx.x;
+        const int row = i4 >> 4, k4 = (i4 & 15) * 4;
+        // U_stride is a multiple of 64 and the columns beyond U are kept zero by the retract kernel
+        v[i] = (i4 < tot4) ? *reinterpret_cast<const cdv_float4*>(Edg + (size_t)row * U_stride + r0 + k4) : z4;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int i4 = base + i * 256 + (int)threadIdx.x;
+        const int row = i4 >> 4, k4 = (i4 & 15) * 4;
+        if (i4 < pad4 && row != n6) *reinterpret_cast<cdv_float4*>(Ed + row * ELD + k4) = v[i];
+      }
+    }
   }
   __syncthreads();
+  CDV_STAMP(ba, sslot, 1);
   if (N == 0) return;
-  float* S = sy;
+  float* S = sy + (size_t)(blockIdx.x % BA_REPL) * sy_stride;
   float* y = S + (size_t)n6 * n6;
-  const int T16 = (nrow + 15) / 16;
   const int npairs = T16 * (T16 + 1) / 2;
   for (int pidx = wave; pidx < npairs; pidx += 4) {
     int ti = 0, acc_rows = 0;  // lower-triangular tile pair (ti >= tj)
     while (acc_rows + ti + 1 <= pidx) { acc_rows += ti + 1; ti++; }
     const int tj = pidx - acc_rows;
-    const int ra = 16 * ti + c16, rbw = 16 * tj + c16;
-    const float* pa = Ed + (size_t)min(ra, nrow - 1) * ELD;
-    const float* pb = Ed + (size_t)min(rbw, nrow - 1) * ELD;
-    const bool va = ra < nrow, vb = rbw < nrow;
+    const float* pa = Ed + (size_t)(16 * ti + c16) * ELD;
+    const float* pb = Ed + (size_t)(16 * tj + c16) * ELD;
+    float a[16], bq[16];
+#pragma unroll
+    for (int st = 0; st < 16; st++) {
+      const int k = 4 * st + g4;
+      a[st] = pa[k];
+      bq[st] = qs[k] * pb[k];
+    }
     cdv_float4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int st = 0; st < BA_CHUNK / 4; st += 2) {
-      const int k0 = 4 * st + g4, k1 = k0 + 4;
-      const float a0 = va ? pa[k0] : 0.f, a1 = va ? pa[k1] : 0.f;
-      const float b0 = vb ? qs[k0] * pb[k0] : 0.f, b1 = vb ? qs[k1] * pb[k1] : 0.f;
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc1, 0, 0, 0);
+#pragma unroll
+    for (int st = 0; st < 16; st += 2) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[st], bq[st], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[st + 1], bq[st + 1], acc1, 0, 0, 0);
     }
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -382,6 +431,8 @@ __global__ __launch_bounds__(256) void ba_schur_kernel(const float* __restrict__
       }
     }
   }
+  CDV_STAMP(ba, sslot, 2);
+  CDV_STAMP_RT(ba, sslot, 9);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -416,7 +467,7 @@ __device__ __forceinline__ bool chol6(const float* a, float* Lm) {
 // factors the 6x6 block redundantly in registers (~400-cycle dependent chain) and forward-substitutes its own
 // row (the panel); (2) the trailing update runs as 16x16 tiles on the matrix cores.
 __global__ __launch_bounds__(256) void ba_solve_kernel(float* __restrict__ poses, float* __restrict__ sy,
-                                                       float* __restrict__ dXg, int t0, int N,
+                                                       int sy_stride, float* __restrict__ dXg, int t0, int N,
                                                        const int32_t* __restrict__ gmeta, float* __restrict__ dbg,
                                                        int32_t* __restrict__ info) {
   if (gmeta[GM_ERROR] || info[1]) return;
@@ -432,23 +483,39 @@ __global__ __launch_bounds__(256) void ba_solve_kernel(float* __restrict__ poses
   {
     const int total = n * n + n;
     const float inv_n = 1.0f / (float)n;   // idx / n for idx < 2^23 via one multiply
-    for (int base = 0; base < total; base += 16 * T) {
-      float v[16];
+    // float4 loads of all BA_REPL copies; a copy is padded with (never written) zeros up to sy_stride
+    const int total4 = (total + 3) / 4;
+    const cdv_float4 z4 = {0.f, 0.f, 0.f, 0.f};
+    for (int base = 0; base < total4; base += 4 * T) {
+      cdv_float4 v[4][BA_REPL];
 #pragma unroll
-      for (int i = 0; i < 16; i++) {
-        const int idx = base + i * T + t;
-        v[i] = (idx < total) ? sy[idx] : 0.f;
+      for (int i = 0; i < 4; i++) {
+        const int i4 = base + i * T + t;
+#pragma unroll
+        for (int rep = 0; rep < BA_REPL; rep++)
+          v[i][rep] = (i4 < total4) ? *reinterpret_cast<const cdv_float4*>(sy + (size_t)rep * sy_stride + 4 * i4) : z4;
       }
 #pragma unroll
-      for (int i = 0; i < 16; i++) {
-        const int idx = base + i * T + t;
-        if (idx < total) {
-          sy[idx] = 0.f;  // ready for the next iteration / call
-          float s = v[i];
-          const int a = (int)(((float)idx + 0.5f) * inv_n), b = idx - a * n;   // a == n: the y row
-          if (a == b) s += 1e-4f * s + 1.0f;        // S += I * (1e-4 * S + 1.0)   ba_cuda.cu:589
-          A[a * LD + b] = s;
-          if (dbg) dbg[idx] = s;
+      for (int i = 0; i < 4; i++) {
+        const int i4 = base + i * T + t;
+        if (i4 < total4) {
+          cdv_float4 sum = v[i][0];
+#pragma unroll
+          for (int rep = 1; rep < BA_REPL; rep++) sum += v[i][rep];
+#pragma unroll
+          for (int rep = 0; rep < BA_REPL; rep++)   // ready for the next iteration / call
+            *reinterpret_cast<cdv_float4*>(sy + (size_t)rep * sy_stride + 4 * i4) = z4;
+#pragma unroll
+          for (int c = 0; c < 4; c++) {
+            const int idx = 4 * i4 + c;
+            if (idx < total) {
+              float s = sum[c];
+              const int a = (int)(((float)idx + 0.5f) * inv_n), b = idx - a * n;   // a == n: the y row
+              if (a == b) s += 1e-4f * s + 1.0f;        // S += I * (1e-4 * S + 1.0)   ba_cuda.cu:589
+              A[a * LD + b] = s;
+              if (dbg) dbg[idx] = s;
+            }
+          }
         }
       }
     }
@@ -676,14 +743,14 @@ extern "C" int cdv_ba_forward(float* poses, float* patches, const float* intrins
 
   const int n_chunks = cdv_div_up(L.U_max, BA_CHUNK);
   const size_t smem_asm = sizeof(float) * ASM_WAVES * (size_t)PAIR_LDS_FLOATS;
-  const size_t smem_sch = sizeof(float) * ((size_t)(n6i + 1) * ELD + BA_CHUNK);
+  const size_t smem_sch = sizeof(float) * ((size_t)((n6i + 1 + 15) / 16 * 16) * ELD + BA_CHUNK);
   const size_t smem_sol = sizeof(float) * ((size_t)(n6i + 1) * (n6i + 2) + 36 * (size_t)(N > 0 ? N : 1) + 8);
   // raise the dynamic-LDS limits once (not a stream operation: kept out of the per-call path so that the
   // call sequence can be captured into a hipGraph)
   static std::once_flag attr_once;
   static hipError_t attr_err = hipSuccess;
   std::call_once(attr_once, [] {
-    // worst cases at N = 32: assemble 71 KB (fixed), schur 53 KB, solve 155 KB (+ a few static bytes)
+    // worst cases at N = 32: assemble 71 KB (fixed), schur 57 KB, solve 155 KB (+ a few static bytes)
     hipError_t e1 = hipFuncSetAttribute((const void*)ba_assemble_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         96 * 1024);
     hipError_t e2 = hipFuncSetAttribute((const void*)ba_schur_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -697,12 +764,13 @@ extern "C" int cdv_ba_forward(float* poses, float* patches, const float* intrins
   for (int itr = 0; itr < iterations; itr++) {
     float* d = (dbg && itr == 0) ? dbg : nullptr;
     hipLaunchKernelGGL(ba_assemble_kernel, dim3(n_chunks * ASM_SG), dim3(ASM_THREADS), smem_asm, s, poses, patches,
-                       intrinsics, target, weight, ii, jj, kk, P, t0, N, gv.meta, gv.pcsr, gv.koff_u, sy, Cg, ug, Edg,
-                       (int)L.U_stride, (int)L.U_max, info);
-    hipLaunchKernelGGL(ba_schur_kernel, dim3(n_chunks), dim3(256), smem_sch, s, lmbda, N, gv.meta, sy, Cg, ug, qg, Edg,
-                       (int)L.U_stride, info);
+                       intrinsics, target, weight, ii, jj, kk, P, t0, N, gv.meta, gv.pcsr, gv.koff_u, sy,
+                       (int)L.sy_stride, Cg, ug, Edg, (int)L.U_stride, (int)L.U_max, info);
+    hipLaunchKernelGGL(ba_schur_kernel, dim3(n_chunks), dim3(256), smem_sch, s, lmbda, N, gv.meta, sy,
+                       (int)L.sy_stride, Cg, ug, qg, Edg, (int)L.U_stride, info);
     if (N > 0)
-      hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(256), smem_sol, s, poses, sy, dXg, t0, N, gv.meta, d, info);
+      hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(256), smem_sol, s, poses, sy, (int)L.sy_stride, dXg, t0, N,
+                         gv.meta, d, info);
     // dbg layout: [S n6^2 | y n6 | dX n6 | dZ U_stride | C U_stride | u U_stride | E n6*U_stride]
     float* dbgp = d ? d + (size_t)n6i * n6i + 2 * n6i : nullptr;
     hipLaunchKernelGGL(ba_retract_kernel, dim3(rb), dim3(64), 0, s, patches, P, N, gv.meta, gv.kx, Cg, ug, qg, Edg,

@@ -65,6 +65,14 @@ print("chunks with slow waves:", slow)
 ph = np.stack([asm[:, 3] - asm[:, 0], asm[:, 4] - asm[:, 3], asm[:, 5] - asm[:, 4], asm[:, 2] - asm[:, 5]], 1)
 print("slow waves phases [edge+E atomics, X write, gram+emit, tail] and passes:")
 for o in order[:6]:
-    print("   ", ph[o], asm[o, 6])
+    print("   ", ph[o], asm[o, 6], " gram: read %d mfma %d emit %d" % (asm[o, 10], asm[o, 11], asm[o, 12]))
 fast = np.argsort(span)[len(span) // 2]
 print("median wave phases:", ph[fast], asm[fast, 6])
+sch = b[5000:5000 + 4 * 64]
+sch = sch[sch[:, 0] > 0]
+srt = sch[:, 8:10] / 100.0
+print("schur: waves %d; load+sync %0.f cycles, mfma+emit %.0f (median), max %.0f / %.0f" % (len(sch), np.median(sch[:, 1] - sch[:, 0]), np.median(sch[:, 2] - sch[:, 1]), (sch[:, 1] - sch[:, 0]).max(), (sch[:, 2] - sch[:, 1]).max()))
+print("schur realtime: last start %.1f us, first end %.1f, last end %.1f" % (srt[:, 0].max() - srt[:, 0].min(), srt[:, 1].min() - srt[:, 0].min(), srt[:, 1].max() - srt[:, 0].min()))
+print("assemble phase percentiles (50/90/99/max):")
+for i, nme in enumerate(["edge+E atomics", "X write", "gram+emit", "tail"]):
+    print("   %-16s" % nme, np.percentile(ph[:, i], [50, 90, 99, 100]))
