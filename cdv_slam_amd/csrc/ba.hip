@@ -181,16 +181,17 @@ __device__ __forceinline__ void pair_emit(float val, int row, int col, int ixf, 
   const int rb = ri ? ixf : jxf;
   if (rb < 0) return;
   const int r = 6 * rb + (ri ? row : row - 6);
-  if (col == 12) {
-    atomicAdd(&y[r], ri ? -val : val);  // v[i] -= w r Ji ; v[j] += w r Jj      (ba_cuda.cu:393-398)
-    return;
-  }
+  // column 12: v[i] -= w r Ji ; v[j] += w r Jj  (ba_cuda.cu:393-398); y follows S in memory, so one atomic
+  // instruction serves both.  Other columns: B[ii] += w Ji Ji^T, B[jj] += w Jj Jj^T, B[ij] -= w Ji Jj^T,
+  // B[ji] -= (w Ji Jj^T)^T   (ba_cuda.cu:364-377)
+  const bool isv = col == 12;
   const bool ci = col < 6;
-  const int cb = ci ? ixf : jxf;
+  const int cb = isv ? 0 : (ci ? ixf : jxf);
   if (cb < 0) return;
   const int c = 6 * cb + (ci ? col : col - 6);
-  // B[ii] += w Ji Ji^T, B[jj] += w Jj Jj^T, B[ij] -= w Ji Jj^T, B[ji] -= (w Ji Jj^T)^T   (ba_cuda.cu:364-377)
-  atomicAdd(&S[r * n6 + c], (ri == ci) ? val : -val);
+  const bool neg = isv ? ri : (ri != ci);
+  float* dst = isv ? &y[r] : &S[r * n6 + c];
+  atomicAdd(dst, neg ? -val : val);
 }
 
 __global__ __launch_bounds__(ASM_THREADS) void ba_assemble_kernel(
@@ -309,8 +310,12 @@ __global__ __launch_bounds__(ASM_THREADS) void ba_assemble_kernel(
           const int ci = __shfl(ixf, leader), cj = __shfl(jxf, leader);
           // two accumulators: consecutive f32 MFMAs do not wait on each other's result
           cdv_float4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+          const unsigned long long match = __ballot(active && key == kcur);
 #pragma unroll
           for (int st = 0; st < 32; st += 2) {
+            // k-steps st, st + 1 hold the rows of edges (lanes) 2 st .. 2 st + 3: skipped when none is of this pair
+            // (wave-uniform test; a chunk that straddles two source frames then costs one pass in total, not two)
+            if (((match >> (2 * st)) & 15ull) == 0) continue;
             const float w0 = (xk[st] == kcur) ? xw[st] : 0.f;
             const float w1 = (xk[st + 1] == kcur) ? xw[st + 1] : 0.f;
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[st], w0 * xa[st], acc0, 0, 0, 0);
@@ -321,7 +326,7 @@ __global__ __launch_bounds__(ASM_THREADS) void ba_assemble_kernel(
 #pragma unroll
           for (int q = 0; q < 4; q++) pair_emit(acc0[q] + acc1[q], 4 * g4 + q, c16, ci, cj, n6, S, y);
           CDV_IF_STAMPS(t_em += cdv_now() - t_x;)
-          todo &= ~__ballot(active && key == kcur);
+          todo &= ~match;
         }
       }
       CDV_STAMP(ba, sslot, 5);
