@@ -11,7 +11,7 @@ the timed region.
     python bench.py --gpus N --steps K --warmup W
 (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`;
  every rank runs an independent sequence -- the path does not shard inside a sequence, SURVEY.md 8(e) --
- and the per-rank [fps, pose checksum] pairs are gathered with one RCCL all_gather.)
+ and the per-rank [pose checksum, fps] pairs are gathered with one RCCL all_gather: cdv_slam_amd/replicas.py.)
 """
 import argparse
 import json
@@ -63,7 +63,21 @@ def cpu_baseline(st, max_seconds=30.0):
              np.float32)
     t3 = time.perf_counter()
     total = (t1 - t0) + t_corr + (t3 - t2)
+    # BASELINE.json configs[0]: the reference's Python ba.py path (cdvslam/ba.py:86-185 as restated in oracle/ba_py.py,
+    # numpy float32, ep = 1.0) on the 10-frame / 96-patch fully connected graph, two Gauss-Newton iterations
+    from cdv_slam_amd import synth
+    from oracle import ba_py
+    pr = synth.make_state("pr1", features=False)
+    hh, ww = pr.cfg.ht // pr.cfg.res, pr.cfg.wd // pr.cfg.res
+    P, X = pr.poses, pr.patches
+    tb = time.perf_counter()
+    for _ in range(2):
+        P, X, _ = ba_py.BA(P, X, pr.intrinsics, pr.target, pr.weight, pr.lmbda, pr.ii, pr.jj, pr.kk,
+                           [-64, -64, ww + 64, hh + 64], ep=1.0, fixedp=1, dtype=np.float32)
+    t_bapy = time.perf_counter() - tb
     return {
+        "ba_py_pr1": {"value": 1.0 / t_bapy, "unit": "BA(2 it)/s", "edges": int(pr.E), "seconds": t_bapy,
+                      "what": "oracle/ba_py.py (restated cdvslam/ba.py) on BASELINE.json configs[0], numpy f32"},
         "value": 1.0 / total, "unit": "frames/s", "cores": O.num_threads(), "kind": "port",
         "sample": "1 update of the bench workload (E=%d): reproject + neighbors + BA(2 it) on all edges, "
                   "correlation timed on the first %d edges and scaled to E; oracle/cdv_oracle.c, %d thread(s)"
@@ -79,8 +93,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="default", help="synthetic workload (default | stress | init | pr1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="launch the ~20 kernels of a step one by one instead of "
-                    "replaying a captured hipGraph")
+    ap.add_argument("--graph", action="store_true", help="replay the ~20 launches of a step as one captured hipGraph "
+                    "(default: eager launches on one stream; measured to run at the same rate)")
+    ap.add_argument("--no-graph", action="store_true", help="(default, kept for older command lines)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     args = ap.parse_args()
 
@@ -90,45 +105,34 @@ def main():
     from cdv_slam_amd import synth
     from cdv_slam_amd.update import UpdatePath
 
-    rank = int(os.environ.get("RANK", "0"))
+    from cdv_slam_amd.replicas import ReplicaGroup, aggregate_rate, summarise
+
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
-    dist_on = world > 1
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world_env and world_env > 1:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world_env))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if dist_on:
-        import torch.distributed as dist
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=dev)  # RCCL over xGMI
+    grp = ReplicaGroup(backend="nccl", device=dev)  # "nccl" is RCCL on ROCm: xGMI between the GPUs of the node
+    rank, world = grp.rank, grp.world
 
     # every rank tracks its own sequence: same config, its own seed
-    st = synth.make_state(args.config, buffer_size=64, seed=1234 + rank)
+    st = synth.make_state(args.config, buffer_size=64, seed=grp.sequence_seed())
     up = UpdatePath(st, dev)
 
-    def barrier():
-        if dist_on:
-            dist.barrier(device_ids=[local_rank])
-        torch.cuda.synchronize()
-
-    use_graph = not args.no_graph
+    use_graph = args.graph
     if use_graph:
         up.capture()
     run_step = up.step_graph if use_graph else up.step
     for _ in range(args.warmup):
         run_step()
-    barrier()
+    grp.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         run_step()
-    barrier()
+    grp.barrier()
     elapsed = time.perf_counter() - t0
-
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if dist_on:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed_max = float(el.item())
+    elapsed_max = grp.max_over_ranks(elapsed)
 
     # ---- dominant kernel (fused correlation): HIP events around its launch inside full steps ----------
     corr_ms = []
@@ -149,15 +153,8 @@ def main():
     # per-stage breakdown (informative)
     stages = up.stage_times(reps=20)
 
-    # ---- gather per-rank metrics: [fps, pose checksum] (trajectory-metric gather of SURVEY.md 8(e)) ---
-    mine = torch.tensor([args.steps / elapsed, float(up.poses.double().abs().sum().item())], dtype=torch.float64,
-                        device=dev)
-    if dist_on:
-        allm = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allm, mine)
-        per_rank = [[float(x[0]), float(x[1])] for x in allm]
-    else:
-        per_rank = [[float(mine[0]), float(mine[1])]]
+    # ---- gather per-rank metrics: [pose checksum, fps] (trajectory-metric gather of SURVEY.md 8(e)) ---
+    per_rank = grp.gather_metrics([float(up.poses.double().abs().sum().item()), args.steps / elapsed])
 
     if rank == 0:
         traffic = None
@@ -169,7 +166,7 @@ def main():
                 traffic = None
         res = {
             "metric": "frames/sec per GPU (CDVO update, 96 patches, win=10); ATE vs ref",
-            "value": world * args.steps / elapsed_max,
+            "value": aggregate_rate(args.steps, elapsed_max, world),
             "unit": "frames/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -195,15 +192,14 @@ def main():
             },
             "stages_us": stages,
             "per_rank": per_rank,
+            "per_rank_summary": summarise(per_rank),
         }
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(st, args.cpu_seconds)
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res))
-    if dist_on:
-        dist.barrier(device_ids=[local_rank])
-        dist.destroy_process_group()
+    grp.close()
 
 
 if __name__ == "__main__":
