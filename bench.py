@@ -96,6 +96,8 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the ~20 launches of a step as one captured hipGraph "
                     "(default: eager launches on one stream; measured to run at the same rate)")
     ap.add_argument("--no-graph", action="store_true", help="(default, kept for older command lines)")
+    ap.add_argument("--overlap", action="store_true", help="build the patch-graph index on a side stream under the "
+                    "correlation (measured: no gain, the dispatcher does not interleave the small kernels)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     args = ap.parse_args()
 
@@ -118,7 +120,7 @@ def main():
 
     # every rank tracks its own sequence: same config, its own seed
     st = synth.make_state(args.config, buffer_size=64, seed=grp.sequence_seed())
-    up = UpdatePath(st, dev)
+    up = UpdatePath(st, dev, overlap=args.overlap)
 
     use_graph = args.graph
     if use_graph:

@@ -15,10 +15,14 @@ from . import ops
 
 
 class UpdatePath:
-    def __init__(self, st, device):
-        """st: synth.SynthState (numpy).  Uploads the state once; step() then runs entirely on device."""
+    def __init__(self, st, device, overlap=False):
+        """st: synth.SynthState (numpy).  Uploads the state once; step() then runs entirely on device.
+        overlap: build the patch-graph index and the neighbor lists (they depend on the edge lists only) on a
+        second HIP stream while the main stream reprojects and correlates; the streams join before the BA."""
         self.cfg = st.cfg
         self.dev = device
+        self.overlap = overlap
+        self._aux = torch.cuda.Stream(device=device, priority=-1) if overlap else None  # high priority: tiny kernels
         t = lambda a, dt=None: torch.as_tensor(a, device=device) if dt is None else torch.as_tensor(a, dtype=dt, device=device)
         self.poses = t(st.poses).contiguous()
         self.patches = t(st.patches).contiguous()
@@ -72,6 +76,17 @@ class UpdatePath:
     def step(self, ingest=True, rebuild_graph=True, iterations=2):
         """One update.  Everything is enqueued on the current stream; no host synchronisation."""
         out = {}
+        # patch-graph index (shared by neighbors and BA) + 3. neighbors (net_cdv.py:102 -> ba.cpp:59-97): five small
+        # latency-bound launches that only need (jj, kk) -- on the side stream, under the correlation
+        main = torch.cuda.current_stream()
+        if self.overlap:
+            self._aux.wait_stream(main)      # the previous BA still reads the index this build overwrites
+            with torch.cuda.stream(self._aux):
+                self.graph.build(self.jj, self.kk, force=rebuild_graph)
+                out["ix"], out["jx"] = self.graph.neighbors()
+        else:
+            self.graph.build(self.jj, self.kk, force=rebuild_graph)
+            out["ix"], out["jx"] = self.graph.neighbors()
         if self.has_features and ingest:
             ops.fmap_ingest(self.new_frame, self.fmap1, self.fmap2, self.new_slot)
         # 1. reproject (slam.py:325-329)
@@ -79,13 +94,13 @@ class UpdatePath:
                                layout_e2pp=True)
         out["coords"] = coords
         self.last_coords = coords
-        # patch-graph index: shared by neighbors and BA
-        self.graph.build(self.jj, self.kk, force=rebuild_graph)
         # 2. correlation, both levels (slam.py:316-323)
         if self.has_features:
             out["corr"] = self.corr_only(coords)
-        # 3. neighbors (net_cdv.py:102 -> ba.cpp:59-97)
-        out["ix"], out["jx"] = self.graph.neighbors()
+        if self.overlap:
+            main.wait_stream(self._aux)
+            out["ix"].record_stream(main)
+            out["jx"].record_stream(main)
         # 4. bundle adjustment (slam.py:512-515)
         ops.ba_forward(self.poses, self.patches, self.intrinsics, self.target, self.weight, self.lmbda, self.ii,
                        self.jj, self.kk, self.M, self.t0, self.n, iterations, False, U_max=self.U_max, graph=self.graph)
