@@ -38,18 +38,18 @@ constexpr int PADY = CDV_FMAP_PADY;             // 12
 constexpr int RAW_ROWS = 12;                    // window rows the fast path holds (typical: 10-11 / 8-9)
 constexpr int RAW_MSH = RAW_ROWS * 16 + 8;      // halfs per patch pixel (+8: 16-byte skew between pixels)
 constexpr int RAW_HALFS = 9 * RAW_MSH;          // 1800
-constexpr int OUT_XS = 73;                      // dwords between x offsets in the staged row (= 9 mod 32: conflict-free)
-constexpr int OUT_HALFS = 2 * 7 * OUT_XS + 2;   // 1024
+constexpr int OUT_HALFS = 896;                  // the staged output row: 882 halfs, linear (the copy-out needs no index math)
 constexpr int WAVE_LDS_BYTES = RAW_HALFS * 2 + OUT_HALFS * 2;  // 5,392 B per wave
 
 typedef _Float16 cdv_half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 cdv_half2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void wave_lds_sync() {
   // LDS operations of one wave execute in order; this only has to stop the compiler from moving the
-  // reads above the writes and to wait for outstanding DS ops (s_waitcnt lgkmcnt(0)).
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  // reads above the writes and to wait for outstanding DS ops.  (Not a workgroup-scope release fence: that one
+  // also drains vmcnt, i.e. waits for the window loads of the NEXT level that are meant to fly under the blend.)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
 // all-reduce over the 16 lanes of a DPP row by rotation (row_ror 8,4,2,1): no LDS crossbar traffic
@@ -119,9 +119,10 @@ __device__ __forceinline__ void mfma_row_store(const cdv_half8 (&win)[KS], const
 
 // per-lane blend geometry of one level: lane = 7 m + xo
 struct BlendGeo {
-  int off;       // half offset of raw[m][by][bx + xo]
-  int stride;    // halfs between window rows
-  float dx, dy;  // sub-pixel offsets rounded to f16, as the reference casts them before blending
+  int hb;         // BYTE offset of the half raw[m][by][bx + xo]
+  int stride_b;   // bytes between window rows
+  cdv_half2 wx;   // (1 - dx, dx): horizontal taps, dx rounded to f16 as the reference casts it before blending
+  float dy;       // vertical sub-pixel offset (rounded to f16 likewise)
 };
 
 __device__ __forceinline__ BlendGeo blend_geo(float xm, float ym, int m, int xo, const LevelParams& LP,
@@ -129,33 +130,32 @@ __device__ __forceinline__ BlendGeo blend_geo(float xm, float ym, int m, int xo,
   BlendGeo g;
   const float x = xm * LP.inv_scale, y = ym * LP.inv_scale;
   const float fxf = floorf(x), fyf = floorf(y);
-  g.dx = (float)(_Float16)(x - fxf);   // correlation_kernel.cu:223-224
+  const float dx = (float)(_Float16)(x - fxf);   // correlation_kernel.cu:223-224
+  g.wx = cdv_half2{(_Float16)(1.0f - dx), (_Float16)dx};
   g.dy = (float)(_Float16)(y - fyf);
   const int bx = per_pixel ? 0 : floor_clamped(x) - 3 - b.x0;
   const int by = per_pixel ? 0 : floor_clamped(y) - 3 - b.y0;
-  g.off = m * RAW_MSH + by * b.stride + bx + xo;
-  g.stride = b.stride;
+  g.hb = 2 * (m * RAW_MSH + by * b.stride + bx + xo);
+  g.stride_b = 2 * b.stride;
   return g;
 }
 
-// 8x8 -> 7x7 bilinear blend, separable.  The pair (c0, c1) of a window row starts at an arbitrary half
-// offset; a 4-byte LDS read at an odd half offset is an UNALIGNED access (very slow on the LDS), so the two
-// aligned dwords around it are read and funnel-shifted (v_alignbit) into the pair.
+// 8x8 -> 7x7 bilinear blend, separable.  The pair (c0, c1) of a window row starts at an arbitrary half offset; a
+// 4-byte LDS read at an odd half offset is an UNALIGNED access (very slow on the LDS), so the two aligned dwords
+// around it are read (one ds_read2_b32) and funnel-shifted (v_alignbit) into the pair; the horizontal tap is one
+// v_dot2_f32_f16 (exact f16 products, f32 sum).  5 VALU + 1 LDS instruction per window row.
 __device__ __forceinline__ void blend_level(const _Float16* __restrict__ raw, const BlendGeo& g, float (&res)[7]) {
-  const uint32_t* r32 = reinterpret_cast<const uint32_t*>(raw);   // raw is 16-byte aligned
-  const unsigned sh = (g.off & 1) ? 16u : 0u;
+  const char* rb = reinterpret_cast<const char*>(raw);   // raw is 16-byte aligned
   float h[8];
+  int hb = g.hb;
 #pragma unroll
   for (int r = 0; r < 8; r++) {
-    const int hoff = g.off + r * g.stride;           // half index of c0
-    const unsigned sh_r = ((hoff & 1) ? 16u : 0u);
-    const uint32_t lo = r32[hoff >> 1], hi = r32[(hoff + 1) >> 1];
-    const uint32_t pr = __builtin_amdgcn_alignbit(hi, lo, sh_r);
-    const float c0 = (float)__builtin_bit_cast(_Float16, (unsigned short)(pr & 0xffffu));
-    const float c1 = (float)__builtin_bit_cast(_Float16, (unsigned short)(pr >> 16));
-    h[r] = c0 + g.dx * (c1 - c0);
+    const uint32_t* pd = reinterpret_cast<const uint32_t*>(rb + (hb & ~3));
+    const uint32_t lo = pd[0], hi = pd[1];           // hi is unused when the pair is dword aligned (stays in the wave's LDS)
+    const uint32_t pr = __builtin_amdgcn_alignbit(hi, lo, (unsigned)hb << 3);   // shift = low 5 bits: 0 or 16
+    h[r] = __builtin_amdgcn_fdot2(__builtin_bit_cast(cdv_half2, pr), g.wx, 0.0f, false);
+    hb += g.stride_b;
   }
-  (void)sh;
 #pragma unroll
   for (int yo = 0; yo < 7; yo++) res[yo] = h[yo] + g.dy * (h[yo + 1] - h[yo]);
 }
@@ -250,7 +250,9 @@ __global__ __launch_bounds__(256) void corr_fused_kernel(const _Float16* __restr
   float res0[7], res1[7];
 #pragma unroll
   for (int i = 0; i < 7; i++) { res0[i] = 0.f; res1[i] = 0.f; }
-  _Float16* raw_lane = raw + (n < 9 ? n : 0) * RAW_MSH + 4 * g;   // lanes n >= 9 of the D tile are dropped below
+  // lanes n >= 9 of the D tile are not patch pixels: they store into the (not yet used) staging area instead of
+  // being masked off (no EXEC save/restore around every store)
+  _Float16* raw_lane = (n < 9) ? raw + n * RAW_MSH + 4 * g : outT + ((n - 9) * 4 + g) * 4;
 
   if constexpr (KS == 1) {
     // ---- EVERY window row of both levels is requested before the first MFMA --------------------------
@@ -301,10 +303,8 @@ __global__ __launch_bounds__(256) void corr_fused_kernel(const _Float16* __restr
       if (q < (NQ)) {                                                                              \
         cdv_float4 acc = {0.f, 0.f, 0.f, 0.f};                                                     \
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[q][0], pat[0], acc, 0, 0, 0);               \
-        if (n < 9) {                                                                               \
-          cdv_half4 h = {(_Float16)acc[0], (_Float16)acc[1], (_Float16)acc[2], (_Float16)acc[3]};  \
-          *reinterpret_cast<cdv_half4*>(raw_lane + q * 16) = h;                                    \
-        }                                                                                          \
+        cdv_half4 h = {(_Float16)acc[0], (_Float16)acc[1], (_Float16)acc[2], (_Float16)acc[3]};    \
+        *reinterpret_cast<cdv_half4*>(raw_lane + q * 16) = h;                                      \
       }
     if (do0 && !(exp & 1)) CDV_LOAD_LEVEL(b0, r0, pitch0, nq0)
     const BlendGeo g0 = blend_geo(xb, yb, bm, bxo, L0, b0, !b0.fast);
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256) void corr_fused_kernel(const _Float16* __restr
   // ---- stage the edge's output row [x][y][m][lev] in LDS, then 256-byte coalesced stores ------------
   if (lane < 63 && !(exp & 512)) {
     if (nlev == 2) {
-      uint32_t* o32 = reinterpret_cast<uint32_t*>(outT) + bxo * OUT_XS + bm;   // bank = (9 xo + m + 9 yo) mod 32
+      uint32_t* o32 = reinterpret_cast<uint32_t*>(outT) + bxo * 63 + bm;   // dword (x, y, m) = 63 x + 9 y + m
 #pragma unroll
       for (int yo = 0; yo < 7; yo++) {
         const _Float16 h0 = idx_ok ? (_Float16)res0[yo] : (_Float16)0.f;
@@ -393,9 +393,8 @@ __global__ __launch_bounds__(256) void corr_fused_kernel(const _Float16* __restr
     uint32_t* dst = reinterpret_cast<uint32_t*>(out) + (size_t)e * 441;
 #pragma unroll
     for (int i = 0; i < 7; i++) {
-      const int t = i * 64 + lane;        // output dword t = 63 xo + r  lives at LDS dword OUT_XS xo + r
-      const int xo = (t * 1041) >> 16;    // t / 63 for 0 <= t < 4096
-      if (t < 441) dst[t] = src[t + (OUT_XS - 63) * xo];
+      const int t = i * 64 + lane;
+      if (i < 6 || t < 441) dst[t] = src[t];
     }
   } else {
     _Float16* dst = out + (size_t)e * 441;
