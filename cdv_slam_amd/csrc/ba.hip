@@ -652,6 +652,150 @@ __global__ __launch_bounds__(256) void ba_solve_kernel(float* __restrict__ poses
   CDV_STAMP(ba, sslot, 4);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Small systems (N <= 10 free poses: the default optimisation window): the whole factorisation in the registers
+// of ONE wave.  Lane r holds row r of [S ; y^T] (lane 60 = the right-hand side, so the forward substitution is
+// free); column step k broadcasts L[c][k] with v_readlane (an SGPR operand of the following FMA), two
+// instructions per matrix entry, no barrier and no LDS traffic inside the factorisation.  The system is padded
+// with identity rows / columns up to 60, so one instantiation serves every N <= 10.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int SN = 60;    // unknowns of the single-wave solver
+constexpr int SLD = 68;   // LDS row stride (floats): rows 16-byte aligned; b128 row reads and b32 column reads conflict-free
+
+__device__ __forceinline__ float readlane_f(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+__global__ __launch_bounds__(256) void ba_solve60_kernel(float* __restrict__ poses, float* __restrict__ sy,
+                                                         int sy_stride, float* __restrict__ dXg, int t0, int N,
+                                                         const int32_t* __restrict__ gmeta, float* __restrict__ dbg,
+                                                         int32_t* __restrict__ info) {
+  if (gmeta[GM_ERROR] || info[1]) return;
+  __shared__ __attribute__((aligned(16))) float A[(SN + 1) * SLD];
+  __shared__ float xs[64];
+  const int n = 6 * N;
+  const int T = 256, t = threadIdx.x;
+  CDV_IF_STAMPS(const int sslot = 4096 + (t >> 6);)
+  CDV_STAMP(ba, sslot, 0);
+  // [S | y]: the BA_REPL copies are summed on the way in (one memory round trip: all loads of a thread are issued
+  // before the first use), re-zeroed for the next iteration, damped (ba_cuda.cu:589) and laid out as rows in LDS.
+  {
+    const int total = n * n + n;
+    const float inv_n = 1.0f / (float)n;   // idx / n for idx < 2^23 via one multiply
+    const int total4 = (total + 3) / 4;    // <= 915: one batch of 4 float4 per thread
+    const cdv_float4 z4 = {0.f, 0.f, 0.f, 0.f};
+    cdv_float4 v[4][BA_REPL];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int i4 = i * T + t;
+#pragma unroll
+      for (int rep = 0; rep < BA_REPL; rep++)
+        v[i][rep] = (i4 < total4) ? *reinterpret_cast<const cdv_float4*>(sy + (size_t)rep * sy_stride + 4 * i4) : z4;
+    }
+    // identity padding (rows / columns n .. 59), zero right-hand side
+    for (int idx = t; idx < (SN + 1) * SLD; idx += T) {
+      const int row = idx / SLD, col = idx - row * SLD;
+      A[idx] = (row == col && row < SN) ? 1.0f : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int i4 = i * T + t;
+      if (i4 < total4) {
+        cdv_float4 sum = v[i][0];
+#pragma unroll
+        for (int rep = 1; rep < BA_REPL; rep++) sum += v[i][rep];
+#pragma unroll
+        for (int rep = 0; rep < BA_REPL; rep++)
+          *reinterpret_cast<cdv_float4*>(sy + (size_t)rep * sy_stride + 4 * i4) = z4;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          const int idx = 4 * i4 + c;
+          if (idx < total) {
+            float sv = sum[c];
+            const int a = (int)(((float)idx + 0.5f) * inv_n), b = idx - a * n;   // a == n: the y row
+            if (a == b) sv += 1e-4f * sv + 1.0f;      // S += I * (1e-4 * S + 1.0)   ba_cuda.cu:589
+            A[(a == n ? SN : a) * SLD + b] = sv;
+            if (dbg) dbg[idx] = sv;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  CDV_STAMP(ba, sslot, 1);
+  if (t >= 64) return;   // one wave from here on (no block-wide barrier below)
+  const int lane = t;
+  const int myrow = min(lane, SN);   // lanes 61..63 shadow the right-hand-side row
+  float a[SN];
+#pragma unroll
+  for (int c4 = 0; c4 < SN / 4; c4++) {
+    const cdv_float4 q = *reinterpret_cast<const cdv_float4*>(&A[myrow * SLD + 4 * c4]);
+    a[4 * c4] = q[0]; a[4 * c4 + 1] = q[1]; a[4 * c4 + 2] = q[2]; a[4 * c4 + 3] = q[3];
+  }
+  int badk = 0;
+#pragma unroll
+  for (int k = 0; k < SN; k++) {
+    const float piv = readlane_f(a[k], k);
+    if (!(piv > 0.f) && badk == 0) badk = k / 6 + 1;   // wave-uniform
+    const float inv = __builtin_amdgcn_rsqf(piv);
+    a[k] *= inv;                                         // column k of L (rows >= k), z_k in lane 60
+    // all broadcasts of the step first, then the FMAs: a v_readlane result needs two wait states before a VALU
+    // instruction may read it, which back-to-back (readlane, fma) pairs would pay as an s_nop every time
+    float sb[SN];
+#pragma unroll
+    for (int c = k + 1; c < SN; c++) sb[c] = readlane_f(a[k], c);
+#pragma unroll
+    for (int c = k + 1; c < SN; c++) a[c] = fmaf(-a[k], sb[c], a[c]);
+  }
+  CDV_STAMP(ba, sslot, 2);
+  // L back to LDS (zeros above the diagonal), then lane k picks up COLUMN k: col[r] = L[r][k]
+  wave_lds_sync();
+  if (lane <= SN) {
+#pragma unroll
+    for (int c4 = 0; c4 < SN / 4; c4++) {
+      cdv_float4 q;
+#pragma unroll
+      for (int j = 0; j < 4; j++) q[j] = (4 * c4 + j <= lane) ? a[4 * c4 + j] : 0.f;
+      *reinterpret_cast<cdv_float4*>(&A[lane * SLD + 4 * c4]) = q;
+    }
+  }
+  wave_lds_sync();
+  const int kc = min(lane, SN - 1);
+  float col[SN];
+#pragma unroll
+  for (int r = 0; r < SN; r++) col[r] = A[r * SLD + kc];
+  float z = A[SN * SLD + kc];                       // z = L^-1 y
+  const float invd = 1.0f / A[kc * SLD + kc];
+  // back substitution L^T x = z: x_r = z_r / L[r][r] once every x_j, j > r, has been folded into z
+  float x = 0.f;
+#pragma unroll
+  for (int r = SN - 1; r >= 0; r--) {
+    const float xr = readlane_f(z * invd, r);
+    x = (lane == r) ? xr : x;
+    z = fmaf(-col[r], xr, z);
+  }
+  CDV_STAMP(ba, sslot, 3);
+  if (lane < n) {
+    dXg[lane] = x;
+    if (dbg) dbg[n * n + n + lane] = x;
+  }
+  xs[lane] = x;
+  wave_lds_sync();
+  if (lane == 0) info[0] = badk;
+  // pose_retr_kernel (ba_cuda.cu:178-206)
+  if (lane < N) {
+    float* p = poses + 7 * (size_t)(t0 + lane);
+    float tt[3] = {p[0], p[1], p[2]}, qq[4] = {p[3], p[4], p[5], p[6]}, tn[3], qn[4], xi[6];
+#pragma unroll
+    for (int c = 0; c < 6; c++) xi[c] = xs[6 * lane + c];
+    fb_retrSE3(xi, tt, qq, tn, qn);
+    p[0] = tn[0]; p[1] = tn[1]; p[2] = tn[2];
+    p[3] = qn[0]; p[4] = qn[1]; p[5] = qn[2]; p[6] = qn[3];
+  }
+  CDV_STAMP(ba, sslot, 4);
+}
+
 // dZ = Q (u - E^T dX), inverse-depth update, and re-zeroing of this patch's E column / C / u so that the
 // next iteration (or call) accumulates into zeros.
 __global__ __launch_bounds__(64) void ba_retract_kernel(float* __restrict__ patches, int P, int N,
@@ -773,7 +917,10 @@ extern "C" int cdv_ba_forward(float* poses, float* patches, const float* intrins
                        (int)L.sy_stride, Cg, ug, Edg, (int)L.U_stride, (int)L.U_max, info);
     hipLaunchKernelGGL(ba_schur_kernel, dim3(n_chunks), dim3(256), smem_sch, s, lmbda, N, gv.meta, sy,
                        (int)L.sy_stride, Cg, ug, qg, Edg, (int)L.U_stride, info);
-    if (N > 0)
+    if (N > 0 && 6 * N <= SN)
+      hipLaunchKernelGGL(ba_solve60_kernel, dim3(1), dim3(256), 0, s, poses, sy, (int)L.sy_stride, dXg, t0, N,
+                         gv.meta, d, info);
+    else if (N > 0)
       hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(256), smem_sol, s, poses, sy, (int)L.sy_stride, dXg, t0, N,
                          gv.meta, d, info);
     // dbg layout: [S n6^2 | y n6 | dX n6 | dZ U_stride | C U_stride | u U_stride | E n6*U_stride]

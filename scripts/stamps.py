@@ -40,7 +40,7 @@ pass
 print("  assemble wave total %.0f" % np.median(asm[:, 2] - asm[:, 0]))
 rt = asm[:, 8:10] / 100.0  # s_memrealtime is 100 MHz -> microseconds
 print("  assemble realtime: first start 0, last start %.1f us, first end %.1f, last end %.1f; median wave span %.1f us" % (rt[:, 0].max() - rt[:, 0].min(), rt[:, 1].min() - rt[:, 0].min(), rt[:, 1].max() - rt[:, 0].min(), np.median(rt[:, 1] - rt[:, 0])))
-sol = b[4096:4100]
+sol = b[4096:4097]   # wave 0 (the single-wave solver retires waves 1-3 after the load phase)
 for i, nme in enumerate(["load replicas", "factor loop", "back-subst", "write+retr"]):
     print("solve %-22s %8.0f" % (nme, np.median(sol[:, i + 1] - sol[:, i])))
 print("solve panel(sum) %8.0f trailing(sum) %8.0f" % (np.median(sol[:, 5]), np.median(sol[:, 6])))
