@@ -200,7 +200,8 @@ __global__ __launch_bounds__(256) void corr_fused_kernel(const _Float16* __restr
                                                          const int64_t* __restrict__ jj,
                                                          const int32_t* __restrict__ order,
                                                          _Float16* __restrict__ out, int E, int64_t Ng, int64_t slots,
-                                                         int C, int nlev, int64_t kmod, int64_t jmod, int exp) {
+                                                         int C, int nlev, int64_t kmod, int64_t jmod, int gmap_pm,
+                                                         int exp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -234,7 +235,20 @@ __global__ __launch_bounds__(256) void corr_fused_kernel(const _Float16* __restr
   // finite data: its products meet the zero k-slots of the patch fragment)
   // ---- round trip 2: patch tile (MFMA B operand) ------------------------------------------------------
   cdv_half8 pat[KS];
-  {
+  if (gmap_pm) {
+    // pixel-major tiles [9][C]: one 16-byte buffer load per k-step; the descriptor covers exactly this tile, so the
+    // lanes that are not patch pixels (n >= 9) and the k padding (forced offset) read zeros from the range check
+    typedef int cdv_i32x4p __attribute__((ext_vector_type(4)));
+    const unsigned tile_b = 9u * (unsigned)C * 2u;
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(gmap) + (size_t)kpatch * tile_b), (short)0, (int)tile_b, 0x00020000);
+#pragma unroll
+    for (int s = 0; s < KS; s++) {
+      const int chg = 32 * s + 8 * g;
+      const unsigned voff = (chg < C) ? (unsigned)(n * C + chg) * 2u : 0x40000000u;
+      pat[s] = __builtin_bit_cast(cdv_half8, (cdv_i32x4p)__builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, 0, 0));
+    }
+  } else {
     const _Float16* gp = gmap + (size_t)kpatch * C * 9 + (n < 9 ? n : 0);
 #pragma unroll
     for (int s = 0; s < KS; s++) {
@@ -478,18 +492,50 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const _Float16* __res
   }
 }
 
+// patch tiles planar [C][3][3] -> pixel-major [9][C]: one thread per (tile, pixel, 8-channel group)
+__device__ __forceinline__ void gmap_pm_convert(const _Float16* __restrict__ src, _Float16* __restrict__ dst,
+                                                int64_t first, int64_t count, int C, int64_t tid, int64_t nthreads) {
+  const int G = C / 8;
+  const int64_t total = count * 9 * G;
+  for (int64_t idx = tid; idx < total; idx += nthreads) {
+    int64_t t = idx;
+    const int gq = (int)(t % G); t /= G;
+    const int px = (int)(t % 9); t /= 9;
+    const int64_t tile = first + t;
+    cdv_half8 v;
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = src[(tile * C + 8 * gq + j) * 9 + px];
+    *reinterpret_cast<cdv_half8*>(dst + (tile * 9 + px) * C + 8 * gq) = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void gmap_pm_kernel(const _Float16* __restrict__ src, _Float16* __restrict__ dst,
+                                                      int64_t first, int64_t count, int C) {
+  gmap_pm_convert(src, dst, first, count, C, (int64_t)blockIdx.x * blockDim.x + threadIdx.x,
+                  (int64_t)gridDim.x * blockDim.x);
+}
+
 // one frame [C][H][W] -> ring slot of the level-0 NHWC ring and its 4x4 average pool into level 1
-// (F.avg_pool2d(fmap, 4, 4), slam.py:682: f16 in, f32 sum of 16, * 1/16, rounded to f16)
+// (F.avg_pool2d(fmap, 4, 4), slam.py:682: f16 in, f32 sum of 16, * 1/16, rounded to f16); the last `gblocks`
+// workgroups convert the frame's patch tiles to the pixel-major layout instead
 __global__ __launch_bounds__(256) void fmap_ingest_kernel(const _Float16* __restrict__ src,
                                                           _Float16* __restrict__ f1_nhwc,
                                                           _Float16* __restrict__ f2_nhwc,
                                                           _Float16* __restrict__ f1_nchw,
                                                           _Float16* __restrict__ f2_nchw, int slot, int C, int H,
-                                                          int W) {
+                                                          int W, const _Float16* __restrict__ gsrc,
+                                                          _Float16* __restrict__ gdst, int64_t gfirst, int64_t gcount,
+                                                          int gblocks) {
+  const int fblocks = (int)gridDim.x - gblocks;
+  if ((int)blockIdx.x >= fblocks) {
+    gmap_pm_convert(gsrc, gdst, gfirst, gcount, C, (int64_t)((int)blockIdx.x - fblocks) * blockDim.x + threadIdx.x,
+                    (int64_t)gblocks * blockDim.x);
+    return;
+  }
   const int G = C / 8, H4 = H / 4, W4 = W / 4;
   const int64_t total = (int64_t)H4 * W4 * G;  // one thread per pooled pixel x channel group: handles a 4x4 block
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * blockDim.x) {
+       idx += (int64_t)fblocks * blockDim.x) {
     int64_t t = idx;
     const int xq = (int)(t % W4); t /= W4;
     const int gq = (int)(t % G); t /= G;
@@ -585,16 +631,40 @@ extern "C" int cdv_fmap_to_nhwc(const void* src_nchw, void* dst_nhwc, int64_t N,
   return CDV_OK;
 }
 
-extern "C" int cdv_fmap_ingest(const void* fmap_chw, void* fmap1_nhwc, void* fmap2_nhwc, void* fmap1_nchw,
-                               void* fmap2_nchw, int slot, int C, int H, int W, void* stream) {
+extern "C" int cdv_frame_ingest(const void* fmap_chw, void* fmap1_nhwc, void* fmap2_nhwc, void* fmap1_nchw,
+                                void* fmap2_nchw, int slot, int C, int H, int W, const void* gmap_planar, void* gmap_pm,
+                                int64_t Ng, int64_t gmap_first, int64_t gmap_count, void* stream) {
   CDV_REQUIRE(C % 8 == 0 && C > 0, CDV_ERR_ARG, "cdv_fmap_ingest: C must be a multiple of 8");
   CDV_REQUIRE(H % 4 == 0 && W % 4 == 0, CDV_ERR_ARG, "cdv_fmap_ingest: H and W must be multiples of 4");
   CDV_REQUIRE(slot >= 0, CDV_ERR_ARG, "cdv_fmap_ingest: slot");
+  const bool do_g = gmap_planar != nullptr && gmap_pm != nullptr && gmap_count > 0;
+  CDV_REQUIRE(!do_g || (gmap_first >= 0 && gmap_first + gmap_count <= Ng), CDV_ERR_ARG, "cdv_frame_ingest: tile range");
   const int64_t total = (int64_t)(H / 4) * (W / 4) * (C / 8);
   const int blocks = cdv_div_up(total, 256);
-  hipLaunchKernelGGL(fmap_ingest_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)fmap_chw,
-                     (_Float16*)fmap1_nhwc, (_Float16*)fmap2_nhwc, (_Float16*)fmap1_nchw, (_Float16*)fmap2_nchw, slot,
-                     C, H, W);
+  const int gblocks = do_g ? (int)cdv_div_up(gmap_count * 9 * (C / 8), 256) : 0;
+  hipLaunchKernelGGL(fmap_ingest_kernel, dim3(blocks + gblocks), dim3(256), 0, (hipStream_t)stream,
+                     (const _Float16*)fmap_chw, (_Float16*)fmap1_nhwc, (_Float16*)fmap2_nhwc, (_Float16*)fmap1_nchw,
+                     (_Float16*)fmap2_nchw, slot, C, H, W, (const _Float16*)gmap_planar, (_Float16*)gmap_pm, gmap_first,
+                     gmap_count, gblocks);
+  CDV_LAUNCH_CHECK();
+  return CDV_OK;
+}
+
+extern "C" int cdv_fmap_ingest(const void* fmap_chw, void* fmap1_nhwc, void* fmap2_nhwc, void* fmap1_nchw,
+                               void* fmap2_nchw, int slot, int C, int H, int W, void* stream) {
+  return cdv_frame_ingest(fmap_chw, fmap1_nhwc, fmap2_nhwc, fmap1_nchw, fmap2_nchw, slot, C, H, W, nullptr, nullptr, 0,
+                          0, 0, stream);
+}
+
+extern "C" int cdv_gmap_to_pixel_major(const void* gmap_planar, void* gmap_pm, int64_t Ng, int C, int64_t first,
+                                       int64_t count, void* stream) {
+  CDV_REQUIRE(C % 8 == 0 && C > 0, CDV_ERR_ARG, "cdv_gmap_to_pixel_major: C must be a multiple of 8");
+  CDV_REQUIRE(first >= 0 && count >= 0 && first + count <= Ng, CDV_ERR_ARG, "cdv_gmap_to_pixel_major: tile range");
+  if (count == 0) return CDV_OK;
+  const int64_t total = count * 9 * (C / 8);
+  const int blocks = cdv_div_up(total, 256) < 16384 ? cdv_div_up(total, 256) : 16384;
+  hipLaunchKernelGGL(gmap_pm_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)gmap_planar,
+                     (_Float16*)gmap_pm, first, count, C);
   CDV_LAUNCH_CHECK();
   return CDV_OK;
 }
@@ -602,7 +672,7 @@ extern "C" int cdv_fmap_ingest(const void* fmap_chw, void* fmap1_nhwc, void* fma
 extern "C" int cdv_corr_fused(const void* gmap, const void* fmap0_nhwc, const void* fmap1_nhwc, const float* coords,
                               const int64_t* kk, const int64_t* jj, const int32_t* order, void* out, int64_t E,
                               int64_t Ng, int64_t slots, int C, int H0, int W0, int H1, int W1, float scale0,
-                              float scale1, int nlev, int64_t kmod, int64_t jmod, void* stream) {
+                              float scale1, int nlev, int64_t kmod, int64_t jmod, int gmap_pixel_major, void* stream) {
   CDV_REQUIRE(nlev == 1 || nlev == 2, CDV_ERR_ARG, "cdv_corr_fused: nlev must be 1 or 2");
   CDV_REQUIRE(C % 8 == 0 && C > 0 && C <= 128, CDV_ERR_UNSUPPORTED, "cdv_corr_fused: C must be a multiple of 8, <= 128");
   CDV_REQUIRE(E >= 0 && E < ((int64_t)1 << 31), CDV_ERR_ARG, "cdv_corr_fused: E out of range");
@@ -619,10 +689,10 @@ extern "C" int cdv_corr_fused(const void* gmap, const void* fmap0_nhwc, const vo
   hipStream_t s = (hipStream_t)stream;
   if (C <= 32)
     hipLaunchKernelGGL(corr_fused_kernel<1>, dim3(blocks), dim3(256), smem, s, (const _Float16*)gmap, L0, L1, coords,
-                       kk, jj, order, (_Float16*)out, (int)E, Ng, slots, C, nlev, kmod, jmod, exp);
+                       kk, jj, order, (_Float16*)out, (int)E, Ng, slots, C, nlev, kmod, jmod, gmap_pixel_major, exp);
   else
     hipLaunchKernelGGL(corr_fused_kernel<4>, dim3(blocks), dim3(256), smem, s, (const _Float16*)gmap, L0, L1, coords,
-                       kk, jj, order, (_Float16*)out, (int)E, Ng, slots, C, nlev, kmod, jmod, exp);
+                       kk, jj, order, (_Float16*)out, (int)E, Ng, slots, C, nlev, kmod, jmod, gmap_pixel_major, exp);
   CDV_LAUNCH_CHECK();
   return CDV_OK;
 }

@@ -236,20 +236,46 @@ class NhwcCache:
 _nhwc = NhwcCache()
 
 
-def fmap_ingest(fmap_chw, fmap1_nhwc, fmap2_nhwc, slot, fmap1_nchw=None, fmap2_nchw=None):
+def fmap_ingest(fmap_chw, fmap1_nhwc, fmap2_nhwc, slot, fmap1_nchw=None, fmap2_nchw=None, gmap=None, gmap_pm=None,
+                gmap_first=0, gmap_count=0):
     """One new frame [C,H,W] f16 -> ring slot `slot` of the channels-last level-0 ring and its 4x4
-    average pool into the level-1 ring (slam.py:681-682)."""
+    average pool into the level-1 ring (slam.py:681-682).  With gmap / gmap_pm also converts the frame's
+    patch tiles gmap[gmap_first : gmap_first + gmap_count] ([.,C,3,3]) into the pixel-major array, same launch."""
     lib = _lib.load()
     _need_cuda(fmap_chw, fmap1_nhwc, fmap2_nhwc)
     C, H, W = fmap_chw.shape[-3:]
     fmap_chw = fmap_chw.contiguous()
-    rc = lib.cdv_fmap_ingest(_p(fmap_chw), _p(fmap1_nhwc), _p(fmap2_nhwc), _p(fmap1_nchw), _p(fmap2_nchw), int(slot),
-                             C, H, W, _stream())
-    _lib.check(rc, "cdv_fmap_ingest")
+    if gmap is None or gmap_pm is None:
+        rc = lib.cdv_fmap_ingest(_p(fmap_chw), _p(fmap1_nhwc), _p(fmap2_nhwc), _p(fmap1_nchw), _p(fmap2_nchw),
+                                 int(slot), C, H, W, _stream())
+        _lib.check(rc, "cdv_fmap_ingest")
+        return
+    _need_cuda(gmap, gmap_pm)
+    Ng = gmap.numel() // (C * 9)
+    rc = lib.cdv_frame_ingest(_p(fmap_chw), _p(fmap1_nhwc), _p(fmap2_nhwc), _p(fmap1_nchw), _p(fmap2_nchw), int(slot),
+                              C, H, W, _p(gmap), _p(gmap_pm), Ng, int(gmap_first), int(gmap_count), _stream())
+    _lib.check(rc, "cdv_frame_ingest")
+
+
+def gmap_to_pixel_major(gmap, out=None, first=0, count=None):
+    """[Ng,C,3,3] f16 (reference layout of gmap_) -> [Ng,9,C]: the operand layout of the fused correlation."""
+    lib = _lib.load()
+    _need_cuda(gmap)
+    if gmap.dtype != torch.float16:
+        raise TypeError("gmap_to_pixel_major: float16 tiles")
+    gmap = gmap.contiguous()
+    C = gmap.shape[-3]
+    Ng = gmap.numel() // (C * 9)
+    if out is None:
+        out = torch.empty((Ng, 9, C), dtype=torch.float16, device=gmap.device)
+    count = Ng - first if count is None else count
+    _lib.check(lib.cdv_gmap_to_pixel_major(_p(gmap), _p(out), Ng, C, int(first), int(count), _stream()),
+               "cdv_gmap_to_pixel_major")
+    return out
 
 
 def corr_fused(gmap, fmap0_nhwc, fmap1_nhwc, coords, kk, jj, kmod=0, jmod=0, scales=(1.0, 4.0), order_ptr=None,
-               out=None):
+               out=None, pixel_major=False):
     """SLAM.corr (slam.py:316-323) in one launch.  gmap [Ng,C,3,3] f16 planar, fmapL_nhwc padded
     channels-last rings (alloc_fmap_ring), coords [1,E,2,3,3] f32 -> [1,E,882] f16 (fmap1_nhwc None -> one
     level, [1,E,441])."""
@@ -259,7 +285,7 @@ def corr_fused(gmap, fmap0_nhwc, fmap1_nhwc, coords, kk, jj, kmod=0, jmod=0, sca
         raise TypeError("corr_fused: gmap/fmap must be float16 and coords float32")
     nlev = 1 if fmap1_nhwc is None else 2
     E = kk.numel()
-    C = gmap.shape[-3]
+    C = gmap.shape[-1] if pixel_major else gmap.shape[-3]   # [Ng,9,C] (gmap_to_pixel_major) or [Ng,C,3,3]
     gmap, coords = gmap.contiguous(), coords.contiguous()
     Ng = gmap.numel() // (C * 9)
     slots = fmap0_nhwc.shape[-4]
@@ -271,7 +297,7 @@ def corr_fused(gmap, fmap0_nhwc, fmap1_nhwc, coords, kk, jj, kmod=0, jmod=0, sca
         out = torch.empty((1, E, 441 * nlev), dtype=torch.float16, device=gmap.device)
     rc = lib.cdv_corr_fused(_p(gmap), _p(fmap0_nhwc), _p(fmap1_nhwc), _p(coords), _p(kk.contiguous()),
                             _p(jj.contiguous()), order_ptr, _p(out), E, Ng, slots, C, H0, W0, H1, W1, float(scales[0]),
-                            float(scales[1]), nlev, int(kmod), int(jmod), _stream())
+                            float(scales[1]), nlev, int(kmod), int(jmod), 1 if pixel_major else 0, _stream())
     _lib.check(rc, "cdv_corr_fused")
     return out
 

@@ -51,6 +51,10 @@ class UpdatePath:
             self.new_slot = (st.n - 1) % mem
             self.kmod, self.jmod = st.cfg.M * st.cfg.pmem, st.cfg.mem
             self.corr_out = torch.empty((1, self.E, 882), dtype=torch.float16, device=device)
+            # patch tiles in the pixel-major operand layout; the newest frame's M tiles are re-converted every step
+            # together with its feature maps (what patchify + the ring writes do once per frame, net_cdv.py:355-374)
+            self.gmap_pm = ops.gmap_to_pixel_major(self.gmap)
+            self.new_tiles = ((st.n - 1) % st.cfg.pmem) * st.cfg.M
 
     def reset(self):
         self.poses.copy_(self._poses0)
@@ -88,7 +92,8 @@ class UpdatePath:
             self.graph.build(self.jj, self.kk, force=rebuild_graph)
             out["ix"], out["jx"] = self.graph.neighbors()
         if self.has_features and ingest:
-            ops.fmap_ingest(self.new_frame, self.fmap1, self.fmap2, self.new_slot)
+            ops.fmap_ingest(self.new_frame, self.fmap1, self.fmap2, self.new_slot, gmap=self.gmap, gmap_pm=self.gmap_pm,
+                            gmap_first=self.new_tiles, gmap_count=self.M)
         # 1. reproject (slam.py:325-329)
         coords = ops.transform(self.poses[None], self.patches[None], self.intrinsics[None], self.ii, self.jj, self.kk,
                                layout_e2pp=True)
@@ -109,8 +114,8 @@ class UpdatePath:
     # -- measurement helpers (bench.py) --------------------------------------------------------------
     def corr_only(self, coords):
         """just the fused correlation launch (dominant kernel) on the current stream"""
-        return ops.corr_fused(self.gmap, self.fmap1, self.fmap2, coords, self.kk, self.jj, kmod=self.kmod,
-                              jmod=self.jmod, out=self.corr_out)
+        return ops.corr_fused(self.gmap_pm, self.fmap1, self.fmap2, coords, self.kk, self.jj, kmod=self.kmod,
+                              jmod=self.jmod, out=self.corr_out, pixel_major=True)
 
     def stage_times(self, reps=20):
         """median microseconds per stage, each timed with HIP events on the current stream"""
@@ -130,7 +135,9 @@ class UpdatePath:
         coords = self.last_coords if hasattr(self, "last_coords") else self.step()["coords"]
         res = {}
         if self.has_features:
-            res["ingest"] = timed(lambda: ops.fmap_ingest(self.new_frame, self.fmap1, self.fmap2, self.new_slot))
+            res["ingest"] = timed(lambda: ops.fmap_ingest(self.new_frame, self.fmap1, self.fmap2, self.new_slot,
+                                                          gmap=self.gmap, gmap_pm=self.gmap_pm,
+                                                          gmap_first=self.new_tiles, gmap_count=self.M))
         res["reproject"] = timed(lambda: ops.transform(self.poses[None], self.patches[None], self.intrinsics[None],
                                                        self.ii, self.jj, self.kk, layout_e2pp=True))
         res["graph_build"] = timed(lambda: self.graph.build(self.jj, self.kk, force=True))

@@ -93,9 +93,25 @@ int cdv_fmap_ingest(const void* fmap_chw, void* fmap1_nhwc, void* fmap2_nhwc, vo
                     int slot, int C, int H, int W, void* stream);
 
 /*
+ * Patch feature tiles in "pixel-major" layout [Ng][9][C] f16: the 3x3 patch pixels outermost, the C channels of a
+ * pixel contiguous -- the MFMA operand of the fused correlation is then ONE 16-byte load per lane instead of eight
+ * strided 2-byte gathers from the reference's [Ng][C][3][3] (gmap_, slam.py:71,250-251).
+ *   cdv_gmap_to_pixel_major: converts tiles first .. first+count-1 of a planar array (a whole ring, or the M tiles
+ *   patchify just produced for the new frame, net_cdv.py:355-374).
+ *   cdv_frame_ingest: cdv_fmap_ingest plus that conversion for the new frame's tiles, in the SAME launch
+ *   (gmap_planar / gmap_pm may be NULL: then identical to cdv_fmap_ingest).
+ */
+int cdv_gmap_to_pixel_major(const void* gmap_planar, void* gmap_pm, int64_t Ng, int C, int64_t first, int64_t count,
+                            void* stream);
+int cdv_frame_ingest(const void* fmap_chw, void* fmap1_nhwc, void* fmap2_nhwc, void* fmap1_nchw, void* fmap2_nchw,
+                     int slot, int C, int H, int W, const void* gmap_planar, void* gmap_pm, int64_t Ng,
+                     int64_t gmap_first, int64_t gmap_count, void* stream);
+
+/*
  * Fused multi-level correlation: SLAM.corr (slam.py:316-323) = two cuda_corr.forward calls +
  * torch.stack(..., -1).view(1, E, -1), in ONE launch on MFMA.
- *   gmap        [Ng][C][3][3] f16 planar (view of gmap_, slam.py:250-251)
+ *   gmap        [Ng][C][3][3] f16 planar (view of gmap_, slam.py:250-251), or -- gmap_pixel_major != 0 -- the
+ *               [Ng][9][C] layout of cdv_gmap_to_pixel_major
  *   fmapL_nhwc  padded channels-last rings (layout above) with interior H_L x W_L, L = 0 .. nlev-1 ;
  *               coords are divided by scale[L] (1 and 4 in SLAM.corr)
  *   coords      [E][2][3][3] f32
@@ -109,7 +125,7 @@ int cdv_fmap_ingest(const void* fmap_chw, void* fmap1_nhwc, void* fmap2_nhwc, vo
 int cdv_corr_fused(const void* gmap, const void* fmap0_nhwc, const void* fmap1_nhwc, const float* coords,
                    const int64_t* kk, const int64_t* jj, const int32_t* order, void* out, int64_t E, int64_t Ng,
                    int64_t slots, int C, int H0, int W0, int H1, int W1, float scale0, float scale1, int nlev,
-                   int64_t kmod, int64_t jmod, void* stream);
+                   int64_t kmod, int64_t jmod, int gmap_pixel_major, void* stream);
 
 /* cuda_corr.patchify_forward(net, coords, radius) -- correlation.cpp:49-52, kernel :16-47.
  *   net [B][C][H][W] (f16 or f32), coords [B][M][2] f32 -> patches [B][M][C][D][D], zero when OOB */

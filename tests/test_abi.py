@@ -34,7 +34,7 @@ def test_argument_errors_are_codes_not_exits():
     rc = lib.cdv_lie_op(2, 0, 1, 4, None, None, None, None)
     assert rc == -4 and b"SO3" in lib.cdv_last_error()
     rc = lib.cdv_corr_fused(None, None, None, None, None, None, None, None, 10, 1, 1, 24, 8, 8, 2, 2, 1.0, 4.0, 3, 0,
-                            0, None)
+                            0, 0, None)
     assert rc == -2
     rc = lib.cdv_graph_build(None, None, 10, None, 0, 16, 16, None)
     assert rc == -2

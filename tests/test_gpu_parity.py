@@ -249,6 +249,29 @@ def test_corr_fused_vs_oracle(name):
         assert np.abs(got - ref).max() <= 4 * _corr_tol(truth)
 
 
+def test_corr_pixel_major_tiles_bit_identical():
+    """the [Ng,9,C] operand layout (cdv_gmap_to_pixel_major / cdv_frame_ingest) changes loads, not results"""
+    from cdv_slam_amd.update import UpdatePath
+    st = synth.make_state("small")
+    up = UpdatePath(st, torch.device(DEV))
+    pm = ops.gmap_to_pixel_major(up.gmap)
+    assert torch.equal(pm, up.gmap.reshape(up.gmap.shape[0], up.gmap.shape[1], 9).permute(0, 2, 1).contiguous())
+    coords = _gpu_coords(st)
+    a = ops.corr_fused(up.gmap, up.fmap1, up.fmap2, coords, up.kk, up.jj, kmod=up.kmod, jmod=up.jmod)
+    b = ops.corr_fused(pm, up.fmap1, up.fmap2, coords, up.kk, up.jj, kmod=up.kmod, jmod=up.jmod, pixel_major=True)
+    assert torch.equal(a, b)
+    # the per-frame ingest converts exactly the new frame's tiles and nothing else
+    pm2 = torch.full_like(pm, 7.0)
+    ops.fmap_ingest(up.new_frame, up.fmap1, up.fmap2, up.new_slot, gmap=up.gmap, gmap_pm=pm2, gmap_first=up.new_tiles,
+                    gmap_count=up.M)
+    torch.cuda.synchronize()
+    sl = slice(up.new_tiles, up.new_tiles + up.M)
+    assert torch.equal(pm2[sl], pm[sl])
+    rest = torch.ones(pm.shape[0], dtype=torch.bool)
+    rest[sl] = False
+    assert bool((pm2[rest.to(pm2.device)] == 7.0).all())
+
+
 def test_corr_edge_cases():
     """out-of-bounds windows, windows straddling the border, wide footprints (per-pixel path), exact
     integer coordinates, and the per-level drop-in signature (planar inputs, f16 and f32)."""
