@@ -221,9 +221,14 @@ __global__ __launch_bounds__(256) void corr_fused_kernel(const _Float16* __restr
   if (exp & 16) jslot = 0;                 // experiment bit 4: every edge reads map slot 0 (L2-resident)
   const float* cptr = coords + (size_t)e * 18;
   const int mm = lane < 9 ? lane : 0;       // row 0 of the wave: lanes 0..8 own patch pixel m, 9..15 mirror 0
-  const float xv = cptr[mm], yv = cptr[9 + mm];
   const int bm = min(lane / 7, 8), bxo = lane - 7 * (lane / 7);  // blend role of this lane: (m, x offset)
-  const float xb = cptr[bm], yb = cptr[9 + bm];
+  // ONE vector load for the 18 coordinates (lane l < 18 holds value l), handed to the lanes that need them through
+  // the LDS crossbar (ds_bpermute): the vector-memory pipe is the busy one in this kernel
+  const int cval = __float_as_int(cptr[min(lane, 17)]);
+  const float xv = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * mm, cval));
+  const float yv = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * (9 + mm), cval));
+  const float xb = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * bm, cval));
+  const float yb = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * (9 + bm), cval));
   const float minx = uniform_f(row16_reduce<true>(xv)), maxx = uniform_f(row16_reduce<false>(xv));
   const float miny = uniform_f(row16_reduce<true>(yv)), maxy = uniform_f(row16_reduce<false>(yv));
   const Box b0 = make_box(minx, maxx, miny, maxy, L0);
@@ -403,13 +408,19 @@ __global__ __launch_bounds__(256) void corr_fused_kernel(const _Float16* __restr
   CDV_STAMP(corr, p, 7);
   if (!(exp & 2)) {                             // experiment bit 1: no global store
   if (nlev == 2) {
+    // 441 dwords: two 16-byte-per-lane stores (256 + 184 dwords) and one last dword.  The row starts on a 4-byte
+    // boundary only (1764 B per edge); global memory takes the unaligned 16-byte accesses.
     const uint32_t* src = reinterpret_cast<const uint32_t*>(outT);
     uint32_t* dst = reinterpret_cast<uint32_t*>(out) + (size_t)e * 441;
-#pragma unroll
-    for (int i = 0; i < 7; i++) {
-      const int t = i * 64 + lane;
-      if (i < 6 || t < 441) dst[t] = src[t];
+    typedef uint32_t cdv_u32x4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t cdv_u32x4u __attribute__((ext_vector_type(4), aligned(4)));
+    const cdv_u32x4 v0 = *reinterpret_cast<const cdv_u32x4*>(src + 4 * lane);
+    *reinterpret_cast<cdv_u32x4u*>(dst + 4 * lane) = v0;
+    if (lane < 46) {
+      const cdv_u32x4 v1 = *reinterpret_cast<const cdv_u32x4*>(src + 256 + 4 * lane);
+      *reinterpret_cast<cdv_u32x4u*>(dst + 256 + 4 * lane) = v1;
     }
+    if (lane == 63) dst[440] = src[440];
   } else {
     _Float16* dst = out + (size_t)e * 441;
 #pragma unroll
