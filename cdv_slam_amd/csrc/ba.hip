@@ -694,7 +694,7 @@ __global__ __launch_bounds__(256) void ba_solve60_kernel(float* __restrict__ pos
     }
     // identity padding (rows / columns n .. 59), zero right-hand side
     for (int idx = t; idx < (SN + 1) * SLD; idx += T) {
-      const int row = idx / SLD, col = idx - row * SLD;
+      const int row = (int)(((float)idx + 0.5f) * (1.0f / (float)SLD)), col = idx - row * SLD;   // exact for idx < 2^22
       A[idx] = (row == col && row < SN) ? 1.0f : 0.0f;
     }
     __syncthreads();
@@ -780,25 +780,17 @@ __global__ __launch_bounds__(256) void ba_solve60_kernel(float* __restrict__ pos
     dXg[lane] = x;
     if (dbg) dbg[n * n + n + lane] = x;
   }
-  xs[lane] = x;
-  wave_lds_sync();
   if (lane == 0) info[0] = badk;
-  // pose_retr_kernel (ba_cuda.cu:178-206)
-  if (lane < N) {
-    float* p = poses + 7 * (size_t)(t0 + lane);
-    float tt[3] = {p[0], p[1], p[2]}, qq[4] = {p[3], p[4], p[5], p[6]}, tn[3], qn[4], xi[6];
-#pragma unroll
-    for (int c = 0; c < 6; c++) xi[c] = xs[6 * lane + c];
-    fb_retrSE3(xi, tt, qq, tn, qn);
-    p[0] = tn[0]; p[1] = tn[1]; p[2] = tn[2];
-    p[3] = qn[0]; p[4] = qn[1]; p[5] = qn[2]; p[6] = qn[3];
-  }
+  // the pose retraction (sin / cos of the update) runs in ba_retract_kernel, next to the depth updates, instead of
+  // lengthening this single-wave critical path
+  (void)poses; (void)t0; (void)xs;
   CDV_STAMP(ba, sslot, 4);
 }
 
 // dZ = Q (u - E^T dX), inverse-depth update, and re-zeroing of this patch's E column / C / u so that the
 // next iteration (or call) accumulates into zeros.
-__global__ __launch_bounds__(64) void ba_retract_kernel(float* __restrict__ patches, int P, int N,
+__global__ __launch_bounds__(64) void ba_retract_kernel(float* __restrict__ poses, int t0, int pose_retr,
+                                                        float* __restrict__ patches, int P, int N,
                                                         const int32_t* __restrict__ gmeta,
                                                         const int64_t* __restrict__ kx, float* __restrict__ Cg,
                                                         float* __restrict__ ug, const float* __restrict__ qg,
@@ -807,6 +799,17 @@ __global__ __launch_bounds__(64) void ba_retract_kernel(float* __restrict__ patc
                                                         const int32_t* __restrict__ info) {
   if (gmeta[GM_ERROR] || info[1]) return;
   const int U = gmeta[GM_U];
+  // pose_retr_kernel (ba_cuda.cu:178-206) for the small-system solver: T <- Exp(dX_i) T, one lane per free pose, in the
+  // last workgroup (the first ones carry the longest E-column sweeps)
+  if (pose_retr && blockIdx.x == gridDim.x - 1 && (int)threadIdx.x < N) {
+    float* p = poses + 7 * (size_t)(t0 + (int)threadIdx.x);
+    float tt[3] = {p[0], p[1], p[2]}, qq[4] = {p[3], p[4], p[5], p[6]}, tn[3], qn[4], xi[6];
+#pragma unroll
+    for (int c = 0; c < 6; c++) xi[c] = dXg[6 * threadIdx.x + c];
+    fb_retrSE3(xi, tt, qq, tn, qn);
+    p[0] = tn[0]; p[1] = tn[1]; p[2] = tn[2];
+    p[3] = qn[0]; p[4] = qn[1]; p[5] = qn[2]; p[6] = qn[3];
+  }
   const int PP = P * P;
   for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < U; r += gridDim.x * blockDim.x) {
     // u - E^T dX  (ba_cuda.cu:592); six independent partial sums keep six loads in flight
@@ -925,7 +928,8 @@ extern "C" int cdv_ba_forward(float* poses, float* patches, const float* intrins
                          gv.meta, d, info);
     // dbg layout: [S n6^2 | y n6 | dX n6 | dZ U_stride | C U_stride | u U_stride | E n6*U_stride]
     float* dbgp = d ? d + (size_t)n6i * n6i + 2 * n6i : nullptr;
-    hipLaunchKernelGGL(ba_retract_kernel, dim3(rb), dim3(64), 0, s, patches, P, N, gv.meta, gv.kx, Cg, ug, qg, Edg,
+    hipLaunchKernelGGL(ba_retract_kernel, dim3(rb), dim3(64), 0, s, poses, t0, (N > 0 && 6 * N <= SN) ? 1 : 0, patches, P,
+                       N, gv.meta, gv.kx, Cg, ug, qg, Edg,
                        (int)L.U_stride, dXg, dbgp, info);
     CDV_LAUNCH_CHECK();
   }
