@@ -28,6 +28,7 @@ SIGNATURES = {
     "cdv_fastba_reproject": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "cdv_graph_workspace_bytes": (_sz, [_i64, _i64]),
     "cdv_graph_build": (_i32, [_vp, _vp, _i64, _vp, _sz, _i64, _i64, _vp]),
+    "cdv_graph_build_neighbors": (_i32, [_vp, _vp, _i64, _vp, _sz, _i64, _i64, _vp, _vp, _vp]),
     "cdv_graph_read_meta_host": (_i32, [_vp, _vp, _vp]),
     "cdv_graph_get_unique": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp]),
     "cdv_neighbors": (_i32, [_vp, _i64, _vp, _vp, _vp]),

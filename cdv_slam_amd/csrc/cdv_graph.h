@@ -19,9 +19,11 @@ enum {
   GM_WORDS = 64
 };
 
+constexpr int GRAPH_MAX_BLOCKS = 1024;   // workgroups of the per-edge kernels (one min/max staging slot each)
+
 struct GraphLayout {
   int64_t E_max, k_range;
-  size_t meta, kcount, kcursor, krank, koff_u, kx, ku, pcsr_tmp, pcsr, total;
+  size_t meta, stage, khist, kcount, kcursor, krank, koff_u, kx, ku, pcsr_tmp, pcsr, nprev, nnext, total;
 };
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -32,7 +34,9 @@ static inline GraphLayout graph_layout(int64_t E_max, int64_t k_range) {
   const int64_t U_max = k_range < E_max ? k_range : E_max;
   size_t o = 0;
   L.meta = o;     o = align256(o + sizeof(int32_t) * GM_WORDS);
-  L.kcount = o;   o = align256(o + sizeof(int32_t) * (size_t)(k_range + 1));   // histogram -> dense offsets
+  L.stage = o;    o = align256(o + sizeof(int32_t) * 4 * GRAPH_MAX_BLOCKS);   // per-block (kmin, kmax, jmin, jmax) of the build in flight
+  L.khist = o;    o = align256(o + sizeof(int32_t) * (size_t)(k_range + 1));   // histogram over id mod k_range (zero between builds)
+  L.kcount = o;   o = align256(o + sizeof(int32_t) * (size_t)(k_range + 1));   // dense CSR offsets by id - kmin
   L.kcursor = o;  o = align256(o + sizeof(int32_t) * (size_t)(k_range + 1));
   L.krank = o;    o = align256(o + sizeof(int32_t) * (size_t)k_range);
   L.koff_u = o;   o = align256(o + sizeof(int32_t) * (size_t)(U_max + 1));
@@ -40,13 +44,15 @@ static inline GraphLayout graph_layout(int64_t E_max, int64_t k_range) {
   L.ku = o;       o = align256(o + sizeof(int32_t) * (size_t)E_max);
   L.pcsr_tmp = o; o = align256(o + sizeof(int32_t) * (size_t)E_max);
   L.pcsr = o;     o = align256(o + sizeof(int32_t) * (size_t)E_max);
+  L.nprev = o;    o = align256(o + sizeof(int32_t) * (size_t)E_max);   // neighbors: previous / next edge of the same patch in time
+  L.nnext = o;    o = align256(o + sizeof(int32_t) * (size_t)E_max);
   L.total = o;
   return L;
 }
 
 struct GraphView {
   int32_t* meta;
-  int32_t *kcount, *kcursor, *krank, *koff_u, *ku, *pcsr_tmp, *pcsr;
+  int32_t *stage, *khist, *kcount, *kcursor, *krank, *koff_u, *ku, *pcsr_tmp, *pcsr, *nprev, *nnext;
   int64_t* kx;
 };
 
@@ -54,6 +60,8 @@ static inline GraphView graph_view(void* ws, const GraphLayout& L) {
   char* b = (char*)ws;
   GraphView v;
   v.meta = (int32_t*)(b + L.meta);
+  v.stage = (int32_t*)(b + L.stage);
+  v.khist = (int32_t*)(b + L.khist);
   v.kcount = (int32_t*)(b + L.kcount);
   v.kcursor = (int32_t*)(b + L.kcursor);
   v.krank = (int32_t*)(b + L.krank);
@@ -62,6 +70,8 @@ static inline GraphView graph_view(void* ws, const GraphLayout& L) {
   v.ku = (int32_t*)(b + L.ku);
   v.pcsr_tmp = (int32_t*)(b + L.pcsr_tmp);
   v.pcsr = (int32_t*)(b + L.pcsr);
+  v.nprev = (int32_t*)(b + L.nprev);
+  v.nnext = (int32_t*)(b + L.nnext);
   return v;
 }
 

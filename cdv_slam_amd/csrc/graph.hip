@@ -11,13 +11,16 @@
 // without giving every XCD a contiguous share: no measurable gain -- that kernel is not bound by L2 misses --
 // so it is not built.)
 //
-// Pipeline, 5 small launches, no host sync:
-//   1 minmax+clear : min/max of kk, jj (one atomic per block) and re-zeroing of the histogram range the
-//                    PREVIOUS build used (so no separate memset pass)
-//   2 hist         : count[k - kmin]++           (about E/U adders per address: no hot spot)
-//   3 scan (1 WG)  : validate range, publish meta, exclusive scan -> dense offsets + unique ranks
-//   4 fill         : kx / koff_u from the dense bins, ku and the (unordered) CSR slots per edge
-//   5 segsort      : rank every edge inside its patch segment by (jj, edge id)
+// Pipeline, 4 small launches, no host sync (every launch costs ~5 us of latency on an otherwise idle GPU, the
+// work itself is a few hundred KB):
+//   1 hist     : count[k mod R]++ (R = workspace capacity; the ids of one build span less than R, checked) and
+//                min/max of kk, jj (one atomic per block).  Indexing by k mod R needs no kmin, so the min/max pass
+//                and the histogram are ONE launch; the histogram is zero between builds (the scan clears it).
+//   2 scan     : (1 WG) validate the range, publish meta, exclusive scan in id order (starting at bin kmin mod R)
+//                -> dense offsets by id - kmin and unique ranks; clears the histogram
+//   3 fill     : kx / koff_u from the dense bins, ku and the (unordered) CSR slots per edge
+//   4 segsort  : rank every edge inside its patch segment by (jj, edge id); the same sweep finds the edge's
+//                predecessor / successor in time (fastba.neighbors); clears the fill cursors
 #include <mutex>
 #include <unordered_map>
 
@@ -38,10 +41,10 @@ std::unordered_map<const void*, RegEntry> g_registry;
 constexpr int IMAX = 0x7fffffff;
 constexpr int IMIN = (int)0x80000000;
 
-__global__ __launch_bounds__(256) void graph_init_kernel(int32_t* meta, int32_t* kcount, int32_t* kcursor,
+__global__ __launch_bounds__(256) void graph_init_kernel(int32_t* meta, int32_t* khist, int32_t* kcursor,
                                                          int64_t k_cap) {
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t <= k_cap; t += (int64_t)gridDim.x * blockDim.x) {
-    kcount[t] = 0;
+    khist[t] = 0;
     kcursor[t] = 0;
     if (t < GM_WORDS) {
       int32_t v = 0;
@@ -52,20 +55,24 @@ __global__ __launch_bounds__(256) void graph_init_kernel(int32_t* meta, int32_t*
   }
 }
 
-__global__ __launch_bounds__(256) void graph_minmax_clear_kernel(const int64_t* __restrict__ jj,
-                                                                 const int64_t* __restrict__ kk, int32_t E,
-                                                                 int32_t* meta, int32_t* kcount, int32_t* kcursor) {
-  // re-zero what the previous build left in the histogram / cursor arrays
-  const int old = meta[GM_KRANGE];
-  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t <= old; t += gridDim.x * blockDim.x) {
-    kcount[t] = 0;
-    kcursor[t] = 0;
-  }
+// histogram over (id mod R) + min / max of kk, jj
+__global__ __launch_bounds__(256) void graph_hist_kernel(const int64_t* __restrict__ jj, const int64_t* __restrict__ kk,
+                                                         int32_t E, int32_t* __restrict__ stage, int32_t* khist,
+                                                         int32_t R) {
   int kmin = IMAX, kmax = IMIN, jmin = IMAX, jmax = IMIN;
+  const float rinv = 1.0f / (float)R;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) {
     const int k = (int)kk[e], j = (int)jj[e];
     kmin = min(kmin, k); kmax = max(kmax, k);
     jmin = min(jmin, j); jmax = max(jmax, j);
+    if (k >= 0) {
+      // k mod R without an integer division: float quotient estimate, then one correction step each way
+      int q = (int)((float)k * rinv);
+      int m = k - q * R;
+      m = (m < 0) ? m + R : m;
+      m = (m >= R) ? m - R : m;
+      atomicAdd(&khist[m], 1);
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -81,49 +88,59 @@ __global__ __launch_bounds__(256) void graph_minmax_clear_kernel(const int64_t* 
       kmin = min(kmin, s[w][0]); kmax = max(kmax, s[w][1]);
       jmin = min(jmin, s[w][2]); jmax = max(jmax, s[w][3]);
     }
-    atomicMin(&meta[GM_STAGE + 0], kmin);
-    atomicMax(&meta[GM_STAGE + 1], kmax);
-    atomicMin(&meta[GM_STAGE + 2], jmin);
-    atomicMax(&meta[GM_STAGE + 3], jmax);
+    // one private slot per workgroup, reduced by the scan kernel: no contended atomics (~90 ns each on one word)
+    int32_t* st = stage + 4 * blockIdx.x;
+    st[0] = kmin; st[1] = kmax; st[2] = jmin; st[3] = jmax;
   }
 }
 
-__global__ __launch_bounds__(256) void graph_hist_kernel(const int64_t* __restrict__ kk, int32_t E,
-                                                         const int32_t* __restrict__ meta, int32_t* kcount,
-                                                         int64_t k_cap) {
-  const int kmin = meta[GM_STAGE + 0], kmax = meta[GM_STAGE + 1];
-  if (kmin < 0 || (int64_t)kmax - kmin + 1 > k_cap) return;  // reported by the scan kernel
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x)
-    atomicAdd(&kcount[(int)kk[e] - kmin], 1);
-}
-
-// One workgroup of 1024 threads: publish meta, exclusive scan of the histogram in place
-// (kcount -> dense CSR offsets), krank[d] = number of non-empty bins before d.
-__global__ __launch_bounds__(1024) void graph_scan_kernel(int32_t* meta, int32_t* kcount, int32_t* krank,
-                                                          int32_t E, int64_t k_cap) {
+// One workgroup of 1024 threads: publish meta, exclusive scan of the histogram in id order (bin of id kmin + i is
+// (kmin + i) mod R) -> kcount[i] = dense CSR offset, krank[i] = number of non-empty bins before i; clears the histogram.
+__global__ __launch_bounds__(1024) void graph_scan_kernel(int32_t* meta, const int32_t* __restrict__ stage,
+                                                          int nstage, int32_t* khist, int32_t* kcount,
+                                                          int32_t* krank, int32_t E, int64_t k_cap) {
   __shared__ int32_t s_sum[1024];
   __shared__ int32_t s_cnt[1024];
+  __shared__ int32_t s_mm[16][4];
   const int T = blockDim.x, t = threadIdx.x;
-  const int kmin = meta[GM_STAGE + 0], kmax = meta[GM_STAGE + 1];
-  const int jmin = meta[GM_STAGE + 2], jmax = meta[GM_STAGE + 3];
+  // min / max over the per-workgroup slots of the histogram launch
+  int kmin = IMAX, kmax = IMIN, jmin = IMAX, jmax = IMIN;
+  if (t < nstage) { kmin = stage[4 * t]; kmax = stage[4 * t + 1]; jmin = stage[4 * t + 2]; jmax = stage[4 * t + 3]; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    kmin = min(kmin, __shfl_xor(kmin, o)); kmax = max(kmax, __shfl_xor(kmax, o));
+    jmin = min(jmin, __shfl_xor(jmin, o)); jmax = max(jmax, __shfl_xor(jmax, o));
+  }
+  if ((t & 63) == 0) { s_mm[t >> 6][0] = kmin; s_mm[t >> 6][1] = kmax; s_mm[t >> 6][2] = jmin; s_mm[t >> 6][3] = jmax; }
+  __syncthreads();
+  for (int w = 0; w < T / 64; w++) {
+    kmin = min(kmin, s_mm[w][0]); kmax = max(kmax, s_mm[w][1]);
+    jmin = min(jmin, s_mm[w][2]); jmax = max(jmax, s_mm[w][3]);
+  }
   const int64_t krange = (E > 0) ? (int64_t)kmax - kmin + 1 : 0;
   const bool bad = E > 0 && (kmin < 0 || krange > k_cap);
-  __syncthreads();  // every thread has read the staging words
   if (t == 0) {
-    meta[GM_STAGE + 0] = IMAX; meta[GM_STAGE + 1] = IMIN;  // ready for the next build
-    meta[GM_STAGE + 2] = IMAX; meta[GM_STAGE + 3] = IMIN;
     meta[GM_KMIN] = kmin; meta[GM_KMAX] = kmax; meta[GM_JMIN] = jmin; meta[GM_JMAX] = jmax;
     meta[GM_E] = E;
     meta[GM_ERROR] = bad ? 1 : 0;
-    meta[GM_KRANGE] = bad ? 0 : (int32_t)krange;  // hist was skipped when bad: the arrays are still zero
+    meta[GM_KRANGE] = bad ? 0 : (int32_t)krange;
     if (bad || E == 0) meta[GM_U] = 0;
   }
-  if (bad || E == 0) return;
+  const int R = (int)k_cap;
+  if (bad || E == 0) {
+    for (int i = t; i < R; i += T) khist[i] = 0;   // a failed build leaves a clean histogram too
+    return;
+  }
+  const int b0 = kmin % R;
   const int64_t n = krange;
   const int64_t per = (n + T - 1) / T;
   const int64_t lo = min((int64_t)t * per, n), hi = min(lo + per, n);
   int32_t sum = 0, cnt = 0;
-  for (int64_t i = lo; i < hi; i++) { const int32_t v = kcount[i]; sum += v; cnt += (v > 0); }
+  for (int64_t i = lo; i < hi; i++) {
+    int bin = b0 + (int)i; bin = (bin >= R) ? bin - R : bin;
+    const int32_t v = khist[bin];
+    sum += v; cnt += (v > 0);
+  }
   s_sum[t] = sum; s_cnt[t] = cnt;
   __syncthreads();
   for (int o = 1; o < T; o <<= 1) {  // Hillis-Steele inclusive scan over the per-thread partials
@@ -135,7 +152,9 @@ __global__ __launch_bounds__(1024) void graph_scan_kernel(int32_t* meta, int32_t
   }
   int32_t run = s_sum[t] - sum, rk = s_cnt[t] - cnt;
   for (int64_t i = lo; i < hi; i++) {
-    const int32_t v = kcount[i];
+    int bin = b0 + (int)i; bin = (bin >= R) ? bin - R : bin;
+    const int32_t v = khist[bin];
+    khist[bin] = 0;
     kcount[i] = run;
     krank[i] = rk;
     run += v; rk += (v > 0);
@@ -172,42 +191,64 @@ __global__ __launch_bounds__(256) void graph_fill_kernel(const int64_t* __restri
 }
 
 // Deterministic order inside every patch segment: rank by (jj, edge id) == std::stable_sort by jj over an
-// ascending index list (ba.cpp:84-86).  O(d^2) per segment, d ~ 25 in a SLAM graph.
+// ascending index list (ba.cpp:84-86).  O(d^2) per segment, d ~ 25 in a SLAM graph.  The same sweep yields the
+// edge's neighbours in time (ba.cpp:88-94): the largest key below its own and the smallest key above.
 __global__ __launch_bounds__(256) void graph_segsort_kernel(const int64_t* __restrict__ jj,
                                                             const int64_t* __restrict__ kk, int32_t E,
                                                             const int32_t* __restrict__ meta,
                                                             const int32_t* __restrict__ kcount,
                                                             const int32_t* __restrict__ pcsr_tmp,
-                                                            int32_t* __restrict__ pcsr) {
+                                                            int32_t* __restrict__ pcsr, int32_t* __restrict__ nprev,
+                                                            int32_t* __restrict__ nnext, int32_t* __restrict__ kcursor,
+                                                            int64_t* __restrict__ ix, int64_t* __restrict__ jx) {
   if (meta[GM_ERROR]) return;
-  const int kmin = meta[GM_KMIN];
+  const int kmin = meta[GM_KMIN], krange = meta[GM_KRANGE];
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t <= krange; t += gridDim.x * blockDim.x)
+    kcursor[t] = 0;   // the fill cursors of this build: zero again for the next one
   for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < E; p += gridDim.x * blockDim.x) {
     const int e = pcsr_tmp[p];
     const int d = (int)kk[e] - kmin;
     const int lo = kcount[d], hi = kcount[d + 1];
-    const int64_t je = jj[e];
+    // one 64-bit key per edge: (jj, edge id), both below 2^31
+    const uint64_t ke = ((uint64_t)jj[e] << 32) | (uint32_t)e;
     int r = 0;
-    for (int s = lo; s < hi; s++) {
-      const int o = pcsr_tmp[s];
-      const int64_t jo = jj[o];
-      r += (jo < je) || (jo == je && o < e);
+    uint64_t pk = 0, nk = ~(uint64_t)0;   // best predecessor / successor key so far (sentinels: none)
+    for (int s0 = lo; s0 < hi; s0 += 4) {
+      int o[4];
+      uint64_t ko[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) o[u] = pcsr_tmp[min(s0 + u, hi - 1)];
+#pragma unroll
+      for (int u = 0; u < 4; u++) ko[u] = ((uint64_t)jj[o[u]] << 32) | (uint32_t)o[u];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const bool in = s0 + u < hi;
+        const bool below = in && ko[u] < ke, above = in && ko[u] > ke;
+        r += below;
+        pk = (below && (ko[u] >= pk)) ? ko[u] : pk;
+        nk = (above && (ko[u] <= nk)) ? ko[u] : nk;
+      }
     }
+    const bool hasp = r > 0, hasn = lo + r + 1 < hi;
+    const int pe = hasp ? (int)(uint32_t)pk : -1, ne = hasn ? (int)(uint32_t)nk : -1;
     pcsr[lo + r] = e;
+    nprev[e] = pe;             // kept in the workspace for a later cdv_neighbors
+    nnext[e] = ne;
+    if (ix) {
+      ix[e] = (int64_t)pe;     // previous edge in time (-1: none)   ba.cpp:88-94
+      jx[e] = (int64_t)ne;     // next edge in time
+    }
   }
 }
 
 __global__ __launch_bounds__(256) void graph_neighbors_kernel(int32_t E, const int32_t* __restrict__ meta,
-                                                              const int32_t* __restrict__ koff_u,
-                                                              const int32_t* __restrict__ ku,
-                                                              const int32_t* __restrict__ pcsr,
+                                                              const int32_t* __restrict__ nprev,
+                                                              const int32_t* __restrict__ nnext,
                                                               int64_t* __restrict__ ix, int64_t* __restrict__ jx) {
   if (meta[GM_ERROR]) return;
-  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < E; p += gridDim.x * blockDim.x) {
-    const int e = pcsr[p];
-    const int r = ku[e];
-    const int lo = koff_u[r], hi = koff_u[r + 1];
-    ix[e] = (p > lo) ? (int64_t)pcsr[p - 1] : -1;      // previous edge in time
-    jx[e] = (p + 1 < hi) ? (int64_t)pcsr[p + 1] : -1;  // next edge in time
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) {
+    ix[e] = (int64_t)nprev[e];   // previous edge in time (-1: none)
+    jx[e] = (int64_t)nnext[e];   // next edge in time
   }
 }
 
@@ -248,6 +289,12 @@ extern "C" size_t cdv_graph_workspace_bytes(int64_t E_max, int64_t k_range) {
 
 extern "C" int cdv_graph_build(const int64_t* jj, const int64_t* kk, int64_t E, void* ws, size_t ws_bytes,
                                int64_t E_max, int64_t k_range, void* stream) {
+  return cdv_graph_build_neighbors(jj, kk, E, ws, ws_bytes, E_max, k_range, nullptr, nullptr, stream);
+}
+
+extern "C" int cdv_graph_build_neighbors(const int64_t* jj, const int64_t* kk, int64_t E, void* ws, size_t ws_bytes,
+                                         int64_t E_max, int64_t k_range, int64_t* ix, int64_t* jx, void* stream) {
+  CDV_REQUIRE((ix == nullptr) == (jx == nullptr), CDV_ERR_ARG, "cdv_graph_build_neighbors: give both ix and jx or neither");
   CDV_REQUIRE(ws != nullptr, CDV_ERR_ARG, "cdv_graph_build: workspace is NULL");
   CDV_REQUIRE(E >= 0 && E < (int64_t)1 << 31, CDV_ERR_ARG, "cdv_graph_build: E out of range");
   CDV_REQUIRE(k_range >= 1 && E_max >= 1 && E <= E_max, CDV_ERR_ARG,
@@ -267,19 +314,18 @@ extern "C" int cdv_graph_build(const int64_t* jj, const int64_t* kk, int64_t E, 
   const int32_t En = (int32_t)E;
   const int tb = 256;
   if (need_init)
-    hipLaunchKernelGGL(graph_init_kernel, dim3(grid_for(k_range + 1, tb, 2048)), dim3(tb), 0, s, v.meta, v.kcount,
+    hipLaunchKernelGGL(graph_init_kernel, dim3(grid_for(k_range + 1, tb, 2048)), dim3(tb), 0, s, v.meta, v.khist,
                        v.kcursor, k_range);
-  // ~47 blocks for E = 47,712: few enough that one min/max atomic per block is free, enough to stream kk/jj
-  const int eb = grid_for(E, 1024, 256);
-  hipLaunchKernelGGL(graph_minmax_clear_kernel, dim3(eb), dim3(tb), 0, s, jj, kk, En, v.meta, v.kcount, v.kcursor);
-  const int fb = grid_for(E, tb, 1024);
-  if (E > 0) hipLaunchKernelGGL(graph_hist_kernel, dim3(fb), dim3(tb), 0, s, kk, En, v.meta, v.kcount, k_range);
-  hipLaunchKernelGGL(graph_scan_kernel, dim3(1), dim3(1024), 0, s, v.meta, v.kcount, v.krank, En, k_range);
+  const int fb = grid_for(E, tb, GRAPH_MAX_BLOCKS);
+  const int hb = E > 0 ? fb : 0;
+  if (E > 0) hipLaunchKernelGGL(graph_hist_kernel, dim3(hb), dim3(tb), 0, s, jj, kk, En, v.stage, v.khist, (int32_t)k_range);
+  hipLaunchKernelGGL(graph_scan_kernel, dim3(1), dim3(1024), 0, s, v.meta, v.stage, hb, v.khist, v.kcount, v.krank, En,
+                     k_range);
   if (E > 0) {
     hipLaunchKernelGGL(graph_fill_kernel, dim3(fb), dim3(tb), 0, s, kk, En, v.meta, v.kcount, v.kcursor, v.krank,
                        v.koff_u, v.kx, v.ku, v.pcsr_tmp);
     hipLaunchKernelGGL(graph_segsort_kernel, dim3(fb), dim3(tb), 0, s, jj, kk, En, v.meta, v.kcount, v.pcsr_tmp,
-                       v.pcsr);
+                       v.pcsr, v.nprev, v.nnext, v.kcursor, ix, jx);
   }
   CDV_LAUNCH_CHECK();
   return CDV_OK;
@@ -315,7 +361,7 @@ extern "C" int cdv_neighbors(const void* ws, int64_t E, int64_t* ix, int64_t* jx
   if (E == 0) return CDV_OK;
   const GraphView v = graph_view((void*)ws, L);
   hipLaunchKernelGGL(graph_neighbors_kernel, dim3(grid_for(E, 256, 1024)), dim3(256), 0, (hipStream_t)stream,
-                     (int32_t)E, v.meta, v.koff_u, v.ku, v.pcsr, ix, jx);
+                     (int32_t)E, v.meta, v.nprev, v.nnext, ix, jx);
   CDV_LAUNCH_CHECK();
   return CDV_OK;
 }

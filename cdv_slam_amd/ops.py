@@ -67,9 +67,10 @@ class GraphIndex:
         self.ws_bytes = nbytes
         self._key = None
 
-    def build(self, jj, kk, force=False):
+    def build(self, jj, kk, force=False, with_neighbors=False):
         """Enqueue the index build for (jj, kk).  Re-used when called again with the same, unmodified
-        tensor objects (neighbors() and BA() of one update share one build)."""
+        tensor objects (neighbors() and BA() of one update share one build).  with_neighbors: the build also
+        produces fastba.neighbors(kk, jj) (picked up by neighbors() without another launch)."""
         _need_cuda(jj, kk)
         if jj.dtype != torch.int64 or kk.dtype != torch.int64:
             raise TypeError("index tensors must be int64")
@@ -82,9 +83,18 @@ class GraphIndex:
         if jj.numel() != E:
             raise ValueError("jj and kk must have the same length")
         self._reserve(E)
-        rc = self.lib.cdv_graph_build(_p(jj), _p(kk), E, _p(self.ws), self.ws_bytes, self.E_cap, self.k_range,
-                                      _stream())
-        _lib.check(rc, "cdv_graph_build")
+        self._nbr = None
+        if with_neighbors and E > 0:
+            ix = torch.empty(E, dtype=torch.int64, device=self.device)
+            jx = torch.empty(E, dtype=torch.int64, device=self.device)
+            rc = self.lib.cdv_graph_build_neighbors(_p(jj), _p(kk), E, _p(self.ws), self.ws_bytes, self.E_cap,
+                                                    self.k_range, _p(ix), _p(jx), _stream())
+            _lib.check(rc, "cdv_graph_build_neighbors")
+            self._nbr = (ix, jx)
+        else:
+            rc = self.lib.cdv_graph_build(_p(jj), _p(kk), E, _p(self.ws), self.ws_bytes, self.E_cap, self.k_range,
+                                          _stream())
+            _lib.check(rc, "cdv_graph_build")
         self._key = key  # strong refs pin the tensors so that identity implies content
         self.E = E
         if _sync_check():
@@ -102,6 +112,8 @@ class GraphIndex:
         return m
 
     def neighbors(self):
+        if getattr(self, "_nbr", None) is not None:
+            return self._nbr
         ix = torch.empty(self.E, dtype=torch.int64, device=self.device)
         jx = torch.empty(self.E, dtype=torch.int64, device=self.device)
         _lib.check(self.lib.cdv_neighbors(_p(self.ws), self.E, _p(ix), _p(jx), _stream()), "cdv_neighbors")

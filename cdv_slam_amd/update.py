@@ -86,10 +86,10 @@ class UpdatePath:
         if self.overlap:
             self._aux.wait_stream(main)      # the previous BA still reads the index this build overwrites
             with torch.cuda.stream(self._aux):
-                self.graph.build(self.jj, self.kk, force=rebuild_graph)
+                self.graph.build(self.jj, self.kk, force=rebuild_graph, with_neighbors=True)
                 out["ix"], out["jx"] = self.graph.neighbors()
         else:
-            self.graph.build(self.jj, self.kk, force=rebuild_graph)
+            self.graph.build(self.jj, self.kk, force=rebuild_graph, with_neighbors=True)
             out["ix"], out["jx"] = self.graph.neighbors()
         if self.has_features and ingest:
             ops.fmap_ingest(self.new_frame, self.fmap1, self.fmap2, self.new_slot, gmap=self.gmap, gmap_pm=self.gmap_pm,
@@ -140,7 +140,7 @@ class UpdatePath:
                                                           gmap_first=self.new_tiles, gmap_count=self.M))
         res["reproject"] = timed(lambda: ops.transform(self.poses[None], self.patches[None], self.intrinsics[None],
                                                        self.ii, self.jj, self.kk, layout_e2pp=True))
-        res["graph_build"] = timed(lambda: self.graph.build(self.jj, self.kk, force=True))
+        res["graph_build"] = timed(lambda: self.graph.build(self.jj, self.kk, force=True, with_neighbors=True))
         if self.has_features:
             res["corr"] = timed(lambda: self.corr_only(coords))
         res["neighbors"] = timed(lambda: self.graph.neighbors())

@@ -178,6 +178,12 @@ int cdv_graph_build(const int64_t* jj, const int64_t* kk, int64_t E, void* ws, s
                     int64_t k_range, void* stream);
 
 /* meta_host[8] <- {U, 0, kmin, kmax, jmin, jmax, error, E}; synchronises `stream`. */
+/* cdv_graph_build that also writes fastba.neighbors' result (ba.cpp:59-97) for the same (kk, jj) straight into
+ * ix / jx [E] int64 -- the sweep that orders a patch's edges in time sees each edge's predecessor and successor
+ * anyway, so the update path needs no separate neighbors launch.  ix == jx == NULL: same as cdv_graph_build. */
+int cdv_graph_build_neighbors(const int64_t* jj, const int64_t* kk, int64_t E, void* ws, size_t ws_bytes,
+                              int64_t E_max, int64_t k_range, int64_t* ix, int64_t* jx, void* stream);
+
 int cdv_graph_read_meta_host(const void* ws, int64_t* meta_host, void* stream);
 
 /* copy out torch::_unique results (kx needs U from cdv_graph_read_meta_host to size it) */
