@@ -36,6 +36,9 @@ constexpr int PADY = CDV_FMAP_PADY;             // 12
 // Per-wave LDS: the raw correlation volume of ONE level in f16 (the reference's raw volume is f16 too,
 // correlation_kernel.cu:207) + the staged output row of the edge.
 constexpr int RAW_ROWS = 12;                    // window rows the fast path holds (typical: 10-11 / 8-9)
+constexpr int NQ_MAX = 9;                       // 16-pixel groups of the densely packed window kept in registers at a time (144 pixels; typical
+                                                // windows: 110-121 / 81 pixels; larger ones take a second round): 78 VGPRs,
+                                                // 6 waves per SIMD
 constexpr int RAW_MSH = RAW_ROWS * 16 + 8;      // halfs per patch pixel (+8: 16-byte skew between pixels)
 constexpr int RAW_HALFS = 9 * RAW_MSH;          // 1800
 constexpr int OUT_HALFS = 896;                  // the staged output row: 882 halfs, linear (the copy-out needs no index math)
@@ -90,7 +93,8 @@ __device__ __forceinline__ int floor_clamped(float v) {
   return (int)fminf(fmaxf(floorf(v), -1.0e6f), 1.0e6f);
 }
 
-__device__ __forceinline__ Box make_box(float minx, float maxx, float miny, float maxy, const LevelParams& LP) {
+__device__ __forceinline__ Box make_box(float minx, float maxx, float miny, float maxy, const LevelParams& LP,
+                                        bool dense) {
   Box b;
   // floor(x / s) is monotone in x, so the extreme pixels give the extreme integer coordinates
   b.x0 = __builtin_amdgcn_readfirstlane(floor_clamped(minx * LP.inv_scale) - 3);   // slam.py:321-322
@@ -98,6 +102,7 @@ __device__ __forceinline__ Box make_box(float minx, float maxx, float miny, floa
   b.Wb = __builtin_amdgcn_readfirstlane(floor_clamped(maxx * LP.inv_scale) + 4 - b.x0 + 1);
   b.Hb = __builtin_amdgcn_readfirstlane(floor_clamped(maxy * LP.inv_scale) + 4 - b.y0 + 1);
   b.fast = (b.Wb <= 16) && (b.Hb <= RAW_ROWS);
+  (void)dense;
   b.stride = b.fast ? b.Wb : 16;
   b.x0c = min(max(b.x0, -PADX), LP.W);
   b.y0c = min(max(b.y0, -PADY), LP.H);
@@ -231,8 +236,8 @@ __global__ __launch_bounds__(256) void corr_fused_kernel(const _Float16* __restr
   const float yb = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * (9 + bm), cval));
   const float minx = uniform_f(row16_reduce<true>(xv)), maxx = uniform_f(row16_reduce<false>(xv));
   const float miny = uniform_f(row16_reduce<true>(yv)), maxy = uniform_f(row16_reduce<false>(yv));
-  const Box b0 = make_box(minx, maxx, miny, maxy, L0);
-  const Box b1 = make_box(minx, maxx, miny, maxy, nlev == 2 ? L1 : L0);
+  const Box b0 = make_box(minx, maxx, miny, maxy, L0, KS == 1);
+  const Box b1 = make_box(minx, maxx, miny, maxy, nlev == 2 ? L1 : L0, KS == 1);
   CDV_STAMP(corr, p, 1);
 
   const int n = lane & 15, g = lane >> 4;
@@ -291,24 +296,25 @@ __global__ __launch_bounds__(256) void corr_fused_kernel(const _Float16* __restr
     // is Hb rows: the hardware range check returns zeros for the lanes past the last pixel and for the
     // k-padding lanes (offset forced out of range) -- no EXEC masking, no zero-initialised fragments.
     typedef int cdv_i32x4 __attribute__((ext_vector_type(4)));
-    cdv_half8 w[RAW_ROWS][1];
+    cdv_half8 w[NQ_MAX][1];
     const bool do0 = b0.fast && !b0.outside;
     const bool do1 = nlev == 2 && b1.fast && !b1.outside;
     const unsigned CB = (unsigned)C * 2u;                              // bytes per pixel
     const unsigned gbyte = (8 * g < C) ? (unsigned)(8 * g) * 2u : 0x40000000u;  // k padding -> out of range
     const int nq0 = (b0.Wb * b0.Hb + 15) >> 4, nq1 = (b1.Wb * b1.Hb + 15) >> 4;
-#define CDV_LOAD_LEVEL(BX, RB, PITCH, NQ)                                                          \
+#define CDV_LOAD_LEVEL(BX, RB, PITCH, NQ, Q0)                                                      \
     {                                                                                              \
       const unsigned Wb_ = (unsigned)(BX).Wb, pitch_ = (unsigned)(PITCH);                          \
       const auto rsrc_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(RB), (short)0,        \
                                                            (int)((unsigned)(BX).Hb * pitch_), 0x00020000); \
       const unsigned a_ = (Wb_ == 8u) ? 2u : 1u, b_ = 16u - a_ * Wb_;                              \
       const unsigned step_ = a_ * pitch_ + b_ * CB, wrap_ = pitch_ - Wb_ * CB;                     \
-      const unsigned row0_ = ((unsigned)n >= Wb_) ? 1u : 0u;                                       \
-      unsigned col_ = (unsigned)n - row0_ * Wb_;                                                   \
+      /* first pixel of this lane: P = 16 Q0 + n = (row0, col); Q0 > 0 (windows above 16 NQ_MAX pixels) is rare */ \
+      const unsigned row0_ = ((Q0) == 0) ? (((unsigned)n >= Wb_) ? 1u : 0u) : (16u * (Q0) + (unsigned)n) / Wb_; \
+      unsigned col_ = 16u * (Q0) + (unsigned)n - row0_ * Wb_;                                     \
       unsigned voff_ = row0_ * pitch_ + col_ * CB + gbyte;                                         \
-      _Pragma("unroll") for (int q = 0; q < RAW_ROWS; q++) {                                       \
-        if (q < (NQ)) {                                                                            \
+      _Pragma("unroll") for (int q = 0; q < NQ_MAX; q++) {                                         \
+        if ((Q0) + q < (NQ)) {                                                                     \
           const cdv_i32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(rsrc_, (int)voff_, 0, 0);     \
           w[q][0] = __builtin_bit_cast(cdv_half8, v_);                                             \
           col_ += b_; voff_ += step_;                                                              \
@@ -317,25 +323,29 @@ __global__ __launch_bounds__(256) void corr_fused_kernel(const _Float16* __restr
         }                                                                                          \
       }                                                                                            \
     }
-#define CDV_MFMA_LEVEL(NQ)                                                                         \
-    _Pragma("unroll") for (int q = 0; q < RAW_ROWS; q++)                                           \
-      if (q < (NQ)) {                                                                              \
+#define CDV_MFMA_LEVEL(NQ, Q0)                                                                     \
+    _Pragma("unroll") for (int q = 0; q < NQ_MAX; q++)                                             \
+      if ((Q0) + q < (NQ)) {                                                                       \
         cdv_float4 acc = {0.f, 0.f, 0.f, 0.f};                                                     \
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[q][0], pat[0], acc, 0, 0, 0);               \
         cdv_half4 h = {(_Float16)acc[0], (_Float16)acc[1], (_Float16)acc[2], (_Float16)acc[3]};    \
-        *reinterpret_cast<cdv_half4*>(raw_lane + q * 16) = h;                                      \
+        *reinterpret_cast<cdv_half4*>(raw_lane + ((Q0) + q) * 16) = h;                             \
       }
-    if (do0 && !(exp & 1)) CDV_LOAD_LEVEL(b0, r0, pitch0, nq0)
+    if (do0 && !(exp & 1)) CDV_LOAD_LEVEL(b0, r0, pitch0, nq0, 0)
     const BlendGeo g0 = blend_geo(xb, yb, bm, bxo, L0, b0, !b0.fast);
     const BlendGeo g1 = blend_geo(xb, yb, bm, bxo, nlev == 2 ? L1 : L0, b1, !b1.fast);
     CDV_STAMP(corr, p, 2);
     // level 0: MFMA per pixel group; the registers are immediately re-used for the level-1 request
     if (do0 && !(exp & 256)) {
-      CDV_MFMA_LEVEL(nq0)
+      CDV_MFMA_LEVEL(nq0, 0)
+      if (nq0 > NQ_MAX) {   // window of more than 16 NQ_MAX pixels: a second round through the same registers
+        CDV_LOAD_LEVEL(b0, r0, pitch0, nq0, NQ_MAX)
+        CDV_MFMA_LEVEL(nq0, NQ_MAX)
+      }
     } else if (!b0.fast) {
       slow_level<1>(L0, jslot, xv, yv, pat, raw, lane, C);
     }
-    if (do1 && !(exp & 1)) CDV_LOAD_LEVEL(b1, r1, pitch1, nq1)
+    if (do1 && !(exp & 1)) CDV_LOAD_LEVEL(b1, r1, pitch1, nq1, 0)
     wave_lds_sync();
     CDV_STAMP(corr, p, 3);
     if ((do0 || !b0.fast) && !(exp & 128)) blend_level(raw, g0, res0);
@@ -343,7 +353,11 @@ __global__ __launch_bounds__(256) void corr_fused_kernel(const _Float16* __restr
     if (nlev == 2) {
       wave_lds_sync();
       if (do1 && !(exp & 256)) {
-        CDV_MFMA_LEVEL(nq1)
+        CDV_MFMA_LEVEL(nq1, 0)
+        if (nq1 > NQ_MAX) {
+          CDV_LOAD_LEVEL(b1, r1, pitch1, nq1, NQ_MAX)
+          CDV_MFMA_LEVEL(nq1, NQ_MAX)
+        }
       } else if (!b1.fast) {
         slow_level<1>(L1, jslot, xv, yv, pat, raw, lane, C);
       }

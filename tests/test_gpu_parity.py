@@ -282,9 +282,13 @@ def test_corr_edge_cases():
     gmap = (rng.standard_normal((1, Ng, C, 3, 3)) / 4).astype(np.float16)
     cases = []
     base = np.stack(np.meshgrid(np.arange(3.0), np.arange(3.0), indexing="xy"))  # [2,3,3] x then y offsets
-    for cx, cy, s in [(10.3, 8.7, 1.0), (-20.0, 5.0, 1.0), (0.2, 0.4, 1.0), (27.9, 19.9, 1.0), (40.0, 40.0, 1.0),
-                      (12.0, 9.0, 1.0), (12.5, 9.5, 6.0), (5.0, 5.0, 12.0), (-1.0, -1.0, 3.3), (13.999, 7.001, 0.2)]:
-        cases.append(np.stack([cx + s * (base[0] - 1), cy + s * (base[1] - 1)]))
+    # (centre, x / y stretch of the 3x3 patch): windows of 11x11 (one round of 9 register groups), 13x13 = 169 and
+    # 16x12 = 192 pixels (second round through the registers), wider ones (per-pixel path), off-image ones
+    for cx, cy, sx, sy in [(10.3, 8.7, 1.0, 1.0), (-20.0, 5.0, 1.0, 1.0), (0.2, 0.4, 1.0, 1.0), (27.9, 19.9, 1.0, 1.0),
+                           (40.0, 40.0, 1.0, 1.0), (12.0, 9.0, 1.0, 1.0), (12.5, 9.5, 6.0, 6.0), (5.0, 5.0, 12.0, 12.0),
+                           (-1.0, -1.0, 3.3, 3.3), (13.999, 7.001, 0.2, 0.2), (11.2, 9.4, 2.0, 2.0),
+                           (14.6, 10.1, 2.4, 1.2), (12.1, 8.2, 3.5, 1.5), (3.3, 15.8, 1.5, 1.9), (25.7, 2.2, 2.2, 2.2)]:
+        cases.append(np.stack([cx + sx * (base[0] - 1), cy + sy * (base[1] - 1)]))
     coords = np.stack(cases)[None].astype(np.float32)  # [1,M,2,3,3]
     M = coords.shape[1]
     us = rng.integers(0, Ng, M).astype(np.int64)
