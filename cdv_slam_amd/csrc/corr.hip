@@ -149,17 +149,32 @@ __device__ __forceinline__ BlendGeo blend_geo(float xm, float ym, int m, int xo,
 // 4-byte LDS read at an odd half offset is an UNALIGNED access (very slow on the LDS), so the two aligned dwords
 // around it are read (one ds_read2_b32) and funnel-shifted (v_alignbit) into the pair; the horizontal tap is one
 // v_dot2_f32_f16 (exact f16 products, f32 sum).  5 VALU + 1 LDS instruction per window row.
+__device__ __forceinline__ float dot2_f16(uint32_t pair, uint32_t w) {
+  // v_dot2_f32_f16 with a literal zero accumulator (the compiler's pick, v_dot2c, needs a v_mov 0 every time)
+  float r;
+  asm("v_dot2_f32_f16 %0, %1, %2, 0" : "=v"(r) : "v"(pair), "v"(w));
+  return r;
+}
+
 __device__ __forceinline__ void blend_level(const _Float16* __restrict__ raw, const BlendGeo& g, float (&res)[7]) {
   const char* rb = reinterpret_cast<const char*>(raw);   // raw is 16-byte aligned
   float h[8];
-  int hb = g.hb;
+  // even and odd rows keep their own aligned LDS pointer and funnel shift: two rows further down the byte offset
+  // moves by 2 stride_b = 4 stride, a multiple of 4, so neither alignment changes -- 3 VALU per row
+  // (pointer add, v_alignbit, v_dot2)
+  const int hb1 = g.hb + g.stride_b;
+  const char* p0 = rb + (g.hb & ~3);
+  const char* p1 = rb + (hb1 & ~3);
+  const unsigned s0 = (unsigned)g.hb << 3, s1 = (unsigned)hb1 << 3;   // shift = low 5 bits: 0 or 16
+  const int step2 = 2 * g.stride_b;
+  const uint32_t wxb = __builtin_bit_cast(uint32_t, g.wx);
 #pragma unroll
   for (int r = 0; r < 8; r++) {
-    const uint32_t* pd = reinterpret_cast<const uint32_t*>(rb + (hb & ~3));
+    const uint32_t* pd = reinterpret_cast<const uint32_t*>((r & 1) ? p1 : p0);
     const uint32_t lo = pd[0], hi = pd[1];           // hi is unused when the pair is dword aligned (stays in the wave's LDS)
-    const uint32_t pr = __builtin_amdgcn_alignbit(hi, lo, (unsigned)hb << 3);   // shift = low 5 bits: 0 or 16
-    h[r] = __builtin_amdgcn_fdot2(__builtin_bit_cast(cdv_half2, pr), g.wx, 0.0f, false);
-    hb += g.stride_b;
+    const uint32_t pr = __builtin_amdgcn_alignbit(hi, lo, (r & 1) ? s1 : s0);
+    h[r] = dot2_f16(pr, wxb);
+    if (r & 1) p1 += step2; else p0 += step2;
   }
 #pragma unroll
   for (int yo = 0; yo < 7; yo++) res[yo] = h[yo] + g.dy * (h[yo + 1] - h[yo]);
