@@ -55,15 +55,14 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
-// all-reduce over the 16 lanes of a DPP row by rotation (row_ror 8,4,2,1): no LDS crossbar traffic
+// all-reduce (min or max) of an int over the 16 lanes of a DPP row by rotation (row_ror 8,4,2,1): the DPP operand is
+// folded into the min / max itself (one VALU instruction per step; integers need no NaN canonicalisation).  The
+// s_nop covers the two wait states between a VALU write and a DPP read of the same register.
 template <bool IS_MIN>
-__device__ __forceinline__ float row16_reduce(float v) {
-#define CDV_ROR(n)                                                                                        \
-  {                                                                                                       \
-    const float o = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x120 + (n), \
-                                                               0xf, 0xf, false));                          \
-    v = IS_MIN ? fminf(v, o) : fmaxf(v, o);                                                               \
-  }
+__device__ __forceinline__ int row16_reduce_i32(int v) {
+#define CDV_ROR(n)                                                                                             \
+  if (IS_MIN) asm volatile("s_nop 1\n\tv_min_i32_dpp %0, %1, %1 row_ror:" #n " row_mask:0xf bank_mask:0xf" : "=v"(v) : "0"(v)); \
+  else asm volatile("s_nop 1\n\tv_max_i32_dpp %0, %1, %1 row_ror:" #n " row_mask:0xf bank_mask:0xf" : "=v"(v) : "0"(v));
   CDV_ROR(8) CDV_ROR(4) CDV_ROR(2) CDV_ROR(1)
 #undef CDV_ROR
   return v;
@@ -77,6 +76,7 @@ struct LevelParams {
   const _Float16* fmap;  // [slots][H + 2 PADY][W + 2 PADX][C]
   int H, W;
   float inv_scale;       // 1 / scale, scale a power of two: x * inv_scale == x / scale exactly (slam.py:321-322)
+  int shift;             // log2(scale / scale of level 0) >= 0: floor(x / scale) == floor(x / scale0) >> shift
 };
 
 // wave-uniform window box of one level (all members live in SGPRs)
@@ -93,16 +93,15 @@ __device__ __forceinline__ int floor_clamped(float v) {
   return (int)fminf(fmaxf(floorf(v), -1.0e6f), 1.0e6f);
 }
 
-__device__ __forceinline__ Box make_box(float minx, float maxx, float miny, float maxy, const LevelParams& LP,
-                                        bool dense) {
+// ixmin .. iymax: extreme floor(coordinate / scale) over the 9 patch pixels (floor is monotone, so the extreme pixels
+// give the extreme integer coordinates)
+__device__ __forceinline__ Box make_box(int ixmin, int ixmax, int iymin, int iymax, const LevelParams& LP) {
   Box b;
-  // floor(x / s) is monotone in x, so the extreme pixels give the extreme integer coordinates
-  b.x0 = __builtin_amdgcn_readfirstlane(floor_clamped(minx * LP.inv_scale) - 3);   // slam.py:321-322
-  b.y0 = __builtin_amdgcn_readfirstlane(floor_clamped(miny * LP.inv_scale) - 3);
-  b.Wb = __builtin_amdgcn_readfirstlane(floor_clamped(maxx * LP.inv_scale) + 4 - b.x0 + 1);
-  b.Hb = __builtin_amdgcn_readfirstlane(floor_clamped(maxy * LP.inv_scale) + 4 - b.y0 + 1);
+  b.x0 = ixmin - 3;   // slam.py:321-322, correlation_kernel.cu:107-110
+  b.y0 = iymin - 3;
+  b.Wb = ixmax + 4 - b.x0 + 1;
+  b.Hb = iymax + 4 - b.y0 + 1;
   b.fast = (b.Wb <= 16) && (b.Hb <= RAW_ROWS);
-  (void)dense;
   b.stride = b.fast ? b.Wb : 16;
   b.x0c = min(max(b.x0, -PADX), LP.W);
   b.y0c = min(max(b.y0, -PADY), LP.H);
@@ -249,10 +248,16 @@ __global__ __launch_bounds__(256) void corr_fused_kernel(const _Float16* __restr
   const float yv = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * (9 + mm), cval));
   const float xb = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * bm, cval));
   const float yb = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * (9 + bm), cval));
-  const float minx = uniform_f(row16_reduce<true>(xv)), maxx = uniform_f(row16_reduce<false>(xv));
-  const float miny = uniform_f(row16_reduce<true>(yv)), maxy = uniform_f(row16_reduce<false>(yv));
-  const Box b0 = make_box(minx, maxx, miny, maxy, L0, KS == 1);
-  const Box b1 = make_box(minx, maxx, miny, maxy, nlev == 2 ? L1 : L0, KS == 1);
+  // integer pixel coordinates at level 0 per lane, their extremes over the patch (DPP row reductions), and from
+  // those -- all scalar from here -- the window boxes of both levels (level 1: an arithmetic shift)
+  const int ixl = floor_clamped(xv * L0.inv_scale), iyl = floor_clamped(yv * L0.inv_scale);
+  const int ixmin = __builtin_amdgcn_readfirstlane(row16_reduce_i32<true>(ixl));
+  const int ixmax = __builtin_amdgcn_readfirstlane(row16_reduce_i32<false>(ixl));
+  const int iymin = __builtin_amdgcn_readfirstlane(row16_reduce_i32<true>(iyl));
+  const int iymax = __builtin_amdgcn_readfirstlane(row16_reduce_i32<false>(iyl));
+  const Box b0 = make_box(ixmin, ixmax, iymin, iymax, L0);
+  const int sh1 = nlev == 2 ? L1.shift : 0;
+  const Box b1 = make_box(ixmin >> sh1, ixmax >> sh1, iymin >> sh1, iymax >> sh1, nlev == 2 ? L1 : L0);
   CDV_STAMP(corr, p, 1);
 
   const int n = lane & 15, g = lane >> 4;
@@ -721,8 +726,9 @@ extern "C" int cdv_corr_fused(const void* gmap, const void* fmap0_nhwc, const vo
               CDV_ERR_UNSUPPORTED, "cdv_corr_fused: pyramid scales must be powers of two (1 and 4 in SLAM.corr)");
   CDV_REQUIRE(fmap0_nhwc != nullptr && (nlev == 1 || fmap1_nhwc != nullptr), CDV_ERR_ARG, "cdv_corr_fused: NULL map");
   if (E == 0) return CDV_OK;
-  LevelParams L0{(const _Float16*)fmap0_nhwc, H0, W0, 1.0f / scale0};
-  LevelParams L1{(const _Float16*)fmap1_nhwc, H1, W1, nlev == 2 ? 1.0f / scale1 : 1.0f};
+  CDV_REQUIRE(nlev == 1 || ex1 >= ex0, CDV_ERR_UNSUPPORTED, "cdv_corr_fused: level 1 must not be finer than level 0");
+  LevelParams L0{(const _Float16*)fmap0_nhwc, H0, W0, 1.0f / scale0, 0};
+  LevelParams L1{(const _Float16*)fmap1_nhwc, H1, W1, nlev == 2 ? 1.0f / scale1 : 1.0f, nlev == 2 ? ex1 - ex0 : 0};
   const int blocks = cdv_div_up(E, 4);
   const size_t smem = 4 * (size_t)WAVE_LDS_BYTES;
   static const int exp = getenv("CDV_CORR_EXP") ? atoi(getenv("CDV_CORR_EXP")) : 0;  // diagnostics only
