@@ -36,6 +36,10 @@ namespace {
 
 constexpr int BA_CHUNK = 64;      // unique patches per workgroup (= lanes of a wave)
 constexpr int BA_NMAX = 32;       // free poses supported by the single-workgroup solver
+constexpr int BA_NBIG = 1024;     // free poses supported by the global-BA path (dense E in HBM, blocked Cholesky)
+constexpr int BIG_PB = 32;        // poses per panel of the panel-sparse Schur products (192 rows; <= 32 panels: one mask word)
+constexpr int BIG_PR = 6 * BIG_PB;
+constexpr int CNB = 64;           // block size of the multi-workgroup Cholesky
 constexpr int XLD = 17;           // floats per residual row in the Gram staging buffer (16 + 1 pad)
 constexpr int PAIR_LDS_FLOATS = 128 * XLD + 64;  // per wave: [128][XLD] rows + 64 per-edge pair keys
 constexpr int ELD = BA_CHUNK + 4; // row stride of the chunk's E block in LDS (2-way bank conflicts at most)
@@ -47,7 +51,8 @@ constexpr int BA_REPL = 4;        // copies of [S | y] the assemble / schur work
                                   // (the memory-side atomic units serialise adds to one address); summed by the solve
 
 struct BaLayout {
-  size_t sy, C, u, Ed, zero_bytes, q, dX, info, total;
+  size_t sy, C, u, Ed, cmask, zero_bytes, q, dX, info, Abig, total;
+  int64_t npad;                         // global-BA path: 6 N rounded up to the Cholesky block (0: not used)
   int64_t U_max, U_stride, sy_stride;   // sy_stride: floats between two copies of [S | y]
   int N_max;
 };
@@ -64,10 +69,16 @@ inline BaLayout ba_layout(int64_t U_max, int N_max) {
   L.C = o;    o = align256(o + sizeof(float) * (size_t)L.U_stride);
   L.u = o;    o = align256(o + sizeof(float) * (size_t)L.U_stride);
   L.Ed = o;   o = align256(o + sizeof(float) * n6 * (size_t)L.U_stride);
+  L.cmask = o; o = align256(o + sizeof(uint32_t) * (size_t)(L.U_stride / BA_CHUNK));   // active pose panels per chunk
   L.zero_bytes = o;
   L.q = o;    o = align256(o + sizeof(float) * (size_t)L.U_stride);
   L.dX = o;   o = align256(o + sizeof(float) * (n6 + 8));
   L.info = o; o = align256(o + sizeof(int32_t) * 16);
+  L.npad = 0; L.Abig = o;
+  if (N_max > BA_NMAX) {   // working copy of [S ; y^T] for the blocked Cholesky, padded with identity to 64-blocks
+    L.npad = (int64_t)((n6 + CNB - 1) / CNB * CNB);
+    o = align256(o + sizeof(float) * (size_t)(L.npad + 1) * (size_t)L.npad);
+  }
   L.total = o;
   return L;
 }
@@ -200,7 +211,7 @@ __global__ __launch_bounds__(ASM_THREADS) void ba_assemble_kernel(
     const int64_t* __restrict__ jj, const int64_t* __restrict__ kk, int P, int t0, int N,
     const int32_t* __restrict__ gmeta, const int32_t* __restrict__ pcsr, const int32_t* __restrict__ koff_u,
     float* __restrict__ sy, int sy_stride, float* __restrict__ Cg, float* __restrict__ ug, float* __restrict__ Edg,
-    int U_stride, int U_max, int32_t* __restrict__ info) {
+    int U_stride, int U_max, int32_t* __restrict__ info, uint32_t* __restrict__ cmask) {
   if (gmeta[GM_ERROR]) return;
   const int U = gmeta[GM_U];
   if (U > U_max) {
@@ -246,6 +257,7 @@ __global__ __launch_bounds__(ASM_THREADS) void ba_assemble_kernel(
       const int a = idx.ix - t0, b = idx.jx - t0;
       ixf = (a >= 0 && a < N) ? a : -1;
       jxf = (b >= 0 && b < N) ? b : -1;
+
       // E, C, u of this lane's patch (ba_cuda.cu:380-390, 401-402).  Lanes are consecutive unique patches, so
       // every atomic wave-instruction below is one contiguous 256-byte row segment of E.
       float ei[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ej[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -266,6 +278,12 @@ __global__ __launch_bounds__(ASM_THREADS) void ba_assemble_kernel(
 #pragma unroll
         for (int c = 0; c < 6; c++) atomicAdd(&Edg[(size_t)(6 * jxf + c) * U_stride + r], ej[c]);
       }
+    }
+    if (cmask) {   // global-BA path: which 32-pose panels have a non-zero E block in this chunk (wave-uniform branch)
+      unsigned pm = (ixf >= 0 ? 1u << (ixf >> 5) : 0u) | (jxf >= 0 ? 1u << (jxf >> 5) : 0u);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) pm |= __shfl_xor(pm, o);
+      if (pm && lane == 0) atomicOr(&cmask[chunk], pm);
     }
     CDV_STAMP(ba, sslot, 3);
     if (N > 0) {
@@ -787,6 +805,321 @@ __global__ __launch_bounds__(256) void ba_solve60_kernel(float* __restrict__ pos
   CDV_STAMP(ba, sslot, 4);
 }
 
+
+// =========================================================================================================
+// Global bundle adjustment (N > 32 free poses; slam.py:460-478 calls fastba.BA(..., eff_impl=True) over the active
+// and the inactive edges).  The reference switches to a block-sparse E (block_e.cu) because a dense [6N x U] E does
+// not fit its GPUs' budget; the numbers it computes -- S = B - E Q E^T, y = v - E Q u, dX, dZ -- are those of the
+// dense path (ba_cuda.cu:567-580 vs :583-592).  On a 288 GB part the dense E simply stays in HBM (assemble and
+// retract are unchanged); what changes is where zeros would be multiplied:
+//   * the Schur products run per (chunk of 64 patches, pair of 32-pose panels), and only for panels in which the chunk
+//     has a non-zero E block (one mask word per chunk, set by the assemble kernel) -- a patch is seen from ~25-40 of
+//     the hundreds of free poses;
+//   * the 6N x 6N system is factored by a right-looking blocked Cholesky over many workgroups (two launches per
+//     64-column block: diagonal block + panel, trailing update on the matrix cores), the right-hand side carried as
+//     an extra row, then one back-substitution launch.
+// =========================================================================================================
+
+// S -= E_pa diag(q) E_pb^T (lower part), y -= E_pa (q .* u) for one chunk and one pair of pose panels.
+__global__ __launch_bounds__(256) void ba_big_schur_kernel(const float* __restrict__ lmbda, int N,
+                                                           const int32_t* __restrict__ gmeta, float* __restrict__ sy,
+                                                           int sy_stride, const float* __restrict__ Cg,
+                                                           const float* __restrict__ ug, const float* __restrict__ Edg,
+                                                           int U_stride, const uint32_t* __restrict__ cmask, int npair,
+                                                           const int32_t* __restrict__ info) {
+  if (gmeta[GM_ERROR] || info[1]) return;
+  const int U = gmeta[GM_U];
+  const int chunk = blockIdx.x / npair, pidx = blockIdx.x - chunk * npair;
+  const int r0 = chunk * BA_CHUNK;
+  if (r0 >= U) return;
+  int pa = 0, acc_rows = 0;   // pidx -> (pa >= pb)
+  while (acc_rows + pa + 1 <= pidx) { acc_rows += pa + 1; pa++; }
+  const int pb = pidx - acc_rows;
+  const uint32_t mask = cmask[chunk];
+  if (!((mask >> pa) & 1u) || !((mask >> pb) & 1u)) return;
+  const int n6 = 6 * N;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ea = smem;                          // [BIG_PR][ELD]
+  float* Eb = Ea + (size_t)BIG_PR * ELD;     // [BIG_PR][ELD]  (aliases Ea when pa == pb)
+  float* qs = Eb + (size_t)BIG_PR * ELD;     // [64]
+  float* qu = qs + BA_CHUNK;                 // [64] q .* u
+  if (pa == pb) Eb = Ea;
+  const float lm = lmbda[0];
+  if (threadIdx.x < BA_CHUNK) {
+    const int rr = r0 + threadIdx.x;
+    const float q = (rr < U) ? 1.0f / (Cg[rr] + lm) : 0.f;
+    qs[threadIdx.x] = q;
+    qu[threadIdx.x] = (rr < U) ? q * ug[rr] : 0.f;
+  }
+  const cdv_float4 z4 = {0.f, 0.f, 0.f, 0.f};
+  for (int half = 0; half < (pa == pb ? 1 : 2); half++) {
+    float* dstE = half == 0 ? Ea : Eb;
+    const int rowbase = BIG_PR * (half == 0 ? pa : pb);
+    for (int i4 = threadIdx.x; i4 < BIG_PR * (BA_CHUNK / 4); i4 += 256) {
+      const int row = i4 >> 4, k4 = (i4 & 15) * 4;
+      const int grow = rowbase + row;
+      const cdv_float4 v = (grow < n6) ? *reinterpret_cast<const cdv_float4*>(Edg + (size_t)grow * U_stride + r0 + k4) : z4;
+      *reinterpret_cast<cdv_float4*>(dstE + row * ELD + k4) = v;
+    }
+  }
+  __syncthreads();
+  float* S = sy + (size_t)(blockIdx.x % BA_REPL) * sy_stride;
+  float* y = S + (size_t)n6 * n6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c16 = lane & 15, g4 = lane >> 4;
+  constexpr int TT = BIG_PR / 16;   // 12 tiles per panel side
+  const int ntile = (pa == pb) ? TT * (TT + 1) / 2 : TT * TT;
+  for (int tix = wave; tix < ntile; tix += 4) {
+    int ti, tj;
+    if (pa == pb) {
+      ti = 0; int ar = 0;
+      while (ar + ti + 1 <= tix) { ar += ti + 1; ti++; }
+      tj = tix - ar;
+    } else {
+      ti = tix / TT; tj = tix - ti * TT;
+    }
+    const float* pra = Ea + (size_t)(16 * ti + c16) * ELD;
+    const float* prb = Eb + (size_t)(16 * tj + c16) * ELD;
+    float a[16], bq[16];
+#pragma unroll
+    for (int st = 0; st < 16; st++) {
+      const int k = 4 * st + g4;
+      a[st] = pra[k];
+      bq[st] = qs[k] * prb[k];
+    }
+    cdv_float4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int st = 0; st < 16; st += 2) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[st], bq[st], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[st + 1], bq[st + 1], acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int R = BIG_PR * pa + 16 * ti + 4 * g4 + q, Cc = BIG_PR * pb + 16 * tj + c16;
+      const float v = acc0[q] + acc1[q];
+      if (v == 0.f || R >= n6 || Cc > R) continue;   // lower triangle only: the blocked Cholesky reads nothing else
+      atomicAdd(&S[(size_t)R * n6 + Cc], -v);
+    }
+  }
+  if (pa == pb && threadIdx.x < BIG_PR) {
+    const int R = BIG_PR * pa + threadIdx.x;
+    if (R < n6) {
+      float sacc = 0.f;
+      const float* pr = Ea + (size_t)threadIdx.x * ELD;
+#pragma unroll 8
+      for (int k = 0; k < BA_CHUNK; k++) sacc += pr[k] * qu[k];
+      if (sacc != 0.f) atomicAdd(&y[R], -sacc);
+    }
+  }
+}
+
+// copies of [S | y] -> working matrix A [(npad + 1)][npad]: rows 0..n-1 = S with the damping of ba_cuda.cu:589, identity
+// on the padded diagonal, row npad = y^T; re-zeroes the copies.
+__global__ __launch_bounds__(256) void ba_big_fold_kernel(float* __restrict__ sy, int sy_stride, int n, int npad,
+                                                          float* __restrict__ A, const int32_t* __restrict__ gmeta,
+                                                          float* __restrict__ dbg, const int32_t* __restrict__ info) {
+  if (gmeta[GM_ERROR] || info[1]) return;
+  const int64_t total = (int64_t)(npad + 1) * npad;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int a = (int)(idx / npad), b = (int)(idx - (int64_t)a * npad);
+    float v = 0.f;
+    if (b < n && (a < n || a == npad)) {
+      const size_t src = (a < n) ? (size_t)a * n + b : (size_t)n * n + b;
+#pragma unroll
+      for (int rep = 0; rep < BA_REPL; rep++) {
+        float* p = sy + (size_t)rep * sy_stride + src;
+        v += *p;
+        *p = 0.f;
+      }
+      if (a == b) v += 1e-4f * v + 1.0f;
+      if (dbg) dbg[src] = v;
+    } else if (a == b) {
+      v = 1.0f;
+    }
+    A[idx] = v;
+  }
+}
+
+// 16x16 tiles of X Y^T for two 64x64 blocks in LDS (row stride CLD), K = 64: tile (ti, tj) -> lane (c16, g4) holds
+// rows 16 ti + 4 g4 + q, column 16 tj + c16
+constexpr int CLD = CNB + 4;
+__device__ __forceinline__ cdv_float4 tile64_xyt(const float* X, const float* Y, int ti, int tj, int c16, int g4) {
+  const float* pa = X + (size_t)(16 * ti + c16) * CLD;
+  const float* pb = Y + (size_t)(16 * tj + c16) * CLD;
+  cdv_float4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int st = 0; st < 16; st += 2) {
+    const int k0 = 4 * st + g4, k1 = k0 + 4;
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[k0], pb[k0], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[k1], pb[k1], acc1, 0, 0, 0);
+  }
+  return acc0 + acc1;
+}
+
+// Block step kb, part 1.  Every workgroup factors the diagonal block in LDS (redundantly: 64 columns) and inverts the
+// factor; workgroup 0 writes L_kk back, workgroup b > 0 turns block row kb + b of the panel into A L_kk^-T (one GEMM
+// on the matrix cores instead of 64 dependent substitution steps per row); the last workgroup does the same for the
+// right-hand-side row.
+__global__ __launch_bounds__(256) void ba_big_panel_kernel(float* __restrict__ A, int npad, int kb,
+                                                           const int32_t* __restrict__ gmeta, int32_t* __restrict__ info) {
+  if (gmeta[GM_ERROR] || info[1]) return;
+  __shared__ float D[CNB * CLD];    // diagonal block -> L
+  __shared__ float Li[CNB * CLD];   // L^-1
+  __shared__ float X[CNB * CLD];    // block row of the panel
+  __shared__ int s_bad;
+  const int t = threadIdx.x;
+  const int nb = npad / CNB;
+  const int rb = kb + blockIdx.x;               // block row handled here; rb == nb: the right-hand-side row
+  const size_t lda = (size_t)npad;
+  const int c0 = CNB * kb;
+  if (t == 0) s_bad = 0;
+  for (int i = t; i < CNB * CNB; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    D[r * CLD + c] = A[(size_t)(c0 + r) * lda + c0 + c];
+    Li[r * CLD + c] = 0.f;
+    if (rb > kb) {
+      const bool rhs = rb == nb;
+      X[r * CLD + c] = rhs ? (r == 0 ? A[(size_t)npad * lda + c0 + c] : 0.f) : A[(size_t)(CNB * rb + r) * lda + c0 + c];
+    }
+  }
+  __syncthreads();
+  // right-looking Cholesky of the 64x64 block (lower part)
+  for (int j = 0; j < CNB; j++) {
+    const float piv = D[j * CLD + j];
+    if (t == 0 && !(piv > 0.f) && s_bad == 0) s_bad = 1;
+    const float inv = __builtin_amdgcn_rsqf(piv);
+    __syncthreads();
+    if (t >= j && t < CNB) D[t * CLD + j] = (t == j) ? piv * inv : D[t * CLD + j] * inv;
+    __syncthreads();
+    for (int i = t; i < CNB * CNB; i += 256) {
+      const int r = i >> 6, c = i & 63;
+      if (c > j && r >= c) D[r * CLD + c] -= D[r * CLD + j] * D[c * CLD + j];
+    }
+    __syncthreads();
+  }
+  // Li = L^-1, one column per thread (forward substitution)
+  if (t < CNB) {
+    const int c = t;
+    for (int r = c; r < CNB; r++) {
+      float sacc = (r == c) ? 1.0f : 0.0f;
+      for (int j = c; j < r; j++) sacc -= D[r * CLD + j] * Li[j * CLD + c];
+      Li[r * CLD + c] = sacc / D[r * CLD + r];
+    }
+  }
+  __syncthreads();
+  if (blockIdx.x == 0) {
+    if (t == 0 && s_bad && info[0] == 0) info[0] = kb + 1;
+    for (int i = t; i < CNB * CNB; i += 256) {
+      const int r = i >> 6, c = i & 63;
+      if (c <= r) A[(size_t)(c0 + r) * lda + c0 + c] = D[r * CLD + c];
+    }
+    return;
+  }
+  // X <- X L^-T:  out[r][c] = sum_j X[r][j] Li[c][j]
+  const int lane = t & 63, wave = t >> 6, c16 = lane & 15, g4 = lane >> 4;
+  const bool rhs = rb == nb;
+  for (int tix = wave; tix < 16; tix += 4) {
+    const int ti = tix >> 2, tj = tix & 3;
+    const cdv_float4 acc = tile64_xyt(X, Li, ti, tj, c16, g4);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int r = 16 * ti + 4 * g4 + q, c = 16 * tj + c16;
+      if (rhs) {
+        if (r == 0) A[(size_t)npad * lda + c0 + c] = acc[q];
+      } else {
+        A[(size_t)(CNB * rb + r) * lda + c0 + c] = acc[q];
+      }
+    }
+  }
+}
+
+// Block step kb, part 2: trailing update A[rb][cb] -= P_rb P_cb^T for kb < cb <= rb (and the right-hand-side row
+// against every cb) on the matrix cores; every target block is owned by one workgroup (no atomics).
+__global__ __launch_bounds__(256) void ba_big_update_kernel(float* __restrict__ A, int npad, int kb,
+                                                            const int32_t* __restrict__ gmeta,
+                                                            const int32_t* __restrict__ info) {
+  if (gmeta[GM_ERROR] || info[1]) return;
+  __shared__ float Pr[CNB * CLD];
+  __shared__ float Pc[CNB * CLD];
+  const int t = threadIdx.x;
+  const int nb = npad / CNB;
+  const int T = nb - kb - 1;                 // trailing block rows / columns
+  const int ntri = T * (T + 1) / 2;
+  int rb, cb;
+  bool rhs = false;
+  if ((int)blockIdx.x < ntri) {
+    int ri = 0, ar = 0;
+    while (ar + ri + 1 <= (int)blockIdx.x) { ar += ri + 1; ri++; }
+    rb = kb + 1 + ri; cb = kb + 1 + ((int)blockIdx.x - ar);
+  } else {
+    rhs = true; rb = nb; cb = kb + 1 + ((int)blockIdx.x - ntri);
+  }
+  const size_t lda = (size_t)npad;
+  const int c0 = CNB * kb;
+  for (int i = t; i < CNB * CNB; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    Pr[r * CLD + c] = rhs ? (r == 0 ? A[(size_t)npad * lda + c0 + c] : 0.f) : A[(size_t)(CNB * rb + r) * lda + c0 + c];
+    Pc[r * CLD + c] = A[(size_t)(CNB * cb + r) * lda + c0 + c];
+  }
+  __syncthreads();
+  const int lane = t & 63, wave = t >> 6, c16 = lane & 15, g4 = lane >> 4;
+  for (int tix = wave; tix < 16; tix += 4) {
+    const int ti = tix >> 2, tj = tix & 3;
+    const cdv_float4 acc = tile64_xyt(Pr, Pc, ti, tj, c16, g4);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int r = 16 * ti + 4 * g4 + q, c = 16 * tj + c16;
+      if (rhs) {
+        if (r == 0) A[(size_t)npad * lda + CNB * cb + c] -= acc[q];
+      } else {
+        A[(size_t)(CNB * rb + r) * lda + CNB * cb + c] -= acc[q];
+      }
+    }
+  }
+}
+
+// L^T x = z (z = row npad of A after the factorisation), blocks from the bottom; one workgroup.
+__global__ __launch_bounds__(256) void ba_big_backsolve_kernel(const float* __restrict__ A, int npad, int n,
+                                                               float* __restrict__ dXg, const int32_t* __restrict__ gmeta,
+                                                               float* __restrict__ dbg, const int32_t* __restrict__ info) {
+  if (gmeta[GM_ERROR] || info[1]) return;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* zs = smem;                 // [npad]
+  float* Lb = zs + npad;            // [CNB][CLD]
+  __shared__ float s_x;
+  const int t = threadIdx.x;
+  const size_t lda = (size_t)npad;
+  const int nb = npad / CNB;
+  for (int i = t; i < npad; i += 256) zs[i] = A[(size_t)npad * lda + i];
+  __syncthreads();
+  for (int kb = nb - 1; kb >= 0; kb--) {
+    const int c0 = CNB * kb;
+    for (int i = t; i < CNB * CNB; i += 256) {
+      const int r = i >> 6, c = i & 63;
+      Lb[r * CLD + c] = A[(size_t)(c0 + r) * lda + c0 + c];
+    }
+    __syncthreads();
+    for (int c = CNB - 1; c >= 0; c--) {   // x_c = z_c / L[c][c]; z_j -= L[c][j] x_c for j < c
+      if (t == 0) { const float xc = zs[c0 + c] / Lb[c * CLD + c]; zs[c0 + c] = xc; s_x = xc; }
+      __syncthreads();
+      if (t < c) zs[c0 + t] -= Lb[c * CLD + t] * s_x;
+      __syncthreads();
+    }
+    // z[c'] -= sum_r L[c0 + r][c'] x_r for the columns left of the block
+    for (int cc = t; cc < c0; cc += 256) {
+      float sacc = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < CNB; r++) sacc += A[(size_t)(c0 + r) * lda + cc] * zs[c0 + r];
+      zs[cc] -= sacc;
+    }
+    __syncthreads();
+  }
+  for (int i = t; i < n; i += 256) {
+    dXg[i] = zs[i];
+    if (dbg) dbg[(size_t)n * n + n + i] = zs[i];
+  }
+}
+
 // dZ = Q (u - E^T dX), inverse-depth update, and re-zeroing of this patch's E column / C / u so that the
 // next iteration (or call) accumulates into zeros.
 __global__ __launch_bounds__(64) void ba_retract_kernel(float* __restrict__ poses, int t0, int pose_retr,
@@ -796,16 +1129,22 @@ __global__ __launch_bounds__(64) void ba_retract_kernel(float* __restrict__ pose
                                                         float* __restrict__ ug, const float* __restrict__ qg,
                                                         float* __restrict__ Edg, int U_stride,
                                                         const float* __restrict__ dXg, float* __restrict__ dbgp,
-                                                        const int32_t* __restrict__ info) {
+                                                        const int32_t* __restrict__ info,
+                                                        const float* __restrict__ lmbda_q, uint32_t* __restrict__ cmask,
+                                                        int n_chunks) {
   if (gmeta[GM_ERROR] || info[1]) return;
   const int U = gmeta[GM_U];
+  if (cmask)   // global-BA path: the panel masks of this iteration are consumed
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_chunks; i += gridDim.x * blockDim.x) cmask[i] = 0u;
   // pose_retr_kernel (ba_cuda.cu:178-206) for the small-system solver: T <- Exp(dX_i) T, one lane per free pose, in the
   // last workgroup (the first ones carry the longest E-column sweeps)
-  if (pose_retr && blockIdx.x == gridDim.x - 1 && (int)threadIdx.x < N) {
-    float* p = poses + 7 * (size_t)(t0 + (int)threadIdx.x);
+  const int gid_rev = (int)(gridDim.x * blockDim.x) - 1 - (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (pose_retr && gid_rev < N) {
+    const int pi = gid_rev;
+    float* p = poses + 7 * (size_t)(t0 + pi);
     float tt[3] = {p[0], p[1], p[2]}, qq[4] = {p[3], p[4], p[5], p[6]}, tn[3], qn[4], xi[6];
 #pragma unroll
-    for (int c = 0; c < 6; c++) xi[c] = dXg[6 * threadIdx.x + c];
+    for (int c = 0; c < 6; c++) xi[c] = dXg[6 * pi + c];
     fb_retrSE3(xi, tt, qq, tn, qn);
     p[0] = tn[0]; p[1] = tn[1]; p[2] = tn[2];
     p[3] = qn[0]; p[4] = qn[1]; p[5] = qn[2]; p[6] = qn[3];
@@ -825,7 +1164,7 @@ __global__ __launch_bounds__(64) void ba_retract_kernel(float* __restrict__ pose
       }
     }
     const float cv = Cg[r], uv = ug[r];
-    const float qv = qg[r];
+    const float qv = lmbda_q ? 1.0f / (cv + lmbda_q[0]) : qg[r];
     const float dz = qv * (uv - (((s[0] + s[1]) + (s[2] + s[3])) + (s[4] + s[5])));
     if (dbgp) { dbgp[r] = dz; dbgp[U_stride + r] = cv; dbgp[2 * (size_t)U_stride + r] = uv; }
     Cg[r] = 0.f;
@@ -845,7 +1184,7 @@ extern "C" size_t cdv_ba_workspace_bytes(int64_t E_max, int64_t U_max, int N_max
   (void)E_max;
   if (U_max < 1) U_max = 1;
   if (N_max < 1) N_max = 1;
-  if (N_max > BA_NMAX) N_max = BA_NMAX;
+  if (N_max > BA_NBIG) N_max = BA_NBIG;
   return ba_layout(U_max, N_max).total;
 }
 
@@ -856,8 +1195,8 @@ extern "C" int cdv_ba_forward(float* poses, float* patches, const float* intrins
                               void* stream) {
   const int N = t1 - t0;
   CDV_REQUIRE(N >= 0, CDV_ERR_ARG, "cdv_ba_forward: t1 < t0");
-  CDV_REQUIRE(N <= BA_NMAX, CDV_ERR_UNSUPPORTED,
-              "cdv_ba_forward: more than 32 free poses needs the block-sparse global-BA path (not built yet)");
+  CDV_REQUIRE(N <= BA_NBIG, CDV_ERR_UNSUPPORTED, "cdv_ba_forward: more than 1024 free poses");
+  const bool big = N > BA_NMAX;   // global BA: panel-sparse Schur products + blocked multi-workgroup Cholesky
   CDV_REQUIRE(P == 3 || P == 1, CDV_ERR_UNSUPPORTED, "cdv_ba_forward: patch size P must be 3 or 1");
   CDV_REQUIRE(E >= 0 && E < ((int64_t)1 << 31), CDV_ERR_ARG, "cdv_ba_forward: E out of range");
   if (E == 0 || iterations <= 0) return CDV_OK;
@@ -876,6 +1215,8 @@ extern "C" int cdv_ba_forward(float* poses, float* patches, const float* intrins
   float* qg = (float*)(b + L.q);
   float* Edg = (float*)(b + L.Ed);
   int32_t* info = (int32_t*)(b + L.info);
+  uint32_t* cmask = big ? (uint32_t*)(b + L.cmask) : nullptr;
+  float* Abig = (float*)(b + L.Abig);
   hipStream_t s = (hipStream_t)stream;
 
   const int n6i = 6 * N;
@@ -902,6 +1243,11 @@ extern "C" int cdv_ba_forward(float* poses, float* patches, const float* intrins
   static std::once_flag attr_once;
   static hipError_t attr_err = hipSuccess;
   std::call_once(attr_once, [] {
+    hipError_t e4 = hipFuncSetAttribute((const void*)ba_big_schur_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        112 * 1024);
+    hipError_t e5 = hipFuncSetAttribute((const void*)ba_big_backsolve_kernel,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    if (e4 != hipSuccess || e5 != hipSuccess) { attr_err = e4 != hipSuccess ? e4 : e5; return; }
     // worst cases at N = 32: assemble 71 KB (fixed), schur 57 KB, solve 155 KB (+ a few static bytes)
     hipError_t e1 = hipFuncSetAttribute((const void*)ba_assemble_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         96 * 1024);
@@ -912,25 +1258,45 @@ extern "C" int cdv_ba_forward(float* poses, float* patches, const float* intrins
     attr_err = e1 != hipSuccess ? e1 : e2 != hipSuccess ? e2 : e3;
   });
   CDV_HIP_CHECK(attr_err);
-  const int rb = cdv_div_up(L.U_max, 64);
+  const int rb = cdv_div_up(L.U_max > N ? L.U_max : N, 64);
+  const int NP = cdv_div_up(N, BIG_PB), npair = NP * (NP + 1) / 2;
+  const int npad = (int)L.npad, nbk = npad / CNB;
+  const size_t smem_bsch = sizeof(float) * (2 * (size_t)BIG_PR * ELD + 2 * BA_CHUNK);
+  const size_t smem_bsol = sizeof(float) * ((size_t)npad + (size_t)CNB * CLD);
   for (int itr = 0; itr < iterations; itr++) {
     float* d = (dbg && itr == 0) ? dbg : nullptr;
     hipLaunchKernelGGL(ba_assemble_kernel, dim3(n_chunks * ASM_SG), dim3(ASM_THREADS), smem_asm, s, poses, patches,
                        intrinsics, target, weight, ii, jj, kk, P, t0, N, gv.meta, gv.pcsr, gv.koff_u, sy,
-                       (int)L.sy_stride, Cg, ug, Edg, (int)L.U_stride, (int)L.U_max, info);
-    hipLaunchKernelGGL(ba_schur_kernel, dim3(n_chunks), dim3(256), smem_sch, s, lmbda, N, gv.meta, sy,
-                       (int)L.sy_stride, Cg, ug, qg, Edg, (int)L.U_stride, info);
-    if (N > 0 && 6 * N <= SN)
-      hipLaunchKernelGGL(ba_solve60_kernel, dim3(1), dim3(256), 0, s, poses, sy, (int)L.sy_stride, dXg, t0, N,
-                         gv.meta, d, info);
-    else if (N > 0)
-      hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(256), smem_sol, s, poses, sy, (int)L.sy_stride, dXg, t0, N,
-                         gv.meta, d, info);
+                       (int)L.sy_stride, Cg, ug, Edg, (int)L.U_stride, (int)L.U_max, info, cmask);
+    if (big) {
+      hipLaunchKernelGGL(ba_big_schur_kernel, dim3(n_chunks * npair), dim3(256), smem_bsch, s, lmbda, N, gv.meta, sy,
+                         (int)L.sy_stride, Cg, ug, Edg, (int)L.U_stride, cmask, npair, info);
+      hipLaunchKernelGGL(ba_big_fold_kernel, dim3(1024), dim3(256), 0, s, sy, (int)L.sy_stride, n6i, npad, Abig, gv.meta,
+                         d, info);
+      for (int kb = 0; kb < nbk; kb++) {
+        hipLaunchKernelGGL(ba_big_panel_kernel, dim3(nbk - kb + 1), dim3(256), 0, s, Abig, npad, kb, gv.meta, info);
+        const int T = nbk - kb - 1;
+        if (T > 0)
+          hipLaunchKernelGGL(ba_big_update_kernel, dim3(T * (T + 1) / 2 + T), dim3(256), 0, s, Abig, npad, kb, gv.meta,
+                             info);
+      }
+      hipLaunchKernelGGL(ba_big_backsolve_kernel, dim3(1), dim3(256), smem_bsol, s, Abig, npad, n6i, dXg, gv.meta, d, info);
+    } else {
+      hipLaunchKernelGGL(ba_schur_kernel, dim3(n_chunks), dim3(256), smem_sch, s, lmbda, N, gv.meta, sy,
+                         (int)L.sy_stride, Cg, ug, qg, Edg, (int)L.U_stride, info);
+      if (N > 0 && 6 * N <= SN)
+        hipLaunchKernelGGL(ba_solve60_kernel, dim3(1), dim3(256), 0, s, poses, sy, (int)L.sy_stride, dXg, t0, N,
+                           gv.meta, d, info);
+      else if (N > 0)
+        hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(256), smem_sol, s, poses, sy, (int)L.sy_stride, dXg, t0, N,
+                           gv.meta, d, info);
+    }
     // dbg layout: [S n6^2 | y n6 | dX n6 | dZ U_stride | C U_stride | u U_stride | E n6*U_stride]
     float* dbgp = d ? d + (size_t)n6i * n6i + 2 * n6i : nullptr;
-    hipLaunchKernelGGL(ba_retract_kernel, dim3(rb), dim3(64), 0, s, poses, t0, (N > 0 && 6 * N <= SN) ? 1 : 0, patches, P,
-                       N, gv.meta, gv.kx, Cg, ug, qg, Edg,
-                       (int)L.U_stride, dXg, dbgp, info);
+    const int pose_retr = (N > 0 && (6 * N <= SN || big)) ? 1 : 0;
+    hipLaunchKernelGGL(ba_retract_kernel, dim3(rb), dim3(64), 0, s, poses, t0, pose_retr, patches, P, N, gv.meta, gv.kx,
+                       Cg, ug, qg, Edg, (int)L.U_stride, dXg, dbgp, info, big ? lmbda : (const float*)nullptr, cmask,
+                       n_chunks);
     CDV_LAUNCH_CHECK();
   }
   return CDV_OK;

@@ -387,8 +387,10 @@ def ba_forward(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, PP
         if t.dtype != torch.float32 or not t.is_contiguous():
             raise TypeError("BA: poses / patches / intrinsics must be contiguous float32 (updated in place)")
     N = int(t1) - int(t0)
-    if N > 32 or eff_impl:
-        raise NotImplementedError("global BA (eff_impl / more than 32 free poses) is not built yet")
+    # eff_impl only selects the reference's block-sparse E storage (ba_cuda.cu:506-509): the numbers are those of the
+    # dense path.  Here the library picks its own path by N (<= 10, <= 32, global BA up to 1024 free poses).
+    if N > 1024:
+        raise NotImplementedError("BA with more than 1024 free poses")
     E, P = kk.numel(), patches.shape[-1]
     dev = poses.device
     if E == 0:

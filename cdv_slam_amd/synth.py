@@ -42,6 +42,12 @@ CONFIGS = {
     # small graphs for fast CPU tests
     "tiny": GraphConfig(name="tiny", frames=6, M=8, ht=128, wd=160, mem=8, pmem=8, buffer_size=8),
     "small": GraphConfig(name="small", frames=30, M=16, ht=192, wd=256, buffer_size=40),
+    # global bundle adjustment (slam.py:460-478): inactive edges kept, every pose but the first free -> N = 79, E = 30k
+    "global": GraphConfig(name="global", frames=80, M=16, ht=192, wd=256, buffer_size=96, removal_window=10 ** 6,
+                          opt_window=10 ** 6),
+    # the same with three pose panels' worth of free poses in a wider graph: N = 139
+    "global_l": GraphConfig(name="global_l", frames=140, M=12, ht=192, wd=256, buffer_size=160, removal_window=10 ** 6,
+                            opt_window=10 ** 6),
 }
 
 
