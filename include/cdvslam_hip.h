@@ -196,13 +196,16 @@ int cdv_neighbors(const void* ws, int64_t E, int64_t* ix, int64_t* jx, void* str
  * fastba  (replaces cuda_ba.forward, ba.cpp:31-45, ba_cuda.cu:462-611)
  * ---------------------------------------------------------------------------------------------- */
 
-/* bytes of device workspace for up to U_max unique patches and N_max <= 32 free poses */
+/* bytes of device workspace for up to U_max unique patches and N_max <= 1024 free poses (the dense E,
+ * 6 N_max x round_up(U_max, 64) floats, dominates: 2.4 GB at N = 1024, U = 100k) */
 size_t cdv_ba_workspace_bytes(int64_t E_max, int64_t U_max, int N_max);
 
 /*
  * In-place bundle adjustment: `iterations` Gauss-Newton steps with Schur complement over patch
  * inverse depths; poses[t0:t1] and patches[kx] are updated in place, nothing is returned
- * (ba_cuda.cu:462-611, dense-E path; t1 == t0 is the structure-only branch :550-560).
+ * (ba_cuda.cu:462-611; t1 == t0 is the structure-only branch :550-560).  The reference's eff_impl flag only
+ * selects a block-sparse storage of E (block_e.cu:38-300) for the same S, y, dX, dZ; there is no such flag here:
+ * E stays dense in HBM and the library picks the solver by N.
  *   poses [*][7] f32, patches [*][3][P][P] f32, intrinsics [*][4] (only row 0 is read, :253-259),
  *   target/weight [E][2] f32, lmbda: DEVICE pointer to 1 float, ii/jj/kk [E] int64.
  *   graph_ws: a workspace on which cdv_graph_build(jj, kk, E) has been enqueued on `stream`.
@@ -212,7 +215,10 @@ size_t cdv_ba_workspace_bytes(int64_t E_max, int64_t U_max, int N_max);
  *             between calls; do not write into it.
  *   dbg (optional, NULL): receives iteration-0 values, with n = 6N and Us = round_up(U_max, 64):
  *             [S n*n (damped) | y n | dX n | dZ Us | C Us | u Us | E n*Us]
- * Supports N = t1 - t0 <= 32 (single-workgroup LDS Cholesky).
+ *             (N > 32: only the lower triangle of S is accumulated)
+ * N = t1 - t0 <= 10: one-wave register Cholesky; <= 32: single-workgroup LDS Cholesky; <= 1024 (global BA,
+ * slam.py:460-478): Schur products per (64-patch chunk, pair of 32-pose panels with non-zero E), blocked
+ * multi-workgroup Cholesky.  More: CDV_ERR_UNSUPPORTED.
  */
 int cdv_ba_forward(float* poses, float* patches, const float* intrinsics, const float* target, const float* weight,
                    const float* lmbda, const int64_t* ii, const int64_t* jj, const int64_t* kk, int64_t E, int P,
