@@ -12,7 +12,7 @@ Layout (only what the path needs):
   synth.py             seeded synthetic patch-graph states
 """
 
-__all__ = ["ops", "altcorr", "fastba", "lietorch", "projective_ops", "synth", "install_dropin"]
+__all__ = ["ops", "altcorr", "fastba", "lietorch", "projective_ops", "ba", "synth", "install_dropin"]
 
 
 def install_dropin():

@@ -454,6 +454,31 @@ def test_global_ba_vs_oracle(name):
     assert np.abs(poses2 - poses).max() <= 1e-5 and np.abs(patches2 - patches).max() <= 1e-4
 
 
+@pytest.mark.parametrize("tag", ["fc", "win"])
+def test_ba_py_mirror_vs_reference_golden(golden_dir, tag):
+    """cdv_slam_amd.ba.BA == the reference's own cdvslam/ba.py run on the same inputs (tests/golden/ba_py_*.npz,
+    generated by tests/golden/make_golden.py): both `ep` settings, a second step from the first result, and the
+    structure-only branch.  Tolerances as in the oracle's own golden test (float32 Gauss-Newton)."""
+    from cdv_slam_amd import ba
+    from cdv_slam_amd.lietorch import SE3
+    g = np.load(os.path.join(golden_dir, "ba_py_%s.npz" % tag))
+    G = lambda k: T(g[k].astype(np.float32) if g[k].dtype.kind == "f" else g[k])
+    args = (G("intrinsics")[None], G("target")[None], G("weight")[None], torch.tensor([1e-4], device=DEV), G("ii"),
+            G("jj"), G("kk"), [float(b) for b in g["bounds"]])
+    for ep in (1.0, 100.0):
+        tol = 1e-4 if ep == 1.0 else 2e-5
+        P2, X2 = ba.BA(SE3(G("poses")[None]), G("patches")[None], *args, ep=ep, fixedp=1)
+        assert isinstance(P2, SE3)
+        assert np.allclose(P2.data[0].cpu().numpy(), g["poses_ep%g" % ep], atol=tol)
+        assert np.allclose(X2[0].cpu().numpy(), g["patches_ep%g" % ep], rtol=10 * tol, atol=tol)
+        P3, X3 = ba.BA(P2, X2, *args, ep=ep, fixedp=1)
+        assert np.allclose(P3.data[0].cpu().numpy(), g["poses2_ep%g" % ep], atol=3 * tol)
+        assert np.allclose(X3[0].cpu().numpy(), g["patches2_ep%g" % ep], rtol=30 * tol, atol=3 * tol)
+    Ps, Xs = ba.BA(SE3(G("poses")[None]), G("patches")[None], *args, ep=1.0, fixedp=1, structure_only=True)
+    assert np.allclose(Xs[0].cpu().numpy(), g["patches_structure_only"], rtol=2e-4, atol=2e-5)
+    assert torch.equal(Ps.data, G("poses")[None])
+
+
 def test_ba_structure_only_and_gates():
     """t1 == t0 branch (ba_cuda.cu:550-560, caller long_term.py:124-125) and the depth clamps"""
     st = synth.make_state("small", features=False)
