@@ -40,10 +40,15 @@ def test_argument_errors_are_codes_not_exits():
     assert rc == -2
     assert lib.cdv_graph_workspace_bytes(1000, 100) > 1000 * 4 * 3
     assert lib.cdv_ba_workspace_bytes(1000, 100, 10) > 4 * 3660 * 4  # BA_REPL copies of [S | y]
-    # more than 32 free poses is a clean error
+    # more than 1024 free poses is a clean error; 40 free poses (global BA) get past that check to the next one
+    rc = lib.cdv_ba_forward(None, None, None, None, None, None, None, None, None, 10, 3, 0, 2000, 2, None, None, 0, 10,
+                            None, None)
+    assert rc == -4 and b"1024" in lib.cdv_last_error()
     rc = lib.cdv_ba_forward(None, None, None, None, None, None, None, None, None, 10, 3, 0, 40, 2, None, None, 0, 10,
                             None, None)
-    assert rc == -4
+    assert rc == -2 and b"graph_ws" in lib.cdv_last_error()
+    # the global-BA workspace holds the dense E and the Cholesky working matrix
+    assert lib.cdv_ba_workspace_bytes(100000, 10000, 300) > 6 * 300 * 10000 * 4 + (6 * 300) ** 2 * 4
 
 
 def test_operator_surface_names():
