@@ -79,3 +79,10 @@ static inline GraphView graph_view(void* ws, const GraphLayout& L) {
 
 // host-side registry: workspace pointer -> layout (filled by cdv_graph_build)
 bool cdv_graph_lookup(const void* ws, cdv::GraphLayout* out);
+
+// the index build in two halves (graph.hip), for cdv_update_prologue
+namespace cdv { struct HistArgs; }
+int cdv_graph_prepare(const int64_t* jj, const int64_t* kk, int64_t E, void* ws, size_t ws_bytes, int64_t E_max,
+                      int64_t k_range, int64_t* ix, int64_t* jx, void* stream, cdv::HistArgs* hist, int* hist_blocks);
+int cdv_graph_finish(const int64_t* jj, const int64_t* kk, int64_t E, void* ws, int64_t E_max, int64_t k_range,
+                     int hist_blocks, int64_t* ix, int64_t* jx, void* stream);

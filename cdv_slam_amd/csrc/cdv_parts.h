@@ -1,0 +1,225 @@
+// cdv_parts.h -- bodies of the three independent per-frame kernels that open an update (feature / tile ingest,
+// reprojection, patch-id histogram), as device functions taking an explicit (block, number of blocks): each is
+// launched on its own behind its C entry point (corr.hip, reproject.hip, graph.hip) and all three side by side in
+// ONE launch by cdv_update_prologue (prologue.hip) -- they are latency-bound (a few microseconds of work each), so
+// sharing a launch costs the longest of them instead of their sum.
+#pragma once
+#include "cdv_common.h"
+#include "cdv_se3.h"
+
+namespace cdv {
+
+// ---- padded channels-last feature rings (corr.hip) --------------------------------------------------------
+constexpr int PART_PADX = CDV_FMAP_PADX, PART_PADY = CDV_FMAP_PADY;
+
+struct IngestArgs {
+  const _Float16* src;     // new frame [C][H][W]
+  _Float16 *f1_nhwc, *f2_nhwc, *f1_nchw, *f2_nchw;
+  int slot, C, H, W;
+  const _Float16* gsrc;    // planar patch tiles [Ng][C][3][3] (may be null)
+  _Float16* gdst;          // pixel-major tiles [Ng][9][C]
+  int64_t gfirst, gcount;
+  int fblocks, gblocks;    // workgroups for the feature maps / for the tiles
+};
+
+// patch tiles planar [C][3][3] -> pixel-major [9][C]: one thread per (tile, pixel, 8-channel group)
+__device__ __forceinline__ void gmap_pm_convert(const _Float16* __restrict__ src, _Float16* __restrict__ dst,
+                                                int64_t first, int64_t count, int C, int64_t tid, int64_t nthreads) {
+  const int G = C / 8;
+  const int64_t total = count * 9 * G;
+  for (int64_t idx = tid; idx < total; idx += nthreads) {
+    int64_t t = idx;
+    const int gq = (int)(t % G); t /= G;
+    const int px = (int)(t % 9); t /= 9;
+    const int64_t tile = first + t;
+    cdv_half8 v;
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = src[(tile * C + 8 * gq + j) * 9 + px];
+    *reinterpret_cast<cdv_half8*>(dst + (tile * 9 + px) * C + 8 * gq) = v;
+  }
+}
+
+// one frame [C][H][W] -> ring slot of the level-0 NHWC ring and its 4x4 average pool into level 1
+// (F.avg_pool2d(fmap, 4, 4), slam.py:682: f16 in, f32 sum of 16, * 1/16, rounded to f16); blocks
+// [fblocks, fblocks + gblocks) convert the frame's patch tiles to the pixel-major layout instead
+__device__ __forceinline__ void ingest_body(const IngestArgs& a, int bid, int nthreads_per_block, int tid) {
+  if (bid >= a.fblocks) {
+    gmap_pm_convert(a.gsrc, a.gdst, a.gfirst, a.gcount, a.C, (int64_t)(bid - a.fblocks) * nthreads_per_block + tid,
+                    (int64_t)a.gblocks * nthreads_per_block);
+    return;
+  }
+  // one thread per (full-resolution pixel, 8-channel group); the 16 pixels of a 4x4 pooling block are the 16 lanes of a
+  // DPP row, so the pooled sum is four row rotations (no LDS, no 128-gather serial loop per thread)
+  const int C = a.C, H = a.H, W = a.W, slot = a.slot;
+  const int G = C / 8, H4 = H / 4, W4 = W / 4;
+  const int64_t total = (int64_t)H4 * W4 * G * 16;   // a multiple of 64: whole rows of 16 lanes stay together
+  for (int64_t idx = (int64_t)bid * nthreads_per_block + tid; idx < total; idx += (int64_t)a.fblocks * nthreads_per_block) {
+    int64_t t = idx;
+    const int sp = (int)(t & 15); t >>= 4;    // sub-pixel of the pooling block: row sp >> 2, column sp & 3
+    const int xq = (int)(t % W4); t /= W4;
+    const int gq = (int)(t % G); t /= G;
+    const int yq = (int)t;
+    const int yh = 4 * yq + (sp >> 2), xw = 4 * xq + (sp & 3);
+    cdv_half8 v;
+    float sum[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const _Float16 sv = a.src[((int64_t)(8 * gq + j) * H + yh) * W + xw];
+      v[j] = sv;
+      sum[j] = (float)sv;
+      if (a.f1_nchw) a.f1_nchw[(((int64_t)slot * C + 8 * gq + j) * H + yh) * W + xw] = sv;
+    }
+    *reinterpret_cast<cdv_half8*>(a.f1_nhwc + (((int64_t)slot * (H + 2 * PART_PADY) + yh + PART_PADY) *
+                                                   (W + 2 * PART_PADX) + xw + PART_PADX) * C + 8 * gq) = v;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+#define CDV_ROR_ADD(n) sum[j] += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sum[j]), 0x120 + (n), 0xf, 0xf, false));
+      CDV_ROR_ADD(8) CDV_ROR_ADD(4) CDV_ROR_ADD(2) CDV_ROR_ADD(1)
+#undef CDV_ROR_ADD
+    }
+    if (sp == 0) {
+      cdv_half8 pv;
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        pv[j] = (_Float16)(sum[j] * (1.0f / 16.0f));
+        if (a.f2_nchw) a.f2_nchw[(((int64_t)slot * C + 8 * gq + j) * H4 + yq) * W4 + xq] = pv[j];
+      }
+      *reinterpret_cast<cdv_half8*>(a.f2_nhwc + (((int64_t)slot * (H4 + 2 * PART_PADY) + yq + PART_PADY) *
+                                                     (W4 + 2 * PART_PADX) + xq + PART_PADX) * C + 8 * gq) = pv;
+    }
+  }
+}
+
+// ---- pops.transform (reproject.hip) ----------------------------------------------------------------------
+struct TfArgs {
+  const float *poses, *patches, *intr;
+  const int64_t *ii, *jj, *kk;
+  int64_t E;
+  int flags;
+  float *coords, *validpx, *valid, *Ji, *Jj, *Jz;
+};
+
+template <int P>
+__device__ __forceinline__ void transform_body(const TfArgs& A, int64_t n) {
+  if (n >= A.E) return;
+  const float* __restrict__ poses = A.poses;
+  const float* __restrict__ intr = A.intr;
+  float* __restrict__ coords = A.coords;
+  const int64_t ix = A.ii[n], jx = A.jj[n], kx = A.kk[n];
+  constexpr int PP = P * P;
+
+  float Pi[7], Pj[7], Pinv[7], G[7];
+#pragma unroll
+  for (int a = 0; a < 7; a++) { Pi[a] = poses[7 * ix + a]; Pj[a] = poses[7 * jx + a]; }
+  lt_se3_inv(Pi, Pinv);          // poses[:, ii].inv()          projective_ops.py:60
+  lt_se3_mul(Pj, Pinv, G);       // poses[:, jj] * ...
+  if (A.flags & CDV_TF_TONLY) { G[3] = 0.f; G[4] = 0.f; G[5] = 0.f; G[6] = 1.f; }
+  float t[3], q[4];
+  lt_se3_load(G, t, q);          // Act4 reloads (re-normalises) Gij  so3.h:30-37
+
+  const float fxi = intr[4 * ix + 0], fyi = intr[4 * ix + 1], cxi = intr[4 * ix + 2], cyi = intr[4 * ix + 3];
+  const float fxj = intr[4 * jx + 0], fyj = intr[4 * jx + 1], cxj = intr[4 * jx + 2], cyj = intr[4 * jx + 3];
+  const float* pk = A.patches + kx * 3 * PP;
+  const bool e2pp = (A.flags & CDV_TF_LAYOUT_E2PP) != 0;
+
+  float Xc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int a = 0; a < PP; a++) {
+    float X0[4], X1[4];
+    X0[0] = (pk[a] - cxi) / fxi;              // iproj, projective_ops.py:19-29
+    X0[1] = (pk[PP + a] - cyi) / fyi;
+    X0[2] = 1.f;
+    X0[3] = pk[2 * PP + a];
+    lt_act4_loaded(t, q, X0, X1);
+    const float d = 1.0f / fmaxf(X1[2], 0.1f); // proj, projective_ops.py:43
+    const float x = fxj * (d * X1[0]) + cxj;
+    const float y = fyj * (d * X1[1]) + cyj;
+    if (e2pp) {
+      coords[(n * 2 + 0) * PP + a] = x;
+      coords[(n * 2 + 1) * PP + a] = y;
+    } else {
+      coords[(n * PP + a) * 2 + 0] = x;
+      coords[(n * PP + a) * 2 + 1] = y;
+    }
+    if (A.validpx) A.validpx[n * PP + a] = (X1[2] > 0.2f) ? 1.f : 0.f;
+    if (a == (P / 2) * P + P / 2) { Xc[0] = X1[0]; Xc[1] = X1[1]; Xc[2] = X1[2]; Xc[3] = X1[3]; }
+  }
+
+  if (A.Ji) {  // projective_ops.py:71-108
+    const float X = Xc[0], Y = Xc[1], Z = Xc[2], H = Xc[3];
+    const float d = (fabsf(Z) > 0.2f) ? 1.0f / Z : 0.f;
+    float R[9];
+    lt_quat_to_R(q, R);
+    // rows of Jp*Ja: Jp = [fx d, 0, -fx X d^2, 0 ; 0, fy d, -fy Y d^2, 0], Ja = [H I | -[X]x ; 0]
+    float row[2][6];
+    const float a0 = fxj * d, a2 = -fxj * X * d * d;
+    row[0][0] = a0 * H; row[0][1] = 0.f;    row[0][2] = a2 * H;
+    row[0][3] = a2 * Y; row[0][4] = a0 * Z - a2 * X; row[0][5] = -a0 * Y;
+    const float b1 = fyj * d, b2 = -fyj * Y * d * d;
+    row[1][0] = 0.f;    row[1][1] = b1 * H; row[1][2] = b2 * H;
+    row[1][3] = -b1 * Z + b2 * Y; row[1][4] = -b2 * X; row[1][5] = b1 * X;
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      float o[6];
+      lt_se3_adjT_loaded(t, R, row[r], o);   // Ji = -Gij.adjT(Jj)
+#pragma unroll
+      for (int c = 0; c < 6; c++) {
+        A.Jj[(n * 2 + r) * 6 + c] = row[r][c];
+        A.Ji[(n * 2 + r) * 6 + c] = -o[c];
+      }
+    }
+    // Jz = Jp * Gij.matrix()[:, 3]  (column (t, 1); Jp's 4th column is zero)
+    A.Jz[n * 2 + 0] = a0 * t[0] + a2 * t[2];
+    A.Jz[n * 2 + 1] = b1 * t[1] + b2 * t[2];
+    A.valid[n] = (Z > 0.2f) ? 1.f : 0.f;
+  }
+}
+
+// ---- patch-id histogram over (id mod R) + min / max of kk, jj (graph.hip, launch 1 of the index build) ----
+struct HistArgs {
+  const int64_t *jj, *kk;
+  int32_t E;
+  int32_t* stage;   // [blocks][4] per-workgroup (kmin, kmax, jmin, jmax)
+  int32_t* khist;
+  int32_t R;
+};
+
+__device__ __forceinline__ void graph_hist_body(const HistArgs& a, int bid, int nblocks, int nthreads_per_block, int tid) {
+  constexpr int IMAXV = 0x7fffffff, IMINV = (int)0x80000000;
+  int kmin = IMAXV, kmax = IMINV, jmin = IMAXV, jmax = IMINV;
+  const int R = a.R;
+  const float rinv = 1.0f / (float)R;
+  for (int e = bid * nthreads_per_block + tid; e < a.E; e += nblocks * nthreads_per_block) {
+    const int k = (int)a.kk[e], j = (int)a.jj[e];
+    kmin = min(kmin, k); kmax = max(kmax, k);
+    jmin = min(jmin, j); jmax = max(jmax, j);
+    if (k >= 0) {
+      // k mod R without an integer division: float quotient estimate, then one correction step each way
+      int q = (int)((float)k * rinv);
+      int m = k - q * R;
+      m = (m < 0) ? m + R : m;
+      m = (m >= R) ? m - R : m;
+      atomicAdd(&a.khist[m], 1);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    kmin = min(kmin, __shfl_xor(kmin, o)); kmax = max(kmax, __shfl_xor(kmax, o));
+    jmin = min(jmin, __shfl_xor(jmin, o)); jmax = max(jmax, __shfl_xor(jmax, o));
+  }
+  __shared__ int s_mm[16][4];
+  const int lane = tid & 63, wave = tid >> 6, nw = nthreads_per_block >> 6;
+  if (lane == 0) { s_mm[wave][0] = kmin; s_mm[wave][1] = kmax; s_mm[wave][2] = jmin; s_mm[wave][3] = jmax; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < nw; w++) {
+      kmin = min(kmin, s_mm[w][0]); kmax = max(kmax, s_mm[w][1]);
+      jmin = min(jmin, s_mm[w][2]); jmax = max(jmax, s_mm[w][3]);
+    }
+    // one private slot per workgroup, reduced by the scan kernel: no contended atomics (~90 ns each on one word)
+    int32_t* st = a.stage + 4 * bid;
+    st[0] = kmin; st[1] = kmax; st[2] = jmin; st[3] = jmax;
+  }
+}
+
+}  // namespace cdv

@@ -20,6 +20,7 @@
 #include <stdlib.h>
 
 #include "cdv_common.h"
+#include "cdv_parts.h"
 
 CDV_STAMP_TU(corr)
 
@@ -537,80 +538,15 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const _Float16* __res
   }
 }
 
-// patch tiles planar [C][3][3] -> pixel-major [9][C]: one thread per (tile, pixel, 8-channel group)
-__device__ __forceinline__ void gmap_pm_convert(const _Float16* __restrict__ src, _Float16* __restrict__ dst,
-                                                int64_t first, int64_t count, int C, int64_t tid, int64_t nthreads) {
-  const int G = C / 8;
-  const int64_t total = count * 9 * G;
-  for (int64_t idx = tid; idx < total; idx += nthreads) {
-    int64_t t = idx;
-    const int gq = (int)(t % G); t /= G;
-    const int px = (int)(t % 9); t /= 9;
-    const int64_t tile = first + t;
-    cdv_half8 v;
-#pragma unroll
-    for (int j = 0; j < 8; j++) v[j] = src[(tile * C + 8 * gq + j) * 9 + px];
-    *reinterpret_cast<cdv_half8*>(dst + (tile * 9 + px) * C + 8 * gq) = v;
-  }
-}
-
 __global__ __launch_bounds__(256) void gmap_pm_kernel(const _Float16* __restrict__ src, _Float16* __restrict__ dst,
                                                       int64_t first, int64_t count, int C) {
-  gmap_pm_convert(src, dst, first, count, C, (int64_t)blockIdx.x * blockDim.x + threadIdx.x,
-                  (int64_t)gridDim.x * blockDim.x);
+  cdv::gmap_pm_convert(src, dst, first, count, C, (int64_t)blockIdx.x * blockDim.x + threadIdx.x,
+                       (int64_t)gridDim.x * blockDim.x);
 }
 
-// one frame [C][H][W] -> ring slot of the level-0 NHWC ring and its 4x4 average pool into level 1
-// (F.avg_pool2d(fmap, 4, 4), slam.py:682: f16 in, f32 sum of 16, * 1/16, rounded to f16); the last `gblocks`
-// workgroups convert the frame's patch tiles to the pixel-major layout instead
-__global__ __launch_bounds__(256) void fmap_ingest_kernel(const _Float16* __restrict__ src,
-                                                          _Float16* __restrict__ f1_nhwc,
-                                                          _Float16* __restrict__ f2_nhwc,
-                                                          _Float16* __restrict__ f1_nchw,
-                                                          _Float16* __restrict__ f2_nchw, int slot, int C, int H,
-                                                          int W, const _Float16* __restrict__ gsrc,
-                                                          _Float16* __restrict__ gdst, int64_t gfirst, int64_t gcount,
-                                                          int gblocks) {
-  const int fblocks = (int)gridDim.x - gblocks;
-  if ((int)blockIdx.x >= fblocks) {
-    gmap_pm_convert(gsrc, gdst, gfirst, gcount, C, (int64_t)((int)blockIdx.x - fblocks) * blockDim.x + threadIdx.x,
-                    (int64_t)gblocks * blockDim.x);
-    return;
-  }
-  const int G = C / 8, H4 = H / 4, W4 = W / 4;
-  const int64_t total = (int64_t)H4 * W4 * G;  // one thread per pooled pixel x channel group: handles a 4x4 block
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (int64_t)fblocks * blockDim.x) {
-    int64_t t = idx;
-    const int xq = (int)(t % W4); t /= W4;
-    const int gq = (int)(t % G); t /= G;
-    const int yq = (int)t;
-    float sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int a = 0; a < 4; a++)
-#pragma unroll
-      for (int b = 0; b < 4; b++) {
-        const int yh = 4 * yq + a, xw = 4 * xq + b;
-        cdv_half8 v;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-          const _Float16 s = src[((int64_t)(8 * gq + j) * H + yh) * W + xw];
-          v[j] = s;
-          sum[j] += (float)s;
-          if (f1_nchw) f1_nchw[(((int64_t)slot * C + 8 * gq + j) * H + yh) * W + xw] = s;
-        }
-        *reinterpret_cast<cdv_half8*>(f1_nhwc + (((int64_t)slot * (H + 2 * PADY) + yh + PADY) * (W + 2 * PADX) + xw +
-                                                 PADX) * C + 8 * gq) = v;
-      }
-    cdv_half8 pv;
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-      pv[j] = (_Float16)(sum[j] * (1.0f / 16.0f));
-      if (f2_nchw) f2_nchw[(((int64_t)slot * C + 8 * gq + j) * H4 + yq) * W4 + xq] = pv[j];
-    }
-    *reinterpret_cast<cdv_half8*>(f2_nhwc + (((int64_t)slot * (H4 + 2 * PADY) + yq + PADY) * (W4 + 2 * PADX) + xq +
-                                             PADX) * C + 8 * gq) = pv;
-  }
+// feature-map ring write + 4x4 pool (+ the frame's patch tiles): body in cdv_parts.h
+__global__ __launch_bounds__(256) void fmap_ingest_kernel(cdv::IngestArgs a) {
+  cdv::ingest_body(a, (int)blockIdx.x, (int)blockDim.x, (int)threadIdx.x);
 }
 
 // patchify forward (correlation_kernel.cu:16-47): gather (2R+2)^2 tiles, zero when OOB
@@ -684,13 +620,13 @@ extern "C" int cdv_frame_ingest(const void* fmap_chw, void* fmap1_nhwc, void* fm
   CDV_REQUIRE(slot >= 0, CDV_ERR_ARG, "cdv_fmap_ingest: slot");
   const bool do_g = gmap_planar != nullptr && gmap_pm != nullptr && gmap_count > 0;
   CDV_REQUIRE(!do_g || (gmap_first >= 0 && gmap_first + gmap_count <= Ng), CDV_ERR_ARG, "cdv_frame_ingest: tile range");
-  const int64_t total = (int64_t)(H / 4) * (W / 4) * (C / 8);
+  const int64_t total = (int64_t)(H / 4) * (W / 4) * (C / 8) * 16;   // one thread per pixel and 8-channel group
   const int blocks = cdv_div_up(total, 256);
   const int gblocks = do_g ? (int)cdv_div_up(gmap_count * 9 * (C / 8), 256) : 0;
-  hipLaunchKernelGGL(fmap_ingest_kernel, dim3(blocks + gblocks), dim3(256), 0, (hipStream_t)stream,
-                     (const _Float16*)fmap_chw, (_Float16*)fmap1_nhwc, (_Float16*)fmap2_nhwc, (_Float16*)fmap1_nchw,
-                     (_Float16*)fmap2_nchw, slot, C, H, W, (const _Float16*)gmap_planar, (_Float16*)gmap_pm, gmap_first,
-                     gmap_count, gblocks);
+  const cdv::IngestArgs a{(const _Float16*)fmap_chw, (_Float16*)fmap1_nhwc, (_Float16*)fmap2_nhwc, (_Float16*)fmap1_nchw,
+                          (_Float16*)fmap2_nchw, slot, C, H, W, (const _Float16*)gmap_planar, (_Float16*)gmap_pm,
+                          gmap_first, gmap_count, blocks, gblocks};
+  hipLaunchKernelGGL(fmap_ingest_kernel, dim3(blocks + gblocks), dim3(256), 0, (hipStream_t)stream, a);
   CDV_LAUNCH_CHECK();
   return CDV_OK;
 }

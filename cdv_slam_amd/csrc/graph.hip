@@ -26,6 +26,7 @@
 
 #include "cdv_common.h"
 #include "cdv_graph.h"
+#include "cdv_parts.h"
 
 using namespace cdv;
 
@@ -55,43 +56,9 @@ __global__ __launch_bounds__(256) void graph_init_kernel(int32_t* meta, int32_t*
   }
 }
 
-// histogram over (id mod R) + min / max of kk, jj
-__global__ __launch_bounds__(256) void graph_hist_kernel(const int64_t* __restrict__ jj, const int64_t* __restrict__ kk,
-                                                         int32_t E, int32_t* __restrict__ stage, int32_t* khist,
-                                                         int32_t R) {
-  int kmin = IMAX, kmax = IMIN, jmin = IMAX, jmax = IMIN;
-  const float rinv = 1.0f / (float)R;
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) {
-    const int k = (int)kk[e], j = (int)jj[e];
-    kmin = min(kmin, k); kmax = max(kmax, k);
-    jmin = min(jmin, j); jmax = max(jmax, j);
-    if (k >= 0) {
-      // k mod R without an integer division: float quotient estimate, then one correction step each way
-      int q = (int)((float)k * rinv);
-      int m = k - q * R;
-      m = (m < 0) ? m + R : m;
-      m = (m >= R) ? m - R : m;
-      atomicAdd(&khist[m], 1);
-    }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    kmin = min(kmin, __shfl_xor(kmin, o)); kmax = max(kmax, __shfl_xor(kmax, o));
-    jmin = min(jmin, __shfl_xor(jmin, o)); jmax = max(jmax, __shfl_xor(jmax, o));
-  }
-  __shared__ int s[4][4];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) { s[wave][0] = kmin; s[wave][1] = kmax; s[wave][2] = jmin; s[wave][3] = jmax; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int w = 1; w < 4; w++) {
-      kmin = min(kmin, s[w][0]); kmax = max(kmax, s[w][1]);
-      jmin = min(jmin, s[w][2]); jmax = max(jmax, s[w][3]);
-    }
-    // one private slot per workgroup, reduced by the scan kernel: no contended atomics (~90 ns each on one word)
-    int32_t* st = stage + 4 * blockIdx.x;
-    st[0] = kmin; st[1] = kmax; st[2] = jmin; st[3] = jmax;
-  }
+// histogram over (id mod R) + min / max of kk, jj: body in cdv_parts.h
+__global__ __launch_bounds__(256) void graph_hist_kernel(cdv::HistArgs a) {
+  cdv::graph_hist_body(a, (int)blockIdx.x, (int)gridDim.x, (int)blockDim.x, (int)threadIdx.x);
 }
 
 // One workgroup of 1024 threads: publish meta, exclusive scan of the histogram in id order (bin of id kmin + i is
@@ -292,8 +259,12 @@ extern "C" int cdv_graph_build(const int64_t* jj, const int64_t* kk, int64_t E, 
   return cdv_graph_build_neighbors(jj, kk, E, ws, ws_bytes, E_max, k_range, nullptr, nullptr, stream);
 }
 
-extern "C" int cdv_graph_build_neighbors(const int64_t* jj, const int64_t* kk, int64_t E, void* ws, size_t ws_bytes,
-                                         int64_t E_max, int64_t k_range, int64_t* ix, int64_t* jx, void* stream) {
+// Index build in two halves, so that cdv_update_prologue (prologue.hip) can run the histogram launch fused with the
+// other independent per-frame kernels: prepare = argument checks, registry, one-time initialisation;
+// finish = scan, fill, segment sort (+ neighbors).
+int cdv_graph_prepare(const int64_t* jj, const int64_t* kk, int64_t E, void* ws, size_t ws_bytes, int64_t E_max,
+                      int64_t k_range, int64_t* ix, int64_t* jx, void* stream, cdv::HistArgs* hist, int* hist_blocks) {
+  (void)jj; (void)kk;
   CDV_REQUIRE((ix == nullptr) == (jx == nullptr), CDV_ERR_ARG, "cdv_graph_build_neighbors: give both ix and jx or neither");
   CDV_REQUIRE(ws != nullptr, CDV_ERR_ARG, "cdv_graph_build: workspace is NULL");
   CDV_REQUIRE(E >= 0 && E < (int64_t)1 << 31, CDV_ERR_ARG, "cdv_graph_build: E out of range");
@@ -310,17 +281,24 @@ extern "C" int cdv_graph_build_neighbors(const int64_t* jj, const int64_t* kk, i
     g_registry[ws] = RegEntry{L, true};
   }
   const GraphView v = graph_view(ws, L);
+  if (need_init)
+    hipLaunchKernelGGL(graph_init_kernel, dim3(grid_for(k_range + 1, 256, 2048)), dim3(256), 0, (hipStream_t)stream,
+                       v.meta, v.khist, v.kcursor, k_range);
+  *hist = cdv::HistArgs{jj, kk, (int32_t)E, v.stage, v.khist, (int32_t)k_range};
+  *hist_blocks = E > 0 ? grid_for(E, 256, GRAPH_MAX_BLOCKS) : 0;
+  return CDV_OK;
+}
+
+int cdv_graph_finish(const int64_t* jj, const int64_t* kk, int64_t E, void* ws, int64_t E_max, int64_t k_range,
+                     int hist_blocks, int64_t* ix, int64_t* jx, void* stream) {
+  const GraphLayout L = graph_layout(E_max, k_range);
+  const GraphView v = graph_view(ws, L);
   hipStream_t s = (hipStream_t)stream;
   const int32_t En = (int32_t)E;
   const int tb = 256;
-  if (need_init)
-    hipLaunchKernelGGL(graph_init_kernel, dim3(grid_for(k_range + 1, tb, 2048)), dim3(tb), 0, s, v.meta, v.khist,
-                       v.kcursor, k_range);
   const int fb = grid_for(E, tb, GRAPH_MAX_BLOCKS);
-  const int hb = E > 0 ? fb : 0;
-  if (E > 0) hipLaunchKernelGGL(graph_hist_kernel, dim3(hb), dim3(tb), 0, s, jj, kk, En, v.stage, v.khist, (int32_t)k_range);
-  hipLaunchKernelGGL(graph_scan_kernel, dim3(1), dim3(1024), 0, s, v.meta, v.stage, hb, v.khist, v.kcount, v.krank, En,
-                     k_range);
+  hipLaunchKernelGGL(graph_scan_kernel, dim3(1), dim3(1024), 0, s, v.meta, v.stage, hist_blocks, v.khist, v.kcount, v.krank,
+                     En, k_range);
   if (E > 0) {
     hipLaunchKernelGGL(graph_fill_kernel, dim3(fb), dim3(tb), 0, s, kk, En, v.meta, v.kcount, v.kcursor, v.krank,
                        v.koff_u, v.kx, v.ku, v.pcsr_tmp);
@@ -329,6 +307,16 @@ extern "C" int cdv_graph_build_neighbors(const int64_t* jj, const int64_t* kk, i
   }
   CDV_LAUNCH_CHECK();
   return CDV_OK;
+}
+
+extern "C" int cdv_graph_build_neighbors(const int64_t* jj, const int64_t* kk, int64_t E, void* ws, size_t ws_bytes,
+                                         int64_t E_max, int64_t k_range, int64_t* ix, int64_t* jx, void* stream) {
+  cdv::HistArgs h;
+  int hb = 0;
+  const int rc = cdv_graph_prepare(jj, kk, E, ws, ws_bytes, E_max, k_range, ix, jx, stream, &h, &hb);
+  if (rc != CDV_OK) return rc;
+  if (hb > 0) hipLaunchKernelGGL(graph_hist_kernel, dim3(hb), dim3(256), 0, (hipStream_t)stream, h);
+  return cdv_graph_finish(jj, kk, E, ws, E_max, k_range, hb, ix, jx, stream);
 }
 
 extern "C" int cdv_graph_read_meta_host(const void* ws, int64_t* meta_host, void* stream) {

@@ -129,6 +129,34 @@ class GraphIndex:
         return kx, ku
 
 
+def update_prologue(graph, fmap_chw, fmap1_nhwc, fmap2_nhwc, slot, gmap, gmap_pm, gmap_first, gmap_count, poses, patches,
+                    intrinsics, ii, jj, kk, layout_e2pp=True):
+    """cdv_update_prologue: ring / tile ingest of the new frame, reprojection of all edges and the start of the
+    patch-graph index in ONE launch (then the rest of the index build, with neighbors).  Returns coords; the
+    neighbors are picked up with graph.neighbors()."""
+    lib = _lib.load()
+    _need_cuda(fmap_chw, fmap1_nhwc, fmap2_nhwc, poses, patches, intrinsics, ii, jj, kk)
+    C, H, W = fmap_chw.shape[-3:]
+    E, P = kk.numel(), patches.shape[-1]
+    if P != 3 or poses.dtype != torch.float32:
+        raise TypeError("update_prologue: float32 state, 3x3 patches")
+    dev = poses.device
+    graph._reserve(E)
+    coords = torch.empty((1, E, 2, P, P) if layout_e2pp else (1, E, P, P, 2), dtype=torch.float32, device=dev)
+    ix = torch.empty(E, dtype=torch.int64, device=dev)
+    jx = torch.empty(E, dtype=torch.int64, device=dev)
+    Ng = gmap.numel() // (C * 9) if gmap is not None else 0
+    rc = lib.cdv_update_prologue(_p(fmap_chw.contiguous()), _p(fmap1_nhwc), _p(fmap2_nhwc), int(slot), C, H, W, _p(gmap),
+                                 _p(gmap_pm), Ng, int(gmap_first), int(gmap_count), _p(poses), _p(patches),
+                                 _p(intrinsics), _p(ii), _p(jj), _p(kk), E, 1 if layout_e2pp else 0, _p(coords),
+                                 _p(graph.ws), graph.ws_bytes, graph.E_cap, graph.k_range, _p(ix), _p(jx), _stream())
+    _lib.check(rc, "cdv_update_prologue")
+    graph._key = (jj, kk, jj._version, kk._version)
+    graph.E = E
+    graph._nbr = (ix, jx)
+    return coords
+
+
 _graphs = {}
 
 

@@ -22,6 +22,7 @@ class UpdatePath:
         self.cfg = st.cfg
         self.dev = device
         self.overlap = overlap
+        self.fused_prologue = True   # ingest + reproject + index histogram in one launch (cdv_update_prologue)
         self._aux = torch.cuda.Stream(device=device, priority=-1) if overlap else None  # high priority: tiny kernels
         t = lambda a, dt=None: torch.as_tensor(a, device=device) if dt is None else torch.as_tensor(a, dtype=dt, device=device)
         self.poses = t(st.poses).contiguous()
@@ -80,23 +81,30 @@ class UpdatePath:
     def step(self, ingest=True, rebuild_graph=True, iterations=2):
         """One update.  Everything is enqueued on the current stream; no host synchronisation."""
         out = {}
-        # patch-graph index (shared by neighbors and BA) + 3. neighbors (net_cdv.py:102 -> ba.cpp:59-97): five small
-        # latency-bound launches that only need (jj, kk) -- on the side stream, under the correlation
         main = torch.cuda.current_stream()
-        if self.overlap:
-            self._aux.wait_stream(main)      # the previous BA still reads the index this build overwrites
-            with torch.cuda.stream(self._aux):
+        if self.has_features and ingest and rebuild_graph and not self.overlap and self.fused_prologue:
+            # ring / tile ingest, 1. reproject (slam.py:325-329) and the first launch of the patch-graph index side by
+            # side in ONE launch, then the rest of the index build with 3. neighbors (net_cdv.py:102 -> ba.cpp:59-97)
+            coords = ops.update_prologue(self.graph, self.new_frame, self.fmap1, self.fmap2, self.new_slot, self.gmap,
+                                         self.gmap_pm, self.new_tiles, self.M, self.poses, self.patches, self.intrinsics,
+                                         self.ii, self.jj, self.kk)
+            out["ix"], out["jx"] = self.graph.neighbors()
+        else:
+            # patch-graph index (shared by neighbors and BA) + 3. neighbors: launches that only need (jj, kk)
+            if self.overlap:
+                self._aux.wait_stream(main)      # the previous BA still reads the index this build overwrites
+                with torch.cuda.stream(self._aux):
+                    self.graph.build(self.jj, self.kk, force=rebuild_graph, with_neighbors=True)
+                    out["ix"], out["jx"] = self.graph.neighbors()
+            else:
                 self.graph.build(self.jj, self.kk, force=rebuild_graph, with_neighbors=True)
                 out["ix"], out["jx"] = self.graph.neighbors()
-        else:
-            self.graph.build(self.jj, self.kk, force=rebuild_graph, with_neighbors=True)
-            out["ix"], out["jx"] = self.graph.neighbors()
-        if self.has_features and ingest:
-            ops.fmap_ingest(self.new_frame, self.fmap1, self.fmap2, self.new_slot, gmap=self.gmap, gmap_pm=self.gmap_pm,
-                            gmap_first=self.new_tiles, gmap_count=self.M)
-        # 1. reproject (slam.py:325-329)
-        coords = ops.transform(self.poses[None], self.patches[None], self.intrinsics[None], self.ii, self.jj, self.kk,
-                               layout_e2pp=True)
+            if self.has_features and ingest:
+                ops.fmap_ingest(self.new_frame, self.fmap1, self.fmap2, self.new_slot, gmap=self.gmap,
+                                gmap_pm=self.gmap_pm, gmap_first=self.new_tiles, gmap_count=self.M)
+            # 1. reproject (slam.py:325-329)
+            coords = ops.transform(self.poses[None], self.patches[None], self.intrinsics[None], self.ii, self.jj,
+                                   self.kk, layout_e2pp=True)
         out["coords"] = coords
         self.last_coords = coords
         # 2. correlation, both levels (slam.py:316-323)
@@ -147,5 +155,9 @@ class UpdatePath:
         res["ba_2it"] = timed(lambda: ops.ba_forward(self.poses, self.patches, self.intrinsics, self.target,
                                                      self.weight, self.lmbda, self.ii, self.jj, self.kk, self.M,
                                                      self.t0, self.n, 2, False, U_max=self.U_max, graph=self.graph))
+        if self.has_features:
+            res["prologue_fused"] = timed(lambda: (ops.update_prologue(
+                self.graph, self.new_frame, self.fmap1, self.fmap2, self.new_slot, self.gmap, self.gmap_pm, self.new_tiles,
+                self.M, self.poses, self.patches, self.intrinsics, self.ii, self.jj, self.kk), self.graph.neighbors()))
         res["step"] = timed(lambda: self.step())
         return res

@@ -226,6 +226,24 @@ int cdv_ba_forward(float* poses, float* patches, const float* intrinsics, const 
                    int64_t U_max, float* dbg, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Start of an update in one launch
+ * ---------------------------------------------------------------------------------------------- */
+
+/*
+ * cdv_frame_ingest + cdv_transform (P = 3, coordinates only) + the first launch of
+ * cdv_graph_build_neighbors SIDE BY SIDE in one grid, then the rest of the index build.  The three have no mutual
+ * dependency at the start of SLAM.update (slam.py:480-526: ring writes :676-682, reproject :325-329, the edge
+ * lists of this update) and each is a few microseconds of latency-bound work, so one launch costs the longest of
+ * them instead of their sum.  Arguments as in the three functions (tf_flags: CDV_TF_LAYOUT_* / CDV_TF_TONLY);
+ * gmap_planar / gmap_pm and ix / jx may be NULL as there.
+ */
+int cdv_update_prologue(const void* fmap_chw, void* fmap1_nhwc, void* fmap2_nhwc, int slot, int C, int H, int W,
+                        const void* gmap_planar, void* gmap_pm, int64_t Ng, int64_t gmap_first, int64_t gmap_count,
+                        const float* poses, const float* patches, const float* intrinsics, const int64_t* ii,
+                        const int64_t* jj, const int64_t* kk, int64_t E, int tf_flags, float* coords, void* graph_ws,
+                        size_t graph_ws_bytes, int64_t E_max, int64_t k_range, int64_t* ix, int64_t* jx, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * lietorch forward ops  (replaces lietorch_backends.{expm,logm,inv,mul,adj,adjT,act,act4,as_matrix})
  * group ids as the reference: SO3 = 1, SE3 = 3 (lietorch.cpp:286-316, groups.py:236-290).
  * op: 0 exp, 1 log, 2 inv, 3 mul, 4 adj, 5 adjT, 6 act, 7 act4, 8 as_matrix.  Flat [n][dim] rows.

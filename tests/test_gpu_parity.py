@@ -272,6 +272,29 @@ def test_corr_pixel_major_tiles_bit_identical():
     assert bool((pm2[rest.to(pm2.device)] == 7.0).all())
 
 
+def test_update_prologue_equals_separate_launches():
+    """cdv_update_prologue (ingest + reproject + index histogram in one launch, then the rest of the index build) gives
+    bit-identical rings, tiles, coordinates, index and neighbors to the three separate entry points"""
+    from cdv_slam_amd.update import UpdatePath
+    st = synth.make_state("small")
+    dev = torch.device(DEV)
+    a, b = UpdatePath(st, dev), UpdatePath(st, dev)
+    a.fused_prologue, b.fused_prologue = True, False
+    for up in (a, b):   # make the ingest visible: a new frame that differs from what the rings hold
+        up.new_frame = (up.new_frame.float() * 0.5 + 0.125).half()
+        up.gmap[up.new_tiles:up.new_tiles + up.M] += 0.25
+    oa, ob = a.step(iterations=0), b.step(iterations=0)
+    torch.cuda.synchronize()
+    for k in ("coords", "ix", "jx", "corr"):
+        assert torch.equal(oa[k], ob[k]), k
+    assert torch.equal(a.fmap1, b.fmap1) and torch.equal(a.fmap2, b.fmap2) and torch.equal(a.gmap_pm, b.gmap_pm)
+    kxa, kua = a.graph.unique()
+    kxb, kub = b.graph.unique()
+    assert torch.equal(kxa, kxb) and torch.equal(kua, kub)
+    ix_o, jx_o = O.neighbors(st.kk, st.jj)
+    assert np.array_equal(oa["ix"].cpu().numpy(), ix_o) and np.array_equal(oa["jx"].cpu().numpy(), jx_o)
+
+
 def test_corr_edge_cases():
     """out-of-bounds windows, windows straddling the border, wide footprints (per-pixel path), exact
     integer coordinates, and the per-level drop-in signature (planar inputs, f16 and f32)."""
