@@ -108,15 +108,31 @@ __global__ __launch_bounds__(1024) void graph_scan_kernel(int32_t* meta, const i
     const int32_t v = khist[bin];
     sum += v; cnt += (v > 0);
   }
-  s_sum[t] = sum; s_cnt[t] = cnt;
-  __syncthreads();
-  for (int o = 1; o < T; o <<= 1) {  // Hillis-Steele inclusive scan over the per-thread partials
-    int32_t a1 = 0, c1 = 0;
-    if (t >= o) { a1 = s_sum[t - o]; c1 = s_cnt[t - o]; }
-    __syncthreads();
-    s_sum[t] += a1; s_cnt[t] += c1;
-    __syncthreads();
+  // inclusive scan of the 1024 per-thread partials: shuffle scan inside each wave, then the 16 wave totals
+  // (three barriers instead of the twenty of a Hillis-Steele sweep over LDS)
+  int32_t isum = sum, icnt = cnt;
+  const int lane = t & 63, wv = t >> 6;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int32_t a1 = __shfl_up(isum, o), c1 = __shfl_up(icnt, o);
+    if (lane >= o) { isum += a1; icnt += c1; }
   }
+  if (lane == 63) { s_sum[wv] = isum; s_cnt[wv] = icnt; }
+  __syncthreads();
+  if (t < 64) {
+    int32_t ws = (t < T / 64) ? s_sum[t] : 0, wc = (t < T / 64) ? s_cnt[t] : 0;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+      const int32_t a1 = __shfl_up(ws, o), c1 = __shfl_up(wc, o);
+      if (t >= o) { ws += a1; wc += c1; }
+    }
+    if (t < T / 64) { s_sum[64 + t] = ws; s_cnt[64 + t] = wc; }   // inclusive totals of waves 0..t
+  }
+  __syncthreads();
+  if (wv > 0) { isum += s_sum[64 + wv - 1]; icnt += s_cnt[64 + wv - 1]; }
+  __syncthreads();
+  s_sum[t] = isum; s_cnt[t] = icnt;
+  __syncthreads();
   int32_t run = s_sum[t] - sum, rk = s_cnt[t] - cnt;
   for (int64_t i = lo; i < hi; i++) {
     int bin = b0 + (int)i; bin = (bin >= R) ? bin - R : bin;
