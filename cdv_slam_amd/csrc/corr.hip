@@ -220,7 +220,8 @@ __global__ __launch_bounds__(256) void corr_fused_kernel(const _Float16* __restr
                                                          const int64_t* __restrict__ jj,
                                                          const int32_t* __restrict__ order,
                                                          _Float16* __restrict__ out, int E, int64_t Ng, int64_t slots,
-                                                         int C, int nlev, int64_t kmod, int64_t jmod, int gmap_pm,
+                                                         int C, int nlev, int64_t kmod, int64_t jmod, uint32_t kmagic,
+                                                         uint32_t jmagic, int gmap_pm,
                                                          int exp) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lane = threadIdx.x & 63;
@@ -234,8 +235,20 @@ __global__ __launch_bounds__(256) void corr_fused_kernel(const _Float16* __restr
 
   // ---- round trip 1: indices (scalar) and the 18 coordinates ----------------------------------------
   int64_t kpatch = kk[e], jslot = jj[e];
-  if (kmod > 0) kpatch %= kmod;
-  if (jmod > 0) jslot %= jmod;
+  // index % modulus (slam.py:319-320) with the host's reciprocal: q = mulhi(x, ceil(2^32 / d)) is x / d or one more
+  // for 0 <= x < 2^31, so one correction step; the 64-bit division the compiler would emit is ~150 scalar instructions
+  if (kmod > 0 && kpatch >= 0 && kpatch < ((int64_t)1 << 31)) {
+    const uint32_t x = (uint32_t)kpatch, d = (uint32_t)kmod;
+    const uint32_t q = __builtin_amdgcn_readfirstlane((int)__umulhi(x, kmagic));
+    const int32_t r = (int32_t)(x - q * d);
+    kpatch = (d == 1u) ? 0 : (r < 0 ? r + (int32_t)d : r);
+  }
+  if (jmod > 0 && jslot >= 0 && jslot < ((int64_t)1 << 31)) {
+    const uint32_t x = (uint32_t)jslot, d = (uint32_t)jmod;
+    const uint32_t q = __builtin_amdgcn_readfirstlane((int)__umulhi(x, jmagic));
+    const int32_t r = (int32_t)(x - q * d);
+    jslot = (d == 1u) ? 0 : (r < 0 ? r + (int32_t)d : r);
+  }
   const bool idx_ok = kpatch >= 0 && kpatch < Ng && jslot >= 0 && jslot < slots;
   if (!idx_ok) { kpatch = 0; jslot = 0; }  // reference behaviour is undefined here; stay in bounds
   if (exp & 16) jslot = 0;                 // experiment bit 4: every edge reads map slot 0 (L2-resident)
@@ -303,9 +316,11 @@ __global__ __launch_bounds__(256) void corr_fused_kernel(const _Float16* __restr
     // ---- EVERY window row of both levels is requested before the first MFMA --------------------------
     const int Wp0 = L0.W + 2 * PADX, Hp0 = L0.H + 2 * PADY, Wp1 = L1.W + 2 * PADX, Hp1 = L1.H + 2 * PADY;
     const char* r0 = reinterpret_cast<const char*>(L0.fmap) +
-                     (((size_t)jslot * Hp0 + (b0.y0c + PADY)) * Wp0 + (b0.x0c + PADX)) * C * 2;
+                     (size_t)((((unsigned)jslot * (unsigned)Hp0 + (unsigned)(b0.y0c + PADY)) * (unsigned)Wp0 +
+                               (unsigned)(b0.x0c + PADX)) * (unsigned)(C * 2));   // rings are below 4 GB (host check)
     const char* r1 = reinterpret_cast<const char*>(nlev == 2 ? L1.fmap : L0.fmap) +
-                     (((size_t)jslot * Hp1 + (b1.y0c + PADY)) * Wp1 + (b1.x0c + PADX)) * C * 2;
+                     (size_t)((((unsigned)jslot * (unsigned)Hp1 + (unsigned)(b1.y0c + PADY)) * (unsigned)Wp1 +
+                               (unsigned)(b1.x0c + PADX)) * (unsigned)(C * 2));
     const size_t pitch0 = (size_t)Wp0 * C * 2, pitch1 = (size_t)Wp1 * C * 2;
     // The CU's vector-memory return path (~70 GB/s per CU from L2) is what bounds this kernel, so only
     // the useful lanes load: pixels n < Wb and the 3 real channel groups.  Rows n >= Wb of D are never read
@@ -661,6 +676,14 @@ extern "C" int cdv_corr_fused(const void* gmap, const void* fmap0_nhwc, const vo
   CDV_REQUIRE(scale0 > 0.f && frexpf(scale0, &ex0) == 0.5f && (nlev == 1 || (scale1 > 0.f && frexpf(scale1, &ex1) == 0.5f)),
               CDV_ERR_UNSUPPORTED, "cdv_corr_fused: pyramid scales must be powers of two (1 and 4 in SLAM.corr)");
   CDV_REQUIRE(fmap0_nhwc != nullptr && (nlev == 1 || fmap1_nhwc != nullptr), CDV_ERR_ARG, "cdv_corr_fused: NULL map");
+  CDV_REQUIRE(cdv_fmap_padded_elems(slots, C, H0, W0) * 2 < ((size_t)1 << 32) &&
+                  (nlev == 1 || cdv_fmap_padded_elems(slots, C, H1, W1) * 2 < ((size_t)1 << 32)),
+              CDV_ERR_UNSUPPORTED, "cdv_corr_fused: a feature ring of 4 GB or more");
+  CDV_REQUIRE(kmod >= 0 && jmod >= 0 && kmod < ((int64_t)1 << 31) && jmod < ((int64_t)1 << 31), CDV_ERR_ARG,
+              "cdv_corr_fused: kmod / jmod out of range");
+  // ceil(2^32 / d): mulhi(x, magic) is x / d or x / d + 1 for 0 <= x < 2^31
+  const uint32_t kmagic = kmod > 1 ? (uint32_t)((((uint64_t)1 << 32) + (uint64_t)kmod - 1) / (uint64_t)kmod) : 0u;
+  const uint32_t jmagic = jmod > 1 ? (uint32_t)((((uint64_t)1 << 32) + (uint64_t)jmod - 1) / (uint64_t)jmod) : 0u;
   if (E == 0) return CDV_OK;
   CDV_REQUIRE(nlev == 1 || ex1 >= ex0, CDV_ERR_UNSUPPORTED, "cdv_corr_fused: level 1 must not be finer than level 0");
   LevelParams L0{(const _Float16*)fmap0_nhwc, H0, W0, 1.0f / scale0, 0};
@@ -671,10 +694,12 @@ extern "C" int cdv_corr_fused(const void* gmap, const void* fmap0_nhwc, const vo
   hipStream_t s = (hipStream_t)stream;
   if (C <= 32)
     hipLaunchKernelGGL(corr_fused_kernel<1>, dim3(blocks), dim3(256), smem, s, (const _Float16*)gmap, L0, L1, coords,
-                       kk, jj, order, (_Float16*)out, (int)E, Ng, slots, C, nlev, kmod, jmod, gmap_pixel_major, exp);
+                       kk, jj, order, (_Float16*)out, (int)E, Ng, slots, C, nlev, kmod, jmod, kmagic, jmagic,
+                       gmap_pixel_major, exp);
   else
     hipLaunchKernelGGL(corr_fused_kernel<4>, dim3(blocks), dim3(256), smem, s, (const _Float16*)gmap, L0, L1, coords,
-                       kk, jj, order, (_Float16*)out, (int)E, Ng, slots, C, nlev, kmod, jmod, gmap_pixel_major, exp);
+                       kk, jj, order, (_Float16*)out, (int)E, Ng, slots, C, nlev, kmod, jmod, kmagic, jmagic,
+                       gmap_pixel_major, exp);
   CDV_LAUNCH_CHECK();
   return CDV_OK;
 }
