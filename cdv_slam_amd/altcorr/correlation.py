@@ -19,6 +19,8 @@ def corr(fmap1, fmap2, coords, ii, jj, radius=1, dropout=1):
 def patchify(net, coords, radius, mode='bilinear'):
     """Extract (2r+1)^2 patches around coords (correlation.py:51-71)."""
     _no_grad_inputs(net)
+    if mode in ('bilinear', 'upperleft') and net.is_cuda and net.dim() == 4 and coords.dim() == 3:
+        return ops.patchify_blend(net, coords, radius, mode)      # gather + blend in one launch
     patches = ops.patchify_forward(net, coords, radius)
     if mode == 'bilinear':
         offset = (coords - coords.floor()).to(net.device)

@@ -588,7 +588,64 @@ __global__ __launch_bounds__(256) void patchify_kernel(const T* __restrict__ net
   }
 }
 
+// altcorr.patchify(net, coords, radius, mode) (correlation.py:51-71) in one pass: mode 1 = 'bilinear' (the (2r+2)^2
+// gather of patchify_forward blended to (2r+1)^2 with the sub-pixel offset of the patch centre, in the reference's
+// operation order x00 + x01 + x10 + x11), mode 2 = 'upperleft' (the 1x1 corner tile).  Out-of-image taps are zero.
+// (the blend multiplies float32 offsets into the tile, so torch's type promotion makes the 'bilinear' result float32
+// whatever the map's dtype; 'upperleft' is a slice and keeps the dtype)
+template <typename T>
+__global__ __launch_bounds__(256) void patchify_blend_kernel(const T* __restrict__ net, const float* __restrict__ coords,
+                                                             void* __restrict__ outv, int B, int64_t M, int C, int H,
+                                                             int W, int R, int mode) {
+  const int d = (mode == 2) ? 1 : 2 * R + 1;
+  const int64_t total = (int64_t)B * M * C * d * d;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t t = idx;
+    const int b2 = (int)(t % d); t /= d;
+    const int a2 = (int)(t % d); t /= d;
+    const int ch = (int)(t % C); t /= C;
+    const int64_t m = t % M; t /= M;
+    const int bb = (int)t;
+    const float x = coords[(bb * M + m) * 2 + 0], y = coords[(bb * M + m) * 2 + 1];
+    const float fxf = floorf(x), fyf = floorf(y);
+    const int i0 = (int)fminf(fmaxf(fyf, -1.0e6f), 1.0e6f) + (a2 - R);
+    const int j0 = (int)fminf(fmaxf(fxf, -1.0e6f), 1.0e6f) + (b2 - R);
+    const T* np = net + ((int64_t)bb * C + ch) * H * W;
+    auto tap = [&](int i, int j) -> T { return (i >= 0 && i < H && j >= 0 && j < W) ? np[(int64_t)i * W + j] : (T)0.f; };
+    if (mode == 2) {
+      reinterpret_cast<T*>(outv)[idx] = tap(i0, j0);
+    } else {
+      const float dx = x - fxf, dy = y - fyf;   // correlation.py:58-66, same operation order
+      const float x00 = (1.0f - dy) * (1.0f - dx) * (float)tap(i0, j0);
+      const float x01 = (1.0f - dy) * dx * (float)tap(i0, j0 + 1);
+      const float x10 = dy * (1.0f - dx) * (float)tap(i0 + 1, j0);
+      const float x11 = dy * dx * (float)tap(i0 + 1, j0 + 1);
+      reinterpret_cast<float*>(outv)[idx] = ((x00 + x01) + x10) + x11;
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int cdv_patchify_blend(const void* net, const float* coords, void* out, int B, int64_t M, int C, int H, int W,
+                                  int radius, int mode, int dtype, void* stream) {
+  CDV_REQUIRE(dtype == CDV_F16 || dtype == CDV_F32, CDV_ERR_UNSUPPORTED, "cdv_patchify_blend: dtype must be f16 or f32");
+  CDV_REQUIRE(mode == 1 || mode == 2, CDV_ERR_ARG, "cdv_patchify_blend: mode 1 (bilinear) or 2 (upperleft)");
+  const int d = (mode == 2) ? 1 : 2 * radius + 1;
+  const int64_t total = (int64_t)B * M * C * d * d;
+  if (total == 0) return CDV_OK;
+  const int blocks = cdv_div_up(total, 256) < 16384 ? cdv_div_up(total, 256) : 16384;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CDV_F16)
+    hipLaunchKernelGGL(patchify_blend_kernel<_Float16>, dim3(blocks), dim3(256), 0, s, (const _Float16*)net, coords, out,
+                       B, M, C, H, W, radius, mode);
+  else
+    hipLaunchKernelGGL(patchify_blend_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)net, coords, out, B, M,
+                       C, H, W, radius, mode);
+  CDV_LAUNCH_CHECK();
+  return CDV_OK;
+}
 
 extern "C" int cdv_corr_fwd(const void* fmap1, const void* fmap2, const float* coords, const int64_t* us,
                             const int64_t* vs, void* out, int64_t M, int64_t N1, int64_t N2, int C, int P, int H2,

@@ -47,7 +47,119 @@ __global__ __launch_bounds__(256) void fastba_reproject_kernel(const float* __re
   }
 }
 
+// pops.flow_mag (projective_ops.py:120-130): three reprojections per edge -- (i -> i), (i -> j), (i -> j, translation
+// only) -- in one pass; flow = beta |x_ij - x_ii| + (1 - beta) |x_ij^t - x_ii| per patch pixel, valid = X_ij.z > 0.2.
+// The (i -> i) pose goes through the same inv / mul / re-normalised load as the reference's Gij = Pi * Pi^-1.
+template <int P>
+__global__ __launch_bounds__(256) void flow_mag_kernel(const float* __restrict__ poses, const float* __restrict__ patches,
+                                                       const float* __restrict__ intr, const int64_t* __restrict__ ii,
+                                                       const int64_t* __restrict__ jj, const int64_t* __restrict__ kk,
+                                                       int64_t E, float beta, float* __restrict__ flow,
+                                                       uint8_t* __restrict__ valid) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= E) return;
+  constexpr int PP = P * P;
+  const int64_t ix = ii[n], jx = jj[n], kx = kk[n];
+  float Pi[7], Pj[7], Pinv[7], G[3][7];
+#pragma unroll
+  for (int a = 0; a < 7; a++) { Pi[a] = poses[7 * ix + a]; Pj[a] = poses[7 * jx + a]; }
+  cdv::lt_se3_inv(Pi, Pinv);
+  cdv::lt_se3_mul(Pi, Pinv, G[0]);
+  cdv::lt_se3_mul(Pj, Pinv, G[1]);
+#pragma unroll
+  for (int a = 0; a < 3; a++) G[2][a] = G[1][a];
+  G[2][3] = 0.f; G[2][4] = 0.f; G[2][5] = 0.f; G[2][6] = 1.f;   // tonly (projective_ops.py:62)
+  float t[3][3], q[3][4];
+#pragma unroll
+  for (int v = 0; v < 3; v++) cdv::lt_se3_load(G[v], t[v], q[v]);
+  const float fxi = intr[4 * ix + 0], fyi = intr[4 * ix + 1], cxi = intr[4 * ix + 2], cyi = intr[4 * ix + 3];
+  const float fxj = intr[4 * jx + 0], fyj = intr[4 * jx + 1], cxj = intr[4 * jx + 2], cyj = intr[4 * jx + 3];
+  const float* pk = patches + kx * 3 * PP;
+#pragma unroll
+  for (int a = 0; a < PP; a++) {
+    float X0[4], X1[4], xy[3][2];
+    X0[0] = (pk[a] - cxi) / fxi;
+    X0[1] = (pk[PP + a] - cyi) / fyi;
+    X0[2] = 1.f;
+    X0[3] = pk[2 * PP + a];
+    bool ok = false;
+#pragma unroll
+    for (int v = 0; v < 3; v++) {
+      cdv::lt_act4_loaded(t[v], q[v], X0, X1);
+      const float d = 1.0f / fmaxf(X1[2], 0.1f);
+      const float fx = v == 0 ? fxi : fxj, fy = v == 0 ? fyi : fyj, cx = v == 0 ? cxi : cxj, cy = v == 0 ? cyi : cyj;
+      xy[v][0] = fx * (d * X1[0]) + cx;
+      xy[v][1] = fy * (d * X1[1]) + cy;
+      if (v == 1) ok = X1[2] > 0.2f;
+    }
+    const float ax = xy[1][0] - xy[0][0], ay = xy[1][1] - xy[0][1];
+    const float bx = xy[2][0] - xy[0][0], by = xy[2][1] - xy[0][1];
+    flow[n * PP + a] = beta * sqrtf(ax * ax + ay * ay) + (1.0f - beta) * sqrtf(bx * bx + by * by);
+    valid[n * PP + a] = ok ? 1 : 0;
+  }
+}
+
+// pops.point_cloud (projective_ops.py:115-117): X = P_ix^-1 * iproj(patch) for every patch pixel, one thread per patch
+template <int P>
+__global__ __launch_bounds__(256) void point_cloud_kernel(const float* __restrict__ poses, const float* __restrict__ patches,
+                                                          const float* __restrict__ intr, const int64_t* __restrict__ ix,
+                                                          int64_t M, float* __restrict__ points) {
+  const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  constexpr int PP = P * P;
+  const int64_t f = ix[m];
+  float Pi[7], Pinv[7], t[3], q[4];
+#pragma unroll
+  for (int a = 0; a < 7; a++) Pi[a] = poses[7 * f + a];
+  cdv::lt_se3_inv(Pi, Pinv);
+  cdv::lt_se3_load(Pinv, t, q);
+  const float fx = intr[4 * f + 0], fy = intr[4 * f + 1], cx = intr[4 * f + 2], cy = intr[4 * f + 3];
+  const float* pk = patches + m * 3 * PP;
+#pragma unroll
+  for (int a = 0; a < PP; a++) {
+    float X0[4], X1[4];
+    X0[0] = (pk[a] - cx) / fx;
+    X0[1] = (pk[PP + a] - cy) / fy;
+    X0[2] = 1.f;
+    X0[3] = pk[2 * PP + a];
+    cdv::lt_act4_loaded(t, q, X0, X1);
+#pragma unroll
+    for (int c = 0; c < 4; c++) points[(m * PP + a) * 4 + c] = X1[c];
+  }
+}
+
 }  // namespace
+
+extern "C" int cdv_flow_mag(const float* poses, const float* patches, const float* intrinsics, const int64_t* ii,
+                            const int64_t* jj, const int64_t* kk, int64_t E, int P, float beta, float* flow,
+                            uint8_t* valid, void* stream) {
+  CDV_REQUIRE(P == 3 || P == 1, CDV_ERR_UNSUPPORTED, "cdv_flow_mag: patch size P must be 3 or 1");
+  if (E == 0) return CDV_OK;
+  const int blocks = cdv_div_up(E, 64);
+  if (P == 3)
+    hipLaunchKernelGGL(flow_mag_kernel<3>, dim3(blocks), dim3(64), 0, (hipStream_t)stream, poses, patches, intrinsics, ii,
+                       jj, kk, E, beta, flow, valid);
+  else
+    hipLaunchKernelGGL(flow_mag_kernel<1>, dim3(blocks), dim3(64), 0, (hipStream_t)stream, poses, patches, intrinsics, ii,
+                       jj, kk, E, beta, flow, valid);
+  CDV_LAUNCH_CHECK();
+  return CDV_OK;
+}
+
+extern "C" int cdv_point_cloud(const float* poses, const float* patches, const float* intrinsics, const int64_t* ix,
+                               int64_t M, int P, float* points, void* stream) {
+  CDV_REQUIRE(P == 3 || P == 1, CDV_ERR_UNSUPPORTED, "cdv_point_cloud: patch size P must be 3 or 1");
+  if (M == 0) return CDV_OK;
+  const int blocks = cdv_div_up(M, 64);
+  if (P == 3)
+    hipLaunchKernelGGL(point_cloud_kernel<3>, dim3(blocks), dim3(64), 0, (hipStream_t)stream, poses, patches, intrinsics,
+                       ix, M, points);
+  else
+    hipLaunchKernelGGL(point_cloud_kernel<1>, dim3(blocks), dim3(64), 0, (hipStream_t)stream, poses, patches, intrinsics,
+                       ix, M, points);
+  CDV_LAUNCH_CHECK();
+  return CDV_OK;
+}
 
 extern "C" int cdv_transform(const float* poses, const float* patches, const float* intrinsics, const int64_t* ii,
                              const int64_t* jj, const int64_t* kk, int64_t E, int P, int flags, float* coords,

@@ -390,6 +390,49 @@ def patchify_forward(net, coords, radius):
     return out
 
 
+def patchify_blend(net, coords, radius, mode):
+    """altcorr.patchify with mode 'bilinear' / 'upperleft' (correlation.py:51-71) in one launch."""
+    lib = _lib.load()
+    _need_cuda(net, coords)
+    if net.dtype not in (torch.float16, torch.float32):
+        raise TypeError("patchify: net must be float16 or float32")
+    net, coords = net.contiguous(), coords.contiguous().float()
+    B, C, H, W = net.shape
+    M = coords.shape[1]
+    d = 1 if mode == "upperleft" else 2 * radius + 1
+    out = torch.empty((B, M, C, d, d), dtype=net.dtype if mode == "upperleft" else torch.float32, device=net.device)
+    rc = lib.cdv_patchify_blend(_p(net), _p(coords), _p(out), B, M, C, H, W, radius, 2 if mode == "upperleft" else 1,
+                                _DT[net.dtype], _stream())
+    _lib.check(rc, "cdv_patchify_blend")
+    return out
+
+
+def flow_mag(poses, patches, intrinsics, ii, jj, kk, beta):
+    """pops.flow_mag (projective_ops.py:120-130) fused: -> (flow [1,E,P,P] f32, valid [1,E,P,P] bool)"""
+    lib = _lib.load()
+    _need_cuda(poses, patches, intrinsics, ii, jj, kk)
+    poses, patches, intrinsics = poses.contiguous(), patches.contiguous(), intrinsics.contiguous()
+    E, P = ii.numel(), patches.shape[-1]
+    flow = torch.empty((1, E, P, P), dtype=torch.float32, device=poses.device)
+    val = torch.empty((1, E, P, P), dtype=torch.uint8, device=poses.device)
+    rc = lib.cdv_flow_mag(_p(poses), _p(patches), _p(intrinsics), _p(ii.contiguous()), _p(jj.contiguous()),
+                          _p(kk.contiguous()), E, P, float(beta), _p(flow), _p(val), _stream())
+    _lib.check(rc, "cdv_flow_mag")
+    return flow, val.bool()
+
+
+def point_cloud(poses, patches, intrinsics, ix):
+    """pops.point_cloud (projective_ops.py:115-117) fused: patches [1,M,3,P,P], ix [M] -> [1,M,P,P,4]"""
+    lib = _lib.load()
+    _need_cuda(poses, patches, intrinsics, ix)
+    poses, patches, intrinsics = poses.contiguous(), patches.contiguous(), intrinsics.contiguous()
+    M, P = ix.numel(), patches.shape[-1]
+    pts = torch.empty((1, M, P, P, 4), dtype=torch.float32, device=poses.device)
+    rc = lib.cdv_point_cloud(_p(poses), _p(patches), _p(intrinsics), _p(ix.contiguous()), M, P, _p(pts), _stream())
+    _lib.check(rc, "cdv_point_cloud")
+    return pts
+
+
 # ---------------------------------------------------------------------------------------------------
 # fastba
 # ---------------------------------------------------------------------------------------------------

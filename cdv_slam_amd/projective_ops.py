@@ -81,12 +81,19 @@ def _transform_composed(poses, patches, intrinsics, ii, jj, kk, depth, valid, ja
 
 def point_cloud(poses, patches, intrinsics, ix):
     """world points of patches (projective_ops.py:115-117)"""
+    data = _pose_data(poses)
+    if (data.dtype == torch.float32 and data.shape[0] == 1 and patches.dtype == torch.float32
+            and patches.shape[1] == ix.numel()):
+        return ops.point_cloud(data, patches, intrinsics, ix)     # one launch
     poses = poses if isinstance(poses, SE3) else SE3(poses)
     return poses[:, ix, None, None].inv() * iproj(patches, intrinsics[:, ix])
 
 
 def flow_mag(poses, patches, intrinsics, ii, jj, kk, beta=0.3):
     """flow magnitude used by the keyframe test (projective_ops.py:120-130)"""
+    data = _pose_data(poses)
+    if data.dtype == torch.float32 and data.shape[0] == 1 and patches.dtype == torch.float32:
+        return ops.flow_mag(data, patches, intrinsics, ii, jj, kk, beta)   # one launch instead of three + torch ops
     coords0 = transform(poses, patches, intrinsics, ii, ii, kk)
     coords1, val = transform(poses, patches, intrinsics, ii, jj, kk, tonly=False, valid=True)
     coords2 = transform(poses, patches, intrinsics, ii, jj, kk, tonly=True)

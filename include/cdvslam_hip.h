@@ -225,6 +225,25 @@ int cdv_ba_forward(float* poses, float* patches, const float* intrinsics, const 
                    int t0, int t1, int iterations, const void* graph_ws, void* ba_ws, size_t ba_ws_bytes,
                    int64_t U_max, float* dbg, void* stream);
 
+/* altcorr.patchify(net, coords, radius, mode) -- correlation.py:51-71 -- in one launch: the gather of
+ * patchify_forward plus the blend the reference composes from four slice products.
+ *   mode 1 'bilinear': out [B][M][C][2r+1][2r+1] FLOAT32 (the reference multiplies float32 offsets into the tile);
+ *   mode 2 'upperleft': out [B][M][C][1][1] in the map's dtype. */
+int cdv_patchify_blend(const void* net, const float* coords, void* out, int B, int64_t M, int C, int H, int W,
+                       int radius, int mode, int dtype, void* stream);
+
+/* pops.flow_mag(poses, patches, intrinsics, ii, jj, kk, beta) -- projective_ops.py:120-130, the keyframe test's motion
+ * measure (slam.py:399-406): three reprojections per edge in one launch.
+ *   flow [E][P][P] f32 ; valid [E][P][P] uint8 (X_ij.z > 0.2) */
+int cdv_flow_mag(const float* poses, const float* patches, const float* intrinsics, const int64_t* ii,
+                 const int64_t* jj, const int64_t* kk, int64_t E, int P, float beta, float* flow, uint8_t* valid,
+                 void* stream);
+
+/* pops.point_cloud(poses, patches, intrinsics, ix) -- projective_ops.py:115-117 (slam.py:524-526): world points
+ * P_ix^-1 * iproj(patch) of M patches, patches [M][3][P][P], ix [M] -> points [M][P][P][4] */
+int cdv_point_cloud(const float* poses, const float* patches, const float* intrinsics, const int64_t* ix, int64_t M,
+                    int P, float* points, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Start of an update in one launch
  * ---------------------------------------------------------------------------------------------- */

@@ -502,6 +502,49 @@ def test_ba_py_mirror_vs_reference_golden(golden_dir, tag):
     assert torch.equal(Ps.data, G("poses")[None])
 
 
+def test_fused_flow_mag_point_cloud_patchify_vs_composed():
+    """the one-launch forms of pops.flow_mag / pops.point_cloud / altcorr.patchify(mode=...) against the op-by-op
+    composition the reference writes (projective_ops.py:115-130, correlation.py:51-71) and the oracle"""
+    from cdv_slam_amd import projective_ops as pops, altcorr
+    from cdv_slam_amd.lietorch import SE3
+    st = synth.make_state("small")
+    poses, patches, intr = T(st.poses)[None], T(st.patches)[None], T(st.intrinsics)[None]
+    ii, jj, kk = T(st.ii), T(st.jj), T(st.kk)
+    # flow_mag: fused vs composed out of three transforms
+    flow, val = pops.flow_mag(SE3(poses), patches, intr, ii, jj, kk, beta=0.5)
+    c0 = pops.transform(SE3(poses), patches, intr, ii, ii, kk)
+    c1, v1 = pops.transform(SE3(poses), patches, intr, ii, jj, kk, valid=True)
+    c2 = pops.transform(SE3(poses), patches, intr, ii, jj, kk, tonly=True)
+    want = 0.5 * (c1 - c0).norm(dim=-1) + 0.5 * (c2 - c0).norm(dim=-1)
+    assert flow.shape == want.shape and val.dtype == torch.bool
+    assert float((flow - want).abs().max()) <= 2e-3 and torch.equal(val, v1 > 0.5)
+    # point_cloud: fused vs inv * iproj, and vs the oracle's Lie arithmetic
+    m = 200
+    ix = T((np.arange(m) // st.cfg.M).astype(np.int64))
+    pc = pops.point_cloud(SE3(poses), patches[:, :m], intr, ix)
+    comp = SE3(poses)[:, ix, None, None].inv() * pops.iproj(patches[:, :m], intr[:, ix])
+    assert pc.shape == (1, m, 3, 3, 4) and float((pc - comp).abs().max()) <= 1e-5 * float(comp.abs().max())
+    # patchify with blend modes: fused vs gather + four slice products, float16 and float32 maps
+    fmap = T(st.fmap1[:2])                                   # [2,C,h,w] f16
+    M = 64
+    rng = np.random.default_rng(3)
+    coords = T(np.stack([rng.uniform(-2, fmap.shape[-1] + 1, (2, M)), rng.uniform(-2, fmap.shape[-2] + 1, (2, M))], -1)
+               .astype(np.float32))
+    for net in (fmap, fmap.float()):
+        for r in (0, 1):
+            raw = ops.patchify_forward(net, coords, r)
+            off = coords - coords.floor()
+            dx, dy = off[:, :, None, None, None].unbind(dim=-1)
+            d = 2 * r + 1
+            want = ((1 - dy) * (1 - dx) * raw[..., :d, :d] + (1 - dy) * dx * raw[..., :d, 1:]
+                    + dy * (1 - dx) * raw[..., 1:, :d] + dy * dx * raw[..., 1:, 1:])
+            got = altcorr.patchify(net, coords, r, mode='bilinear')
+            assert got.dtype == want.dtype == torch.float32 and got.shape == want.shape
+            assert float((got - want).abs().max()) <= 1e-6 * max(1.0, float(want.abs().max()))
+            ul = altcorr.patchify(net, coords, r, mode='upperleft')
+            assert ul.dtype == net.dtype and torch.equal(ul, raw[..., :1, :1])
+
+
 def test_ba_structure_only_and_gates():
     """t1 == t0 branch (ba_cuda.cu:550-560, caller long_term.py:124-125) and the depth clamps"""
     st = synth.make_state("small", features=False)
