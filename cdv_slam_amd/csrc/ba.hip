@@ -371,8 +371,9 @@ __global__ __launch_bounds__(256) void ba_schur_kernel(const float* __restrict__
                                                        int sy_stride, const float* __restrict__ Cg,
                                                        const float* __restrict__ ug,
                                                        float* __restrict__ qg, const float* __restrict__ Edg,
-                                                       int U_stride, const int32_t* __restrict__ info) {
+                                                       int U_stride, int32_t* __restrict__ info) {
   if (gmeta[GM_ERROR] || info[1]) return;
+  if (blockIdx.x == 0 && threadIdx.x == 0) info[8] = 0;   // hand-off flag of the following solve + retract launch
   const int U = gmeta[GM_U];
   const int r0 = blockIdx.x * BA_CHUNK;
   if (r0 >= U) return;
@@ -684,11 +685,12 @@ __device__ __forceinline__ float readlane_f(float v, int l) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
 
-__global__ __launch_bounds__(256) void ba_solve60_kernel(float* __restrict__ poses, float* __restrict__ sy,
-                                                         int sy_stride, float* __restrict__ dXg, int t0, int N,
-                                                         const int32_t* __restrict__ gmeta, float* __restrict__ dbg,
-                                                         int32_t* __restrict__ info) {
-  if (gmeta[GM_ERROR] || info[1]) return;
+// publish != nullptr: dX is handed to the retract workgroups of the SAME launch (ba_solve60_retract_kernel): written
+// with write-through (sc1) stores, drained, then the flag -- the hand-off recipe of the CDNA programming guide.
+__device__ __forceinline__ void solve60_body(float* __restrict__ poses, float* __restrict__ sy, int sy_stride,
+                                             float* __restrict__ dXg, int t0, int N,
+                                             const int32_t* __restrict__ gmeta, float* __restrict__ dbg,
+                                             int32_t* __restrict__ info, int32_t* publish) {
   __shared__ __attribute__((aligned(16))) float A[(SN + 1) * SLD];
   __shared__ float xs[64];
   const int n = 6 * N;
@@ -795,14 +797,115 @@ __global__ __launch_bounds__(256) void ba_solve60_kernel(float* __restrict__ pos
   }
   CDV_STAMP(ba, sslot, 3);
   if (lane < n) {
-    dXg[lane] = x;
+    if (publish) __hip_atomic_store(&dXg[lane], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else dXg[lane] = x;
     if (dbg) dbg[n * n + n + lane] = x;
   }
   if (lane == 0) info[0] = badk;
+  if (publish) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) __hip_atomic_store(publish, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   // the pose retraction (sin / cos of the update) runs in ba_retract_kernel, next to the depth updates, instead of
   // lengthening this single-wave critical path
   (void)poses; (void)t0; (void)xs;
   CDV_STAMP(ba, sslot, 4);
+}
+
+__global__ __launch_bounds__(256) void ba_solve60_kernel(float* __restrict__ poses, float* __restrict__ sy,
+                                                         int sy_stride, float* __restrict__ dXg, int t0, int N,
+                                                         const int32_t* __restrict__ gmeta, float* __restrict__ dbg,
+                                                         int32_t* __restrict__ info) {
+  if (gmeta[GM_ERROR] || info[1]) return;
+  solve60_body(poses, sy, sy_stride, dXg, t0, N, gmeta, dbg, info, nullptr);
+}
+
+// Solve + retract in ONE launch (N <= 10).  Workgroup 0 is the single-wave solver; workgroups 1.. are the retract
+// workgroups: while the solver runs they load their patches' E columns, C, u, q and depth into registers and re-zero
+// the accumulators, then wait on a flag for dX (one polling lane per workgroup, bounded), and finish with 60 FMAs per
+// patch.  The retract launch's start-up latency and its memory round trips hide under the solver instead of following
+// it.  All workgroups are co-resident (a few dozen on 256 CUs), so the wait cannot deadlock; the flag is reset by the
+// preceding schur launch.
+__global__ __launch_bounds__(256) void ba_solve60_retract_kernel(float* __restrict__ poses, float* __restrict__ sy,
+                                                                 int sy_stride, float* __restrict__ dXg, int t0, int N,
+                                                                 const int32_t* __restrict__ gmeta, float* __restrict__ dbg,
+                                                                 int32_t* __restrict__ info, int32_t* __restrict__ flag,
+                                                                 float* __restrict__ patches, int P,
+                                                                 const int64_t* __restrict__ kx, float* __restrict__ Cg,
+                                                                 float* __restrict__ ug, const float* __restrict__ qg,
+                                                                 float* __restrict__ Edg, int U_stride,
+                                                                 float* __restrict__ dbgp) {
+  if (gmeta[GM_ERROR] || info[1]) return;
+  if (blockIdx.x == 0) {
+    solve60_body(poses, sy, sy_stride, dXg, t0, N, gmeta, dbg, info, flag);
+    return;
+  }
+  __shared__ float sdx[64];
+  const int U = gmeta[GM_U];
+  const int PP = P * P;
+  const int t = threadIdx.x;
+  const int r = ((int)blockIdx.x - 1) * 256 + t;
+  const bool live = r < U;
+  // ---- before dX exists: everything of this patch that does not depend on it -------------------------
+  float ev[SN];
+#pragma unroll
+  for (int b = 0; b < SN / 6; b++) {
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+      float v = 0.f;
+      if (live && b < N) {
+        float* ep = &Edg[(size_t)(6 * b + c) * U_stride + r];
+        v = *ep;
+        if (dbgp) dbgp[3 * (size_t)U_stride + (size_t)(6 * b + c) * U_stride + r] = v;
+        *ep = 0.f;
+      }
+      ev[6 * b + c] = v;
+    }
+  }
+  float cv = 0.f, uv = 0.f, qv = 0.f, d0 = 0.f;
+  float* pk = nullptr;
+  if (live) {
+    cv = Cg[r]; uv = ug[r]; qv = qg[r];
+    Cg[r] = 0.f; ug[r] = 0.f;
+    pk = patches + kx[r] * 3 * PP + 2 * PP;
+    d0 = pk[0];                      // patch_retr_kernel reads pixel [0][0]   ba_cuda.cu:218
+  }
+  // ---- wait for the solver (bounded: a lost hand-off must not hang the device) ------------------------
+  if (t == 0) {
+    int spins = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1 && spins < (1 << 22)) {
+      __builtin_amdgcn_s_sleep(4);
+      spins++;
+    }
+    if (spins >= (1 << 22)) info[2] = 1;
+  }
+  __syncthreads();
+  if (t < 64) sdx[t] = (t < 6 * N) ? __hip_atomic_load(&dXg[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+  __syncthreads();
+  // ---- pose_retr_kernel (ba_cuda.cu:178-206): the last workgroup's first N lanes --------------------------
+  if (blockIdx.x == gridDim.x - 1 && t < N) {
+    float* p = poses + 7 * (size_t)(t0 + t);
+    float tt[3] = {p[0], p[1], p[2]}, qq[4] = {p[3], p[4], p[5], p[6]}, tn[3], qn[4], xi[6];
+#pragma unroll
+    for (int c = 0; c < 6; c++) xi[c] = sdx[6 * t + c];
+    fb_retrSE3(xi, tt, qq, tn, qn);
+    p[0] = tn[0]; p[1] = tn[1]; p[2] = tn[2];
+    p[3] = qn[0]; p[4] = qn[1]; p[5] = qn[2]; p[6] = qn[3];
+  }
+  if (!live) return;
+  // u - E^T dX  (ba_cuda.cu:592), six partial sums as in ba_retract_kernel
+  float sacc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int b = 0; b < SN / 6; b++)
+#pragma unroll
+    for (int c = 0; c < 6; c++) sacc[c] += ev[6 * b + c] * sdx[6 * b + c];
+  const float dz = qv * (uv - (((sacc[0] + sacc[1]) + (sacc[2] + sacc[3])) + (sacc[4] + sacc[5])));
+  if (dbgp) { dbgp[r] = dz; dbgp[U_stride + r] = cv; dbgp[2 * (size_t)U_stride + r] = uv; }
+  float d = d0 + dz;
+  d = (d > 20.f) ? 1.0f : d;
+  d = fmaxf(d, 1e-4f);
+  for (int a = 0; a < PP; a++) pk[a] = d;
 }
 
 
@@ -1284,10 +1387,15 @@ extern "C" int cdv_ba_forward(float* poses, float* patches, const float* intrins
     } else {
       hipLaunchKernelGGL(ba_schur_kernel, dim3(n_chunks), dim3(256), smem_sch, s, lmbda, N, gv.meta, sy,
                          (int)L.sy_stride, Cg, ug, qg, Edg, (int)L.U_stride, info);
-      if (N > 0 && 6 * N <= SN)
-        hipLaunchKernelGGL(ba_solve60_kernel, dim3(1), dim3(256), 0, s, poses, sy, (int)L.sy_stride, dXg, t0, N,
-                           gv.meta, d, info);
-      else if (N > 0)
+      if (N > 0 && 6 * N <= SN) {
+        // solve + retract in one launch (dbg layout as below)
+        float* dbgq = d ? d + (size_t)n6i * n6i + 2 * n6i : nullptr;
+        hipLaunchKernelGGL(ba_solve60_retract_kernel, dim3(1 + cdv_div_up(L.U_max, 256)), dim3(256), 0, s, poses, sy,
+                           (int)L.sy_stride, dXg, t0, N, gv.meta, d, info, info + 8, patches, P, gv.kx, Cg, ug, qg, Edg,
+                           (int)L.U_stride, dbgq);
+        CDV_LAUNCH_CHECK();
+        continue;
+      } else if (N > 0)
         hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(256), smem_sol, s, poses, sy, (int)L.sy_stride, dXg, t0, N,
                            gv.meta, d, info);
     }
