@@ -205,21 +205,48 @@ __device__ __forceinline__ void pair_emit(float val, int row, int col, int ixf, 
   atomicAdd(dst, neg ? -val : val);
 }
 
-__global__ __launch_bounds__(ASM_THREADS) void ba_assemble_kernel(
-    const float* __restrict__ poses, const float* __restrict__ patches, const float* __restrict__ intr,
-    const float* __restrict__ target, const float* __restrict__ weight, const int64_t* __restrict__ ii,
-    const int64_t* __restrict__ jj, const int64_t* __restrict__ kk, int P, int t0, int N,
-    const int32_t* __restrict__ gmeta, const int32_t* __restrict__ pcsr, const int32_t* __restrict__ koff_u,
-    float* __restrict__ sy, int sy_stride, float* __restrict__ Cg, float* __restrict__ ug, float* __restrict__ Edg,
-    int U_stride, int U_max, int32_t* __restrict__ info, uint32_t* __restrict__ cmask) {
+struct AsmArgs {
+  const float *poses, *patches, *intr, *target, *weight;
+  const int64_t *ii, *jj, *kk;
+  int P, t0, N;
+  const int32_t *gmeta, *pcsr, *koff_u;
+  float* sy;
+  int sy_stride;
+  float *Cg, *ug, *Edg;
+  int U_stride, U_max;
+  int32_t* info;
+  uint32_t* cmask;
+};
+
+__device__ __forceinline__ void assemble_body(const AsmArgs& A, int bid, float* smem) {
+  const float* __restrict__ poses = A.poses;
+  const float* __restrict__ patches = A.patches;
+  const float* __restrict__ intr = A.intr;
+  const float* __restrict__ target = A.target;
+  const float* __restrict__ weight = A.weight;
+  const int64_t* __restrict__ ii = A.ii;
+  const int64_t* __restrict__ jj = A.jj;
+  const int64_t* __restrict__ kk = A.kk;
+  const int P = A.P, t0 = A.t0, N = A.N;
+  const int32_t* __restrict__ gmeta = A.gmeta;
+  const int32_t* __restrict__ pcsr = A.pcsr;
+  const int32_t* __restrict__ koff_u = A.koff_u;
+  float* __restrict__ sy = A.sy;
+  const int sy_stride = A.sy_stride;
+  float* __restrict__ Cg = A.Cg;
+  float* __restrict__ ug = A.ug;
+  float* __restrict__ Edg = A.Edg;
+  const int U_stride = A.U_stride, U_max = A.U_max;
+  int32_t* __restrict__ info = A.info;
+  uint32_t* __restrict__ cmask = A.cmask;
   if (gmeta[GM_ERROR]) return;
   const int U = gmeta[GM_U];
-  if (U > U_max) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) info[1] = 1;  // workspace too small: BA is skipped
+  if (U > U_max) {  // workspace too small: BA is skipped
+    if (threadIdx.x == 0 && bid == 0) info[1] = 1;
     return;
   }
   // workgroup = (chunk of 64 unique patches, slot group): wave w takes target slot t = 8 sg + w (+ 32 per pass)
-  const int chunk = blockIdx.x / ASM_SG, sg = blockIdx.x - chunk * ASM_SG;
+  const int chunk = bid / ASM_SG, sg = bid - chunk * ASM_SG;
   const int r0 = chunk * BA_CHUNK;
   if (r0 >= U) return;
   const int n6 = 6 * N;
@@ -227,12 +254,11 @@ __global__ __launch_bounds__(ASM_THREADS) void ba_assemble_kernel(
   const int centre = (P > 1) ? (P + 1) : 0;
   const float fx = intr[0], fy = intr[1], cx = intr[2], cy = intr[3];  // ba_cuda.cu:253-259
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float* S = sy + (size_t)(blockIdx.x % BA_REPL) * sy_stride;
+  float* S = sy + (size_t)(bid % BA_REPL) * sy_stride;
   float* y = S + (size_t)n6 * n6;
-  CDV_IF_STAMPS(const int sslot = blockIdx.x * ASM_WAVES + wave;)
+  CDV_IF_STAMPS(const int sslot = bid * ASM_WAVES + wave;)
   CDV_STAMP(ba, sslot, 0);
   CDV_STAMP_RT(ba, sslot, 8);
-  extern __shared__ float smem[];
   float* X = smem + (size_t)wave * PAIR_LDS_FLOATS;    // per wave [128][XLD]
   int* keys = reinterpret_cast<int*>(X + 128 * XLD);   // per wave [64]
 
@@ -363,27 +389,48 @@ __global__ __launch_bounds__(ASM_THREADS) void ba_assemble_kernel(
   CDV_STAMP_RT(ba, sslot, 9);
 }
 
+__global__ __launch_bounds__(ASM_THREADS) void ba_assemble_kernel(AsmArgs A) {
+  extern __shared__ float smem[];
+  assemble_body(A, (int)blockIdx.x, smem);
+}
+
 // Schur products of one chunk of 64 patches, after E, C, u are complete in global memory:
 //   q = 1 / (C + lambda);  S -= Ed diag(q) Ed^T;  y -= Ed (q .* u)      (ba_cuda.cu:548, 583-587)
 // as [Ed; u] diag(q) [Ed; u]^T on the matrix cores (K = 64 patches, v_mfma_f32_16x16x4_f32).
-__global__ __launch_bounds__(256) void ba_schur_kernel(const float* __restrict__ lmbda, int N,
-                                                       const int32_t* __restrict__ gmeta, float* __restrict__ sy,
-                                                       int sy_stride, const float* __restrict__ Cg,
-                                                       const float* __restrict__ ug,
-                                                       float* __restrict__ qg, const float* __restrict__ Edg,
-                                                       int U_stride, int32_t* __restrict__ info) {
-  if (gmeta[GM_ERROR] || info[1]) return;
-  if (blockIdx.x == 0 && threadIdx.x == 0) info[8] = 0;   // hand-off flag of the following solve + retract launch
+struct SchurArgs {
+  const float* lmbda;
+  int N;
+  const int32_t* gmeta;
+  float* sy;
+  int sy_stride;
+  const float *Cg, *ug;
+  float* qg;
+  const float* Edg;
+  int U_stride;
+  int32_t* info;
+};
+
+// chunk: the 64-patch chunk; nthreads: workgroup size (256 as a launch of its own, 64 as a rider of the assemble launch)
+__device__ __forceinline__ void schur_body(const SchurArgs& A, int chunk, int nthreads, float* smem) {
+  const float* __restrict__ lmbda = A.lmbda;
+  const int N = A.N;
+  const int32_t* __restrict__ gmeta = A.gmeta;
+  float* __restrict__ sy = A.sy;
+  const int sy_stride = A.sy_stride;
+  const float* __restrict__ Cg = A.Cg;
+  const float* __restrict__ ug = A.ug;
+  float* __restrict__ qg = A.qg;
+  const float* __restrict__ Edg = A.Edg;
+  const int U_stride = A.U_stride;
   const int U = gmeta[GM_U];
-  const int r0 = blockIdx.x * BA_CHUNK;
+  const int r0 = chunk * BA_CHUNK;
   if (r0 >= U) return;
   const int n6 = 6 * N, nrow = n6 + 1;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = nthreads >> 6;
   const int c16 = lane & 15, g4 = lane >> 4;
-  CDV_IF_STAMPS(const int sslot = 5000 + blockIdx.x * 4 + wave;)
+  CDV_IF_STAMPS(const int sslot = 5000 + chunk * 4 + wave;)
   CDV_STAMP(ba, sslot, 0);
   CDV_STAMP_RT(ba, sslot, 8);
-  extern __shared__ float smem[];
   const int T16 = (nrow + 15) / 16;
   float* Ed = smem;                          // [16 T16][ELD], row n6 = u, rows beyond it zero
   float* qs = Ed + (size_t)16 * T16 * ELD;   // [64]
@@ -400,18 +447,18 @@ __global__ __launch_bounds__(256) void ba_schur_kernel(const float* __restrict__
   {
     const int tot4 = n6 * (BA_CHUNK / 4), pad4 = 16 * T16 * (BA_CHUNK / 4);
     const cdv_float4 z4 = {0.f, 0.f, 0.f, 0.f};
-    for (int base = 0; base < pad4; base += 4 * 256) {
+    for (int base = 0; base < pad4; base += 4 * nthreads) {
       cdv_float4 v[4];
 #pragma unroll
       for (int i = 0; i < 4; i++) {
-        const int i4 = base + i * 256 + (int)threadIdx.x;
+        const int i4 = base + i * nthreads + (int)threadIdx.x;
         const int row = i4 >> 4, k4 = (i4 & 15) * 4;
         // U_stride is a multiple of 64 and the columns beyond U are kept zero by the retract kernel
         v[i] = (i4 < tot4) ? *reinterpret_cast<const cdv_float4*>(Edg + (size_t)row * U_stride + r0 + k4) : z4;
       }
 #pragma unroll
       for (int i = 0; i < 4; i++) {
-        const int i4 = base + i * 256 + (int)threadIdx.x;
+        const int i4 = base + i * nthreads + (int)threadIdx.x;
         const int row = i4 >> 4, k4 = (i4 & 15) * 4;
         if (i4 < pad4 && row != n6) *reinterpret_cast<cdv_float4*>(Ed + row * ELD + k4) = v[i];
       }
@@ -420,10 +467,10 @@ __global__ __launch_bounds__(256) void ba_schur_kernel(const float* __restrict__
   __syncthreads();
   CDV_STAMP(ba, sslot, 1);
   if (N == 0) return;
-  float* S = sy + (size_t)(blockIdx.x % BA_REPL) * sy_stride;
+  float* S = sy + (size_t)(chunk % BA_REPL) * sy_stride;
   float* y = S + (size_t)n6 * n6;
   const int npairs = T16 * (T16 + 1) / 2;
-  for (int pidx = wave; pidx < npairs; pidx += 4) {
+  for (int pidx = wave; pidx < npairs; pidx += nwaves) {
     int ti = 0, acc_rows = 0;  // lower-triangular tile pair (ti >= tj)
     while (acc_rows + ti + 1 <= pidx) { acc_rows += ti + 1; ti++; }
     const int tj = pidx - acc_rows;
@@ -457,6 +504,13 @@ __global__ __launch_bounds__(256) void ba_schur_kernel(const float* __restrict__
   }
   CDV_STAMP(ba, sslot, 2);
   CDV_STAMP_RT(ba, sslot, 9);
+}
+
+__global__ __launch_bounds__(256) void ba_schur_kernel(SchurArgs A) {
+  if (A.gmeta[GM_ERROR] || A.info[1]) return;
+  if (blockIdx.x == 0 && threadIdx.x == 0) A.info[8] = 0;   // hand-off flag of the following solve + retract launch
+  extern __shared__ float smem[];
+  schur_body(A, (int)blockIdx.x, 256, smem);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1368,9 +1422,10 @@ extern "C" int cdv_ba_forward(float* poses, float* patches, const float* intrins
   const size_t smem_bsol = sizeof(float) * ((size_t)npad + (size_t)CNB * CLD);
   for (int itr = 0; itr < iterations; itr++) {
     float* d = (dbg && itr == 0) ? dbg : nullptr;
-    hipLaunchKernelGGL(ba_assemble_kernel, dim3(n_chunks * ASM_SG), dim3(ASM_THREADS), smem_asm, s, poses, patches,
-                       intrinsics, target, weight, ii, jj, kk, P, t0, N, gv.meta, gv.pcsr, gv.koff_u, sy,
-                       (int)L.sy_stride, Cg, ug, Edg, (int)L.U_stride, (int)L.U_max, info, cmask);
+    const AsmArgs aa{poses, patches, intrinsics, target, weight, ii, jj, kk, P, t0, N, gv.meta, gv.pcsr, gv.koff_u, sy,
+                     (int)L.sy_stride, Cg, ug, Edg, (int)L.U_stride, (int)L.U_max, info, cmask};
+    const SchurArgs sa{lmbda, N, gv.meta, sy, (int)L.sy_stride, Cg, ug, qg, Edg, (int)L.U_stride, info};
+    hipLaunchKernelGGL(ba_assemble_kernel, dim3(n_chunks * ASM_SG), dim3(ASM_THREADS), smem_asm, s, aa);
     if (big) {
       hipLaunchKernelGGL(ba_big_schur_kernel, dim3(n_chunks * npair), dim3(256), smem_bsch, s, lmbda, N, gv.meta, sy,
                          (int)L.sy_stride, Cg, ug, Edg, (int)L.U_stride, cmask, npair, info);
@@ -1385,8 +1440,7 @@ extern "C" int cdv_ba_forward(float* poses, float* patches, const float* intrins
       }
       hipLaunchKernelGGL(ba_big_backsolve_kernel, dim3(1), dim3(256), smem_bsol, s, Abig, npad, n6i, dXg, gv.meta, d, info);
     } else {
-      hipLaunchKernelGGL(ba_schur_kernel, dim3(n_chunks), dim3(256), smem_sch, s, lmbda, N, gv.meta, sy,
-                         (int)L.sy_stride, Cg, ug, qg, Edg, (int)L.U_stride, info);
+      hipLaunchKernelGGL(ba_schur_kernel, dim3(n_chunks), dim3(256), smem_sch, s, sa);
       if (N > 0 && 6 * N <= SN) {
         // solve + retract in one launch (dbg layout as below)
         float* dbgq = d ? d + (size_t)n6i * n6i + 2 * n6i : nullptr;
