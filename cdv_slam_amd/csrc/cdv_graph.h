@@ -15,7 +15,7 @@ enum {
   GM_ERROR = 6,    // != 0: the patch-id range exceeded the workspace capacity (index contents undefined)
   GM_E = 7,
   GM_KRANGE = 8,   // kmax - kmin + 1 of the LAST successful build (0 if none): the range to re-zero
-  GM_STAGE = 16,   // [16..19] staging of min/max for the build in flight: kmin, kmax, jmin, jmax
+  GM_STAGE = 16,   // arrival counter of the histogram launch (its last workgroup does the scan); zero between builds
   GM_WORDS = 64
 };
 

@@ -5,6 +5,7 @@
 // sharing a launch costs the longest of them instead of their sum.
 #pragma once
 #include "cdv_common.h"
+#include "cdv_graph.h"
 #include "cdv_se3.h"
 
 namespace cdv {
@@ -182,7 +183,129 @@ struct HistArgs {
   int32_t* stage;   // [blocks][4] per-workgroup (kmin, kmax, jmin, jmax)
   int32_t* khist;
   int32_t R;
+  int32_t *meta, *kcount, *krank;   // for the scan the last workgroup to finish performs
 };
+
+// One workgroup: publish meta, exclusive scan of the histogram in id order (bin of id kmin + i is (kmin + i) mod R)
+// -> kcount[i] = dense CSR offset, krank[i] = number of non-empty bins before i; clears the histogram.
+__device__ __forceinline__ void graph_scan_body(int32_t* meta, const int32_t* __restrict__ stage, int nstage,
+                                                int32_t* khist, int32_t* kcount, int32_t* krank, int32_t E,
+                                                int64_t k_cap, int T, int t) {
+  constexpr int IMAX = 0x7fffffff, IMIN = (int)0x80000000;
+  __shared__ int32_t s_sum[1024];
+  __shared__ int32_t s_cnt[1024];
+  __shared__ int32_t s_mm[16][4];
+  // min / max over the per-workgroup slots of the histogram launch
+  int kmin = IMAX, kmax = IMIN, jmin = IMAX, jmax = IMIN;
+  for (int i = t; i < nstage; i += T) {   // written through by the other workgroups of this launch: read past the caches
+    kmin = min(kmin, __hip_atomic_load(&stage[4 * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    kmax = max(kmax, __hip_atomic_load(&stage[4 * i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    jmin = min(jmin, __hip_atomic_load(&stage[4 * i + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    jmax = max(jmax, __hip_atomic_load(&stage[4 * i + 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    kmin = min(kmin, __shfl_xor(kmin, o)); kmax = max(kmax, __shfl_xor(kmax, o));
+    jmin = min(jmin, __shfl_xor(jmin, o)); jmax = max(jmax, __shfl_xor(jmax, o));
+  }
+  if ((t & 63) == 0) { s_mm[t >> 6][0] = kmin; s_mm[t >> 6][1] = kmax; s_mm[t >> 6][2] = jmin; s_mm[t >> 6][3] = jmax; }
+  __syncthreads();
+  for (int w = 0; w < T / 64; w++) {
+    kmin = min(kmin, s_mm[w][0]); kmax = max(kmax, s_mm[w][1]);
+    jmin = min(jmin, s_mm[w][2]); jmax = max(jmax, s_mm[w][3]);
+  }
+  const int64_t krange = (E > 0) ? (int64_t)kmax - kmin + 1 : 0;
+  const bool bad = E > 0 && (kmin < 0 || krange > k_cap);
+  if (t == 0) {
+    meta[GM_KMIN] = kmin; meta[GM_KMAX] = kmax; meta[GM_JMIN] = jmin; meta[GM_JMAX] = jmax;
+    meta[GM_E] = E;
+    meta[GM_ERROR] = bad ? 1 : 0;
+    meta[GM_KRANGE] = bad ? 0 : (int32_t)krange;
+    if (bad || E == 0) meta[GM_U] = 0;
+  }
+  const int R = (int)k_cap;
+  if (bad || E == 0) {
+    for (int i = t; i < R; i += T) khist[i] = 0;   // a failed build leaves a clean histogram too
+    return;
+  }
+  const int b0 = kmin % R;
+  const int64_t n = krange;
+  const int64_t per = (n + T - 1) / T;
+  const int64_t lo = min((int64_t)t * per, n), hi = min(lo + per, n);
+  // this thread's bins: loaded once, all loads in flight together (they bypass the caches: ~1 us each), kept in
+  // registers for the second sweep when they fit
+  constexpr int PERMAX = 24;
+  int32_t vals[PERMAX];
+  const bool cached = per <= PERMAX;
+  int32_t sum = 0, cnt = 0;
+  if (cached) {
+#pragma unroll
+    for (int u = 0; u < PERMAX; u++) {
+      const int64_t i = lo + u;
+      int bin = b0 + (int)i; bin = (bin >= R) ? bin - R : bin;
+      vals[u] = (i < hi) ? __hip_atomic_load(&khist[bin], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < PERMAX; u++) { sum += vals[u]; cnt += (vals[u] > 0); }
+  } else {
+    for (int64_t i = lo; i < hi; i++) {
+      int bin = b0 + (int)i; bin = (bin >= R) ? bin - R : bin;
+      const int32_t v = __hip_atomic_load(&khist[bin], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      sum += v; cnt += (v > 0);
+    }
+  }
+  // inclusive scan of the 1024 per-thread partials: shuffle scan inside each wave, then the 16 wave totals
+  // (three barriers instead of the twenty of a Hillis-Steele sweep over LDS)
+  int32_t isum = sum, icnt = cnt;
+  const int lane = t & 63, wv = t >> 6;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int32_t a1 = __shfl_up(isum, o), c1 = __shfl_up(icnt, o);
+    if (lane >= o) { isum += a1; icnt += c1; }
+  }
+  if (lane == 63) { s_sum[wv] = isum; s_cnt[wv] = icnt; }
+  __syncthreads();
+  if (t < 64) {
+    int32_t ws = (t < T / 64) ? s_sum[t] : 0, wc = (t < T / 64) ? s_cnt[t] : 0;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+      const int32_t a1 = __shfl_up(ws, o), c1 = __shfl_up(wc, o);
+      if (t >= o) { ws += a1; wc += c1; }
+    }
+    if (t < T / 64) { s_sum[64 + t] = ws; s_cnt[64 + t] = wc; }   // inclusive totals of waves 0..t
+  }
+  __syncthreads();
+  if (wv > 0) { isum += s_sum[64 + wv - 1]; icnt += s_cnt[64 + wv - 1]; }
+  __syncthreads();
+  s_sum[t] = isum; s_cnt[t] = icnt;
+  __syncthreads();
+  int32_t run = s_sum[t] - sum, rk = s_cnt[t] - cnt;
+  if (cached) {
+#pragma unroll
+    for (int u = 0; u < PERMAX; u++) {
+      const int64_t i = lo + u;
+      if (i < hi) {
+        int bin = b0 + (int)i; bin = (bin >= R) ? bin - R : bin;
+        khist[bin] = 0;
+        kcount[i] = run;
+        krank[i] = rk;
+        run += vals[u]; rk += (vals[u] > 0);
+      }
+    }
+  } else {
+    for (int64_t i = lo; i < hi; i++) {
+      int bin = b0 + (int)i; bin = (bin >= R) ? bin - R : bin;
+      const int32_t v = __hip_atomic_load(&khist[bin], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      khist[bin] = 0;
+      kcount[i] = run;
+      krank[i] = rk;
+      run += v; rk += (v > 0);
+    }
+  }
+  if (t == T - 1) { kcount[n] = s_sum[t]; meta[GM_U] = s_cnt[t]; }
+}
+
+
 
 __device__ __forceinline__ void graph_hist_body(const HistArgs& a, int bid, int nblocks, int nthreads_per_block, int tid) {
   constexpr int IMAXV = 0x7fffffff, IMINV = (int)0x80000000;
@@ -216,10 +339,28 @@ __device__ __forceinline__ void graph_hist_body(const HistArgs& a, int bid, int 
       kmin = min(kmin, s_mm[w][0]); kmax = max(kmax, s_mm[w][1]);
       jmin = min(jmin, s_mm[w][2]); jmax = max(jmax, s_mm[w][3]);
     }
-    // one private slot per workgroup, reduced by the scan kernel: no contended atomics (~90 ns each on one word)
+    // one private slot per workgroup: no contended atomics (~90 ns each on one word); written through, because the
+    // last workgroup of THIS launch reads them
     int32_t* st = a.stage + 4 * bid;
-    st[0] = kmin; st[1] = kmax; st[2] = jmin; st[3] = jmax;
+    __hip_atomic_store(&st[0], kmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&st[1], kmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&st[2], jmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&st[3], jmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  // ---- last workgroup done -> scan (saves a launch).  Every wave drains its histogram atomics, the workgroup meets,
+  // one lane counts the workgroup in (after its own slot stores are acknowledged); whoever sees nblocks - 1 is last.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  __shared__ int s_last;
+  if (tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int prev = __hip_atomic_fetch_add(&a.meta[GM_STAGE], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (prev == nblocks - 1) ? 1 : 0;
+    if (s_last) __hip_atomic_store(&a.meta[GM_STAGE], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next build
+  }
+  __syncthreads();
+  if (!s_last) return;
+  graph_scan_body(a.meta, a.stage, nblocks, a.khist, a.kcount, a.krank, a.E, (int64_t)a.R, nthreads_per_block, tid);
 }
 
 }  // namespace cdv

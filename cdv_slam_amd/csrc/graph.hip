@@ -11,15 +11,17 @@
 // without giving every XCD a contiguous share: no measurable gain -- that kernel is not bound by L2 misses --
 // so it is not built.)
 //
-// Pipeline, 4 small launches, no host sync (every launch costs ~5 us of latency on an otherwise idle GPU, the
+// Pipeline, 3 small launches, no host sync (every launch costs ~5 us of latency on an otherwise idle GPU, the
 // work itself is a few hundred KB):
 //   1 hist     : count[k mod R]++ (R = workspace capacity; the ids of one build span less than R, checked) and
 //                min/max of kk, jj (one atomic per block).  Indexing by k mod R needs no kmin, so the min/max pass
 //                and the histogram are ONE launch; the histogram is zero between builds (the scan clears it).
-//   2 scan     : (1 WG) validate the range, publish meta, exclusive scan in id order (starting at bin kmin mod R)
-//                -> dense offsets by id - kmin and unique ranks; clears the histogram
-//   3 fill     : kx / koff_u from the dense bins, ku and the (unordered) CSR slots per edge
-//   4 segsort  : rank every edge inside its patch segment by (jj, edge id); the same sweep finds the edge's
+//     scan     : by the LAST workgroup of launch 1 to finish (arrival counter; the others' histogram atomics and
+//                min/max slots are drained and written through before they count themselves in): validate the
+//                range, publish meta, exclusive scan in id order (starting at bin kmin mod R) -> dense offsets by
+//                id - kmin and unique ranks; clears the histogram
+//   2 fill     : kx / koff_u from the dense bins, ku and the (unordered) CSR slots per edge
+//   3 segsort  : rank every edge inside its patch segment by (jj, edge id); the same sweep finds the edge's
 //                predecessor / successor in time (fastba.neighbors); clears the fill cursors
 #include <mutex>
 #include <unordered_map>
@@ -39,8 +41,6 @@ struct RegEntry {
 std::mutex g_reg_mutex;
 std::unordered_map<const void*, RegEntry> g_registry;
 
-constexpr int IMAX = 0x7fffffff;
-constexpr int IMIN = (int)0x80000000;
 
 __global__ __launch_bounds__(256) void graph_init_kernel(int32_t* meta, int32_t* khist, int32_t* kcursor,
                                                          int64_t k_cap) {
@@ -48,10 +48,7 @@ __global__ __launch_bounds__(256) void graph_init_kernel(int32_t* meta, int32_t*
     khist[t] = 0;
     kcursor[t] = 0;
     if (t < GM_WORDS) {
-      int32_t v = 0;
-      if (t == GM_STAGE + 0 || t == GM_STAGE + 2) v = IMAX;
-      if (t == GM_STAGE + 1 || t == GM_STAGE + 3) v = IMIN;
-      meta[t] = v;
+      meta[t] = 0;   // incl. the arrival counter of the histogram launch (GM_STAGE)
     }
   }
 }
@@ -61,88 +58,12 @@ __global__ __launch_bounds__(256) void graph_hist_kernel(cdv::HistArgs a) {
   cdv::graph_hist_body(a, (int)blockIdx.x, (int)gridDim.x, (int)blockDim.x, (int)threadIdx.x);
 }
 
-// One workgroup of 1024 threads: publish meta, exclusive scan of the histogram in id order (bin of id kmin + i is
-// (kmin + i) mod R) -> kcount[i] = dense CSR offset, krank[i] = number of non-empty bins before i; clears the histogram.
+// exclusive scan of the histogram as a launch of its own: only when there are no edges (no histogram launch whose last
+// workgroup would do it) -- body in cdv_parts.h
 __global__ __launch_bounds__(1024) void graph_scan_kernel(int32_t* meta, const int32_t* __restrict__ stage,
                                                           int nstage, int32_t* khist, int32_t* kcount,
                                                           int32_t* krank, int32_t E, int64_t k_cap) {
-  __shared__ int32_t s_sum[1024];
-  __shared__ int32_t s_cnt[1024];
-  __shared__ int32_t s_mm[16][4];
-  const int T = blockDim.x, t = threadIdx.x;
-  // min / max over the per-workgroup slots of the histogram launch
-  int kmin = IMAX, kmax = IMIN, jmin = IMAX, jmax = IMIN;
-  if (t < nstage) { kmin = stage[4 * t]; kmax = stage[4 * t + 1]; jmin = stage[4 * t + 2]; jmax = stage[4 * t + 3]; }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    kmin = min(kmin, __shfl_xor(kmin, o)); kmax = max(kmax, __shfl_xor(kmax, o));
-    jmin = min(jmin, __shfl_xor(jmin, o)); jmax = max(jmax, __shfl_xor(jmax, o));
-  }
-  if ((t & 63) == 0) { s_mm[t >> 6][0] = kmin; s_mm[t >> 6][1] = kmax; s_mm[t >> 6][2] = jmin; s_mm[t >> 6][3] = jmax; }
-  __syncthreads();
-  for (int w = 0; w < T / 64; w++) {
-    kmin = min(kmin, s_mm[w][0]); kmax = max(kmax, s_mm[w][1]);
-    jmin = min(jmin, s_mm[w][2]); jmax = max(jmax, s_mm[w][3]);
-  }
-  const int64_t krange = (E > 0) ? (int64_t)kmax - kmin + 1 : 0;
-  const bool bad = E > 0 && (kmin < 0 || krange > k_cap);
-  if (t == 0) {
-    meta[GM_KMIN] = kmin; meta[GM_KMAX] = kmax; meta[GM_JMIN] = jmin; meta[GM_JMAX] = jmax;
-    meta[GM_E] = E;
-    meta[GM_ERROR] = bad ? 1 : 0;
-    meta[GM_KRANGE] = bad ? 0 : (int32_t)krange;
-    if (bad || E == 0) meta[GM_U] = 0;
-  }
-  const int R = (int)k_cap;
-  if (bad || E == 0) {
-    for (int i = t; i < R; i += T) khist[i] = 0;   // a failed build leaves a clean histogram too
-    return;
-  }
-  const int b0 = kmin % R;
-  const int64_t n = krange;
-  const int64_t per = (n + T - 1) / T;
-  const int64_t lo = min((int64_t)t * per, n), hi = min(lo + per, n);
-  int32_t sum = 0, cnt = 0;
-  for (int64_t i = lo; i < hi; i++) {
-    int bin = b0 + (int)i; bin = (bin >= R) ? bin - R : bin;
-    const int32_t v = khist[bin];
-    sum += v; cnt += (v > 0);
-  }
-  // inclusive scan of the 1024 per-thread partials: shuffle scan inside each wave, then the 16 wave totals
-  // (three barriers instead of the twenty of a Hillis-Steele sweep over LDS)
-  int32_t isum = sum, icnt = cnt;
-  const int lane = t & 63, wv = t >> 6;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int32_t a1 = __shfl_up(isum, o), c1 = __shfl_up(icnt, o);
-    if (lane >= o) { isum += a1; icnt += c1; }
-  }
-  if (lane == 63) { s_sum[wv] = isum; s_cnt[wv] = icnt; }
-  __syncthreads();
-  if (t < 64) {
-    int32_t ws = (t < T / 64) ? s_sum[t] : 0, wc = (t < T / 64) ? s_cnt[t] : 0;
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) {
-      const int32_t a1 = __shfl_up(ws, o), c1 = __shfl_up(wc, o);
-      if (t >= o) { ws += a1; wc += c1; }
-    }
-    if (t < T / 64) { s_sum[64 + t] = ws; s_cnt[64 + t] = wc; }   // inclusive totals of waves 0..t
-  }
-  __syncthreads();
-  if (wv > 0) { isum += s_sum[64 + wv - 1]; icnt += s_cnt[64 + wv - 1]; }
-  __syncthreads();
-  s_sum[t] = isum; s_cnt[t] = icnt;
-  __syncthreads();
-  int32_t run = s_sum[t] - sum, rk = s_cnt[t] - cnt;
-  for (int64_t i = lo; i < hi; i++) {
-    int bin = b0 + (int)i; bin = (bin >= R) ? bin - R : bin;
-    const int32_t v = khist[bin];
-    khist[bin] = 0;
-    kcount[i] = run;
-    krank[i] = rk;
-    run += v; rk += (v > 0);
-  }
-  if (t == T - 1) { kcount[n] = s_sum[t]; meta[GM_U] = s_cnt[t]; }
+  cdv::graph_scan_body(meta, stage, nstage, khist, kcount, krank, E, k_cap, (int)blockDim.x, (int)threadIdx.x);
 }
 
 __global__ __launch_bounds__(256) void graph_fill_kernel(const int64_t* __restrict__ kk, int32_t E,
@@ -300,7 +221,7 @@ int cdv_graph_prepare(const int64_t* jj, const int64_t* kk, int64_t E, void* ws,
   if (need_init)
     hipLaunchKernelGGL(graph_init_kernel, dim3(grid_for(k_range + 1, 256, 2048)), dim3(256), 0, (hipStream_t)stream,
                        v.meta, v.khist, v.kcursor, k_range);
-  *hist = cdv::HistArgs{jj, kk, (int32_t)E, v.stage, v.khist, (int32_t)k_range};
+  *hist = cdv::HistArgs{jj, kk, (int32_t)E, v.stage, v.khist, (int32_t)k_range, v.meta, v.kcount, v.krank};
   *hist_blocks = E > 0 ? grid_for(E, 256, GRAPH_MAX_BLOCKS) : 0;
   return CDV_OK;
 }
@@ -313,8 +234,9 @@ int cdv_graph_finish(const int64_t* jj, const int64_t* kk, int64_t E, void* ws, 
   const int32_t En = (int32_t)E;
   const int tb = 256;
   const int fb = grid_for(E, tb, GRAPH_MAX_BLOCKS);
-  hipLaunchKernelGGL(graph_scan_kernel, dim3(1), dim3(1024), 0, s, v.meta, v.stage, hist_blocks, v.khist, v.kcount, v.krank,
-                     En, k_range);
+  if (hist_blocks == 0)   // otherwise the last workgroup of the histogram launch has done the scan
+    hipLaunchKernelGGL(graph_scan_kernel, dim3(1), dim3(1024), 0, s, v.meta, v.stage, hist_blocks, v.khist, v.kcount,
+                       v.krank, En, k_range);
   if (E > 0) {
     hipLaunchKernelGGL(graph_fill_kernel, dim3(fb), dim3(tb), 0, s, kk, En, v.meta, v.kcount, v.kcursor, v.krank,
                        v.koff_u, v.kx, v.ku, v.pcsr_tmp);
