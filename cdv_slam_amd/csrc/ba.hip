@@ -506,11 +506,11 @@ __device__ __forceinline__ void schur_body(const SchurArgs& A, int chunk, int nt
   CDV_STAMP_RT(ba, sslot, 9);
 }
 
-__global__ __launch_bounds__(256) void ba_schur_kernel(SchurArgs A) {
+__global__ __launch_bounds__(1024) void ba_schur_kernel(SchurArgs A) {
   if (A.gmeta[GM_ERROR] || A.info[1]) return;
   if (blockIdx.x == 0 && threadIdx.x == 0) A.info[8] = 0;   // hand-off flag of the following solve + retract launch
   extern __shared__ float smem[];
-  schur_body(A, (int)blockIdx.x, 256, smem);
+  schur_body(A, (int)blockIdx.x, (int)blockDim.x, smem);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1440,7 +1440,9 @@ extern "C" int cdv_ba_forward(float* poses, float* patches, const float* intrins
       }
       hipLaunchKernelGGL(ba_big_backsolve_kernel, dim3(1), dim3(256), smem_bsol, s, Abig, npad, n6i, dXg, gv.meta, d, info);
     } else {
-      hipLaunchKernelGGL(ba_schur_kernel, dim3(n_chunks), dim3(256), smem_sch, s, sa);
+      // one wave per lower-triangular tile pair of [Ed; u] (10 at N = 10): the pairs run side by side
+      const int t16 = (n6i + 1 + 15) / 16, sch_waves = t16 * (t16 + 1) / 2 < 16 ? t16 * (t16 + 1) / 2 : 16;
+      hipLaunchKernelGGL(ba_schur_kernel, dim3(n_chunks), dim3(64 * (sch_waves < 4 ? 4 : sch_waves)), smem_sch, s, sa);
       if (N > 0 && 6 * N <= SN) {
         // solve + retract in one launch (dbg layout as below)
         float* dbgq = d ? d + (size_t)n6i * n6i + 2 * n6i : nullptr;
