@@ -196,7 +196,7 @@ def main():
             "per_rank": per_rank,
             "per_rank_summary": summarise(per_rank),
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the CPU port is timed next to the single-GPU number only
             res["cpu_baseline"] = cpu_baseline(st, args.cpu_seconds)
         else:
             res["cpu_baseline"] = None
