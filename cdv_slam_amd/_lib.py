@@ -25,6 +25,12 @@ SIGNATURES = {
     "cdv_frame_ingest": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i64, _i64, _i64, _vp]),
     "cdv_patchify_fwd": (_i32, [_vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
     "cdv_patchify_blend": (_i32, [_vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "cdv_edges_frame": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp]),
+    "cdv_edges_append": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
+    "cdv_edges_workspace_bytes": (_sz, [_i64]),
+    "cdv_edges_remove": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                _vp, _vp, _vp, _i64, _vp, _vp]),
+    "cdv_edges_keyframe_shift": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "cdv_flow_mag": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp]),
     "cdv_point_cloud": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "cdv_transform": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

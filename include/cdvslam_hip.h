@@ -263,6 +263,35 @@ int cdv_update_prologue(const void* fmap_chw, void* fmap1_nhwc, void* fmap2_nhwc
                         size_t graph_ws_bytes, int64_t E_max, int64_t k_range, int64_t* ix, int64_t* jx, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Edge bookkeeping of the patch graph on the device (the steps either side of the update path)
+ * Edge arrays ii / jj / kk (int64), target / weight ([E][2] f32) and the per-edge hidden state live in
+ * fixed-capacity device buffers; nothing is reallocated per call.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* append_factors(*edges_forw()) + append_factors(*edges_back()) of the frame that just arrived (slam.py:331-337,
+ * 528-541, call site :707-709): written at ii/jj/kk[E0 ...]; ix [patches] = frame of every patch; n = number of
+ * frames including the new one, M = patches per frame, r = PATCH_LIFETIME.  *added_host = number of new edges. */
+int cdv_edges_frame(int64_t* ii, int64_t* jj, int64_t* kk, const int64_t* ix, int64_t E0, int64_t capacity, int n,
+                    int M, int r, int64_t* added_host, void* stream);
+/* append_factors(new_k, new_j) for arbitrary (loop-closure) edges: kk <- new_k, jj <- new_j, ii <- ix[new_k] */
+int cdv_edges_append(int64_t* ii, int64_t* jj, int64_t* kk, const int64_t* ix, const int64_t* new_k,
+                     const int64_t* new_j, int64_t E0, int64_t count, int64_t capacity, void* stream);
+/* remove_factors(mask, store) (slam.py:339-354) as a stable stream compaction -- the order boolean-mask indexing
+ * gives, bit-exact.  remove [E] uint8 (1 = drop).  Kept edges go, compacted, to the *_out buffers (twin buffers of
+ * the same capacity); dropped ones are appended to the inactive arrays at index r0 when ii_r != NULL (store = True).
+ * target / weight / net (+ their outputs) may be NULL; net rows are net_bytes wide (multiple of 4).
+ * ws: cdv_edges_workspace_bytes(capacity) bytes, zeroed once by the caller.  counts_host (optional) receives
+ * {kept, removed} by an async copy: valid after the stream is synchronised. */
+size_t cdv_edges_workspace_bytes(int64_t capacity);
+int cdv_edges_remove(const uint8_t* remove, int64_t E, void* ws, const int64_t* ii, const int64_t* jj, const int64_t* kk,
+                     const float* target, const float* weight, const void* net, int net_bytes, int64_t* ii_out,
+                     int64_t* jj_out, int64_t* kk_out, float* target_out, float* weight_out, void* net_out,
+                     int64_t* ii_r, int64_t* jj_r, int64_t* kk_r, float* target_r, float* weight_r, int64_t r0,
+                     int32_t* counts_host, void* stream);
+/* keyframe(): index shift after frame k is dropped (slam.py:425-427): kk[ii > k] -= M; ii[ii > k] -= 1; jj[jj > k] -= 1 */
+int cdv_edges_keyframe_shift(int64_t* ii, int64_t* jj, int64_t* kk, int64_t E, int k, int M, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * lietorch forward ops  (replaces lietorch_backends.{expm,logm,inv,mul,adj,adjT,act,act4,as_matrix})
  * group ids as the reference: SO3 = 1, SE3 = 3 (lietorch.cpp:286-316, groups.py:236-290).
  * op: 0 exp, 1 log, 2 inv, 3 mul, 4 adj, 5 adjT, 6 act, 7 act4, 8 as_matrix.  Flat [n][dim] rows.

@@ -1,0 +1,85 @@
+"""Edge bookkeeping: the numpy restatement of slam.py's append / remove / keyframe logic against
+the replay SURVEY.md quotes the graph sizes from (CPU), and the device EdgeStore against that restatement, bit-exact, over
+a stream of frames with random keyframe drops (GPU)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from cdv_slam_amd import synth            # noqa: E402
+from oracle.edges_py import EdgesPy       # noqa: E402
+
+
+def test_edges_oracle_reproduces_the_survey_replay():
+    cfg = synth.CONFIGS["default"]
+    M, r = cfg.M, cfg.patch_lifetime
+    ix = np.repeat(np.arange(cfg.buffer_size), M)
+    g = EdgesPy()
+    for n in range(1, cfg.frames + 1):
+        g.append_factors(*g.edges_forw(n, M, r), ix)
+        g.append_factors(*g.edges_back(n, M, r), ix)
+        if n < cfg.frames and n >= 8:
+            g.keyframe(-1, n, M, ix, cfg.removal_window, drop=False)
+    ii, jj, kk = synth.replay_edges(cfg)
+    assert len(g.ii) == 47712
+    assert np.array_equal(g.ii, ii) and np.array_equal(g.jj, jj) and np.array_equal(g.kk, kk)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,M,r,rw", [(0, 8, 5, 9), (1, 96, 13, 22)])
+def test_edge_store_stream_bit_exact(seed, M, r, rw):
+    import torch
+    from cdv_slam_amd.edges import EdgeStore
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(seed)
+    frames = 60
+    ix_np = np.repeat(np.arange(frames + 8), M)
+    ix = torch.as_tensor(ix_np, device=dev)
+    st = EdgeStore(dev, capacity=M * (rw + 4) * 2 * r, net_dim=16)
+    g = EdgesPy()
+    n = 0
+    for f in range(frames):
+        n += 1
+        # frame arrival (slam.py:697-709)
+        E0 = len(g.ii)
+        g.append_factors(*g.edges_forw(n, M, r), ix_np)
+        g.append_factors(*g.edges_back(n, M, r), ix_np)
+        added = st.append_frame(ix, n, M, r)
+        assert added == len(g.ii) - E0 and st.E == len(g.ii)
+        # update(): new target / weight / hidden state for every edge (slam.py:486-511)
+        tgt = rng.standard_normal((st.E, 2)).astype(np.float32)
+        wgt = rng.uniform(0, 1, (st.E, 2)).astype(np.float32)
+        g.target, g.weight = tgt.copy(), wgt.copy()
+        st.target[0].copy_(torch.as_tensor(tgt, device=dev)); st.weight[0].copy_(torch.as_tensor(wgt, device=dev))
+        if n >= 8:
+            drop = bool(rng.uniform() < 0.35) and n > 6
+            k = n - 4                                          # KEYFRAME_INDEX = 4 (slam.py:409-417)
+            n_new = g.keyframe(k, n, M, ix_np, rw, drop=drop)
+            n_dev = st.keyframe(k, n, M, ix, rw, drop=drop)
+            assert n_dev == n_new
+            n = n_new
+        for name in ("ii", "jj", "kk"):
+            assert np.array_equal(getattr(st, name).cpu().numpy(), getattr(g, name)), (f, name)
+        assert np.array_equal(st.target[0].cpu().numpy(), g.target) and np.array_equal(st.weight[0].cpu().numpy(), g.weight)
+        a = st.E_inac
+        assert a == len(g.ii_inac)
+        for name in ("ii_inac", "jj_inac", "kk_inac", "target_inac", "weight_inac"):
+            assert np.array_equal(getattr(st, name)[:a].cpu().numpy(), getattr(g, name)), (f, name)
+    # hidden-state payload check: tag rows with their (kk, jj) and make sure a removal keeps rows with their edges
+    tag = torch.stack([st.kk.to(torch.float16) % 997, st.jj.to(torch.float16)], 1)
+    st.net[0][:, :2].copy_(tag)
+    mask = torch.as_tensor(rng.uniform(size=st.E) < 0.5, device=dev)
+    st.remove_factors(mask, store=False)
+    assert torch.equal(st.net[0][:, 0], st.kk.to(torch.float16) % 997) and torch.equal(st.net[0][:, 1], st.jj.to(torch.float16))
+    # generic append (loop-closure edges) and the concatenated view the global BA takes
+    nk = torch.as_tensor(rng.integers(0, n * M, 50), device=dev)
+    nj = torch.as_tensor(rng.integers(0, n, 50), device=dev)
+    E0 = st.E
+    st.append_factors(nk, nj, ix)
+    assert st.E == E0 + 50 and torch.equal(st.kk[E0:], nk) and torch.equal(st.jj[E0:], nj) and torch.equal(st.ii[E0:], ix[nk])
+    ft, fw, fi, fj, fk = st.full_edges()
+    assert fi.numel() == st.E + st.E_inac and ft.shape == (1, st.E + st.E_inac, 2)
