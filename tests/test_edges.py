@@ -83,3 +83,29 @@ def test_edge_store_stream_bit_exact(seed, M, r, rw):
     assert st.E == E0 + 50 and torch.equal(st.kk[E0:], nk) and torch.equal(st.jj[E0:], nj) and torch.equal(st.ii[E0:], ix[nk])
     ft, fw, fi, fj, fk = st.full_edges()
     assert fi.numel() == st.E + st.E_inac and ft.shape == (1, st.E + st.E_inac, 2)
+
+
+@pytest.mark.gpu
+def test_stream_runner_end_to_end():
+    """a whole synthetic stream (state write, edge append, prologue, correlation, BA, keyframe drops) stays finite and
+    keeps exactly the edge lists the reference bookkeeping would"""
+    import torch
+    from cdv_slam_amd.stream import StreamRunner
+    dev = torch.device("cuda:0")
+    run = StreamRunner(dev, M=16, ht=192, wd=256, buffer_size=96, mem=36, pmem=36)
+    g = EdgesPy()
+    ix_np = np.repeat(np.arange(96), 16)
+    n = 0
+    for f in range(70):
+        drop = f % 4 == 3
+        n_dev, E = run.frame(drop=drop)
+        n += 1
+        g.append_factors(*g.edges_forw(n, 16, run.r), ix_np)
+        g.append_factors(*g.edges_back(n, 16, run.r), ix_np)
+        if n >= 8:
+            n = g.keyframe(n - run.ki, n, 16, ix_np, run.rw, drop=drop and n > run.ki + 2)
+        assert n_dev == n and E == len(g.ii)
+        assert np.array_equal(run.edges.kk.cpu().numpy(), g.kk) and np.array_equal(run.edges.jj.cpu().numpy(), g.jj)
+    assert run.n_updates == 70 - 7
+    assert torch.isfinite(run.poses[:n]).all() and torch.isfinite(run.patches[:n * 16]).all()
+    assert float(run.poses[:n, :3].abs().max()) < 50.0 and float((run.poses[:n, 3:].norm(dim=-1) - 1).abs().max()) < 1e-3

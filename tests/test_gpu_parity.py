@@ -474,7 +474,8 @@ def test_global_ba_vs_oracle(name):
     assert np.array_equal(poses[:st.t0], st.poses[:st.t0])
     # a second call on the same workspace (accumulators re-zeroed by their consumers) gives the same answer
     poses2, patches2, _ = _run_ba(st, iterations=2)
-    assert np.abs(poses2 - poses).max() <= 1e-5 and np.abs(patches2 - patches).max() <= 1e-4
+    # (float atomics: the summation order, hence the last bits, differ from run to run -- same bound as against the oracle)
+    assert np.abs(poses2 - poses).max() <= 1e-5 * slack * 3 and np.abs(patches2 - patches).max() <= 3e-4 * slack
 
 
 @pytest.mark.parametrize("tag", ["fc", "win"])
