@@ -801,27 +801,37 @@ __device__ __forceinline__ void solve60_body(float* __restrict__ poses, float* _
   if (t >= 64) return;   // one wave from here on (no block-wide barrier below)
   const int lane = t;
   const int myrow = min(lane, SN);   // lanes 61..63 shadow the right-hand-side row
-  float a[SN];
+  // the row as 30 float2 registers: the rank-1 updates of a column step run two columns per v_pk_fma_f32
+  typedef float cdv_float2 __attribute__((ext_vector_type(2)));
+  cdv_float2 a2[SN / 2];
 #pragma unroll
   for (int c4 = 0; c4 < SN / 4; c4++) {
     const cdv_float4 q = *reinterpret_cast<const cdv_float4*>(&A[myrow * SLD + 4 * c4]);
-    a[4 * c4] = q[0]; a[4 * c4 + 1] = q[1]; a[4 * c4 + 2] = q[2]; a[4 * c4 + 3] = q[3];
+    a2[2 * c4] = cdv_float2{q[0], q[1]};
+    a2[2 * c4 + 1] = cdv_float2{q[2], q[3]};
   }
   int badk = 0;
 #pragma unroll
   for (int k = 0; k < SN; k++) {
-    const float piv = readlane_f(a[k], k);
+    float ak = a2[k >> 1][k & 1];
+    const float piv = readlane_f(ak, k);
     if (!(piv > 0.f) && badk == 0) badk = k / 6 + 1;   // wave-uniform
     const float inv = __builtin_amdgcn_rsqf(piv);
-    a[k] *= inv;                                         // column k of L (rows >= k), z_k in lane 60
+    ak *= inv;                                           // column k of L (rows >= k), z_k in lane 60
+    a2[k >> 1][k & 1] = ak;
+    if ((k & 1) == 0) a2[k >> 1][1] = fmaf(-ak, readlane_f(ak, k + 1), a2[k >> 1][1]);   // the partner column of an even k
     // all broadcasts of the step first, then the FMAs: a v_readlane result needs two wait states before a VALU
     // instruction may read it, which back-to-back (readlane, fma) pairs would pay as an s_nop every time
-    float sb[SN];
+    const cdv_float2 nak = {-ak, -ak};
+    cdv_float2 sb[SN / 2];
 #pragma unroll
-    for (int c = k + 1; c < SN; c++) sb[c] = readlane_f(a[k], c);
+    for (int p = (k >> 1) + 1; p < SN / 2; p++) sb[p] = cdv_float2{readlane_f(ak, 2 * p), readlane_f(ak, 2 * p + 1)};
 #pragma unroll
-    for (int c = k + 1; c < SN; c++) a[c] = fmaf(-a[k], sb[c], a[c]);
+    for (int p = (k >> 1) + 1; p < SN / 2; p++) a2[p] = __builtin_elementwise_fma(nak, sb[p], a2[p]);
   }
+  float a[SN];
+#pragma unroll
+  for (int c = 0; c < SN; c++) a[c] = a2[c >> 1][c & 1];
   CDV_STAMP(ba, sslot, 2);
   // L back to LDS (zeros above the diagonal), then lane k picks up COLUMN k: col[r] = L[r][k]
   wave_lds_sync();
