@@ -24,6 +24,13 @@
 
 CDV_STAMP_TU(corr)
 
+// ablation switches of the diagnostic build (make STAMPS=1, env CDV_CORR_EXP): compiled out of the product library
+#ifdef CDV_STAMPS
+#define CDV_EXP(bit) ((exp & (bit)) != 0)
+#else
+#define CDV_EXP(bit) false
+#endif
+
 namespace {
 
 // HBM layout of the feature rings the fused kernel gathers from ("padded channels-last"):
@@ -67,10 +74,6 @@ __device__ __forceinline__ int row16_reduce_i32(int v) {
   CDV_ROR(8) CDV_ROR(4) CDV_ROR(2) CDV_ROR(1)
 #undef CDV_ROR
   return v;
-}
-
-__device__ __forceinline__ float uniform_f(float v) {
-  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
 }
 
 struct LevelParams {
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(256) void corr_fused_kernel(const _Float16* __restr
   }
   const bool idx_ok = kpatch >= 0 && kpatch < Ng && jslot >= 0 && jslot < slots;
   if (!idx_ok) { kpatch = 0; jslot = 0; }  // reference behaviour is undefined here; stay in bounds
-  if (exp & 16) jslot = 0;                 // experiment bit 4: every edge reads map slot 0 (L2-resident)
+  if (CDV_EXP(16)) jslot = 0;                 // experiment bit 4: every edge reads map slot 0 (L2-resident)
   const float* cptr = coords + (size_t)e * 18;
   const int mm = lane < 9 ? lane : 0;       // row 0 of the wave: lanes 0..8 own patch pixel m, 9..15 mirror 0
   const int bm = min(lane / 7, 8), bxo = lane - 7 * (lane / 7);  // blend role of this lane: (m, x offset)
@@ -367,12 +370,12 @@ __global__ __launch_bounds__(256) void corr_fused_kernel(const _Float16* __restr
         cdv_half4 h = {(_Float16)acc[0], (_Float16)acc[1], (_Float16)acc[2], (_Float16)acc[3]};    \
         *reinterpret_cast<cdv_half4*>(raw_lane + ((Q0) + q) * 16) = h;                             \
       }
-    if (do0 && !(exp & 1)) CDV_LOAD_LEVEL(b0, r0, pitch0, nq0, 0)
+    if (do0 && !CDV_EXP(1)) CDV_LOAD_LEVEL(b0, r0, pitch0, nq0, 0)
     const BlendGeo g0 = blend_geo(xb, yb, bm, bxo, L0, b0, !b0.fast);
     const BlendGeo g1 = blend_geo(xb, yb, bm, bxo, nlev == 2 ? L1 : L0, b1, !b1.fast);
     CDV_STAMP(corr, p, 2);
     // level 0: MFMA per pixel group; the registers are immediately re-used for the level-1 request
-    if (do0 && !(exp & 256)) {
+    if (do0 && !CDV_EXP(256)) {
       CDV_MFMA_LEVEL(nq0, 0)
       if (nq0 > NQ_MAX) {   // window of more than 16 NQ_MAX pixels: a second round through the same registers
         CDV_LOAD_LEVEL(b0, r0, pitch0, nq0, NQ_MAX)
@@ -381,14 +384,14 @@ __global__ __launch_bounds__(256) void corr_fused_kernel(const _Float16* __restr
     } else if (!b0.fast) {
       slow_level<1>(L0, jslot, xv, yv, pat, raw, lane, C);
     }
-    if (do1 && !(exp & 1)) CDV_LOAD_LEVEL(b1, r1, pitch1, nq1, 0)
+    if (do1 && !CDV_EXP(1)) CDV_LOAD_LEVEL(b1, r1, pitch1, nq1, 0)
     wave_lds_sync();
     CDV_STAMP(corr, p, 3);
-    if ((do0 || !b0.fast) && !(exp & 128)) blend_level(raw, g0, res0);
+    if ((do0 || !b0.fast) && !CDV_EXP(128)) blend_level(raw, g0, res0);
     CDV_STAMP(corr, p, 4);
     if (nlev == 2) {
       wave_lds_sync();
-      if (do1 && !(exp & 256)) {
+      if (do1 && !CDV_EXP(256)) {
         CDV_MFMA_LEVEL(nq1, 0)
         if (nq1 > NQ_MAX) {
           CDV_LOAD_LEVEL(b1, r1, pitch1, nq1, NQ_MAX)
@@ -399,7 +402,7 @@ __global__ __launch_bounds__(256) void corr_fused_kernel(const _Float16* __restr
       }
       wave_lds_sync();
       CDV_STAMP(corr, p, 5);
-      if ((do1 || !b1.fast) && !(exp & 128)) blend_level(raw, g1, res1);
+      if ((do1 || !b1.fast) && !CDV_EXP(128)) blend_level(raw, g1, res1);
       CDV_STAMP(corr, p, 6);
     }
 #undef CDV_LOAD_LEVEL
@@ -439,7 +442,7 @@ __global__ __launch_bounds__(256) void corr_fused_kernel(const _Float16* __restr
   }
 
   // ---- stage the edge's output row [x][y][m][lev] in LDS, then 256-byte coalesced stores ------------
-  if (lane < 63 && !(exp & 512)) {
+  if (lane < 63 && !CDV_EXP(512)) {
     if (nlev == 2) {
       uint32_t* o32 = reinterpret_cast<uint32_t*>(outT) + bxo * 63 + bm;   // dword (x, y, m) = 63 x + 9 y + m
 #pragma unroll
@@ -456,7 +459,7 @@ __global__ __launch_bounds__(256) void corr_fused_kernel(const _Float16* __restr
   }
   wave_lds_sync();
   CDV_STAMP(corr, p, 7);
-  if (!(exp & 2)) {                             // experiment bit 1: no global store
+  if (!CDV_EXP(2)) {                             // experiment bit 1: no global store
   if (nlev == 2) {
     // 441 dwords: two 16-byte-per-lane stores (256 + 184 dwords) and one last dword.  The row starts on a 4-byte
     // boundary only (1764 B per edge); global memory takes the unaligned 16-byte accesses.
