@@ -177,7 +177,9 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f16 features / f32 accumulate+geometry",
+            "dtype": "f32",
+            "dtype_detail": "f32 arithmetic throughout (MFMA accumulate, geometry, BA); feature maps, patch tiles and the "
+                            "correlation output are stored as f16 like the reference's",
             "data": "synthetic",
             "config": {
                 "workload": "%s: SLAM.update hot path on a synthetic 512x384 stream, M=%d patches/frame, "
