@@ -546,6 +546,31 @@ def test_fused_flow_mag_point_cloud_patchify_vs_composed():
             assert ul.dtype == net.dtype and torch.equal(ul, raw[..., :1, :1])
 
 
+def test_single_pixel_patches():
+    """P = 1 patches (the structure-only caller of the classic loop closure passes 1x1 patches, long_term.py:118-135):
+    reprojection, BA and the fused helpers take the centre-pixel code path"""
+    from cdv_slam_amd import projective_ops as pops
+    from cdv_slam_amd.lietorch import SE3
+    st = synth.make_state("small", features=False)
+    p1 = np.ascontiguousarray(st.patches[:, :, 1:2, 1:2])
+    coords = ops.transform(T(st.poses)[None], T(p1)[None], T(st.intrinsics)[None], T(st.ii), T(st.jj), T(st.kk))
+    want = O.transform(st.poses, p1, st.intrinsics, st.ii, st.jj, st.kk)
+    assert coords.shape == (1, st.E, 1, 1, 2) and np.abs(coords[0].cpu().numpy() - want).max() <= 1e-3
+    poses, patches = T(st.poses).clone(), T(p1).clone()
+    ops.ba_forward(poses, patches, T(st.intrinsics), T(st.target), T(st.weight), torch.tensor([st.lmbda], device=DEV),
+                   T(st.ii), T(st.jj), T(st.kk), st.cfg.M, st.t0, st.n, 2, False)
+    p64, x64, info = O.fastba(st.poses, p1, st.intrinsics[0], st.target, st.weight, st.lmbda, st.ii, st.jj, st.kk, st.t0,
+                              st.n, 2, np.float64)
+    p32, _, _ = O.fastba(st.poses, p1, st.intrinsics[0], st.target, st.weight, st.lmbda, st.ii, st.jj, st.kk, st.t0, st.n,
+                         2, np.float32)
+    slack = max(1.0, np.abs(p32 - p64).max() / 1e-6)
+    assert np.abs(poses.cpu().numpy()[:, :3] - p64[:, :3]).max() <= 1e-5 * slack * 3
+    d, d64 = patches.cpu().numpy()[:, 2, 0, 0], x64[:, 2, 0, 0]
+    assert np.abs(d - d64).max() <= 1e-4 * slack * np.maximum(np.abs(d64), 1e-2).max()
+    flow, val = pops.flow_mag(SE3(T(st.poses)[None]), T(p1)[None], T(st.intrinsics)[None], T(st.ii), T(st.jj), T(st.kk))
+    assert flow.shape == (1, st.E, 1, 1) and bool(torch.isfinite(flow).all())
+
+
 def test_ba_structure_only_and_gates():
     """t1 == t0 branch (ba_cuda.cu:550-560, caller long_term.py:124-125) and the depth clamps"""
     st = synth.make_state("small", features=False)
