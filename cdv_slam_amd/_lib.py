@@ -15,6 +15,7 @@ _vp, _i32, _i64, _sz, _f32 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctyp
 SIGNATURES = {
     "cdv_last_error": (ctypes.c_char_p, []),
     "cdv_version": (ctypes.c_char_p, []),
+    "cdv_workspace_forget": (None, [_vp]),
     "cdv_corr_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "cdv_fmap_padded_elems": (_sz, [_i64, _i32, _i32, _i32]),
     "cdv_fmap_to_nhwc": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i64, _i64, _vp]),

@@ -1347,6 +1347,17 @@ __global__ __launch_bounds__(64) void ba_retract_kernel(float* __restrict__ pose
 
 }  // namespace
 
+// The library remembers, per workspace ADDRESS, that it has initialised the accumulators in it.  A caller that frees a
+// workspace and later gets the same address back from its allocator (torch's caching allocator does that) must say so,
+// or stale bytes would be taken for zeroed accumulators.
+extern "C" void cdv_workspace_forget(const void* ws) {
+  {
+    std::lock_guard<std::mutex> lk(g_ws_mutex);
+    g_ws_state.erase(ws);
+  }
+  cdv_graph_forget(ws);
+}
+
 extern "C" size_t cdv_ba_workspace_bytes(int64_t E_max, int64_t U_max, int N_max) {
   (void)E_max;
   if (U_max < 1) U_max = 1;

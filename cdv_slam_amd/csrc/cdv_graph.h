@@ -80,6 +80,8 @@ static inline GraphView graph_view(void* ws, const GraphLayout& L) {
 // host-side registry: workspace pointer -> layout (filled by cdv_graph_build)
 bool cdv_graph_lookup(const void* ws, cdv::GraphLayout* out);
 
+void cdv_graph_forget(const void* ws);
+
 // the index build in two halves (graph.hip), for cdv_update_prologue
 namespace cdv { struct HistArgs; }
 int cdv_graph_prepare(const int64_t* jj, const int64_t* kk, int64_t E, void* ws, size_t ws_bytes, int64_t E_max,

@@ -44,9 +44,12 @@ std::unordered_map<const void*, RegEntry> g_registry;
 
 __global__ __launch_bounds__(256) void graph_init_kernel(int32_t* meta, int32_t* khist, int32_t* kcursor,
                                                          int64_t k_cap) {
-  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t <= k_cap; t += (int64_t)gridDim.x * blockDim.x) {
-    khist[t] = 0;
-    kcursor[t] = 0;
+  const int64_t n = k_cap + 1 > GM_WORDS ? k_cap + 1 : GM_WORDS;   // the meta words too when the id range is tiny
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+    if (t <= k_cap) {
+      khist[t] = 0;
+      kcursor[t] = 0;
+    }
     if (t < GM_WORDS) {
       meta[t] = 0;   // incl. the arrival counter of the histogram launch (GM_STAGE)
     }
@@ -185,6 +188,12 @@ bool cdv_graph_lookup(const void* ws, GraphLayout* out) {
   return true;
 }
 
+// forget what is known about a workspace address (see cdv_workspace_forget in the header)
+void cdv_graph_forget(const void* ws) {
+  std::lock_guard<std::mutex> lk(g_reg_mutex);
+  g_registry.erase(ws);
+}
+
 extern "C" size_t cdv_graph_workspace_bytes(int64_t E_max, int64_t k_range) {
   if (E_max < 1) E_max = 1;
   if (k_range < 1) k_range = 1;
@@ -219,8 +228,8 @@ int cdv_graph_prepare(const int64_t* jj, const int64_t* kk, int64_t E, void* ws,
   }
   const GraphView v = graph_view(ws, L);
   if (need_init)
-    hipLaunchKernelGGL(graph_init_kernel, dim3(grid_for(k_range + 1, 256, 2048)), dim3(256), 0, (hipStream_t)stream,
-                       v.meta, v.khist, v.kcursor, k_range);
+    hipLaunchKernelGGL(graph_init_kernel, dim3(grid_for(k_range + 1 + GM_WORDS, 256, 2048)), dim3(256), 0,
+                       (hipStream_t)stream, v.meta, v.khist, v.kcursor, k_range);
   *hist = cdv::HistArgs{jj, kk, (int32_t)E, v.stage, v.khist, (int32_t)k_range, v.meta, v.kcount, v.krank};
   *hist_blocks = E > 0 ? grid_for(E, 256, GRAPH_MAX_BLOCKS) : 0;
   return CDV_OK;

@@ -64,6 +64,7 @@ class GraphIndex:
         self.E_cap = max(E, int(self.E_cap * 1.5), 1024)
         nbytes = self.lib.cdv_graph_workspace_bytes(self.E_cap, self.k_range)
         self.ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        self.lib.cdv_workspace_forget(_p(self.ws))   # a fresh allocation may reuse the address of a dead workspace
         self.ws_bytes = nbytes
         self._key = None
 
@@ -446,6 +447,7 @@ def _ba_workspace(dev, E, U_max, N):
     ws = _ba_ws.get(dev)
     if ws is None or ws.numel() < need:
         ws = _ba_ws[dev] = torch.empty(int(need * 1.25) + 4096, dtype=torch.uint8, device=dev)
+        lib.cdv_workspace_forget(_p(ws))             # a fresh allocation may reuse the address of a dead workspace
     return ws
 
 

@@ -45,6 +45,10 @@ extern "C" {
 const char* cdv_last_error(void);
 /* "gfx950" + build info; also a cheap symbol to probe that the library loaded */
 const char* cdv_version(void);
+/* Workspaces (cdv_graph_*, cdv_ba_forward) are initialised by the library the first time it sees their address and kept
+ * consistent between calls.  Call this for an address that was freed and may have been written by someone else before
+ * it is used as a workspace again (allocators hand addresses back); the next call re-initialises it. */
+void cdv_workspace_forget(const void* ws);
 
 /* ------------------------------------------------------------------------------------------------
  * altcorr  (replaces cuda_corr.forward / patchify_forward)

@@ -182,6 +182,21 @@ def test_graph_index_irregular():
         assert np.array_equal(kx.cpu().numpy(), kx_o) and np.array_equal(ku.cpu().numpy(), ku_o)
 
 
+def test_graph_index_wrapping_ids_and_many_edges():
+    """the histogram is indexed by id mod R: id ranges that straddle a multiple of the workspace capacity R (a patch
+    ring that has wrapped many times), and more edges than one pass of the per-edge grids (1024 workgroups x 256)"""
+    rng = np.random.default_rng(21)
+    R = 6144
+    for lo, span in ((7 * R + R - 50, 250), (123 * R - 3000, 6000), (5 * R, R)):
+        kk = rng.integers(lo, lo + span, 30000).astype(np.int64)
+        jj = rng.integers(0, 36, 30000).astype(np.int64)
+        _check_graph(kk, jj, R)
+    E = 300000
+    kk = rng.integers(10 * R + 100, 10 * R + 100 + 5000, E).astype(np.int64)
+    jj = rng.integers(0, 64, E).astype(np.int64)
+    _check_graph(kk, jj, R)
+
+
 def test_graph_range_overflow_is_reported():
     g = ops.GraphIndex(torch.device(DEV), E_cap=16, k_range=8)
     os.environ["CDV_CHECK"] = "0"
