@@ -1123,81 +1123,96 @@ __device__ __forceinline__ cdv_float4 tile64_xyt(const float* X, const float* Y,
   return acc0 + acc1;
 }
 
-// Block step kb, part 1.  Every workgroup factors the diagonal block in LDS (redundantly: 64 columns) and inverts the
-// factor; workgroup 0 writes L_kk back, workgroup b > 0 turns block row kb + b of the panel into A L_kk^-T (one GEMM
-// on the matrix cores instead of 64 dependent substitution steps per row); the last workgroup does the same for the
-// right-hand-side row.
-__global__ __launch_bounds__(256) void ba_big_panel_kernel(float* __restrict__ A, int npad, int kb,
-                                                           const int32_t* __restrict__ gmeta, int32_t* __restrict__ info) {
+// Block step kb, part 1.  One wave per workgroup, lane = matrix row.  Every workgroup factors the 64x64 diagonal block
+// in its registers (redundantly; the single-wave scheme of ba_solve60_kernel: v_readlane broadcasts, v_pk_fma_f32
+// rank-1 updates, no barrier) and parks L_kk in LDS; workgroup 0 writes it back; workgroup b > 0 solves its 64 rows of
+// the panel, X L_kk^T = A, by forward substitution along the row (L entries as LDS broadcast reads, 16 bytes at a
+// time); the last workgroup does the same for the right-hand-side row.
+__global__ __launch_bounds__(64) void ba_big_panel_kernel(float* __restrict__ A, int npad, int kb,
+                                                          const int32_t* __restrict__ gmeta, int32_t* __restrict__ info) {
   if (gmeta[GM_ERROR] || info[1]) return;
-  __shared__ float D[CNB * CLD];    // diagonal block -> L
-  __shared__ float Li[CNB * CLD];   // L^-1
-  __shared__ float X[CNB * CLD];    // block row of the panel
-  __shared__ int s_bad;
-  const int t = threadIdx.x;
+  __shared__ __attribute__((aligned(16))) float Ls[CNB * CLD];   // L_kk, row stride CLD (16-byte aligned rows)
+  typedef float cdv_float2 __attribute__((ext_vector_type(2)));
+  const int lane = threadIdx.x;
   const int nb = npad / CNB;
   const int rb = kb + blockIdx.x;               // block row handled here; rb == nb: the right-hand-side row
   const size_t lda = (size_t)npad;
   const int c0 = CNB * kb;
-  if (t == 0) s_bad = 0;
-  for (int i = t; i < CNB * CNB; i += 256) {
-    const int r = i >> 6, c = i & 63;
-    D[r * CLD + c] = A[(size_t)(c0 + r) * lda + c0 + c];
-    Li[r * CLD + c] = 0.f;
-    if (rb > kb) {
-      const bool rhs = rb == nb;
-      X[r * CLD + c] = rhs ? (r == 0 ? A[(size_t)npad * lda + c0 + c] : 0.f) : A[(size_t)(CNB * rb + r) * lda + c0 + c];
+  // ---- diagonal block: row `lane`, columns 0..63 -------------------------------------------------------
+  cdv_float2 a2[CNB / 2];
+  {
+    const float* src = A + (size_t)(c0 + lane) * lda + c0;
+#pragma unroll
+    for (int c4 = 0; c4 < CNB / 4; c4++) {
+      const cdv_float4 q = *reinterpret_cast<const cdv_float4*>(src + 4 * c4);
+      a2[2 * c4] = cdv_float2{q[0], q[1]};
+      a2[2 * c4 + 1] = cdv_float2{q[2], q[3]};
     }
   }
-  __syncthreads();
-  // right-looking Cholesky of the 64x64 block (lower part)
-  for (int j = 0; j < CNB; j++) {
-    const float piv = D[j * CLD + j];
-    if (t == 0 && !(piv > 0.f) && s_bad == 0) s_bad = 1;
+  bool bad = false;
+#pragma unroll
+  for (int k = 0; k < CNB; k++) {
+    float ak = a2[k >> 1][k & 1];
+    const float piv = readlane_f(ak, k);
+    bad = bad || !(piv > 0.f);                          // wave-uniform
     const float inv = __builtin_amdgcn_rsqf(piv);
-    __syncthreads();
-    if (t >= j && t < CNB) D[t * CLD + j] = (t == j) ? piv * inv : D[t * CLD + j] * inv;
-    __syncthreads();
-    for (int i = t; i < CNB * CNB; i += 256) {
-      const int r = i >> 6, c = i & 63;
-      if (c > j && r >= c) D[r * CLD + c] -= D[r * CLD + j] * D[c * CLD + j];
-    }
-    __syncthreads();
+    ak *= inv;                                           // column k of L (rows >= k)
+    a2[k >> 1][k & 1] = ak;
+    if ((k & 1) == 0) a2[k >> 1][1] = fmaf(-ak, readlane_f(ak, k + 1), a2[k >> 1][1]);
+    const cdv_float2 nak = {-ak, -ak};
+    cdv_float2 sb[CNB / 2];
+#pragma unroll
+    for (int p = (k >> 1) + 1; p < CNB / 2; p++) sb[p] = cdv_float2{readlane_f(ak, 2 * p), readlane_f(ak, 2 * p + 1)};
+#pragma unroll
+    for (int p = (k >> 1) + 1; p < CNB / 2; p++) a2[p] = __builtin_elementwise_fma(nak, sb[p], a2[p]);
   }
-  // Li = L^-1, one column per thread (forward substitution)
-  if (t < CNB) {
-    const int c = t;
-    for (int r = c; r < CNB; r++) {
-      float sacc = (r == c) ? 1.0f : 0.0f;
-      for (int j = c; j < r; j++) sacc -= D[r * CLD + j] * Li[j * CLD + c];
-      Li[r * CLD + c] = sacc / D[r * CLD + r];
+  // L_kk -> LDS (zeros above the diagonal), and back to the matrix from workgroup 0
+#pragma unroll
+  for (int c4 = 0; c4 < CNB / 4; c4++) {
+    cdv_float4 q;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int c = 4 * c4 + j;
+      q[j] = (c <= lane) ? a2[c >> 1][c & 1] : 0.f;
+    }
+    *reinterpret_cast<cdv_float4*>(&Ls[lane * CLD + 4 * c4]) = q;
+    if (blockIdx.x == 0) {
+      float* dst = A + (size_t)(c0 + lane) * lda + c0 + 4 * c4;
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if (4 * c4 + j <= lane) dst[j] = q[j];
     }
   }
-  __syncthreads();
   if (blockIdx.x == 0) {
-    if (t == 0 && s_bad && info[0] == 0) info[0] = kb + 1;
-    for (int i = t; i < CNB * CNB; i += 256) {
-      const int r = i >> 6, c = i & 63;
-      if (c <= r) A[(size_t)(c0 + r) * lda + c0 + c] = D[r * CLD + c];
-    }
+    if (lane == 0 && bad && info[0] == 0) info[0] = kb + 1;
     return;
   }
-  // X <- X L^-T:  out[r][c] = sum_j X[r][j] Li[c][j]
-  const int lane = t & 63, wave = t >> 6, c16 = lane & 15, g4 = lane >> 4;
+  wave_lds_sync();
+  // ---- this workgroup's rows of the panel: x L^T = a, c = 0..63 in turn ------------------------------------
   const bool rhs = rb == nb;
-  for (int tix = wave; tix < 16; tix += 4) {
-    const int ti = tix >> 2, tj = tix & 3;
-    const cdv_float4 acc = tile64_xyt(X, Li, ti, tj, c16, g4);
+  if (rhs && lane > 0) return;                    // the right-hand side is one row
+  float* rowp = A + (size_t)(rhs ? npad : CNB * rb + lane) * lda + c0;
+  float x[CNB];
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int r = 16 * ti + 4 * g4 + q, c = 16 * tj + c16;
-      if (rhs) {
-        if (r == 0) A[(size_t)npad * lda + c0 + c] = acc[q];
-      } else {
-        A[(size_t)(CNB * rb + r) * lda + c0 + c] = acc[q];
-      }
-    }
+  for (int c4 = 0; c4 < CNB / 4; c4++) {
+    const cdv_float4 q = *reinterpret_cast<const cdv_float4*>(rowp + 4 * c4);
+    x[4 * c4] = q[0]; x[4 * c4 + 1] = q[1]; x[4 * c4 + 2] = q[2]; x[4 * c4 + 3] = q[3];
   }
+#pragma unroll
+  for (int c = 0; c < CNB; c++) {
+    float sacc = x[c];
+#pragma unroll
+    for (int j4 = 0; j4 < (c + 3) / 4; j4++) {      // L[c][4 j4 .. 4 j4 + 3]: one broadcast read of 16 bytes
+      const cdv_float4 l = *reinterpret_cast<const cdv_float4*>(&Ls[c * CLD + 4 * j4]);
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if (4 * j4 + j < c) sacc = fmaf(-x[4 * j4 + j], l[j], sacc);
+    }
+    x[c] = sacc / Ls[c * CLD + c];
+  }
+#pragma unroll
+  for (int c4 = 0; c4 < CNB / 4; c4++)
+    *reinterpret_cast<cdv_float4*>(rowp + 4 * c4) = cdv_float4{x[4 * c4], x[4 * c4 + 1], x[4 * c4 + 2], x[4 * c4 + 3]};
 }
 
 // Block step kb, part 2: trailing update A[rb][cb] -= P_rb P_cb^T for kb < cb <= rb (and the right-hand-side row
@@ -1453,7 +1468,7 @@ extern "C" int cdv_ba_forward(float* poses, float* patches, const float* intrins
       hipLaunchKernelGGL(ba_big_fold_kernel, dim3(1024), dim3(256), 0, s, sy, (int)L.sy_stride, n6i, npad, Abig, gv.meta,
                          d, info);
       for (int kb = 0; kb < nbk; kb++) {
-        hipLaunchKernelGGL(ba_big_panel_kernel, dim3(nbk - kb + 1), dim3(256), 0, s, Abig, npad, kb, gv.meta, info);
+        hipLaunchKernelGGL(ba_big_panel_kernel, dim3(nbk - kb + 1), dim3(64), 0, s, Abig, npad, kb, gv.meta, info);
         const int T = nbk - kb - 1;
         if (T > 0)
           hipLaunchKernelGGL(ba_big_update_kernel, dim3(T * (T + 1) / 2 + T), dim3(256), 0, s, Abig, npad, kb, gv.meta,
