@@ -1260,7 +1260,9 @@ __global__ __launch_bounds__(256) void ba_big_update_kernel(float* __restrict__ 
   }
 }
 
-// L^T x = z (z = row npad of A after the factorisation), blocks from the bottom; one workgroup.
+// L^T x = z (z = row npad of A after the factorisation), blocks from the bottom; one workgroup.  Per 64-block: the
+// diagonal block goes to LDS, wave 0 solves its 64 unknowns in registers (lane k holds column k of L_kk: one
+// v_readlane + FMA per unknown, no barrier inside), then all threads fold x_kb into the z of the columns to the left.
 __global__ __launch_bounds__(256) void ba_big_backsolve_kernel(const float* __restrict__ A, int npad, int n,
                                                                float* __restrict__ dXg, const int32_t* __restrict__ gmeta,
                                                                float* __restrict__ dbg, const int32_t* __restrict__ info) {
@@ -1268,7 +1270,6 @@ __global__ __launch_bounds__(256) void ba_big_backsolve_kernel(const float* __re
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* zs = smem;                 // [npad]
   float* Lb = zs + npad;            // [CNB][CLD]
-  __shared__ float s_x;
   const int t = threadIdx.x;
   const size_t lda = (size_t)npad;
   const int nb = npad / CNB;
@@ -1278,19 +1279,29 @@ __global__ __launch_bounds__(256) void ba_big_backsolve_kernel(const float* __re
     const int c0 = CNB * kb;
     for (int i = t; i < CNB * CNB; i += 256) {
       const int r = i >> 6, c = i & 63;
-      Lb[r * CLD + c] = A[(size_t)(c0 + r) * lda + c0 + c];
+      Lb[r * CLD + c] = (c <= r) ? A[(size_t)(c0 + r) * lda + c0 + c] : 0.f;
     }
     __syncthreads();
-    for (int c = CNB - 1; c >= 0; c--) {   // x_c = z_c / L[c][c]; z_j -= L[c][j] x_c for j < c
-      if (t == 0) { const float xc = zs[c0 + c] / Lb[c * CLD + c]; zs[c0 + c] = xc; s_x = xc; }
-      __syncthreads();
-      if (t < c) zs[c0 + t] -= Lb[c * CLD + t] * s_x;
-      __syncthreads();
+    if (t < 64) {   // x_r = z_r / L[r][r] once every x_j, j > r, has been folded into z (as in ba_solve60_kernel)
+      float col[CNB];
+#pragma unroll
+      for (int r = 0; r < CNB; r++) col[r] = Lb[r * CLD + t];   // column t of L_kk: L[r][t], zero for r < t
+      float z = zs[c0 + t];
+      const float invd = 1.0f / Lb[t * CLD + t];
+      float x = 0.f;
+#pragma unroll
+      for (int r = CNB - 1; r >= 0; r--) {
+        const float xr = readlane_f(z * invd, r);
+        x = (t == r) ? xr : x;
+        z = fmaf(-col[r], xr, z);
+      }
+      zs[c0 + t] = x;
     }
+    __syncthreads();
     // z[c'] -= sum_r L[c0 + r][c'] x_r for the columns left of the block
     for (int cc = t; cc < c0; cc += 256) {
       float sacc = 0.f;
-#pragma unroll 8
+#pragma unroll 16
       for (int r = 0; r < CNB; r++) sacc += A[(size_t)(c0 + r) * lda + cc] * zs[c0 + r];
       zs[cc] -= sacc;
     }
