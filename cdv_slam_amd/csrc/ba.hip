@@ -996,15 +996,23 @@ __global__ __launch_bounds__(256) void ba_big_schur_kernel(const float* __restri
                                                            const int32_t* __restrict__ info) {
   if (gmeta[GM_ERROR] || info[1]) return;
   const int U = gmeta[GM_U];
-  const int chunk = blockIdx.x / npair, pidx = blockIdx.x - chunk * npair;
+  // workgroup (chunk, slot): the chunk's ACTIVE panel pairs (pa >= pb, both bits set) are dealt round-robin to
+  // BIG_SLOTS workgroups -- a chunk touches 2-3 of the up to 32 panels, so almost every one of the 528 possible pairs
+  // would be an empty workgroup if each had its own
+  const int chunk = blockIdx.x / npair, slot = blockIdx.x - chunk * npair;   // npair == BIG_SLOTS here
   const int r0 = chunk * BA_CHUNK;
   if (r0 >= U) return;
-  int pa = 0, acc_rows = 0;   // pidx -> (pa >= pb)
-  while (acc_rows + pa + 1 <= pidx) { acc_rows += pa + 1; pa++; }
-  const int pb = pidx - acc_rows;
   const uint32_t mask = cmask[chunk];
-  if (!((mask >> pa) & 1u) || !((mask >> pb) & 1u)) return;
   const int n6 = 6 * N;
+  int pair_idx = 0;
+  for (int pa = 0; pa < 32; pa++) {
+    if (!((mask >> pa) & 1u)) continue;
+    for (int pb = 0; pb <= pa; pb++) {
+      if (!((mask >> pb) & 1u)) continue;
+      const bool mine = (pair_idx % npair) == slot;
+      pair_idx++;
+      if (!mine) continue;
+      __syncthreads();   // the previous pair's tiles are done with the LDS panels
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Ea = smem;                          // [BIG_PR][ELD]
   float* Eb = Ea + (size_t)BIG_PR * ELD;     // [BIG_PR][ELD]  (aliases Ea when pa == pb)
@@ -1076,6 +1084,8 @@ __global__ __launch_bounds__(256) void ba_big_schur_kernel(const float* __restri
 #pragma unroll 8
       for (int k = 0; k < BA_CHUNK; k++) sacc += pr[k] * qu[k];
       if (sacc != 0.f) atomicAdd(&y[R], -sacc);
+    }
+  }
     }
   }
 }
@@ -1463,7 +1473,7 @@ extern "C" int cdv_ba_forward(float* poses, float* patches, const float* intrins
   });
   CDV_HIP_CHECK(attr_err);
   const int rb = cdv_div_up(L.U_max > N ? L.U_max : N, 64);
-  const int NP = cdv_div_up(N, BIG_PB), npair = NP * (NP + 1) / 2;
+  const int npair = 6;   // workgroups per chunk that share its active panel pairs (ba_big_schur_kernel)
   const int npad = (int)L.npad, nbk = npad / CNB;
   const size_t smem_bsch = sizeof(float) * (2 * (size_t)BIG_PR * ELD + 2 * BA_CHUNK);
   const size_t smem_bsol = sizeof(float) * ((size_t)npad + (size_t)CNB * CLD);
