@@ -1270,56 +1270,52 @@ __global__ __launch_bounds__(256) void ba_big_update_kernel(float* __restrict__ 
   }
 }
 
-// L^T x = z (z = row npad of A after the factorisation), blocks from the bottom; one workgroup.  Per 64-block: the
-// diagonal block goes to LDS, wave 0 solves its 64 unknowns in registers (lane k holds column k of L_kk: one
-// v_readlane + FMA per unknown, no barrier inside), then all threads fold x_kb into the z of the columns to the left.
-__global__ __launch_bounds__(256) void ba_big_backsolve_kernel(const float* __restrict__ A, int npad, int n,
-                                                               float* __restrict__ dXg, const int32_t* __restrict__ gmeta,
-                                                               float* __restrict__ dbg, const int32_t* __restrict__ info) {
+// L^T x = z (z = row npad of A after the factorisation), one launch per 64-block from the bottom.  Every workgroup of
+// step kb loads L_kk and z_kb and solves the 64 unknowns in wave 0's registers (redundantly; lane k holds column k of
+// L_kk: one v_readlane + FMA per unknown); workgroup 0 publishes x_kb, workgroup w folds it into the z of its 256
+// columns to the left of the block (every column is owned by one workgroup: no atomics).
+__global__ __launch_bounds__(256) void ba_big_backstep_kernel(float* __restrict__ A, int npad, int n, int kb,
+                                                              float* __restrict__ dXg, const int32_t* __restrict__ gmeta,
+                                                              float* __restrict__ dbg, const int32_t* __restrict__ info) {
   if (gmeta[GM_ERROR] || info[1]) return;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* zs = smem;                 // [npad]
-  float* Lb = zs + npad;            // [CNB][CLD]
+  __shared__ __attribute__((aligned(16))) float Lb[CNB * CLD];
+  __shared__ float xs[CNB];
   const int t = threadIdx.x;
   const size_t lda = (size_t)npad;
-  const int nb = npad / CNB;
-  for (int i = t; i < npad; i += 256) zs[i] = A[(size_t)npad * lda + i];
-  __syncthreads();
-  for (int kb = nb - 1; kb >= 0; kb--) {
-    const int c0 = CNB * kb;
-    for (int i = t; i < CNB * CNB; i += 256) {
-      const int r = i >> 6, c = i & 63;
-      Lb[r * CLD + c] = (c <= r) ? A[(size_t)(c0 + r) * lda + c0 + c] : 0.f;
-    }
-    __syncthreads();
-    if (t < 64) {   // x_r = z_r / L[r][r] once every x_j, j > r, has been folded into z (as in ba_solve60_kernel)
-      float col[CNB];
-#pragma unroll
-      for (int r = 0; r < CNB; r++) col[r] = Lb[r * CLD + t];   // column t of L_kk: L[r][t], zero for r < t
-      float z = zs[c0 + t];
-      const float invd = 1.0f / Lb[t * CLD + t];
-      float x = 0.f;
-#pragma unroll
-      for (int r = CNB - 1; r >= 0; r--) {
-        const float xr = readlane_f(z * invd, r);
-        x = (t == r) ? xr : x;
-        z = fmaf(-col[r], xr, z);
-      }
-      zs[c0 + t] = x;
-    }
-    __syncthreads();
-    // z[c'] -= sum_r L[c0 + r][c'] x_r for the columns left of the block
-    for (int cc = t; cc < c0; cc += 256) {
-      float sacc = 0.f;
-#pragma unroll 16
-      for (int r = 0; r < CNB; r++) sacc += A[(size_t)(c0 + r) * lda + cc] * zs[c0 + r];
-      zs[cc] -= sacc;
-    }
-    __syncthreads();
+  const int c0 = CNB * kb;
+  float* zrow = A + (size_t)npad * lda;
+  for (int i = t; i < CNB * CNB; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    Lb[r * CLD + c] = (c <= r) ? A[(size_t)(c0 + r) * lda + c0 + c] : 0.f;
   }
-  for (int i = t; i < n; i += 256) {
-    dXg[i] = zs[i];
-    if (dbg) dbg[(size_t)n * n + n + i] = zs[i];
+  __syncthreads();
+  if (t < 64) {   // x_r = z_r / L[r][r] once every x_j, j > r, has been folded into z (as in ba_solve60_kernel)
+    float col[CNB];
+#pragma unroll
+    for (int r = 0; r < CNB; r++) col[r] = Lb[r * CLD + t];   // column t of L_kk: L[r][t], zero for r < t
+    float z = zrow[c0 + t];
+    const float invd = 1.0f / Lb[t * CLD + t];
+    float x = 0.f;
+#pragma unroll
+    for (int r = CNB - 1; r >= 0; r--) {
+      const float xr = readlane_f(z * invd, r);
+      x = (t == r) ? xr : x;
+      z = fmaf(-col[r], xr, z);
+    }
+    xs[t] = x;
+    if (blockIdx.x == 0 && c0 + t < n) {
+      dXg[c0 + t] = x;
+      if (dbg) dbg[(size_t)n * n + n + c0 + t] = x;
+    }
+  }
+  __syncthreads();
+  // z[c'] -= sum_r L[c0 + r][c'] x_r for this workgroup's columns left of the block
+  const int cc = (int)blockIdx.x * 256 + t;
+  if (cc < c0) {
+    float sacc = 0.f;
+#pragma unroll 16
+    for (int r = 0; r < CNB; r++) sacc += A[(size_t)(c0 + r) * lda + cc] * xs[r];
+    zrow[cc] -= sacc;
   }
 }
 
@@ -1337,8 +1333,14 @@ __global__ __launch_bounds__(64) void ba_retract_kernel(float* __restrict__ pose
                                                         int n_chunks) {
   if (gmeta[GM_ERROR] || info[1]) return;
   const int U = gmeta[GM_U];
-  if (cmask)   // global-BA path: the panel masks of this iteration are consumed
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_chunks; i += gridDim.x * blockDim.x) cmask[i] = 0u;
+  // global-BA path: a workgroup is one chunk of 64 patches; its panel mask says which 32-pose panels of E are non-zero
+  // (the rest of the column is zero and stays zero: not read, not rewritten); the mask is consumed here
+  uint32_t pmask = 0xffffffffu;
+  if (cmask) {
+    pmask = ((int)blockIdx.x < n_chunks) ? cmask[blockIdx.x] : 0u;
+    __syncthreads();
+    if (threadIdx.x == 0 && (int)blockIdx.x < n_chunks) cmask[blockIdx.x] = 0u;
+  }
   // pose_retr_kernel (ba_cuda.cu:178-206) for the small-system solver: T <- Exp(dX_i) T, one lane per free pose, in the
   // last workgroup (the first ones carry the longest E-column sweeps)
   const int gid_rev = (int)(gridDim.x * blockDim.x) - 1 - (int)(blockIdx.x * blockDim.x + threadIdx.x);
@@ -1357,6 +1359,7 @@ __global__ __launch_bounds__(64) void ba_retract_kernel(float* __restrict__ pose
     // u - E^T dX  (ba_cuda.cu:592); six independent partial sums keep six loads in flight
     float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int b = 0; b < N; b++) {
+      if (!((pmask >> (b >> 5)) & 1u)) continue;
 #pragma unroll
       for (int c = 0; c < 6; c++) {
         float* ep = &Edg[(size_t)(6 * b + c) * U_stride + r];
@@ -1459,9 +1462,7 @@ extern "C" int cdv_ba_forward(float* poses, float* patches, const float* intrins
   std::call_once(attr_once, [] {
     hipError_t e4 = hipFuncSetAttribute((const void*)ba_big_schur_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         112 * 1024);
-    hipError_t e5 = hipFuncSetAttribute((const void*)ba_big_backsolve_kernel,
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    if (e4 != hipSuccess || e5 != hipSuccess) { attr_err = e4 != hipSuccess ? e4 : e5; return; }
+    if (e4 != hipSuccess) { attr_err = e4; return; }
     // worst cases at N = 32: assemble 71 KB (fixed), schur 57 KB, solve 155 KB (+ a few static bytes)
     hipError_t e1 = hipFuncSetAttribute((const void*)ba_assemble_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         96 * 1024);
@@ -1476,7 +1477,6 @@ extern "C" int cdv_ba_forward(float* poses, float* patches, const float* intrins
   const int npair = 6;   // workgroups per chunk that share its active panel pairs (ba_big_schur_kernel)
   const int npad = (int)L.npad, nbk = npad / CNB;
   const size_t smem_bsch = sizeof(float) * (2 * (size_t)BIG_PR * ELD + 2 * BA_CHUNK);
-  const size_t smem_bsol = sizeof(float) * ((size_t)npad + (size_t)CNB * CLD);
   for (int itr = 0; itr < iterations; itr++) {
     float* d = (dbg && itr == 0) ? dbg : nullptr;
     const AsmArgs aa{poses, patches, intrinsics, target, weight, ii, jj, kk, P, t0, N, gv.meta, gv.pcsr, gv.koff_u, sy,
@@ -1495,7 +1495,9 @@ extern "C" int cdv_ba_forward(float* poses, float* patches, const float* intrins
           hipLaunchKernelGGL(ba_big_update_kernel, dim3(T * (T + 1) / 2 + T), dim3(256), 0, s, Abig, npad, kb, gv.meta,
                              info);
       }
-      hipLaunchKernelGGL(ba_big_backsolve_kernel, dim3(1), dim3(256), smem_bsol, s, Abig, npad, n6i, dXg, gv.meta, d, info);
+      for (int kb = nbk - 1; kb >= 0; kb--)
+        hipLaunchKernelGGL(ba_big_backstep_kernel, dim3(kb > 0 ? cdv_div_up(CNB * kb, 256) : 1), dim3(256), 0, s, Abig, npad,
+                           n6i, kb, dXg, gv.meta, d, info);
     } else {
       // one wave per lower-triangular tile pair of [Ed; u] (10 at N = 10): the pairs run side by side
       const int t16 = (n6i + 1 + 15) / 16, sch_waves = t16 * (t16 + 1) / 2 < 16 ? t16 * (t16 + 1) / 2 : 16;
