@@ -143,7 +143,7 @@ __device__ __forceinline__ BlendGeo blend_geo(float xm, float ym, int m, int xo,
   g.dy = (float)(_Float16)(y - fyf);
   const int bx = per_pixel ? 0 : floor_clamped(x) - 3 - b.x0;
   const int by = per_pixel ? 0 : floor_clamped(y) - 3 - b.y0;
-  g.hb = 2 * (m * RAW_MSH + by * b.stride + bx + xo);
+  g.hb = 2 * (m * RAW_MSH + __mul24(by, b.stride) + bx + xo);   // |by| is small: not the quarter-rate v_mul_lo_u32
   g.stride_b = 2 * b.stride;
   return g;
 }
@@ -159,7 +159,12 @@ __device__ __forceinline__ float dot2_f16(uint32_t pair, uint32_t w) {
   return r;
 }
 
-__device__ __forceinline__ void blend_level(const _Float16* __restrict__ raw, const BlendGeo& g, float (&res)[7]) {
+// The vertical tap and the rounding of the result to f16 are written as one expression, (f16)fma(dy, h1 - h0, h0): the
+// compiler emits v_fma_mixlo/hi_f16 (f32 arithmetic, ONE rounding to f16) in every kernel that inlines this.
+// (The wide kernel keeps float results and rounds when it packs them: its conditionally blended, zero-initialised f16
+// results were mis-assembled into v_fma_mixhi_f16 chains by the compiler -- every second value wrong.)
+template <typename TR>
+__device__ __forceinline__ void blend_level(const _Float16* __restrict__ raw, const BlendGeo& g, TR (&res)[7]) {
   const char* rb = reinterpret_cast<const char*>(raw);   // raw is 16-byte aligned
   float h[8];
   // even and odd rows keep their own aligned LDS pointer and funnel shift: two rows further down the byte offset
@@ -180,7 +185,7 @@ __device__ __forceinline__ void blend_level(const _Float16* __restrict__ raw, co
     if (r & 1) p1 += step2; else p0 += step2;
   }
 #pragma unroll
-  for (int yo = 0; yo < 7; yo++) res[yo] = h[yo] + g.dy * (h[yo + 1] - h[yo]);
+  for (int yo = 0; yo < 7; yo++) res[yo] = (TR)__builtin_fmaf(g.dy, h[yo + 1] - h[yo], h[yo]);
 }
 
 // wide reprojection footprint (strong zoom / rotation): every patch pixel gets its own 8x8 window; two
@@ -216,8 +221,31 @@ __device__ __forceinline__ void slow_level(const LevelParams& LP, int64_t jslot,
   }
 }
 
+// a level that contributes nothing (window entirely off the padded map, invalid indices): the raw volume is zeroed and
+// the blend runs as always -- no per-value selects, no zero-initialised result registers on the common path
+__device__ __forceinline__ void zero_raw(_Float16* __restrict__ raw, int lane) {
+  typedef uint32_t cdv_u32x4z __attribute__((ext_vector_type(4)));
+  const cdv_u32x4z z = {0u, 0u, 0u, 0u};
+  for (int i = lane; i < RAW_HALFS / 8; i += 64) reinterpret_cast<cdv_u32x4z*>(raw)[i] = z;
+}
+
+// groups q = 0 .. NQ_MAX - 1 of a round, in order, stopping at the first one past the window (nested tests: nothing
+// is tested after the last group).  A window has at least 8 x 8 pixels, so the first four groups of the first
+// round always exist.
+#define CDV_QCHAIN(OP, NQ, Q0)                                                                     \
+      if ((Q0) == 0) {                                                                             \
+        OP(0, Q0) OP(1, Q0) OP(2, Q0) OP(3, Q0)                                                    \
+        if ((NQ) > 4) { OP(4, Q0) if ((NQ) > 5) { OP(5, Q0) if ((NQ) > 6) { OP(6, Q0)              \
+          if ((NQ) > 7) { OP(7, Q0) if ((NQ) > 8) { OP(8, Q0) } } } } }                            \
+      } else {                                                                                     \
+        OP(0, Q0) if ((NQ) > (Q0) + 1) { OP(1, Q0) if ((NQ) > (Q0) + 2) { OP(2, Q0) if ((NQ) > (Q0) + 3) { OP(3, Q0) \
+          if ((NQ) > (Q0) + 4) { OP(4, Q0) if ((NQ) > (Q0) + 5) { OP(5, Q0) if ((NQ) > (Q0) + 6) { OP(6, Q0) \
+          if ((NQ) > (Q0) + 7) { OP(7, Q0) if ((NQ) > (Q0) + 8) { OP(8, Q0) } } } } } } } }        \
+      }
+
+// ---- wide feature vectors (DPVO, C = 128; KS = C / 32 k-steps): one 16-pixel tile per window row ---------------
 template <int KS>
-__global__ __launch_bounds__(256) void corr_fused_kernel(const _Float16* __restrict__ gmap, LevelParams L0,
+__global__ __launch_bounds__(256) void corr_wide_kernel(const _Float16* __restrict__ gmap, LevelParams L0,
                                                          LevelParams L1, const float* __restrict__ coords,
                                                          const int64_t* __restrict__ kk,
                                                          const int64_t* __restrict__ jj,
@@ -315,129 +343,35 @@ __global__ __launch_bounds__(256) void corr_fused_kernel(const _Float16* __restr
   // being masked off (no EXEC save/restore around every store)
   _Float16* raw_lane = (n < 9) ? raw + n * RAW_MSH + 4 * g : outT + ((n - 9) * 4 + g) * 4;
 
-  if constexpr (KS == 1) {
-    // ---- EVERY window row of both levels is requested before the first MFMA --------------------------
-    const int Wp0 = L0.W + 2 * PADX, Hp0 = L0.H + 2 * PADY, Wp1 = L1.W + 2 * PADX, Hp1 = L1.H + 2 * PADY;
-    const char* r0 = reinterpret_cast<const char*>(L0.fmap) +
-                     (size_t)((((unsigned)jslot * (unsigned)Hp0 + (unsigned)(b0.y0c + PADY)) * (unsigned)Wp0 +
-                               (unsigned)(b0.x0c + PADX)) * (unsigned)(C * 2));   // rings are below 4 GB (host check)
-    const char* r1 = reinterpret_cast<const char*>(nlev == 2 ? L1.fmap : L0.fmap) +
-                     (size_t)((((unsigned)jslot * (unsigned)Hp1 + (unsigned)(b1.y0c + PADY)) * (unsigned)Wp1 +
-                               (unsigned)(b1.x0c + PADX)) * (unsigned)(C * 2));
-    const size_t pitch0 = (size_t)Wp0 * C * 2, pitch1 = (size_t)Wp1 * C * 2;
-    // The CU's vector-memory return path (~70 GB/s per CU from L2) is what bounds this kernel, so only
-    // the useful lanes load: pixels n < Wb and the 3 real channel groups.  Rows n >= Wb of D are never read
-    // (garbage allowed); the k-padding lanes must hold zeros (their products meet zeros, but 0 * NaN = NaN).
-    // The union window is packed DENSELY into the 16 pixel slots of the MFMA A operand: slot s of group q
-    // is window pixel P = 16 q + s = (row P / Wb, col P % Wb).  A 10 x 11 window is 7 loads + 7 MFMAs
-    // instead of 11, and D comes out linear in P, which is the LDS layout (row stride Wb).
-    // Loads are BUFFER loads through a per-edge descriptor whose base is the window origin and whose size
-    // is Hb rows: the hardware range check returns zeros for the lanes past the last pixel and for the
-    // k-padding lanes (offset forced out of range) -- no EXEC masking, no zero-initialised fragments.
-    typedef int cdv_i32x4 __attribute__((ext_vector_type(4)));
-    cdv_half8 w[NQ_MAX][1];
-    const bool do0 = b0.fast && !b0.outside;
-    const bool do1 = nlev == 2 && b1.fast && !b1.outside;
-    const unsigned CB = (unsigned)C * 2u;                              // bytes per pixel
-    const unsigned gbyte = (8 * g < C) ? (unsigned)(8 * g) * 2u : 0x40000000u;  // k padding -> out of range
-    const int nq0 = (b0.Wb * b0.Hb + 15) >> 4, nq1 = (b1.Wb * b1.Hb + 15) >> 4;
-#define CDV_LOAD_LEVEL(BX, RB, PITCH, NQ, Q0)                                                      \
-    {                                                                                              \
-      const unsigned Wb_ = (unsigned)(BX).Wb, pitch_ = (unsigned)(PITCH);                          \
-      const auto rsrc_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(RB), (short)0,        \
-                                                           (int)((unsigned)(BX).Hb * pitch_), 0x00020000); \
-      const unsigned a_ = (Wb_ == 8u) ? 2u : 1u, b_ = 16u - a_ * Wb_;                              \
-      const unsigned step_ = a_ * pitch_ + b_ * CB, wrap_ = pitch_ - Wb_ * CB;                     \
-      /* first pixel of this lane: P = 16 Q0 + n = (row0, col); Q0 > 0 (windows above 16 NQ_MAX pixels) is rare */ \
-      const unsigned row0_ = ((Q0) == 0) ? (((unsigned)n >= Wb_) ? 1u : 0u) : (16u * (Q0) + (unsigned)n) / Wb_; \
-      unsigned col_ = 16u * (Q0) + (unsigned)n - row0_ * Wb_;                                     \
-      unsigned voff_ = row0_ * pitch_ + col_ * CB + gbyte;                                         \
-      _Pragma("unroll") for (int q = 0; q < NQ_MAX; q++) {                                         \
-        if ((Q0) + q < (NQ)) {                                                                     \
-          const cdv_i32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(rsrc_, (int)voff_, 0, 0);     \
-          w[q][0] = __builtin_bit_cast(cdv_half8, v_);                                             \
-          col_ += b_; voff_ += step_;                                                              \
-          const bool wr_ = col_ >= Wb_;                                                            \
-          col_ -= wr_ ? Wb_ : 0u; voff_ += wr_ ? wrap_ : 0u;                                       \
-        }                                                                                          \
-      }                                                                                            \
-    }
-#define CDV_MFMA_LEVEL(NQ, Q0)                                                                     \
-    _Pragma("unroll") for (int q = 0; q < NQ_MAX; q++)                                             \
-      if ((Q0) + q < (NQ)) {                                                                       \
-        cdv_float4 acc = {0.f, 0.f, 0.f, 0.f};                                                     \
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[q][0], pat[0], acc, 0, 0, 0);               \
-        cdv_half4 h = {(_Float16)acc[0], (_Float16)acc[1], (_Float16)acc[2], (_Float16)acc[3]};    \
-        *reinterpret_cast<cdv_half4*>(raw_lane + ((Q0) + q) * 16) = h;                             \
+  // wide feature vectors (DPVO, C = 128): rows in batches of 2 to stay inside the register file
+  for (int lev = 0; lev < nlev; lev++) {
+    const LevelParams& LP = lev == 0 ? L0 : L1;
+    Box b = lev == 0 ? b0 : b1;
+    b.stride = 16;  // this path stores one 16-pixel tile per window row
+    const int Wp = LP.W + 2 * PADX, Hp = LP.H + 2 * PADY;
+    if (lev == 1) wave_lds_sync();
+    if (b.fast && !b.outside) {
+      const _Float16* fb = LP.fmap + (((size_t)jslot * Hp + (b.y0c + PADY)) * Wp + (b.x0c + PADX)) * C;
+      for (int t = 0; t < b.Hb; t++) {
+        cdv_half8 wa[KS];
+#pragma unroll
+        for (int s = 0; s < KS; s++)
+          wa[s] = *reinterpret_cast<const cdv_half8*>(fb + ((size_t)t * Wp + n) * C + min(32 * s + 8 * g, C - 8));
+        cdv_float4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; s++) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[s], pat[s], acc, 0, 0, 0);
+        if (n < 9) {
+          cdv_half4 h = {(_Float16)acc[0], (_Float16)acc[1], (_Float16)acc[2], (_Float16)acc[3]};
+          *reinterpret_cast<cdv_half4*>(raw_lane + t * 16) = h;
+        }
       }
-    if (do0 && !CDV_EXP(1)) CDV_LOAD_LEVEL(b0, r0, pitch0, nq0, 0)
-    const BlendGeo g0 = blend_geo(xb, yb, bm, bxo, L0, b0, !b0.fast);
-    const BlendGeo g1 = blend_geo(xb, yb, bm, bxo, nlev == 2 ? L1 : L0, b1, !b1.fast);
-    CDV_STAMP(corr, p, 2);
-    // level 0: MFMA per pixel group; the registers are immediately re-used for the level-1 request
-    if (do0 && !CDV_EXP(256)) {
-      CDV_MFMA_LEVEL(nq0, 0)
-      if (nq0 > NQ_MAX) {   // window of more than 16 NQ_MAX pixels: a second round through the same registers
-        CDV_LOAD_LEVEL(b0, r0, pitch0, nq0, NQ_MAX)
-        CDV_MFMA_LEVEL(nq0, NQ_MAX)
-      }
-    } else if (!b0.fast) {
-      slow_level<1>(L0, jslot, xv, yv, pat, raw, lane, C);
+    } else if (!b.fast) {
+      slow_level<KS>(LP, jslot, xv, yv, pat, raw, lane, C);
     }
-    if (do1 && !CDV_EXP(1)) CDV_LOAD_LEVEL(b1, r1, pitch1, nq1, 0)
     wave_lds_sync();
-    CDV_STAMP(corr, p, 3);
-    if ((do0 || !b0.fast) && !CDV_EXP(128)) blend_level(raw, g0, res0);
-    CDV_STAMP(corr, p, 4);
-    if (nlev == 2) {
-      wave_lds_sync();
-      if (do1 && !CDV_EXP(256)) {
-        CDV_MFMA_LEVEL(nq1, 0)
-        if (nq1 > NQ_MAX) {
-          CDV_LOAD_LEVEL(b1, r1, pitch1, nq1, NQ_MAX)
-          CDV_MFMA_LEVEL(nq1, NQ_MAX)
-        }
-      } else if (!b1.fast) {
-        slow_level<1>(L1, jslot, xv, yv, pat, raw, lane, C);
-      }
-      wave_lds_sync();
-      CDV_STAMP(corr, p, 5);
-      if ((do1 || !b1.fast) && !CDV_EXP(128)) blend_level(raw, g1, res1);
-      CDV_STAMP(corr, p, 6);
-    }
-#undef CDV_LOAD_LEVEL
-#undef CDV_MFMA_LEVEL
-  } else {
-    // wide feature vectors (DPVO, C = 128): rows in batches of 2 to stay inside the register file
-    for (int lev = 0; lev < nlev; lev++) {
-      const LevelParams& LP = lev == 0 ? L0 : L1;
-      Box b = lev == 0 ? b0 : b1;
-      b.stride = 16;  // this path stores one 16-pixel tile per window row
-      const int Wp = LP.W + 2 * PADX, Hp = LP.H + 2 * PADY;
-      if (lev == 1) wave_lds_sync();
-      if (b.fast && !b.outside) {
-        const _Float16* fb = LP.fmap + (((size_t)jslot * Hp + (b.y0c + PADY)) * Wp + (b.x0c + PADX)) * C;
-        for (int t = 0; t < b.Hb; t++) {
-          cdv_half8 wa[KS];
-#pragma unroll
-          for (int s = 0; s < KS; s++)
-            wa[s] = *reinterpret_cast<const cdv_half8*>(fb + ((size_t)t * Wp + n) * C + min(32 * s + 8 * g, C - 8));
-          cdv_float4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int s = 0; s < KS; s++) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[s], pat[s], acc, 0, 0, 0);
-          if (n < 9) {
-            cdv_half4 h = {(_Float16)acc[0], (_Float16)acc[1], (_Float16)acc[2], (_Float16)acc[3]};
-            *reinterpret_cast<cdv_half4*>(raw_lane + t * 16) = h;
-          }
-        }
-      } else if (!b.fast) {
-        slow_level<KS>(LP, jslot, xv, yv, pat, raw, lane, C);
-      }
-      wave_lds_sync();
-      if (!(b.fast && b.outside)) {
-        const BlendGeo gg = blend_geo(xb, yb, bm, bxo, LP, b, !b.fast);
-        if (lev == 0) blend_level(raw, gg, res0); else blend_level(raw, gg, res1);
-      }
+    if (!(b.fast && b.outside)) {
+      const BlendGeo gg = blend_geo(xb, yb, bm, bxo, LP, b, !b.fast);
+      if (lev == 0) blend_level(raw, gg, res0); else blend_level(raw, gg, res1);
     }
   }
 
@@ -482,6 +416,269 @@ __global__ __launch_bounds__(256) void corr_fused_kernel(const _Float16* __restr
       if (t < 441) dst[t] = outT[t];
     }
   }
+  }
+  CDV_STAMP(corr, p, 8);
+}
+
+// ---- the product kernel (C <= 32) ------------------------------------------------------
+// One wave per edge, both levels (header of this file); built around what bounds it on MI355X -- not bytes and not one saturated unit, but the serial chain of one wave (6 waves per SIMD;
+// ~14,000 cycles per edge of which ~1,600 are its VALU issue) and the scalar unit the four SIMDs of a CU share:
+//   * every argument the first instructions need sits at the front of ONE argument struct (one scalar load, not six
+//     dependent ones); strides, pitches and the (biased) ring bases are precomputed by the host;
+//   * the coordinate load is issued before the index loads are waited for (one memory round trip, not two);
+//   * indices are handled in 32-bit scalar arithmetic (a 64-bit compare is a VALU instruction on this ISA);
+//   * window addressing in float arithmetic, 3 VALU per load (see CDV_LD1);
+//   * no result selects: a level that contributes nothing gets a zeroed raw volume, both levels of one output dword
+//     are ONE v_cvt_pk_f16_f32;
+//   * workgroup b runs on XCD b % 8: XCD x takes the x-th contiguous eighth of the edge list (the edges of one target
+//     frame are neighbours in the list, so a frame's windows meet in one L2 instead of eight).
+struct CorrLevel {
+  const char* base_m;   // ring base MINUS 0x4B000000 bytes (the float-bit-pattern offsets of the window loads carry that bias)
+  int H, W;
+  float inv_scale;
+  int shift;
+  uint32_t pitch;       // bytes per padded row
+  uint32_t slot_bytes;  // bytes per slot
+};
+struct CorrArgs2 {
+  const float* coords;
+  const int64_t* kk;
+  const int64_t* jj;
+  const int32_t* order;
+  int E;
+  uint32_t kmod, jmod, kmagic, jmagic;
+  uint32_t Ng, slots;
+  const char* gmap;     // tiles, f16: pixel-major [Ng][9][C] (gmap_pm) or the reference's planar [Ng][C][3][3]
+  _Float16* out;
+  CorrLevel L0, L1;
+  int C;
+  int gmap_pm;
+  int exp;
+};
+
+constexpr uint32_t FBIAS = 0x4B000000u;   // bit pattern of 2^23
+
+__device__ __forceinline__ LevelParams level_params(const CorrLevel& L) {
+  return LevelParams{reinterpret_cast<const _Float16*>(L.base_m + (size_t)FBIAS), L.H, L.W, L.inv_scale, L.shift};
+}
+
+template <int CC, int NLEV>
+__global__ __launch_bounds__(256) void corr_fused2_kernel(const CorrArgs2 a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  _Float16* raw = reinterpret_cast<_Float16*>(smem_raw + (size_t)wave * WAVE_LDS_BYTES);
+  _Float16* outT = raw + RAW_HALFS;
+  const int p = (((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3)) * 4 + wave;
+  if (p >= a.E) return;  // no block-wide barriers below: waves are independent
+  const int e = a.order ? __builtin_amdgcn_readfirstlane(a.order[p]) : p;   // wave-uniform
+  CDV_STAMP(corr, p, 0);
+  const int C = CC ? CC : a.C;
+#ifdef CDV_STAMPS
+  const int exp = a.exp;
+#endif
+
+  // ---- round trip 1: the 18 coordinates (one vector load, lane l < 18 holds value l) and the two indices ----------
+  const int cval = __float_as_int(a.coords[(size_t)e * 18 + min(lane, 17)]);
+  const int64_t k64 = a.kk[e], j64 = a.jj[e];
+  const int mm = lane < 9 ? lane : 0;       // row 0 of the wave: lanes 0..8 own patch pixel m, 9..15 mirror 0
+  const int bm = min(lane / 7, 8), bxo = lane - 7 * (lane / 7);  // blend role of this lane: (m, x offset)
+  const int n = lane & 15, g = lane >> 4;
+  // index % modulus (slam.py:319-320) with the host's reciprocal: q = mulhi(x, ceil(2^32 / d)) is x / d or one more
+  // for 0 <= x < 2^31, so one correction step
+  uint32_t kq = (uint32_t)k64, jq = (uint32_t)j64;
+  const bool k_small = (uint32_t)(k64 >> 32) == 0u && kq < 0x80000000u;
+  const bool j_small = (uint32_t)(j64 >> 32) == 0u && jq < 0x80000000u;
+  if (a.kmod > 1u) {
+    const int32_t r = (int32_t)(kq - __umulhi(kq, a.kmagic) * a.kmod);
+    kq = (uint32_t)(r < 0 ? r + (int32_t)a.kmod : r);
+  } else if (a.kmod == 1u) {
+    kq = 0u;
+  }
+  if (a.jmod > 1u) {
+    const int32_t r = (int32_t)(jq - __umulhi(jq, a.jmagic) * a.jmod);
+    jq = (uint32_t)(r < 0 ? r + (int32_t)a.jmod : r);
+  } else if (a.jmod == 1u) {
+    jq = 0u;
+  }
+  const bool idx_ok = k_small && j_small && kq < a.Ng && jq < a.slots;
+  if (!idx_ok) { kq = 0u; jq = 0u; }  // reference behaviour is undefined here; stay in bounds, emit zeros
+  if (CDV_EXP(16)) jq = 0u;
+  const int64_t jslot = (int64_t)jq;
+
+  // ---- patch tile (MFMA B operand): one 16-byte buffer load; the descriptor covers exactly this tile, so the lanes
+  // that are not patch pixels (n >= 9) and the k padding (forced offset) read zeros from the range check
+  typedef int cdv_i32x4 __attribute__((ext_vector_type(4)));
+  cdv_half8 pat[1];
+  if (a.gmap_pm) {
+    const unsigned tile_b = 9u * (unsigned)C * 2u;
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.gmap) + (size_t)(kq * tile_b), (short)0,
+                                                      (int)tile_b, 0x00020000);   // tiles are below 4 GB (host check)
+    const unsigned voff = (8 * g < C) ? (unsigned)(n * C + 8 * g) * 2u : 0x40000000u;
+    pat[0] = __builtin_bit_cast(cdv_half8, (cdv_i32x4)__builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, 0, 0));
+  } else {
+    // the reference's planar tiles [Ng][C][3][3] (cdv_corr_fused on tensors nobody converted): eight strided gathers
+    const _Float16* gp = reinterpret_cast<const _Float16*>(a.gmap) + (size_t)kq * C * 9 + (n < 9 ? n : 0);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int ch = 8 * g + j;
+      const _Float16 v = gp[min(ch, C - 1) * 9];
+      pat[0][j] = (n < 9 && ch < C) ? v : (_Float16)0.f;
+    }
+  }
+
+  const float xv = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * mm, cval));
+  const float yv = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * (9 + mm), cval));
+  const float xb = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * bm, cval));
+  const float yb = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * (9 + bm), cval));
+  const LevelParams L0 = level_params(a.L0), L1 = level_params(NLEV == 2 ? a.L1 : a.L0);
+  const int ixl = floor_clamped(xv * L0.inv_scale), iyl = floor_clamped(yv * L0.inv_scale);
+  const int ixmin = __builtin_amdgcn_readfirstlane(row16_reduce_i32<true>(ixl));
+  const int ixmax = __builtin_amdgcn_readfirstlane(row16_reduce_i32<false>(ixl));
+  const int iymin = __builtin_amdgcn_readfirstlane(row16_reduce_i32<true>(iyl));
+  const int iymax = __builtin_amdgcn_readfirstlane(row16_reduce_i32<false>(iyl));
+  const Box b0 = make_box(ixmin, ixmax, iymin, iymax, L0);
+  const int sh1 = NLEV == 2 ? L1.shift : 0;
+  const Box b1 = make_box(ixmin >> sh1, ixmax >> sh1, iymin >> sh1, iymax >> sh1, L1);
+  CDV_STAMP(corr, p, 1);
+
+  _Float16 res0[7], res1[7];
+  // lanes n >= 9 of the D tile are not patch pixels: they store into the (not yet used) staging area instead of
+  // being masked off (no EXEC save/restore around every store)
+  _Float16* raw_lane = (n < 9) ? raw + n * RAW_MSH + 4 * g : outT + ((n - 9) * 4 + g) * 4;
+
+  // ---- round trip 2: EVERY window group of a level is requested before its first MFMA; the level-1 request goes out
+  // as soon as level 0 has left the registers and flies under the level-0 blend -------------------------------------
+  const unsigned CB = (unsigned)C * 2u;                              // bytes per pixel
+  const char* r0 = a.L0.base_m + (size_t)(jq * a.L0.slot_bytes + (unsigned)(b0.y0c + PADY) * a.L0.pitch +
+                                          (unsigned)(b0.x0c + PADX) * CB);   // rings are below 4 GB (host check)
+  const CorrLevel& A1 = NLEV == 2 ? a.L1 : a.L0;
+  const char* r1 = A1.base_m + (size_t)(jq * A1.slot_bytes + (unsigned)(b1.y0c + PADY) * A1.pitch +
+                                        (unsigned)(b1.x0c + PADX) * CB);
+  const unsigned pitch0 = a.L0.pitch, pitch1 = A1.pitch;
+  cdv_half8 w[NQ_MAX][1];
+  const bool do0 = b0.fast && !b0.outside && idx_ok;
+  const bool do1 = NLEV == 2 && b1.fast && !b1.outside && idx_ok;
+  const int nq0 = (b0.Wb * b0.Hb + 15) >> 4, nq1 = (b1.Wb * b1.Hb + 15) >> 4;
+  // Window addressing in float arithmetic (exact: every value is an integer below 2^24).  The union window is packed
+  // DENSELY into the 16 pixel slots of the MFMA A operand: slot n of group q is window pixel P = 16 q + n, in window
+  // row floor((P + 0.5) / Wb) -- (P + 0.5) / Wb stays 0.5 / 16 away from every integer, far beyond the rounding of the
+  // reciprocal -- at byte offset row * (pitch - Wb CB) + P CB (+ channel group).  (t, b) = ((P + 0.5) / Wb,
+  // P CB + group + 2^23) advance together with one v_pk_add_f32 per group; the 2^23 makes the low mantissa bits of
+  // fma(row, wrap, b) the integer offset itself, so the float's BIT PATTERN is the buffer offset (no conversion): the
+  // descriptor base is biased by -0x4B000000 (host) and its size by +0x4B000000.  The range check of the descriptor
+  // returns zeros past the last window row; the k-padding lanes start from 2^25 (always out of range).
+  typedef float cdv_f32x2 __attribute__((ext_vector_type(2)));
+  const float nhalf = (float)n + 0.5f;
+  const float lanebase = (8 * g < C) ? (float)((unsigned)n * CB + (unsigned)(8 * g) * 2u) + 8388608.0f : 33554432.0f;
+#define CDV2_LOAD_LEVEL(BX, RB, PITCH, NQ, Q0)                                                     \
+  {                                                                                                \
+    const unsigned Wb_ = (unsigned)(BX).Wb, pitch_ = (PITCH);                                      \
+    const auto rsrc_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(RB), (short)0,          \
+                                                         (int)((unsigned)(BX).Hb * pitch_ + FBIAS), 0x00020000); \
+    const float invW_ = __builtin_amdgcn_rcpf((float)Wb_);                                         \
+    const float wrapf_ = (float)(pitch_ - Wb_ * CB);                                               \
+    cdv_f32x2 tb_ = {(nhalf + (float)(16 * (Q0))) * invW_, lanebase + (float)(16u * (unsigned)(Q0) * CB)}; \
+    const cdv_f32x2 dtb_ = {16.0f * invW_, (float)(16u * CB)};                                     \
+    CDV_QCHAIN(CDV2_LD1, NQ, Q0)                                                                   \
+  }
+#define CDV2_LD1(q, Q0)                                                                            \
+    {                                                                                              \
+      const float vf_ = __builtin_fmaf(__builtin_floorf(tb_[0]), wrapf_, tb_[1]);                  \
+      const cdv_i32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(rsrc_, __float_as_int(vf_), 0, 0); \
+      w[q][0] = __builtin_bit_cast(cdv_half8, v_);                                                 \
+      tb_ += dtb_;                                                                                 \
+    }
+#define CDV2_MF1(q, Q0)                                                                            \
+    {                                                                                              \
+      cdv_float4 acc = {0.f, 0.f, 0.f, 0.f};                                                       \
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[q][0], pat[0], acc, 0, 0, 0);                 \
+      cdv_half4 h = {(_Float16)acc[0], (_Float16)acc[1], (_Float16)acc[2], (_Float16)acc[3]};      \
+      *reinterpret_cast<cdv_half4*>(raw_lane + ((Q0) + q) * 16) = h;                               \
+    }
+#define CDV2_MFMA_LEVEL(NQ, Q0) CDV_QCHAIN(CDV2_MF1, NQ, Q0)
+  if (do0 && !CDV_EXP(1)) CDV2_LOAD_LEVEL(b0, r0, pitch0, nq0, 0)
+  const BlendGeo g0 = blend_geo(xb, yb, bm, bxo, L0, b0, !b0.fast);
+  const BlendGeo g1 = blend_geo(xb, yb, bm, bxo, L1, b1, !b1.fast);
+  CDV_STAMP(corr, p, 2);
+  if (do0 && !CDV_EXP(256)) {
+    CDV2_MFMA_LEVEL(nq0, 0)
+    if (nq0 > NQ_MAX) {   // window of more than 16 NQ_MAX pixels: a second round through the same registers
+      CDV2_LOAD_LEVEL(b0, r0, pitch0, nq0, NQ_MAX)
+      CDV2_MFMA_LEVEL(nq0, NQ_MAX)
+    }
+  } else if (!b0.fast && idx_ok) {
+    slow_level<1>(L0, jslot, xv, yv, pat, raw, lane, C);
+  } else {
+    zero_raw(raw, lane);
+  }
+  if (do1 && !CDV_EXP(1)) CDV2_LOAD_LEVEL(b1, r1, pitch1, nq1, 0)
+  wave_lds_sync();
+  CDV_STAMP(corr, p, 3);
+  if (!CDV_EXP(128)) blend_level(raw, g0, res0);
+  CDV_STAMP(corr, p, 4);
+  if (NLEV == 2) {
+    wave_lds_sync();
+    if (do1 && !CDV_EXP(256)) {
+      CDV2_MFMA_LEVEL(nq1, 0)
+      if (nq1 > NQ_MAX) {
+        CDV2_LOAD_LEVEL(b1, r1, pitch1, nq1, NQ_MAX)
+        CDV2_MFMA_LEVEL(nq1, NQ_MAX)
+      }
+    } else if (!b1.fast && idx_ok) {
+      slow_level<1>(L1, jslot, xv, yv, pat, raw, lane, C);
+    } else {
+      zero_raw(raw, lane);
+    }
+    wave_lds_sync();
+    CDV_STAMP(corr, p, 5);
+    if (!CDV_EXP(128)) blend_level(raw, g1, res1);
+    CDV_STAMP(corr, p, 6);
+  }
+#undef CDV2_LOAD_LEVEL
+#undef CDV2_LD1
+#undef CDV2_MF1
+#undef CDV2_MFMA_LEVEL
+
+  // ---- stage the edge's output row [x][y][m][lev] in LDS, then 16-byte-per-lane stores ------------------------------
+  if (lane < 63 && !CDV_EXP(512)) {
+    if (NLEV == 2) {
+      uint32_t* o32 = reinterpret_cast<uint32_t*>(outT) + ((bxo << 6) - bxo) + bm;   // dword (x, y, m) = 63 x + 9 y + m
+#pragma unroll
+      for (int yo = 0; yo < 7; yo++) {
+        const cdv_half2 h = {res0[yo], res1[yo]};
+        o32[yo * 9] = __builtin_bit_cast(uint32_t, h);
+      }
+    } else {
+#pragma unroll
+      for (int yo = 0; yo < 7; yo++) outT[(bxo * 7 + yo) * 9 + bm] = res0[yo];
+    }
+  }
+  wave_lds_sync();
+  CDV_STAMP(corr, p, 7);
+  if (!CDV_EXP(2)) {
+    if (NLEV == 2) {
+      // 441 dwords: two 16-byte-per-lane stores (256 + 184 dwords) and one last dword.  The row starts on a 4-byte
+      // boundary only (1764 B per edge); global memory takes the unaligned 16-byte accesses.
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(outT);
+      uint32_t* dst = reinterpret_cast<uint32_t*>(a.out) + (size_t)e * 441;
+      typedef uint32_t cdv_u32x4 __attribute__((ext_vector_type(4)));
+      typedef uint32_t cdv_u32x4u __attribute__((ext_vector_type(4), aligned(4)));
+      const cdv_u32x4 v0 = *reinterpret_cast<const cdv_u32x4*>(src + 4 * lane);
+      *reinterpret_cast<cdv_u32x4u*>(dst + 4 * lane) = v0;
+      if (lane < 46) {
+        const cdv_u32x4 v1 = *reinterpret_cast<const cdv_u32x4*>(src + 256 + 4 * lane);
+        *reinterpret_cast<cdv_u32x4u*>(dst + 256 + 4 * lane) = v1;
+      }
+      if (lane == 63) dst[440] = src[440];
+    } else {
+      _Float16* dst = a.out + (size_t)e * 441;
+#pragma unroll
+      for (int i = 0; i < 7; i++) {
+        const int t = i * 64 + lane;
+        if (t < 441) dst[t] = outT[t];
+      }
+    }
   }
   CDV_STAMP(corr, p, 8);
 }
@@ -746,20 +943,34 @@ extern "C" int cdv_corr_fused(const void* gmap, const void* fmap0_nhwc, const vo
   const uint32_t jmagic = jmod > 1 ? (uint32_t)((((uint64_t)1 << 32) + (uint64_t)jmod - 1) / (uint64_t)jmod) : 0u;
   if (E == 0) return CDV_OK;
   CDV_REQUIRE(nlev == 1 || ex1 >= ex0, CDV_ERR_UNSUPPORTED, "cdv_corr_fused: level 1 must not be finer than level 0");
-  LevelParams L0{(const _Float16*)fmap0_nhwc, H0, W0, 1.0f / scale0, 0};
-  LevelParams L1{(const _Float16*)fmap1_nhwc, H1, W1, nlev == 2 ? 1.0f / scale1 : 1.0f, nlev == 2 ? ex1 - ex0 : 0};
-  const int blocks = cdv_div_up(E, 4);
   const size_t smem = 4 * (size_t)WAVE_LDS_BYTES;
   static const int exp = getenv("CDV_CORR_EXP") ? atoi(getenv("CDV_CORR_EXP")) : 0;  // diagnostics only
   hipStream_t s = (hipStream_t)stream;
-  if (C <= 32)
-    hipLaunchKernelGGL(corr_fused_kernel<1>, dim3(blocks), dim3(256), smem, s, (const _Float16*)gmap, L0, L1, coords,
+  if (C <= 32) {
+    CDV_REQUIRE(Ng < ((int64_t)1 << 31) && slots < ((int64_t)1 << 31) && (size_t)Ng * 9 * (size_t)C * 2 < ((size_t)1 << 32),
+                CDV_ERR_UNSUPPORTED, "cdv_corr_fused: 4 GB or more of patch tiles");
+    auto level = [&](const void* ring, int H, int W, float scale, int shift) {
+      const uint32_t pitch = (uint32_t)(W + 2 * PADX) * (uint32_t)C * 2u;
+      return CorrLevel{(const char*)ring - (size_t)FBIAS, H, W, 1.0f / scale, shift, pitch, pitch * (uint32_t)(H + 2 * PADY)};
+    };
+    const CorrLevel A0 = level(fmap0_nhwc, H0, W0, scale0, 0);
+    const CorrArgs2 a{coords, kk, jj, order, (int)E, (uint32_t)kmod, (uint32_t)jmod, kmagic, jmagic, (uint32_t)Ng,
+                      (uint32_t)slots, (const char*)gmap, (_Float16*)out, A0,
+                      nlev == 2 ? level(fmap1_nhwc, H1, W1, scale1, ex1 - ex0) : A0, C, gmap_pixel_major, exp};
+    const int blocks = 8 * (int)cdv_div_up(E, 32);   // a multiple of 8: the kernel deals contiguous eighths to the XCDs
+    if (nlev == 2 && C == 24)
+      hipLaunchKernelGGL((corr_fused2_kernel<24, 2>), dim3(blocks), dim3(256), smem, s, a);
+    else if (nlev == 2)
+      hipLaunchKernelGGL((corr_fused2_kernel<0, 2>), dim3(blocks), dim3(256), smem, s, a);
+    else
+      hipLaunchKernelGGL((corr_fused2_kernel<0, 1>), dim3(blocks), dim3(256), smem, s, a);
+  } else {
+    LevelParams L0{(const _Float16*)fmap0_nhwc, H0, W0, 1.0f / scale0, 0};
+    LevelParams L1{(const _Float16*)fmap1_nhwc, H1, W1, nlev == 2 ? 1.0f / scale1 : 1.0f, nlev == 2 ? ex1 - ex0 : 0};
+    hipLaunchKernelGGL(corr_wide_kernel<4>, dim3(cdv_div_up(E, 4)), dim3(256), smem, s, (const _Float16*)gmap, L0, L1, coords,
                        kk, jj, order, (_Float16*)out, (int)E, Ng, slots, C, nlev, kmod, jmod, kmagic, jmagic,
                        gmap_pixel_major, exp);
-  else
-    hipLaunchKernelGGL(corr_fused_kernel<4>, dim3(blocks), dim3(256), smem, s, (const _Float16*)gmap, L0, L1, coords,
-                       kk, jj, order, (_Float16*)out, (int)E, Ng, slots, C, nlev, kmod, jmod, kmagic, jmagic,
-                       gmap_pixel_major, exp);
+  }
   CDV_LAUNCH_CHECK();
   return CDV_OK;
 }
