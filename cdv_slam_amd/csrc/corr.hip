@@ -44,7 +44,7 @@ constexpr int PADY = CDV_FMAP_PADY;             // 12
 // Per-wave LDS: the raw correlation volume of ONE level in f16 (the reference's raw volume is f16 too,
 // correlation_kernel.cu:207) + the staged output row of the edge.
 constexpr int RAW_ROWS = 12;                    // window rows the fast path holds (typical: 10-11 / 8-9)
-constexpr int NQ_MAX = 9;                       // 16-pixel groups of the densely packed window kept in registers at a time (144 pixels; typical
+constexpr int NQ_MAX = 8;                       // 16-pixel groups of the densely packed window kept in registers at a time (144 pixels; typical
                                                 // windows: 110-121 / 81 pixels; larger ones take a second round): 78 VGPRs,
                                                 // 6 waves per SIMD
 constexpr int RAW_MSH = RAW_ROWS * 16 + 8;      // halfs per patch pixel (+8: 16-byte skew between pixels)
@@ -74,6 +74,22 @@ __device__ __forceinline__ int row16_reduce_i32(int v) {
   CDV_ROR(8) CDV_ROR(4) CDV_ROR(2) CDV_ROR(1)
 #undef CDV_ROR
   return v;
+}
+
+// the four extremes the window boxes need (min / max of x and of y) with the four rotation chains interleaved: every
+// DPP read is three instructions behind the write of its register, so no wait states (s_nop) are needed at all
+__device__ __forceinline__ void row16_minmax4(int x, int y, int& xmin, int& xmax, int& ymin, int& ymax) {
+  int a = x, b = x, c = y, d = y;
+#define CDV_STEP(n)                                                                                  \
+  asm volatile("v_min_i32_dpp %0, %0, %0 row_ror:" #n " row_mask:0xf bank_mask:0xf\n\t"               \
+               "v_max_i32_dpp %1, %1, %1 row_ror:" #n " row_mask:0xf bank_mask:0xf\n\t"               \
+               "v_min_i32_dpp %2, %2, %2 row_ror:" #n " row_mask:0xf bank_mask:0xf\n\t"               \
+               "v_max_i32_dpp %3, %3, %3 row_ror:" #n " row_mask:0xf bank_mask:0xf"                    \
+               : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+  asm volatile("s_nop 1" ::: "memory");   // the copies above may be the instructions right before the first DPP read
+  CDV_STEP(8) CDV_STEP(4) CDV_STEP(2) CDV_STEP(1)
+#undef CDV_STEP
+  xmin = a; xmax = b; ymin = c; ymax = d;
 }
 
 struct LevelParams {
@@ -236,11 +252,11 @@ __device__ __forceinline__ void zero_raw(_Float16* __restrict__ raw, int lane) {
       if ((Q0) == 0) {                                                                             \
         OP(0, Q0) OP(1, Q0) OP(2, Q0) OP(3, Q0)                                                    \
         if ((NQ) > 4) { OP(4, Q0) if ((NQ) > 5) { OP(5, Q0) if ((NQ) > 6) { OP(6, Q0)              \
-          if ((NQ) > 7) { OP(7, Q0) if ((NQ) > 8) { OP(8, Q0) } } } } }                            \
+          if ((NQ) > 7) { OP(7, Q0) if (NQ_MAX > 8 && (NQ) > 8) { OP(8, Q0) } } } } }              \
       } else {                                                                                     \
         OP(0, Q0) if ((NQ) > (Q0) + 1) { OP(1, Q0) if ((NQ) > (Q0) + 2) { OP(2, Q0) if ((NQ) > (Q0) + 3) { OP(3, Q0) \
           if ((NQ) > (Q0) + 4) { OP(4, Q0) if ((NQ) > (Q0) + 5) { OP(5, Q0) if ((NQ) > (Q0) + 6) { OP(6, Q0) \
-          if ((NQ) > (Q0) + 7) { OP(7, Q0) if ((NQ) > (Q0) + 8) { OP(8, Q0) } } } } } } } }        \
+          if ((NQ) > (Q0) + 7) { OP(7, Q0) if (NQ_MAX > 8 && (NQ) > (Q0) + 8) { OP(8, Q0) } } } } } } } } \
       }
 
 // ---- wide feature vectors (DPVO, C = 128; KS = C / 32 k-steps): one 16-pixel tile per window row ---------------
@@ -533,10 +549,10 @@ __global__ __launch_bounds__(256) void corr_fused2_kernel(const CorrArgs2 a) {
   const float yb = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * (9 + bm), cval));
   const LevelParams L0 = level_params(a.L0), L1 = level_params(NLEV == 2 ? a.L1 : a.L0);
   const int ixl = floor_clamped(xv * L0.inv_scale), iyl = floor_clamped(yv * L0.inv_scale);
-  const int ixmin = __builtin_amdgcn_readfirstlane(row16_reduce_i32<true>(ixl));
-  const int ixmax = __builtin_amdgcn_readfirstlane(row16_reduce_i32<false>(ixl));
-  const int iymin = __builtin_amdgcn_readfirstlane(row16_reduce_i32<true>(iyl));
-  const int iymax = __builtin_amdgcn_readfirstlane(row16_reduce_i32<false>(iyl));
+  int vxmin, vxmax, vymin, vymax;
+  row16_minmax4(ixl, iyl, vxmin, vxmax, vymin, vymax);
+  const int ixmin = __builtin_amdgcn_readfirstlane(vxmin), ixmax = __builtin_amdgcn_readfirstlane(vxmax);
+  const int iymin = __builtin_amdgcn_readfirstlane(vymin), iymax = __builtin_amdgcn_readfirstlane(vymax);
   const Box b0 = make_box(ixmin, ixmax, iymin, iymax, L0);
   const int sh1 = NLEV == 2 ? L1.shift : 0;
   const Box b1 = make_box(ixmin >> sh1, ixmax >> sh1, iymin >> sh1, iymax >> sh1, L1);
@@ -586,13 +602,13 @@ __global__ __launch_bounds__(256) void corr_fused2_kernel(const CorrArgs2 a) {
     {                                                                                              \
       const float vf_ = __builtin_fmaf(__builtin_floorf(tb_[0]), wrapf_, tb_[1]);                  \
       const cdv_i32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(rsrc_, __float_as_int(vf_), 0, 0); \
-      w[q][0] = __builtin_bit_cast(cdv_half8, v_);                                                 \
+      w[(q) < NQ_MAX ? (q) : 0][0] = __builtin_bit_cast(cdv_half8, v_);                            \
       tb_ += dtb_;                                                                                 \
     }
 #define CDV2_MF1(q, Q0)                                                                            \
     {                                                                                              \
       cdv_float4 acc = {0.f, 0.f, 0.f, 0.f};                                                       \
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[q][0], pat[0], acc, 0, 0, 0);                 \
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[(q) < NQ_MAX ? (q) : 0][0], pat[0], acc, 0, 0, 0); \
       cdv_half4 h = {(_Float16)acc[0], (_Float16)acc[1], (_Float16)acc[2], (_Float16)acc[3]};      \
       *reinterpret_cast<cdv_half4*>(raw_lane + ((Q0) + q) * 16) = h;                               \
     }
