@@ -47,10 +47,19 @@ constexpr int RAW_ROWS = 12;                    // window rows the fast path hol
 constexpr int NQ_MAX = 8;                       // 16-pixel groups of the densely packed window kept in registers at a time (144 pixels; typical
                                                 // windows: 110-121 / 81 pixels; larger ones take a second round): 78 VGPRs,
                                                 // 6 waves per SIMD
-constexpr int RAW_MSH = RAW_ROWS * 16 + 8;      // halfs per patch pixel (+8: 16-byte skew between pixels)
-constexpr int RAW_HALFS = 9 * RAW_MSH;          // 1800
+// halfs per patch pixel: 102 dwords = 6 (mod 32), so the 16 lanes of a ds_write_b64 group (patch pixels n = 0..15 of
+// one MFMA D tile, 2 banks each) cover all 32 banks exactly once (with the earlier 100 dwords the stores were 3-way
+// conflicted: 112 of 296 LDS cycles per edge)
+constexpr int RAW_MSH = RAW_ROWS * 16 + 12;
+constexpr int RAW_HALFS = 9 * RAW_MSH;          // 1836
 constexpr int OUT_HALFS = 896;                  // the staged output row: 882 halfs, linear (the copy-out needs no index math)
-constexpr int WAVE_LDS_BYTES = RAW_HALFS * 2 + OUT_HALFS * 2;  // 5,392 B per wave
+constexpr int WAVE_LDS_BYTES = RAW_HALFS * 2 + OUT_HALFS * 2;  // wide kernel: raw volume + staged row
+// product kernel: the staged row re-uses the raw volume (written after the last blend has read it); the D-tile lanes
+// that are not patch pixels (n >= 9) store into a 512-byte dump on the banks the same lanes of a full 16-row layout
+// would use
+constexpr int DUMP_OFF_B = 3712;                // >= RAW_HALFS * 2, a multiple of 128 B (bank 0)
+constexpr int WAVE_LDS2_BYTES = DUMP_OFF_B + 512;
+static_assert(RAW_HALFS * 2 <= DUMP_OFF_B && OUT_HALFS * 2 <= RAW_HALFS * 2, "LDS layout");
 
 typedef _Float16 cdv_half4 __attribute__((ext_vector_type(4)));
 typedef _Float16 cdv_half2 __attribute__((ext_vector_type(2)));
@@ -483,8 +492,8 @@ __global__ __launch_bounds__(256) void corr_fused2_kernel(const CorrArgs2 a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  _Float16* raw = reinterpret_cast<_Float16*>(smem_raw + (size_t)wave * WAVE_LDS_BYTES);
-  _Float16* outT = raw + RAW_HALFS;
+  _Float16* raw = reinterpret_cast<_Float16*>(smem_raw + (size_t)wave * WAVE_LDS2_BYTES);
+  _Float16* outT = raw;   // the staged output row takes the place of the raw volume once both blends are done
   const int p = (((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3)) * 4 + wave;
   if (p >= a.E) return;  // no block-wide barriers below: waves are independent
   const int e = a.order ? __builtin_amdgcn_readfirstlane(a.order[p]) : p;   // wave-uniform
@@ -559,9 +568,11 @@ __global__ __launch_bounds__(256) void corr_fused2_kernel(const CorrArgs2 a) {
   CDV_STAMP(corr, p, 1);
 
   _Float16 res0[7], res1[7];
-  // lanes n >= 9 of the D tile are not patch pixels: they store into the (not yet used) staging area instead of
-  // being masked off (no EXEC save/restore around every store)
-  _Float16* raw_lane = (n < 9) ? raw + n * RAW_MSH + 4 * g : outT + ((n - 9) * 4 + g) * 4;
+  // lanes n >= 9 of the D tile are not patch pixels: they store into the dump area instead of being masked off
+  // (no EXEC save/restore around every store)
+  _Float16* raw_lane = (n < 9) ? raw + n * RAW_MSH + 4 * g
+                               : reinterpret_cast<_Float16*>(reinterpret_cast<char*>(raw) + DUMP_OFF_B +
+                                                             4 * ((n * (RAW_MSH / 2) + 2 * g) & 31));
 
   // ---- round trip 2: EVERY window group of a level is requested before its first MFMA; the level-1 request goes out
   // as soon as level 0 has left the registers and flies under the level-0 blend -------------------------------------
@@ -657,6 +668,7 @@ __global__ __launch_bounds__(256) void corr_fused2_kernel(const CorrArgs2 a) {
 #undef CDV2_MFMA_LEVEL
 
   // ---- stage the edge's output row [x][y][m][lev] in LDS, then 16-byte-per-lane stores ------------------------------
+  wave_lds_sync();   // the row overwrites the raw volume: keep the stores behind the last blend's reads
   if (lane < 63 && !CDV_EXP(512)) {
     if (NLEV == 2) {
       uint32_t* o32 = reinterpret_cast<uint32_t*>(outT) + ((bxo << 6) - bxo) + bm;   // dword (x, y, m) = 63 x + 9 y + m
@@ -959,7 +971,7 @@ extern "C" int cdv_corr_fused(const void* gmap, const void* fmap0_nhwc, const vo
   const uint32_t jmagic = jmod > 1 ? (uint32_t)((((uint64_t)1 << 32) + (uint64_t)jmod - 1) / (uint64_t)jmod) : 0u;
   if (E == 0) return CDV_OK;
   CDV_REQUIRE(nlev == 1 || ex1 >= ex0, CDV_ERR_UNSUPPORTED, "cdv_corr_fused: level 1 must not be finer than level 0");
-  const size_t smem = 4 * (size_t)WAVE_LDS_BYTES;
+  const size_t smem = 4 * (size_t)(C <= 32 ? WAVE_LDS2_BYTES : WAVE_LDS_BYTES);
   static const int exp = getenv("CDV_CORR_EXP") ? atoi(getenv("CDV_CORR_EXP")) : 0;  // diagnostics only
   hipStream_t s = (hipStream_t)stream;
   if (C <= 32) {
