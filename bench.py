@@ -192,7 +192,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "corr_fused_kernel<1>", "avg_launch_ms": corr_ms, "algorithmic_bytes": corr_bytes,
+                "kernel": "corr_fused2_kernel<24, 2>", "avg_launch_ms": corr_ms, "algorithmic_bytes": corr_bytes,
             },
             "stages_us": stages,
             "per_rank": per_rank,

@@ -25,7 +25,7 @@ def main():
     fe, wr = per_kernel(d_fetch, "FETCH_SIZE"), per_kernel(d_write, "WRITE_SIZE")
     out = {}
     for name in fe:
-        short = ("corr_fused" if "corr_fused_kernel" in name else "nchw_to_nhwc" if "nchw_to_nhwc" in name else None)
+        short = ("corr_fused" if "corr_fused" in name else "nchw_to_nhwc" if "nchw_to_nhwc" in name else None)
         if short is None:
             continue
         f = sorted(fe[name])[len(fe[name]) // 2]
