@@ -73,7 +73,7 @@ inline BaLayout ba_layout(int64_t U_max, int N_max) {
   L.zero_bytes = o;
   L.q = o;    o = align256(o + sizeof(float) * (size_t)L.U_stride);
   L.dX = o;   o = align256(o + sizeof(float) * (n6 + 8));
-  L.info = o; o = align256(o + sizeof(int32_t) * 16);
+  L.info = o; o = align256(o + sizeof(int32_t) * 16 + sizeof(uint64_t) * 64);   // 16 words + the 64 dX granules of the solve -> retract hand-off
   L.npad = 0; L.Abig = o;
   if (N_max > BA_NMAX) {   // working copy of [S ; y^T] for the blocked Cholesky, padded with identity to 64-blocks
     L.npad = (int64_t)((n6 + CNB - 1) / CNB * CNB);
@@ -508,7 +508,8 @@ __device__ __forceinline__ void schur_body(const SchurArgs& A, int chunk, int nt
 
 __global__ __launch_bounds__(1024) void ba_schur_kernel(SchurArgs A) {
   if (A.gmeta[GM_ERROR] || A.info[1]) return;
-  if (blockIdx.x == 0 && threadIdx.x == 0) A.info[8] = 0;   // hand-off flag of the following solve + retract launch
+  // the dX granules {tag, value} of the following solve + retract launch (its retract workgroups poll the tags)
+  if (blockIdx.x == 0 && threadIdx.x < 64) reinterpret_cast<uint64_t*>(A.info + 16)[threadIdx.x] = 0ull;
   extern __shared__ float smem[];
   schur_body(A, (int)blockIdx.x, (int)blockDim.x, smem);
 }
@@ -739,12 +740,12 @@ __device__ __forceinline__ float readlane_f(float v, int l) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
 
-// publish != nullptr: dX is handed to the retract workgroups of the SAME launch (ba_solve60_retract_kernel): written
-// with write-through (sc1) stores, drained, then the flag -- the hand-off recipe of the CDNA programming guide.
+// publish != nullptr: dX is handed to the retract workgroups of the SAME launch (ba_solve60_retract_kernel) as tagged
+// 8-byte granules (below).
 __device__ __forceinline__ void solve60_body(float* __restrict__ poses, float* __restrict__ sy, int sy_stride,
                                              float* __restrict__ dXg, int t0, int N,
                                              const int32_t* __restrict__ gmeta, float* __restrict__ dbg,
-                                             int32_t* __restrict__ info, int32_t* publish) {
+                                             int32_t* __restrict__ info, uint64_t* publish) {
   __shared__ __attribute__((aligned(16))) float A[(SN + 1) * SLD];
   __shared__ float xs[64];
   const int n = 6 * N;
@@ -861,16 +862,16 @@ __device__ __forceinline__ void solve60_body(float* __restrict__ poses, float* _
   }
   CDV_STAMP(ba, sslot, 3);
   if (lane < n) {
-    if (publish) __hip_atomic_store(&dXg[lane], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else dXg[lane] = x;
+    // the data IS the flag: one 8-byte {tag = 1, value} granule per unknown, written through (an agent-scope atomic
+    // store); the retract workgroups poll the tags of the granules they read -- no drain, no separate flag word, and
+    // their poll is the load of dX (CDNA programming guide, Guideline 16, recipe R2)
+    if (publish)
+      __hip_atomic_store(&publish[lane], (1ull << 32) | (uint64_t)(uint32_t)__float_as_int(x), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    dXg[lane] = x;
     if (dbg) dbg[n * n + n + lane] = x;
   }
   if (lane == 0) info[0] = badk;
-  if (publish) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    if (lane == 0) __hip_atomic_store(publish, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
   // the pose retraction (sin / cos of the update) runs in ba_retract_kernel, next to the depth updates, instead of
   // lengthening this single-wave critical path
   (void)poses; (void)t0; (void)xs;
@@ -887,14 +888,14 @@ __global__ __launch_bounds__(256) void ba_solve60_kernel(float* __restrict__ pos
 
 // Solve + retract in ONE launch (N <= 10).  Workgroup 0 is the single-wave solver; workgroups 1.. are the retract
 // workgroups: while the solver runs they load their patches' E columns, C, u, q and depth into registers and re-zero
-// the accumulators, then wait on a flag for dX (one polling lane per workgroup, bounded), and finish with 60 FMAs per
+// the accumulators, then poll the tagged dX granules (one wave per workgroup, bounded), and finish with 60 FMAs per
 // patch.  The retract launch's start-up latency and its memory round trips hide under the solver instead of following
-// it.  All workgroups are co-resident (a few dozen on 256 CUs), so the wait cannot deadlock; the flag is reset by the
-// preceding schur launch.
+// it.  All workgroups are co-resident (a few dozen on 256 CUs), so the wait cannot deadlock; the granules are reset by
+// the preceding schur launch.
 __global__ __launch_bounds__(256) void ba_solve60_retract_kernel(float* __restrict__ poses, float* __restrict__ sy,
                                                                  int sy_stride, float* __restrict__ dXg, int t0, int N,
                                                                  const int32_t* __restrict__ gmeta, float* __restrict__ dbg,
-                                                                 int32_t* __restrict__ info, int32_t* __restrict__ flag,
+                                                                 int32_t* __restrict__ info, uint64_t* __restrict__ gran,
                                                                  float* __restrict__ patches, int P,
                                                                  const int64_t* __restrict__ kx, float* __restrict__ Cg,
                                                                  float* __restrict__ ug, const float* __restrict__ qg,
@@ -902,7 +903,7 @@ __global__ __launch_bounds__(256) void ba_solve60_retract_kernel(float* __restri
                                                                  float* __restrict__ dbgp) {
   if (gmeta[GM_ERROR] || info[1]) return;
   if (blockIdx.x == 0) {
-    solve60_body(poses, sy, sy_stride, dXg, t0, N, gmeta, dbg, info, flag);
+    solve60_body(poses, sy, sy_stride, dXg, t0, N, gmeta, dbg, info, gran);
     return;
   }
   __shared__ float sdx[64];
@@ -936,16 +937,20 @@ __global__ __launch_bounds__(256) void ba_solve60_retract_kernel(float* __restri
     d0 = pk[0];                      // patch_retr_kernel reads pixel [0][0]   ba_cuda.cu:218
   }
   // ---- wait for the solver (bounded: a lost hand-off must not hang the device) ------------------------
-  if (t == 0) {
-    int spins = 0;
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1 && spins < (1 << 22)) {
-      __builtin_amdgcn_s_sleep(4);
-      spins++;
+  if (t < 64) {   // wave 0: lane t polls the granule of unknown t until its tag shows up; the poll is the load of dX
+    float xv = 0.f;
+    bool ok = t >= 6 * N;
+    for (int spins = 0; spins < (1 << 22); spins++) {
+      if (!ok) {
+        const uint64_t g = __hip_atomic_load(&gran[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)(g >> 32) == 1u) { xv = __int_as_float((int)(uint32_t)g); ok = true; }
+      }
+      if (__all(ok)) break;
+      __builtin_amdgcn_s_sleep(2);
     }
-    if (spins >= (1 << 22)) info[2] = 1;
+    if (!ok) info[2] = 1;   // bounded: a lost hand-off must not hang the device
+    sdx[t] = xv;
   }
-  __syncthreads();
-  if (t < 64) sdx[t] = (t < 6 * N) ? __hip_atomic_load(&dXg[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
   __syncthreads();
   // ---- pose_retr_kernel (ba_cuda.cu:178-206): the last workgroup's first N lanes --------------------------
   if (blockIdx.x == gridDim.x - 1 && t < N) {
@@ -1448,7 +1453,7 @@ extern "C" int cdv_ba_forward(float* poses, float* patches, const float* intrins
   }
   if (fresh) {
     CDV_HIP_CHECK(hipMemsetAsync(b + L.sy, 0, L.zero_bytes, s));
-    CDV_HIP_CHECK(hipMemsetAsync(info, 0, sizeof(int32_t) * 16, s));
+    CDV_HIP_CHECK(hipMemsetAsync(info, 0, sizeof(int32_t) * 16 + sizeof(uint64_t) * 64, s));
   }
 
   const int n_chunks = cdv_div_up(L.U_max, BA_CHUNK);
@@ -1506,7 +1511,7 @@ extern "C" int cdv_ba_forward(float* poses, float* patches, const float* intrins
         // solve + retract in one launch (dbg layout as below)
         float* dbgq = d ? d + (size_t)n6i * n6i + 2 * n6i : nullptr;
         hipLaunchKernelGGL(ba_solve60_retract_kernel, dim3(1 + cdv_div_up(L.U_max, 256)), dim3(256), 0, s, poses, sy,
-                           (int)L.sy_stride, dXg, t0, N, gv.meta, d, info, info + 8, patches, P, gv.kx, Cg, ug, qg, Edg,
+                           (int)L.sy_stride, dXg, t0, N, gv.meta, d, info, reinterpret_cast<uint64_t*>(info + 16), patches, P, gv.kx, Cg, ug, qg, Edg,
                            (int)L.U_stride, dbgq);
         CDV_LAUNCH_CHECK();
         continue;
