@@ -752,6 +752,51 @@ __device__ __forceinline__ void solve60_body(float* __restrict__ poses, float* _
   const int T = 256, t = threadIdx.x;
   CDV_IF_STAMPS(const int sslot = 4096 + (t >> 6);)
   CDV_STAMP(ba, sslot, 0);
+  typedef float cdv_float2 __attribute__((ext_vector_type(2)));
+  cdv_float2 a2[SN / 2];
+  const bool direct = (n == SN);
+  if (direct) {
+    // Full system (N = 10, the steady state): lane r of wave 0 loads row r of every copy of [S | y] (row 60 = the
+    // right-hand side) straight into its registers -- 60 independent 16-byte loads, ONE memory round trip, no LDS
+    // staging, no index arithmetic -- sums them and damps its own diagonal entry (ba_cuda.cu:589).  The other three
+    // waves re-zero the copies for the next iteration once wave 0 holds them.
+    if (t < 64) {
+      const int row = min(t, SN);
+      const float* rp = sy + (size_t)row * SN;
+      cdv_float4 v[BA_REPL][SN / 4];
+#pragma unroll
+      for (int rep = 0; rep < BA_REPL; rep++)
+#pragma unroll
+        for (int c4 = 0; c4 < SN / 4; c4++)
+          v[rep][c4] = *reinterpret_cast<const cdv_float4*>(rp + (size_t)rep * sy_stride + 4 * c4);
+#pragma unroll
+      for (int c4 = 0; c4 < SN / 4; c4++) {
+        cdv_float4 sum = v[0][c4];
+#pragma unroll
+        for (int rep = 1; rep < BA_REPL; rep++) sum += v[rep][c4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          float sv = sum[c];
+          if (row == 4 * c4 + c) sv += 1e-4f * sv + 1.0f;      // S += I * (1e-4 * S + 1.0)   ba_cuda.cu:589
+          sum[c] = sv;
+        }
+        if (dbg && t <= SN) *reinterpret_cast<cdv_float4*>(dbg + (size_t)row * SN + 4 * c4) = sum;
+        a2[2 * c4] = cdv_float2{sum[0], sum[1]};
+        a2[2 * c4 + 1] = cdv_float2{sum[2], sum[3]};
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every copy is in registers before the barrier releases the zeroing
+    }
+    __syncthreads();
+    if (t >= 64) {
+      const int total4 = (SN * SN + SN) / 4;   // 915
+      const cdv_float4 z4 = {0.f, 0.f, 0.f, 0.f};
+      for (int i4 = t - 64; i4 < total4; i4 += T - 64)
+#pragma unroll
+        for (int rep = 0; rep < BA_REPL; rep++)
+          *reinterpret_cast<cdv_float4*>(sy + (size_t)rep * sy_stride + 4 * i4) = z4;
+      return;
+    }
+  } else
   // [S | y]: the BA_REPL copies are summed on the way in (one memory round trip: all loads of a thread are issued
   // before the first use), re-zeroed for the next iteration, damped (ba_cuda.cu:589) and laid out as rows in LDS.
   {
@@ -797,19 +842,19 @@ __device__ __forceinline__ void solve60_body(float* __restrict__ poses, float* _
       }
     }
   }
-  __syncthreads();
+  if (!direct) __syncthreads();
   CDV_STAMP(ba, sslot, 1);
   if (t >= 64) return;   // one wave from here on (no block-wide barrier below)
   const int lane = t;
   const int myrow = min(lane, SN);   // lanes 61..63 shadow the right-hand-side row
   // the row as 30 float2 registers: the rank-1 updates of a column step run two columns per v_pk_fma_f32
-  typedef float cdv_float2 __attribute__((ext_vector_type(2)));
-  cdv_float2 a2[SN / 2];
+  if (!direct) {
 #pragma unroll
-  for (int c4 = 0; c4 < SN / 4; c4++) {
-    const cdv_float4 q = *reinterpret_cast<const cdv_float4*>(&A[myrow * SLD + 4 * c4]);
-    a2[2 * c4] = cdv_float2{q[0], q[1]};
-    a2[2 * c4 + 1] = cdv_float2{q[2], q[3]};
+    for (int c4 = 0; c4 < SN / 4; c4++) {
+      const cdv_float4 q = *reinterpret_cast<const cdv_float4*>(&A[myrow * SLD + 4 * c4]);
+      a2[2 * c4] = cdv_float2{q[0], q[1]};
+      a2[2 * c4 + 1] = cdv_float2{q[2], q[3]};
+    }
   }
   int badk = 0;
 #pragma unroll
