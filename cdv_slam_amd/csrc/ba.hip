@@ -45,7 +45,8 @@ constexpr int PAIR_LDS_FLOATS = 128 * XLD + 64;  // per wave: [128][XLD] rows + 
 constexpr int ELD = BA_CHUNK + 4; // row stride of the chunk's E block in LDS (2-way bank conflicts at most)
 constexpr int ASM_WAVES = 1;      // waves per assemble workgroup, one target slot each (the waves are independent;
                                   // single-wave workgroups spread the atomics of the busy chunks over all CUs)
-constexpr int ASM_SG = 32;        // slot groups (workgroups) per chunk of 64 patches: 32 slots per pass
+constexpr int ASM_SG = 32;        // slot groups (workgroups) per chunk of 64 patches: 32 slots per pass (48, one pass for every patch of the
+                                  // steady-state graph, measured: no change)
 constexpr int ASM_THREADS = 64 * ASM_WAVES;
 constexpr int BA_REPL = 4;        // copies of [S | y] the assemble / schur workgroups spread their atomics over
                                   // (the memory-side atomic units serialise adds to one address); summed by the solve
@@ -755,20 +756,26 @@ __device__ __forceinline__ void solve60_body(float* __restrict__ poses, float* _
   typedef float cdv_float2 __attribute__((ext_vector_type(2)));
   cdv_float2 a2[SN / 2];
   const bool direct = (n == SN);
+  if (!direct && (gmeta[GM_ERROR] || info[1])) return;
   if (direct) {
     // Full system (N = 10, the steady state): lane r of wave 0 loads row r of every copy of [S | y] (row 60 = the
     // right-hand side) straight into its registers -- 60 independent 16-byte loads, ONE memory round trip, no LDS
     // staging, no index arithmetic -- sums them and damps its own diagonal entry (ba_cuda.cu:589).  The other three
     // waves re-zero the copies for the next iteration once wave 0 holds them.
+    const int row = min(t, SN);
+    cdv_float4 v[BA_REPL][SN / 4];
     if (t < 64) {
-      const int row = min(t, SN);
       const float* rp = sy + (size_t)row * SN;
-      cdv_float4 v[BA_REPL][SN / 4];
 #pragma unroll
       for (int rep = 0; rep < BA_REPL; rep++)
 #pragma unroll
         for (int c4 = 0; c4 < SN / 4; c4++)
           v[rep][c4] = *reinterpret_cast<const cdv_float4*>(rp + (size_t)rep * sy_stride + 4 * c4);
+    }
+    // the error words are looked at AFTER the loads are on their way (one round trip instead of two; the loads are
+    // harmless either way); uniform over the workgroup
+    if (gmeta[GM_ERROR] || info[1]) return;
+    if (t < 64) {
 #pragma unroll
       for (int c4 = 0; c4 < SN / 4; c4++) {
         cdv_float4 sum = v[0][c4];
@@ -927,8 +934,7 @@ __global__ __launch_bounds__(256) void ba_solve60_kernel(float* __restrict__ pos
                                                          int sy_stride, float* __restrict__ dXg, int t0, int N,
                                                          const int32_t* __restrict__ gmeta, float* __restrict__ dbg,
                                                          int32_t* __restrict__ info) {
-  if (gmeta[GM_ERROR] || info[1]) return;
-  solve60_body(poses, sy, sy_stride, dXg, t0, N, gmeta, dbg, info, nullptr);
+  solve60_body(poses, sy, sy_stride, dXg, t0, N, gmeta, dbg, info, nullptr);   // looks at the error words itself
 }
 
 // Solve + retract in ONE launch (N <= 10).  Workgroup 0 is the single-wave solver; workgroups 1.. are the retract
@@ -946,11 +952,11 @@ __global__ __launch_bounds__(256) void ba_solve60_retract_kernel(float* __restri
                                                                  float* __restrict__ ug, const float* __restrict__ qg,
                                                                  float* __restrict__ Edg, int U_stride,
                                                                  float* __restrict__ dbgp) {
-  if (gmeta[GM_ERROR] || info[1]) return;
   if (blockIdx.x == 0) {
-    solve60_body(poses, sy, sy_stride, dXg, t0, N, gmeta, dbg, info, gran);
+    solve60_body(poses, sy, sy_stride, dXg, t0, N, gmeta, dbg, info, gran);   // looks at the error words itself
     return;
   }
+  if (gmeta[GM_ERROR] || info[1]) return;
   __shared__ float sdx[64];
   const int U = gmeta[GM_U];
   const int PP = P * P;
