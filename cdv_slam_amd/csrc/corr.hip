@@ -5,16 +5,18 @@
 // by four ATen slice-multiply-add passes), then torch.stack of the two levels (slam.py:323).
 //
 // Here (cdv_corr_fused): ONE launch for both pyramid levels.  One wave per edge:
-//   * the 3x3x24 patch tile is the MFMA A operand (9 of 16 rows used), gathered once per edge;
-//   * the union window of the 9 patch pixels (<= 16x16 feature pixels, typically 10x10) is the B
-//     operand, loaded straight from a CHANNELS-LAST feature ring (one pixel = C contiguous halves, so
-//     a lane's 8 k-values are one 16-byte load -- no LDS staging of the inputs at all);
-//   * v_mfma_f32_16x16x32_f16 produces, per window row, the 16 x 9 correlations (f32 accumulate);
-//   * all window rows of BOTH levels are requested before the first MFMA (two dependent memory round
-//     trips per edge in total: indices+coordinates, then patch tile + windows);
-//   * the raw volume lives only in LDS (f16 like the reference's, 3.6 KB per wave); the 8x8 -> 7x7
-//     bilinear blend of every patch pixel reads it back with its own sub-pixel offset, separably;
-//   * the [882]-half row of the edge is staged in LDS and leaves as 256-byte coalesced stores.
+//   * the union window of the 9 patch pixels (<= 16 x 12 feature pixels, typically 10 x 11) is packed densely into the
+//     16 pixel slots of the MFMA A operand, loaded straight from a CHANNELS-LAST padded feature ring (one pixel = C
+//     contiguous halves, so a lane's 8 k-values are one 16-byte buffer load; the descriptor's range check and the zero
+//     margins give the reference's out-of-bounds rule -- no LDS staging of the inputs, no masks);
+//   * the 3x3xC patch tile is the B operand (9 of 16 columns used), one 16-byte load from the pixel-major tile;
+//   * v_mfma_f32_16x16x32_f16 produces 16 window pixels x 9 patch pixels per instruction (f32 accumulate);
+//   * every window group of a level is requested before its first MFMA, the level-1 request flies under the level-0
+//     blend (two dependent memory round trips per edge: indices + coordinates, then patch tile + windows);
+//   * the raw volume lives only in LDS (f16 like the reference's, 3.7 KB per wave, conflict-free row stride); the
+//     8x8 -> 7x7 bilinear blend of every patch pixel reads it back with its own sub-pixel offset, separably;
+//   * the [882]-half row of the edge is staged in LDS (over the raw volume) and leaves as 16-byte-per-lane stores.
+// corr_fused2_kernel is the product kernel (C <= 32: CDV-SLAM's DIMF = 24); corr_wide_kernel serves C up to 128 (DPVO).
 // Algorithmic HBM bytes per edge: 1764 out + 72 coords + 16 idx (+ the feature maps once): DESIGN.md.
 #include <math.h>
 #include <stdlib.h>
