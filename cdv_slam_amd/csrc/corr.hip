@@ -489,25 +489,15 @@ __device__ __forceinline__ LevelParams level_params(const CorrLevel& L) {
   return LevelParams{reinterpret_cast<const _Float16*>(L.base_m + (size_t)FBIAS), L.H, L.W, L.inv_scale, L.shift};
 }
 
+// one edge; its first round trip (coordinates: lane l < 18 holds value l; indices) was issued by the caller
 template <int CC, int NLEV>
-__global__ __launch_bounds__(256) void corr_fused2_kernel(const CorrArgs2 a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  _Float16* raw = reinterpret_cast<_Float16*>(smem_raw + (size_t)wave * WAVE_LDS2_BYTES);
-  _Float16* outT = raw;   // the staged output row takes the place of the raw volume once both blends are done
-  const int p = (((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3)) * 4 + wave;
-  if (p >= a.E) return;  // no block-wide barriers below: waves are independent
-  const int e = a.order ? __builtin_amdgcn_readfirstlane(a.order[p]) : p;   // wave-uniform
+__device__ __forceinline__ void corr_edge(const CorrArgs2& a, int p, int e, int cval, int64_t k64, int64_t j64, int lane,
+                                          _Float16* __restrict__ raw, _Float16* __restrict__ outT) {
   CDV_STAMP(corr, p, 0);
   const int C = CC ? CC : a.C;
 #ifdef CDV_STAMPS
   const int exp = a.exp;
 #endif
-
-  // ---- round trip 1: the 18 coordinates (one vector load, lane l < 18 holds value l) and the two indices ----------
-  const int cval = __float_as_int(a.coords[(size_t)e * 18 + min(lane, 17)]);
-  const int64_t k64 = a.kk[e], j64 = a.jj[e];
   const int mm = lane < 9 ? lane : 0;       // row 0 of the wave: lanes 0..8 own patch pixel m, 9..15 mirror 0
   const int bm = min(lane / 7, 8), bxo = lane - 7 * (lane / 7);  // blend role of this lane: (m, x offset)
   const int n = lane & 15, g = lane >> 4;
@@ -711,6 +701,24 @@ __global__ __launch_bounds__(256) void corr_fused2_kernel(const CorrArgs2 a) {
     }
   }
   CDV_STAMP(corr, p, 8);
+}
+
+template <int CC, int NLEV>
+__global__ __launch_bounds__(256) void corr_fused2_kernel(const CorrArgs2 a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  _Float16* raw = reinterpret_cast<_Float16*>(smem_raw + (size_t)wave * WAVE_LDS2_BYTES);
+  _Float16* outT = raw;   // the staged output row takes the place of the raw volume once both blends are done
+  // workgroup b runs on XCD b % 8 and takes 4 consecutive edges of the b % 8-th contiguous eighth of the list.  (Two or
+  // three edges per wave, the next edge's coordinates and indices prefetched under the one in progress: measured
+  // 10 % slower -- fewer, longer waves.)
+  const int p0 = (((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3)) * 4 + wave;
+  if (p0 >= a.E) return;  // no block-wide barriers below: waves are independent
+  // ---- round trip 1: the 18 coordinates (one vector load) and the two indices (scalar loads) -----------------------
+  const int e = a.order ? __builtin_amdgcn_readfirstlane(a.order[p0]) : p0;   // wave-uniform
+  const int cval = __float_as_int(a.coords[(size_t)e * 18 + min(lane, 17)]);
+  corr_edge<CC, NLEV>(a, p0, e, cval, a.kk[e], a.jj[e], lane, raw, outT);
 }
 
 // ---- generic per-level kernel: planar layouts, any C / P / radius, f16 or f32 ----------------------
