@@ -352,6 +352,44 @@ def test_corr_edge_cases():
     assert np.abs(got16[0].float().cpu().numpy() - want).max() <= _corr_tol(want)
 
 
+@pytest.mark.parametrize("C", [8, 16, 32])
+def test_corr_two_levels_other_widths(C):
+    """the two-level kernel with a run-time feature width (the build for DIMF = 24 is specialised), planar and
+    pixel-major tiles, ring indices that wrap (kk % kmod, jj % jmod, slam.py:319-320) and indices out of range (zeros)"""
+    rng = np.random.default_rng(20 + C)
+    N2, H, W, Ng, M = 5, 24, 32, 12, 300
+    f1 = (rng.standard_normal((N2, C, H, W)) / 4).astype(np.float16)
+    f2 = f1.reshape(N2, C, H // 4, 4, W // 4, 4).astype(np.float32).mean((3, 5)).astype(np.float16)
+    gmap = (rng.standard_normal((Ng, C, 3, 3)) / 4).astype(np.float16)
+    coords = np.empty((M, 2, 3, 3), np.float32)
+    cx, cy = rng.uniform(-6, W + 6, M), rng.uniform(-6, H + 6, M)
+    sc = rng.uniform(0.3, 2.5, M)
+    off = np.arange(3.0) - 1
+    coords[:, 0] = cx[:, None, None] + sc[:, None, None] * off[None, None, :]
+    coords[:, 1] = cy[:, None, None] + sc[:, None, None] * off[None, :, None]
+    kk = rng.integers(0, 5 * Ng, M).astype(np.int64)     # wraps: kk % Ng
+    jj = rng.integers(0, 7 * N2, M).astype(np.int64)     # wraps: jj % N2
+    dev = torch.device(DEV)
+    r1, r2 = ops.alloc_fmap_ring(N2, C, H, W, dev), ops.alloc_fmap_ring(N2, C, H // 4, W // 4, dev)
+    ops.fmap_interior(r1).copy_(T(f1).permute(0, 2, 3, 1))
+    ops.fmap_interior(r2).copy_(T(f2).permute(0, 2, 3, 1))
+    truth = O.slam_corr(gmap, f1, f2, coords, kk % Ng, jj % N2, 3, "truth")
+    tol = _corr_tol(truth)
+    pm = ops.gmap_to_pixel_major(T(gmap))
+    a = ops.corr_fused(T(gmap), r1, r2, T(coords)[None], T(kk), T(jj), kmod=Ng, jmod=N2)
+    b = ops.corr_fused(pm, r1, r2, T(coords)[None], T(kk), T(jj), kmod=Ng, jmod=N2, pixel_major=True)
+    assert torch.equal(a, b)
+    assert np.abs(a[0].float().cpu().numpy() - truth).max() <= tol
+    # without the modulus the indices beyond the rings are invalid: those rows are zero, the others unchanged
+    c = ops.corr_fused(pm, r1, r2, T(coords)[None], T(kk), T(jj), pixel_major=True)[0].float().cpu().numpy()
+    ok = (kk < Ng) & (jj < N2)
+    assert ok.any() and (~ok).any()
+    assert np.all(c[~ok] == 0) and np.array_equal(c[ok], b[0].float().cpu().numpy()[ok])
+    neg = kk.copy(); neg[::3] = -1 - neg[::3]
+    d = ops.corr_fused(pm, r1, r2, T(coords)[None], T(neg), T(jj), kmod=Ng, jmod=N2, pixel_major=True)[0].float().cpu().numpy()
+    assert np.all(d[::3] == 0) and np.array_equal(d[1::3], b[0].float().cpu().numpy()[1::3])
+
+
 def test_corr_c128():
     """DPVO feature width (DIMF = 128, net_dpv.py:99): four MFMA k-steps"""
     rng = np.random.default_rng(9)
