@@ -32,6 +32,7 @@ SIGNATURES = {
     "cdv_edges_remove": (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                 _vp, _vp, _vp, _i64, _vp, _vp]),
     "cdv_edges_keyframe_shift": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "cdv_frames_keyframe_shift": (_i32, [_vp, _i32, _i32, _i32, _vp]),
     "cdv_flow_mag": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp]),
     "cdv_point_cloud": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "cdv_transform": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -49,6 +50,14 @@ SIGNATURES = {
                               _i64, _vp, _vp]),
     "cdv_lie_op": (_i32, [_i32, _i32, _i32, _i64, _vp, _vp, _vp, _vp]),
 }
+
+class FrameBuf(ctypes.Structure):
+    """cdv_frame_buf (include/cdvslam_hip.h): one per-frame buffer of cdv_frames_keyframe_shift"""
+    _fields_ = [("base", ctypes.c_void_p), ("slot_bytes", ctypes.c_int64), ("modulus", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
+
+
+MAX_FRAME_BUFS = 16
 
 _lib = None
 

@@ -233,6 +233,65 @@ extern "C" int cdv_edges_remove(const uint8_t* remove, int64_t E, void* ws, cons
   return CDV_OK;
 }
 
+// keyframe(): frame k leaves and every per-frame buffer moves frames k + 1 .. n - 1 down by one (slam.py:431-441: a
+// Python loop of nine tensor copies per frame).  One launch: a thread owns one 16-byte (or 4-byte) piece of a slot and
+// walks the frames in the reference's order, buf[i % m] = buf[(i + 1) % m] for i = k .. n - 2 -- the chains of different
+// pieces are independent, so ring buffers that wrap (fmap / gmap rings, m < n) come out exactly as the sequential loop
+// leaves them.
+struct FrameBufs {
+  cdv_frame_buf b[CDV_MAX_FRAME_BUFS];
+  int64_t first[CDV_MAX_FRAME_BUFS + 1];   // prefix sums of the pieces per slot
+  int32_t gran[CDV_MAX_FRAME_BUFS];        // bytes per piece: 16 or 4
+  int n_bufs;
+};
+
+__global__ __launch_bounds__(256) void frames_shift_kernel(const FrameBufs F, int k, int n) {
+  const int64_t total = F.first[F.n_bufs];
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    int bi = 0;
+    while (bi + 1 < F.n_bufs && t >= F.first[bi + 1]) bi++;
+    const int64_t piece = t - F.first[bi];
+    char* base = reinterpret_cast<char*>(F.b[bi].base);
+    const int64_t sb = F.b[bi].slot_bytes;
+    const int m = F.b[bi].modulus;
+    if (F.gran[bi] == 16) {
+      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+      for (int i = k; i < n - 1; i++) {
+        const int64_t d = m > 0 ? i % m : i, s2 = m > 0 ? (i + 1) % m : i + 1;
+        *reinterpret_cast<u32x4*>(base + d * sb + 16 * piece) = *reinterpret_cast<const u32x4*>(base + s2 * sb + 16 * piece);
+      }
+    } else {
+      for (int i = k; i < n - 1; i++) {
+        const int64_t d = m > 0 ? i % m : i, s2 = m > 0 ? (i + 1) % m : i + 1;
+        *reinterpret_cast<uint32_t*>(base + d * sb + 4 * piece) = *reinterpret_cast<const uint32_t*>(base + s2 * sb + 4 * piece);
+      }
+    }
+  }
+}
+
+extern "C" int cdv_frames_keyframe_shift(const cdv_frame_buf* bufs, int n_bufs, int k, int n, void* stream) {
+  CDV_REQUIRE(n_bufs >= 0 && n_bufs <= CDV_MAX_FRAME_BUFS, CDV_ERR_ARG, "cdv_frames_keyframe_shift: too many buffers");
+  CDV_REQUIRE(k >= 0 && n >= 0, CDV_ERR_ARG, "cdv_frames_keyframe_shift: negative frame index");
+  if (n_bufs == 0 || k >= n - 1) return CDV_OK;
+  CDV_REQUIRE(bufs != nullptr, CDV_ERR_ARG, "cdv_frames_keyframe_shift: NULL descriptor array");
+  FrameBufs F;
+  F.n_bufs = n_bufs;
+  F.first[0] = 0;
+  for (int i = 0; i < n_bufs; i++) {
+    const cdv_frame_buf& b = bufs[i];
+    CDV_REQUIRE(b.base != nullptr && b.slot_bytes > 0 && b.slot_bytes % 4 == 0 && b.modulus >= 0 &&
+                    ((uintptr_t)b.base & 3) == 0,
+                CDV_ERR_ARG, "cdv_frames_keyframe_shift: a buffer needs a 4-byte aligned base, slot_bytes % 4 == 0, modulus >= 0");
+    F.b[i] = b;
+    F.gran[i] = (b.slot_bytes % 16 == 0 && ((uintptr_t)b.base & 15) == 0) ? 16 : 4;
+    F.first[i + 1] = F.first[i] + b.slot_bytes / F.gran[i];
+  }
+  hipLaunchKernelGGL(frames_shift_kernel, dim3(grid_of(F.first[n_bufs], 256, 4096)), dim3(256), 0, (hipStream_t)stream, F,
+                     k, n);
+  CDV_LAUNCH_CHECK();
+  return CDV_OK;
+}
+
 extern "C" int cdv_edges_keyframe_shift(int64_t* ii, int64_t* jj, int64_t* kk, int64_t E, int k, int M, void* stream) {
   if (E <= 0) return CDV_OK;
   hipLaunchKernelGGL(edges_shift_kernel, dim3(grid_of(E, 256, 4096)), dim3(256), 0, (hipStream_t)stream, ii, jj, kk, E, k, M);

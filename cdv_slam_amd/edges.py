@@ -126,3 +126,23 @@ class EdgeStore:
         return (torch.cat((self.target_inac[:a][None], self.target), 1), torch.cat((self.weight_inac[:a][None], self.weight), 1),
                 torch.cat((self.ii_inac[:a], self.ii)), torch.cat((self.jj_inac[:a], self.jj)),
                 torch.cat((self.kk_inac[:a], self.kk)))
+
+
+def frames_keyframe_shift(bufs, k, n):
+    """keyframe(): the frame buffers after frame k is dropped (cdvslam/slam.py:431-441) in ONE launch:
+    for i = k .. n - 2: buf[slot(i)] = buf[slot(i + 1)].  bufs: list of (tensor, modulus); the tensor's dim 0 is the
+    slot axis (a frame buffer: modulus 0, slot(i) = i; a ring of m slots: modulus m, slot(i) = i % m).  A tensor whose
+    slots are groups of rows (patches_ viewed as [N * M, ...]) is passed reshaped to [slots, ...]."""
+    import ctypes
+    from . import _lib
+    from .ops import _stream
+    lib = _lib.load()
+    if len(bufs) > _lib.MAX_FRAME_BUFS:
+        raise ValueError("frames_keyframe_shift: more than %d buffers" % _lib.MAX_FRAME_BUFS)
+    arr = (_lib.FrameBuf * max(len(bufs), 1))()
+    for a, (t, m) in zip(arr, bufs):
+        if not t.is_cuda or not t.is_contiguous():
+            raise RuntimeError("frames_keyframe_shift: buffers must be contiguous device tensors")
+        a.base, a.slot_bytes, a.modulus, a.reserved = t.data_ptr(), t[0].numel() * t.element_size(), int(m), 0
+    _lib.check(lib.cdv_frames_keyframe_shift(ctypes.cast(arr, ctypes.c_void_p), len(bufs), int(k), int(n), _stream()),
+               "cdv_frames_keyframe_shift")

@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .edges import EdgeStore
+from .edges import EdgeStore, frames_keyframe_shift
 
 
 class StreamRunner:
@@ -83,15 +83,10 @@ class StreamRunner:
     def _keyframe(self, drop):
         M, n = self.M, self.n
         k = n - self.ki
-        if drop:   # frame k leaves: shift the frame buffers down (slam.py:429-441)
-            self.poses[k:n - 1] = self.poses[k + 1:n].clone()
-            self.intrinsics[k:n - 1] = self.intrinsics[k + 1:n].clone()
-            self.patches[k * M:(n - 1) * M] = self.patches[(k + 1) * M:n * M].clone()
-            for i in range(k, n - 1):
-                self.gmap[(i % self.pmem) * M:(i % self.pmem + 1) * M] = self.gmap[((i + 1) % self.pmem) * M:((i + 1) % self.pmem + 1) * M]
-                self.gmap_pm[(i % self.pmem) * M:(i % self.pmem + 1) * M] = self.gmap_pm[((i + 1) % self.pmem) * M:((i + 1) % self.pmem + 1) * M]
-                self.fmap1[i % self.mem] = self.fmap1[(i + 1) % self.mem]
-                self.fmap2[i % self.mem] = self.fmap2[(i + 1) % self.mem]
+        if drop:   # frame k leaves: every frame buffer shifts down, one launch (slam.py:429-441)
+            frames_keyframe_shift([(self.poses, 0), (self.intrinsics, 0), (self.patches.view(self.N, -1), 0),
+                                   (self.gmap.view(self.pmem, -1), self.pmem), (self.gmap_pm.view(self.pmem, -1), self.pmem),
+                                   (self.fmap1, self.mem), (self.fmap2, self.mem)], k, n)
         self.n = self.edges.keyframe(k, n, M, self.ix, self.rw, drop=drop)
 
     def frame(self, drop=False):

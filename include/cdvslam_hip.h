@@ -295,6 +295,20 @@ int cdv_edges_remove(const uint8_t* remove, int64_t E, void* ws, const int64_t* 
 /* keyframe(): index shift after frame k is dropped (slam.py:425-427): kk[ii > k] -= M; ii[ii > k] -= 1; jj[jj > k] -= 1 */
 int cdv_edges_keyframe_shift(int64_t* ii, int64_t* jj, int64_t* kk, int64_t E, int k, int M, void* stream);
 
+/* keyframe(): the frame buffers after frame k is dropped (slam.py:431-441): for i = k .. n - 2, in this order,
+ * buf[slot(i)] = buf[slot(i + 1)] for every per-frame buffer -- tstamps_, colors_, poses_, patches_, intrinsics_
+ * (modulus 0: slot(i) = i) and the rings imap_, gmap_ (modulus pmem), fmap1_, fmap2_ (modulus mem: slot(i) = i % modulus).
+ * One launch for all of them (the reference: nine tensor copies per shifted frame).  bufs is a HOST array of up to
+ * CDV_MAX_FRAME_BUFS descriptors (device base pointer, 4-byte aligned; bytes per slot, a multiple of 4). */
+#define CDV_MAX_FRAME_BUFS 16
+typedef struct {
+  void* base;
+  int64_t slot_bytes;
+  int32_t modulus;
+  int32_t reserved;
+} cdv_frame_buf;
+int cdv_frames_keyframe_shift(const cdv_frame_buf* bufs, int n_bufs, int k, int n, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * lietorch forward ops  (replaces lietorch_backends.{expm,logm,inv,mul,adj,adjT,act,act4,as_matrix})
  * group ids as the reference: SO3 = 1, SE3 = 3 (lietorch.cpp:286-316, groups.py:236-290).

@@ -109,3 +109,41 @@ def test_stream_runner_end_to_end():
     assert run.n_updates == 70 - 7
     assert torch.isfinite(run.poses[:n]).all() and torch.isfinite(run.patches[:n * 16]).all()
     assert float(run.poses[:n, :3].abs().max()) < 50.0 and float((run.poses[:n, 3:].norm(dim=-1) - 1).abs().max()) < 1e-3
+
+
+@pytest.mark.gpu
+def test_frames_keyframe_shift_matches_the_reference_loop():
+    """cdv_frames_keyframe_shift vs the Python loop of cdvslam/slam.py:431-441 (nine tensor copies per shifted frame):
+    linear frame buffers (28-, 16- and 10,368-byte slots), rings with a modulus that the shift wraps around, an
+    unaligned view, bit-exact"""
+    import torch
+    from cdv_slam_amd.edges import frames_keyframe_shift
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(3)
+    N, M, mem, pmem = 64, 96, 12, 10
+    poses = torch.randn((N, 7), generator=g).to(dev)
+    intr = torch.randn((N, 4), generator=g).to(dev)
+    patches = torch.randn((N * M, 3, 3, 3), generator=g).to(dev)
+    tst = torch.arange(N, dtype=torch.int64).to(dev) * 3 + 1
+    colors = torch.randint(0, 255, (N, M, 3), generator=g, dtype=torch.uint8).to(dev)   # 288-byte slots
+    fmap = torch.randn((mem, 7, 9, 8), generator=g).half().to(dev)
+    gmap = torch.randn((pmem * M, 8, 3, 3), generator=g).half().to(dev)
+    odd = torch.randn((N * 5 + 1,), generator=g).to(dev)[1:].view(N, 5)                 # base only 4-byte aligned
+    for k, n in [(40, 44), (3, 30), (20, 21), (7, 8), (0, 2), (50, 64)]:
+        bufs = [poses, intr, patches, tst, colors, fmap, gmap, odd]
+        want = [b.clone() for b in bufs]
+        wp, wi, wpa, wt, wc, wf, wg, wo = want
+        for i in range(k, n - 1):   # the reference loop, verbatim structure
+            wt[i] = wt[i + 1]
+            wc[i] = wc[i + 1]
+            wp[i] = wp[i + 1]
+            wpa[i * M:(i + 1) * M] = wpa[(i + 1) * M:(i + 2) * M]
+            wi[i] = wi[i + 1]
+            wg[(i % pmem) * M:(i % pmem + 1) * M] = wg[((i + 1) % pmem) * M:((i + 1) % pmem + 1) * M].clone()
+            wf[i % mem] = wf[(i + 1) % mem].clone()
+            wo[i] = wo[i + 1]
+        frames_keyframe_shift([(poses, 0), (intr, 0), (patches.view(N, -1), 0), (tst, 0), (colors, 0), (fmap, mem),
+                               (gmap.view(pmem, -1), pmem), (odd, 0)], k, n)
+        torch.cuda.synchronize()
+        for name, got, w in zip("poses intr patches tstamps colors fmap gmap odd".split(), bufs, want):
+            assert torch.equal(got, w), (name, k, n)
