@@ -25,6 +25,7 @@ SIGNATURES = {
     "cdv_gmap_to_pixel_major": (_i32, [_vp, _vp, _i64, _i32, _i64, _i64, _vp]),
     "cdv_frame_ingest": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i64, _i64, _i64, _vp]),
     "cdv_patchify_fwd": (_i32, [_vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "cdv_patchify_multi": (_i32, [_vp, _i32, _vp, _i64, _vp]),
     "cdv_patchify_blend": (_i32, [_vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "cdv_edges_frame": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp]),
     "cdv_edges_append": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
@@ -58,6 +59,16 @@ class FrameBuf(ctypes.Structure):
 
 
 MAX_FRAME_BUFS = 16
+
+
+class PatchifyJob(ctypes.Structure):
+    """cdv_patchify_job (include/cdvslam_hip.h): one altcorr.patchify call of cdv_patchify_multi"""
+    _fields_ = [("net", ctypes.c_void_p), ("out", ctypes.c_void_p), ("C", ctypes.c_int), ("H", ctypes.c_int),
+                ("W", ctypes.c_int), ("radius", ctypes.c_int), ("mode", ctypes.c_int), ("dtype", ctypes.c_int),
+                ("sx", ctypes.c_float), ("sy", ctypes.c_float), ("ox", ctypes.c_float), ("oy", ctypes.c_float)]
+
+
+MAX_PATCHIFY_JOBS = 8
 
 _lib = None
 

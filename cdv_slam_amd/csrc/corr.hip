@@ -864,7 +864,82 @@ __global__ __launch_bounds__(256) void patchify_blend_kernel(const T* __restrict
   }
 }
 
+// Several altcorr.patchify calls on ONE set of patch centres in one launch: a new frame's imap / gmap / colour / patch
+// tiles (net_cdv.py:355-374).  Job j reads its own map at (coords + o_j) * s_j -- the scaling the reference applies with
+// torch ops before each call (scale_f2i * coords, 4 * (coords + 0.5)), same two float operations -- with its own radius,
+// mode and dtype; workgroups [first[j], first[j + 1]) belong to job j.
+struct PatchifyJobs {
+  cdv_patchify_job j[CDV_MAX_PATCHIFY_JOBS];
+  int first[CDV_MAX_PATCHIFY_JOBS + 1];
+  int n_jobs;
+};
+
+template <typename T>
+__device__ __forceinline__ void patchify_job_body(const cdv_patchify_job& J, const float* __restrict__ coords, int64_t M,
+                                                  int64_t idx0, int64_t stride) {
+  const int R = J.radius, mode = J.mode, C = J.C, H = J.H, W = J.W;
+  const int d = (mode == 2) ? 1 : 2 * R + 1;
+  const int64_t total = M * C * d * d;
+  const T* net = reinterpret_cast<const T*>(J.net);
+  for (int64_t idx = idx0; idx < total; idx += stride) {
+    int64_t t = idx;
+    const int b2 = (int)(t % d); t /= d;
+    const int a2 = (int)(t % d); t /= d;
+    const int ch = (int)(t % C); t /= C;
+    const int64_t m = t;
+    const float x = (coords[m * 2 + 0] + J.ox) * J.sx, y = (coords[m * 2 + 1] + J.oy) * J.sy;
+    const float fxf = floorf(x), fyf = floorf(y);
+    const int i0 = (int)fminf(fmaxf(fyf, -1.0e6f), 1.0e6f) + (a2 - R);
+    const int j0 = (int)fminf(fmaxf(fxf, -1.0e6f), 1.0e6f) + (b2 - R);
+    const T* np = net + (int64_t)ch * H * W;
+    auto tap = [&](int i, int j) -> T { return (i >= 0 && i < H && j >= 0 && j < W) ? np[(int64_t)i * W + j] : (T)0.f; };
+    if (mode == 2) {
+      reinterpret_cast<T*>(J.out)[idx] = tap(i0, j0);
+    } else {
+      const float dx = x - fxf, dy = y - fyf;   // correlation.py:58-66, same operation order
+      const float x00 = (1.0f - dy) * (1.0f - dx) * (float)tap(i0, j0);
+      const float x01 = (1.0f - dy) * dx * (float)tap(i0, j0 + 1);
+      const float x10 = dy * (1.0f - dx) * (float)tap(i0 + 1, j0);
+      const float x11 = dy * dx * (float)tap(i0 + 1, j0 + 1);
+      reinterpret_cast<float*>(J.out)[idx] = ((x00 + x01) + x10) + x11;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void patchify_multi_kernel(const PatchifyJobs P, const float* __restrict__ coords,
+                                                             int64_t M) {
+  int ji = 0;
+  while (ji + 1 < P.n_jobs && (int)blockIdx.x >= P.first[ji + 1]) ji++;
+  const cdv_patchify_job& J = P.j[ji];
+  const int nb = P.first[ji + 1] - P.first[ji];
+  const int64_t idx0 = (int64_t)((int)blockIdx.x - P.first[ji]) * 256 + threadIdx.x, stride = (int64_t)nb * 256;
+  if (J.dtype == CDV_F16) patchify_job_body<_Float16>(J, coords, M, idx0, stride);
+  else patchify_job_body<float>(J, coords, M, idx0, stride);
+}
+
 }  // namespace
+
+extern "C" int cdv_patchify_multi(const cdv_patchify_job* jobs, int n_jobs, const float* coords, int64_t M, void* stream) {
+  CDV_REQUIRE(n_jobs >= 0 && n_jobs <= CDV_MAX_PATCHIFY_JOBS, CDV_ERR_ARG, "cdv_patchify_multi: too many jobs");
+  if (n_jobs == 0 || M == 0) return CDV_OK;
+  CDV_REQUIRE(jobs != nullptr && coords != nullptr && M > 0, CDV_ERR_ARG, "cdv_patchify_multi: NULL argument");
+  PatchifyJobs P;
+  P.n_jobs = n_jobs;
+  P.first[0] = 0;
+  for (int i = 0; i < n_jobs; i++) {
+    const cdv_patchify_job& J = jobs[i];
+    CDV_REQUIRE(J.dtype == CDV_F16 || J.dtype == CDV_F32, CDV_ERR_UNSUPPORTED, "cdv_patchify_multi: dtype must be f16 or f32");
+    CDV_REQUIRE(J.mode == 1 || J.mode == 2, CDV_ERR_ARG, "cdv_patchify_multi: mode 1 (bilinear) or 2 (upperleft)");
+    CDV_REQUIRE(J.net && J.out && J.C > 0 && J.H > 0 && J.W > 0 && J.radius >= 0, CDV_ERR_ARG, "cdv_patchify_multi: bad job");
+    const int d = (J.mode == 2) ? 1 : 2 * J.radius + 1;
+    const int64_t total = M * J.C * d * d;
+    P.j[i] = J;
+    P.first[i + 1] = P.first[i] + (int)(cdv_div_up(total, 256) < 4096 ? cdv_div_up(total, 256) : 4096);
+  }
+  hipLaunchKernelGGL(patchify_multi_kernel, dim3(P.first[n_jobs]), dim3(256), 0, (hipStream_t)stream, P, coords, M);
+  CDV_LAUNCH_CHECK();
+  return CDV_OK;
+}
 
 extern "C" int cdv_patchify_blend(const void* net, const float* coords, void* out, int B, int64_t M, int C, int H, int W,
                                   int radius, int mode, int dtype, void* stream) {

@@ -408,6 +408,43 @@ def patchify_blend(net, coords, radius, mode):
     return out
 
 
+def patchify_multi(jobs, coords):
+    """The altcorr.patchify calls of one new frame (net_cdv.py:355-374) in ONE launch (cdv_patchify_multi).
+    jobs: list of dicts {net [C,H,W] or [1,C,H,W] f16/f32, radius, mode 'bilinear'|'upperleft', scale (sx, sy) or
+    float (default 1), offset (ox, oy) or float (default 0)}: job j = altcorr.patchify(net, (coords + offset) * scale,
+    radius, mode).  coords [1,M,2] or [M,2] f32 (x, y).  Returns the list of outputs, [1,M,C,d,d] each."""
+    import ctypes
+    lib = _lib.load()
+    if len(jobs) > _lib.MAX_PATCHIFY_JOBS:
+        raise ValueError("patchify_multi: more than %d jobs" % _lib.MAX_PATCHIFY_JOBS)
+    coords = coords.reshape(-1, 2).contiguous().float()
+    _need_cuda(coords)
+    M = coords.shape[0]
+    arr = (_lib.PatchifyJob * max(len(jobs), 1))()
+    outs, keep = [], []
+    pair = lambda v, d: (float(v), float(v)) if not isinstance(v, (tuple, list)) else (float(v[0]), float(v[1]))
+    for a, job in zip(arr, jobs):
+        net = job["net"]
+        net = net[0] if net.dim() == 4 else net
+        if net.dtype not in (torch.float16, torch.float32):
+            raise TypeError("patchify: net must be float16 or float32")
+        net = net.contiguous()
+        _need_cuda(net)
+        keep.append(net)
+        C, H, W = net.shape
+        mode = job.get("mode", "bilinear")
+        r = int(job["radius"])
+        d = 1 if mode == "upperleft" else 2 * r + 1
+        out = torch.empty((1, M, C, d, d), dtype=net.dtype if mode == "upperleft" else torch.float32, device=net.device)
+        outs.append(out)
+        (sx, sy), (ox, oy) = pair(job.get("scale", 1.0), 1.0), pair(job.get("offset", 0.0), 0.0)
+        a.net, a.out, a.C, a.H, a.W, a.radius = net.data_ptr(), out.data_ptr(), C, H, W, r
+        a.mode, a.dtype, a.sx, a.sy, a.ox, a.oy = (2 if mode == "upperleft" else 1), _DT[net.dtype], sx, sy, ox, oy
+    rc = lib.cdv_patchify_multi(ctypes.cast(arr, ctypes.c_void_p), len(jobs), _p(coords), M, _stream())
+    _lib.check(rc, "cdv_patchify_multi")
+    return outs
+
+
 def flow_mag(poses, patches, intrinsics, ii, jj, kk, beta):
     """pops.flow_mag (projective_ops.py:120-130) fused: -> (flow [1,E,P,P] f32, valid [1,E,P,P] bool)"""
     lib = _lib.load()

@@ -236,6 +236,22 @@ int cdv_ba_forward(float* poses, float* patches, const float* intrinsics, const 
 int cdv_patchify_blend(const void* net, const float* coords, void* out, int B, int64_t M, int C, int H, int W,
                        int radius, int mode, int dtype, void* stream);
 
+/*
+ * The altcorr.patchify calls of one new frame (net_cdv.py:355-374: imap, gmap, colour and patch tiles, all cut at the
+ * same M patch centres) in ONE launch.  Job j computes altcorr.patchify(net_j, (coords + (ox, oy)) * (sx, sy), radius,
+ * mode) -- the reference scales the centres with the same two float operations before each call -- for batch size 1:
+ * out_j [M][C][d][d], d = 2 radius + 1 (mode 1, FLOAT32) or 1 (mode 2, the map's dtype).  coords [M][2] f32 (x, y);
+ * jobs is a HOST array of up to CDV_MAX_PATCHIFY_JOBS descriptors.
+ */
+#define CDV_MAX_PATCHIFY_JOBS 8
+typedef struct {
+  const void* net;   /* [C][H][W] */
+  void* out;
+  int C, H, W, radius, mode, dtype;
+  float sx, sy, ox, oy;
+} cdv_patchify_job;
+int cdv_patchify_multi(const cdv_patchify_job* jobs, int n_jobs, const float* coords, int64_t M, void* stream);
+
 /* pops.flow_mag(poses, patches, intrinsics, ii, jj, kk, beta) -- projective_ops.py:120-130, the keyframe test's motion
  * measure (slam.py:399-406): three reprojections per edge in one launch.
  *   flow [E][P][P] f32 ; valid [E][P][P] uint8 (X_ij.z > 0.2) */

@@ -599,6 +599,31 @@ def test_fused_flow_mag_point_cloud_patchify_vs_composed():
             assert ul.dtype == net.dtype and torch.equal(ul, raw[..., :1, :1])
 
 
+def test_patchify_frame_in_one_launch():
+    """cdv_patchify_multi: the four altcorr.patchify calls of a new frame (net_cdv.py:355-374: imap at the DINO scale with
+    the configured sampling mode, gmap, colours at 4 (c + 0.5), patches from the coordinate / inverse-depth grid) against
+    the four separate calls on coordinates scaled with torch ops as the reference does -- bit-identical"""
+    from cdv_slam_amd import altcorr
+    g = torch.Generator(device="cpu").manual_seed(11)
+    h, w, M = 24, 32, 96
+    fmap = (torch.randn((1, 24, h, w), generator=g) / 4).half().to(DEV)
+    imap = torch.randn((1, 384, 7, 9), generator=g).half().to(DEV)            # DINO features, coarser grid
+    image = torch.rand((1, 3, 4 * h, 4 * w), generator=g).to(DEV)
+    disps = (torch.rand((h, w), generator=g) * 0.75 + 0.25).to(DEV)
+    ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+    grid = torch.stack([xs.to(DEV), ys.to(DEV), disps])[None]               # coords_grid_with_index: (x, y, disparity)
+    coords = torch.stack([torch.rand(M, generator=g) * (w + 4) - 2, torch.rand(M, generator=g) * (h + 4) - 2], -1)[None].to(DEV)
+    s_f2i = torch.tensor([9.0 / w, 7.0 / h], device=DEV)                      # (x, y) scale feature grid -> DINO grid
+    for imode in ("bilinear", "upperleft"):
+        want = [altcorr.patchify(imap, s_f2i * coords, 0, mode=imode), altcorr.patchify(fmap, coords, 1),
+                altcorr.patchify(image, 4 * (coords + 0.5), 0), altcorr.patchify(grid, coords, 1)]
+        got = ops.patchify_multi([dict(net=imap, radius=0, mode=imode, scale=(9.0 / w, 7.0 / h)),
+                                  dict(net=fmap, radius=1), dict(net=image, radius=0, scale=4.0, offset=0.5),
+                                  dict(net=grid, radius=1)], coords)
+        for a, b in zip(got, want):
+            assert a.shape == b.shape and a.dtype == b.dtype and torch.equal(a, b)
+
+
 def test_single_pixel_patches():
     """P = 1 patches (the structure-only caller of the classic loop closure passes 1x1 patches, long_term.py:118-135):
     reprojection, BA and the fused helpers take the centre-pixel code path"""
