@@ -25,6 +25,7 @@ SIGNATURES = {
     "cdv_gmap_to_pixel_major": (_i32, [_vp, _vp, _i64, _i32, _i64, _i64, _vp]),
     "cdv_frame_ingest": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i64, _i64, _i64, _vp]),
     "cdv_patchify_fwd": (_i32, [_vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "cdv_loop_flow": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _vp, _vp]),
     "cdv_patchify_multi": (_i32, [_vp, _i32, _vp, _i64, _vp]),
     "cdv_patchify_blend": (_i32, [_vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "cdv_edges_frame": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp]),

@@ -99,6 +99,63 @@ __global__ __launch_bounds__(256) void flow_mag_kernel(const float* __restrict__
   }
 }
 
+// patchgraph.edges_loop (patchgraph.py:71-97), the device part: one wave per candidate pair (target frame j, source
+// frame f).  The reference builds nj * nf * M candidate edges with flatmeshgrid, runs pops.flow_mag on the patch CENTRES
+// (three reprojections, a dozen launches over ~10^6 rows) and reduces groups of M with einops; here the wave reprojects
+// the M centres of frame f into frame j (the poses of the pair are wave-uniform), sums flow * valid and valid over its
+// lanes and writes the pair's mean flow, or inf when not more than 0.75 M centres are valid (patchgraph.py:88-90).
+__global__ __launch_bounds__(64) void loop_flow_kernel(const float* __restrict__ poses, const float* __restrict__ patches,
+                                                       const float* __restrict__ intr, const int64_t* __restrict__ ix,
+                                                       int M, int PP, int centre, int j0, int f0, int nf, float beta,
+                                                       float* __restrict__ out) {
+  const int pair = (int)blockIdx.x;
+  const int jl = pair / nf, fl = pair - jl * nf;
+  const int64_t jx = j0 + jl;
+  const int64_t k0 = (int64_t)(f0 + fl) * M;
+  const int64_t iframe = ix[k0];   // ii[::M] of the reference: the source frame of the group
+  const int lane = (int)threadIdx.x;
+  float Pi[7], Pj[7], Pinv[7], G[3][7];
+#pragma unroll
+  for (int a = 0; a < 7; a++) { Pi[a] = poses[7 * iframe + a]; Pj[a] = poses[7 * jx + a]; }
+  cdv::lt_se3_inv(Pi, Pinv);
+  cdv::lt_se3_mul(Pi, Pinv, G[0]);
+  cdv::lt_se3_mul(Pj, Pinv, G[1]);
+#pragma unroll
+  for (int a = 0; a < 3; a++) G[2][a] = G[1][a];
+  G[2][3] = 0.f; G[2][4] = 0.f; G[2][5] = 0.f; G[2][6] = 1.f;   // tonly (projective_ops.py:62)
+  float t[3][3], q[3][4];
+#pragma unroll
+  for (int v = 0; v < 3; v++) cdv::lt_se3_load(G[v], t[v], q[v]);
+  const float fxi = intr[4 * iframe + 0], fyi = intr[4 * iframe + 1], cxi = intr[4 * iframe + 2], cyi = intr[4 * iframe + 3];
+  const float fxj = intr[4 * jx + 0], fyj = intr[4 * jx + 1], cxj = intr[4 * jx + 2], cyj = intr[4 * jx + 3];
+  float fsum = 0.f, nval = 0.f;
+  for (int m = lane; m < M; m += 64) {
+    const float* pk = patches + (k0 + m) * 3 * PP;
+    float X0[4], X1[4], xy[3][2];
+    X0[0] = (pk[centre] - cxi) / fxi;
+    X0[1] = (pk[PP + centre] - cyi) / fyi;
+    X0[2] = 1.f;
+    X0[3] = pk[2 * PP + centre];
+    bool ok = false;
+#pragma unroll
+    for (int v = 0; v < 3; v++) {
+      cdv::lt_act4_loaded(t[v], q[v], X0, X1);
+      const float d = 1.0f / fmaxf(X1[2], 0.1f);
+      const float fx = v == 0 ? fxi : fxj, fy = v == 0 ? fyi : fyj, cx = v == 0 ? cxi : cxj, cy = v == 0 ? cyi : cyj;
+      xy[v][0] = fx * (d * X1[0]) + cx;
+      xy[v][1] = fy * (d * X1[1]) + cy;
+      if (v == 1) ok = X1[2] > 0.2f;
+    }
+    const float ax = xy[1][0] - xy[0][0], ay = xy[1][1] - xy[0][1];
+    const float bx = xy[2][0] - xy[0][0], by = xy[2][1] - xy[0][1];
+    const float fl1 = beta * sqrtf(ax * ax + ay * ay) + (1.0f - beta) * sqrtf(bx * bx + by * by);
+    if (ok) { fsum += fl1; nval += 1.0f; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { fsum += __shfl_xor(fsum, o); nval += __shfl_xor(nval, o); }
+  if (lane == 0) out[pair] = (nval > 0.75f * (float)M) ? fsum / fmaxf(nval, 1.0f) : __builtin_inff();
+}
+
 // pops.point_cloud (projective_ops.py:115-117): X = P_ix^-1 * iproj(patch) for every patch pixel, one thread per patch
 template <int P>
 __global__ __launch_bounds__(256) void point_cloud_kernel(const float* __restrict__ poses, const float* __restrict__ patches,
@@ -142,6 +199,18 @@ extern "C" int cdv_flow_mag(const float* poses, const float* patches, const floa
   else
     hipLaunchKernelGGL(flow_mag_kernel<1>, dim3(blocks), dim3(64), 0, (hipStream_t)stream, poses, patches, intrinsics, ii,
                        jj, kk, E, beta, flow, valid);
+  CDV_LAUNCH_CHECK();
+  return CDV_OK;
+}
+
+extern "C" int cdv_loop_flow(const float* poses, const float* patches, const float* intrinsics, const int64_t* ix, int M,
+                             int P, int j0, int nj, int f0, int nf, float beta, float* flow_out, void* stream) {
+  CDV_REQUIRE(P == 3 || P == 1, CDV_ERR_UNSUPPORTED, "cdv_loop_flow: patch size P must be 3 or 1");
+  CDV_REQUIRE(M > 0 && j0 >= 0 && f0 >= 0 && nj >= 0 && nf >= 0, CDV_ERR_ARG, "cdv_loop_flow: bad range");
+  if (nj == 0 || nf == 0) return CDV_OK;
+  CDV_REQUIRE((int64_t)nj * nf < ((int64_t)1 << 31), CDV_ERR_ARG, "cdv_loop_flow: too many candidate pairs");
+  hipLaunchKernelGGL(loop_flow_kernel, dim3(nj * nf), dim3(64), 0, (hipStream_t)stream, poses, patches, intrinsics, ix, M,
+                     P * P, P > 1 ? P + 1 : 0, j0, f0, nf, beta, flow_out);
   CDV_LAUNCH_CHECK();
   return CDV_OK;
 }

@@ -252,6 +252,17 @@ typedef struct {
 } cdv_patchify_job;
 int cdv_patchify_multi(const cdv_patchify_job* jobs, int n_jobs, const float* coords, int64_t M, void* stream);
 
+/*
+ * PatchGraph.edges_loop (patchgraph.py:71-97), the device part: the mean flow magnitude (pops.flow_mag with beta, patch
+ * CENTRES only, patchgraph.py:86) of the M patches of source frame f reprojected into target frame j, for every pair
+ * j in [j0, j0 + nj), f in [f0, f0 + nf) -- over the valid centres, +inf when not more than 0.75 M of them are valid
+ * (patchgraph.py:87-90).  One launch instead of the reference's flatmeshgrid + three transforms + two reductions over
+ * nj * nf * M candidate edges.  ix [n_patches] int64 (frame of a patch); out [nj][nf] f32.  The greedy selection that
+ * follows (reduce_edges, a sequential numba loop in the reference) stays on the host: cdv_slam_amd/loop.py.
+ */
+int cdv_loop_flow(const float* poses, const float* patches, const float* intrinsics, const int64_t* ix, int M, int P,
+                  int j0, int nj, int f0, int nf, float beta, float* flow_out, void* stream);
+
 /* pops.flow_mag(poses, patches, intrinsics, ii, jj, kk, beta) -- projective_ops.py:120-130, the keyframe test's motion
  * measure (slam.py:399-406): three reprojections per edge in one launch.
  *   flow [E][P][P] f32 ; valid [E][P][P] uint8 (X_ij.z > 0.2) */

@@ -147,3 +147,20 @@ def test_frames_keyframe_shift_matches_the_reference_loop():
         torch.cuda.synchronize()
         for name, got, w in zip("poses intr patches tstamps colors fmap gmap odd".split(), bufs, want):
             assert torch.equal(got, w), (name, k, n)
+
+
+def test_reduce_edges_host_selection():
+    """loop.reduce_edges (optim_utils.py:23-60): increasing flow, pairs < 30 frames apart and flows >= 1000 skipped,
+    a pick suppresses its neighbours i - nms .. i + nms for the same j, at most max_num_edges picks"""
+    from cdv_slam_amd.loop import reduce_edges
+    flow = np.array([5.0, 1.0, 2.0, 3.0, 1500.0, 0.5, 4.0])
+    ii = np.array([10, 11, 12, 40, 5, 50, 14])
+    jj = np.array([60, 60, 60, 60, 60, 60, 61])
+    es = reduce_edges(flow, ii, jj, max_num_edges=1000, nms=1)
+    # order of flow: (50,60) gap 10 -> skipped; (11,60) picked, suppresses 10..12 @ 60; (12,60) suppressed; (40,60) gap 20
+    # skipped; (14,61) picked; (10,60) suppressed; (5,60) flow 1500 skipped
+    assert es.tolist() == [[11, 60], [14, 61]]
+    assert reduce_edges(flow, ii, jj, max_num_edges=1, nms=1).tolist() == [[11, 60]]
+    assert reduce_edges(np.zeros(0), np.zeros(0, np.int64), np.zeros(0, np.int64), 10, 1).shape == (0, 2)
+    es0 = reduce_edges(flow, ii, jj, max_num_edges=1000, nms=0)
+    assert es0.tolist() == [[11, 60], [12, 60], [14, 61], [10, 60]]

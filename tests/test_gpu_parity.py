@@ -624,6 +624,66 @@ def test_patchify_frame_in_one_launch():
             assert a.shape == b.shape and a.dtype == b.dtype and torch.equal(a, b)
 
 
+def _loop_scene(n=90, M=16, seed=5):
+    """a camera going round a circle of 60 frames: frame t sees again what frame t - 60 saw"""
+    rng = np.random.default_rng(seed)
+    N = n + 6
+    ang = 2 * np.pi * np.arange(N) / 60.0
+    poses = np.zeros((N, 7), np.float32); poses[:, 6] = 1
+    poses[:, 0] = 0.5 * np.cos(ang) + rng.normal(0, 0.01, N)
+    poses[:, 1] = 0.5 * np.sin(ang) + rng.normal(0, 0.01, N)
+    poses[:, 2] = rng.normal(0, 0.01, N)
+    h, w = 96, 128
+    cx, cy = rng.uniform(8, w - 8, N * M), rng.uniform(8, h - 8, N * M)
+    patches = np.zeros((N * M, 3, 3, 3), np.float32)
+    off = np.arange(3.0) - 1
+    patches[:, 0] = cx[:, None, None] + off[None, None, :]
+    patches[:, 1] = cy[:, None, None] + off[None, :, None]
+    patches[:, 2] = rng.uniform(0.25, 1.0, N * M)[:, None, None]
+    for f in (10, 25, 41):   # three source frames far along +z: their points fall behind the recent cameras (Z < 0.2)
+        poses[f, 2] = 3.0
+    intr = np.tile(np.array([64, 64, 64, 48], np.float32), (N, 1))
+    ix = np.repeat(np.arange(N), M)
+    return poses, patches, intr, ix, n, M
+
+
+def test_edges_loop_vs_the_reference_composition():
+    """cdv_loop_flow + loop.edges_loop (PatchGraph.edges_loop, patchgraph.py:71-97) against the reference's own sequence
+    of operations -- flatmeshgrid candidates, pops.flow_mag on the patch centres, reductions over groups of M,
+    reduce_edges -- built from the operator surface: same per-pair flow (summation order apart), same inf pattern,
+    same chosen edges"""
+    from cdv_slam_amd import loop, projective_ops as pops
+    from cdv_slam_amd.lietorch import SE3
+    poses, patches, intr, ix, n, M = _loop_scene()
+    tp, tpa, ti, tix = T(poses), T(patches), T(intr), T(ix)
+    RW, AGE, GOF, KI, TH = 22, 1000, 15, 4, 64.0
+    l = n - RW
+    jr = torch.arange(n - GOF, n - KI, device=DEV)
+    kr = torch.arange(max(l - AGE, 0) * M, l * M, device=DEV)
+    jj, kk = [t.reshape(-1) for t in torch.meshgrid(jr, kr, indexing="ij")]
+    ii = tix[kk]
+    fm, val = pops.flow_mag(SE3(tp[None]), tpa[None][..., 1, 1].reshape(1, -1, 3, 1, 1), ti[None], ii, jj, kk, beta=0.5)
+    fsum = (fm * val).reshape(-1, M).sum(1).float()
+    nval = val.reshape(-1, M).sum(1).clamp(min=1)
+    want = torch.where(nval > M * 0.75, fsum / nval, torch.full_like(fsum, float("inf")))
+    got = loop.loop_flow(tp, tpa, ti, tix, M, n - GOF, GOF - KI, max(l - AGE, 0), l - max(l - AGE, 0), 0.5).reshape(-1)
+    inf_w, inf_g = torch.isinf(want), torch.isinf(got)
+    assert torch.equal(inf_w, inf_g) and inf_w.any() and (~inf_w).any()
+    assert torch.allclose(got[~inf_g], want[~inf_w], rtol=1e-5, atol=1e-4)
+    mask = want < TH
+    assert mask.any()
+    es = loop.reduce_edges(want[mask].cpu().numpy(), ii[::M][mask].cpu().numpy(), jj[::M][mask].cpu().numpy(), 1000, 1)
+    assert len(es) > 3 and (es[:, 1] - es[:, 0] >= 30).all()
+    kk_g, jj_g = loop.edges_loop(tp, tpa, ti, tix, n, M, removal_window=RW, max_edge_age=AGE, global_opt_freq=GOF,
+                                 keyframe_index=KI, backend_thresh=TH)
+    want_kk = (torch.as_tensor(es[:, 0], device=DEV)[:, None] * M + torch.arange(M, device=DEV)[None]).reshape(-1)
+    want_jj = torch.as_tensor(es[:, 1], device=DEV)[:, None].repeat(1, M).reshape(-1)
+    assert torch.equal(kk_g, want_kk) and torch.equal(jj_g, want_jj)
+    # nothing old enough yet: no edges
+    k0, j0_ = loop.edges_loop(tp, tpa, ti, tix, 20, M)
+    assert k0.numel() == 0 and j0_.numel() == 0
+
+
 def test_single_pixel_patches():
     """P = 1 patches (the structure-only caller of the classic loop closure passes 1x1 patches, long_term.py:118-135):
     reprojection, BA and the fused helpers take the centre-pixel code path"""
