@@ -663,7 +663,7 @@ __device__ __forceinline__ void corr_edge(const CorrArgs2& a, int p, int e, int 
   wave_lds_sync();   // the row overwrites the raw volume: keep the stores behind the last blend's reads
   if (lane < 63 && !CDV_EXP(512)) {
     if (NLEV == 2) {
-      uint32_t* o32 = reinterpret_cast<uint32_t*>(outT) + ((bxo << 6) - bxo) + bm;   // dword (x, y, m) = 63 x + 9 y + m
+      uint32_t* o32 = reinterpret_cast<uint32_t*>(outT) + __mul24(bxo, 63) + bm;   // dword (x, y, m) = 63 x + 9 y + m (24-bit multiply: full rate)
 #pragma unroll
       for (int yo = 0; yo < 7; yo++) {
         const cdv_half2 h = {res0[yo], res1[yo]};
