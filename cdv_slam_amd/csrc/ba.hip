@@ -543,10 +543,10 @@ __device__ __forceinline__ bool chol6(const float* a, float* Lm) {
   return ok;
 }
 
-// One workgroup (256 threads).  Per block step: (1) one thread per matrix row below the diagonal block
+// One workgroup (1024 threads).  Per block step: (1) one thread per matrix row below the diagonal block
 // factors the 6x6 block redundantly in registers (~400-cycle dependent chain) and forward-substitutes its own
 // row (the panel); (2) the trailing update runs as 16x16 tiles on the matrix cores.
-__global__ __launch_bounds__(256) void ba_solve_kernel(float* __restrict__ poses, float* __restrict__ sy,
+__global__ __launch_bounds__(1024) void ba_solve_kernel(float* __restrict__ poses, float* __restrict__ sy,
                                                        int sy_stride, float* __restrict__ dXg, int t0, int N,
                                                        const int32_t* __restrict__ gmeta, float* __restrict__ dbg,
                                                        int32_t* __restrict__ info) {
@@ -649,12 +649,14 @@ __global__ __launch_bounds__(256) void ba_solve_kernel(float* __restrict__ poses
     CDV_IF_STAMPS({ const unsigned long long t_y = cdv_now(); t_pan += t_y - t_x; t_x = t_y; })
     // trailing update A[R0.., R0..] -= P P^T (P = the panel just formed, rows R0..n, 6 columns) as 16x16 tiles
     // on the matrix cores: K = 6 padded to 8 = two v_mfma_f32_16x16x4_f32 per tile; lower tiles only, dealt
-    // round-robin to the 4 waves.  The y row (row n) is simply the last panel row.
+    // round-robin to the 16 waves (up to 36 tiles per step at N = 22; with 4 waves the nine dependent
+    // LDS-read / MFMA / LDS-update rounds per wave were 73 % of the kernel).  The y row (row n) is simply the last
+    // panel row.
     {
       const int lane = t & 63, wv = t >> 6, c16 = lane & 15, g4 = lane >> 4;
       const int T16 = (nrows + 15) >> 4;
       const int ntile = T16 * (T16 + 1) / 2;
-      for (int pidx = wv; pidx < ntile; pidx += 4) {
+      for (int pidx = wv; pidx < ntile; pidx += (T >> 6)) {
         int ti = 0, acc_rows = 0;
         while (acc_rows + ti + 1 <= pidx) { acc_rows += ti + 1; ti++; }
         const int tj = pidx - acc_rows;
@@ -1567,7 +1569,7 @@ extern "C" int cdv_ba_forward(float* poses, float* patches, const float* intrins
         CDV_LAUNCH_CHECK();
         continue;
       } else if (N > 0)
-        hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(256), smem_sol, s, poses, sy, (int)L.sy_stride, dXg, t0, N,
+        hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(1024), smem_sol, s, poses, sy, (int)L.sy_stride, dXg, t0, N,
                            gv.meta, d, info);
     }
     // dbg layout: [S n6^2 | y n6 | dX n6 | dZ U_stride | C U_stride | u U_stride | E n6*U_stride]
