@@ -124,7 +124,10 @@ int cdv_frame_ingest(const void* fmap_chw, void* fmap1_nhwc, void* fmap2_nhwc, v
  *   order       optional [E] int32 processing order (a permutation of the edge ids), NULL = natural
  *               order.  Output rows are always indexed by edge id.
  *   out         [E][7 (x)][7 (y)][3][3][nlev] f16  == corr.view(E, 882) for nlev = 2
- * Requirements: radius 3, P 3, C % 8 == 0, C <= 128, nlev in {1,2}.
+ * Requirements: radius 3, P 3, C % 8 == 0, C <= 128, nlev in {1,2}, pyramid scales powers of two, every ring and the
+ * tile array below 4 GB, Ng and slots below 2^31.  An index outside its ring (after the modulus) gives a zero row.
+ * C <= 32 (CDV-SLAM: 24) runs the tuned kernel (workgroups dealt to the XCDs in contiguous eighths of the edge list);
+ * wider features (DPVO: 128) a simpler one.
  */
 int cdv_corr_fused(const void* gmap, const void* fmap0_nhwc, const void* fmap1_nhwc, const float* coords,
                    const int64_t* kk, const int64_t* jj, const int32_t* order, void* out, int64_t E, int64_t Ng,
