@@ -37,7 +37,7 @@ def corr_algorithmic_bytes(st):
     return E * 882 * 2 + E * 72 + E * 16 + U * C * 9 * 2 + maps
 
 
-def cpu_baseline(st, max_seconds=30.0):
+def cpu_baseline(st, max_seconds=30.0, gpu_poses=None):
     """The CPU oracle (oracle/, a port of the reference algorithm) timed on this host on a bounded
     sample: one full update of the same workload (all E edges) -- reproject, 2-level correlation with
     the reference's half arithmetic, neighbors, 2 BA iterations."""
@@ -59,8 +59,8 @@ def cpu_baseline(st, max_seconds=30.0):
     t_corr = (time.perf_counter() - tc) * (n / sample)
     t2 = time.perf_counter()
     O.neighbors(st.kk, st.jj)
-    O.fastba(st.poses, st.patches, st.intrinsics[0], st.target, st.weight, st.lmbda, st.ii, st.jj, st.kk, st.t0, st.n, 2,
-             np.float32)
+    p_cpu, _, _ = O.fastba(st.poses, st.patches, st.intrinsics[0], st.target, st.weight, st.lmbda, st.ii, st.jj, st.kk,
+                           st.t0, st.n, 2, np.float32)
     t3 = time.perf_counter()
     total = (t1 - t0) + t_corr + (t3 - t2)
     # BASELINE.json configs[0]: the reference's Python ba.py path (cdvslam/ba.py:86-185 as restated in oracle/ba_py.py,
@@ -75,7 +75,17 @@ def cpu_baseline(st, max_seconds=30.0):
         P, X, _ = ba_py.BA(P, X, pr.intrinsics, pr.target, pr.weight, pr.lmbda, pr.ii, pr.jj, pr.kk,
                            [-64, -64, ww + 64, hh + 64], ep=1.0, fixedp=1, dtype=np.float32)
     t_bapy = time.perf_counter() - tb
+    ate = None
+    if gpu_poses is not None:
+        # "ATE vs ref" of the metric, in the form available here: the trajectory after ONE update on the GPU against the
+        # CPU port's from the same state, Sim(3)-aligned RMSE of the camera centres as evaluate_tartan.py:63-70
+        from cdv_slam_amd import metrics
+        lo = max(st.t0 - 12, 0)
+        ate = {"value": metrics.ate_rmse(p_cpu[lo:st.n], gpu_poses[lo:st.n]), "unit": "scene units (RMSE, Sim(3)-aligned)",
+               "frames": int(st.n - lo), "against": "oracle/cdv_oracle.c float32, same patch-graph state, 1 update (2 GN iterations)",
+               "moved_by_update": metrics.ate_rmse(st.poses[lo:st.n], gpu_poses[lo:st.n])}
     return {
+        "ate_vs_oracle": ate,
         "ba_py_pr1": {"value": 1.0 / t_bapy, "unit": "BA(2 it)/s", "edges": int(pr.E), "seconds": t_bapy,
                       "what": "oracle/ba_py.py (restated cdvslam/ba.py) on BASELINE.json configs[0], numpy f32"},
         "value": 1.0 / total, "unit": "frames/s", "cores": O.num_threads(), "kind": "port",
@@ -199,7 +209,11 @@ def main():
             "per_rank_summary": summarise(per_rank),
         }
         if not args.no_cpu_baseline and world == 1:   # the CPU port is timed next to the single-GPU number only
-            res["cpu_baseline"] = cpu_baseline(st, args.cpu_seconds)
+            up.reset()
+            up.step()
+            torch.cuda.synchronize()
+            res["cpu_baseline"] = cpu_baseline(st, args.cpu_seconds, gpu_poses=up.poses.cpu().numpy())
+            res["ate_vs_oracle"] = res["cpu_baseline"].pop("ate_vs_oracle")
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res))

@@ -684,6 +684,27 @@ def test_edges_loop_vs_the_reference_composition():
     assert k0.numel() == 0 and j0_.numel() == 0
 
 
+@pytest.mark.parametrize("name", ["default", "stress"])
+def test_ate_against_the_oracle_trajectory(name):
+    """the BASELINE metric's second half, in the only form available without the datasets: ATE-RMSE (Sim(3)-aligned, as
+    evaluate_tartan.py:63-70) of the window's trajectory after the GPU update against the float64 oracle's trajectory
+    from the same patch-graph state: within 1e-4"""
+    from cdv_slam_amd import metrics
+    from cdv_slam_amd.update import UpdatePath
+    st = synth.make_state(name)
+    up = UpdatePath(st, torch.device(DEV))
+    up.step()
+    torch.cuda.synchronize()
+    p_o, _, _ = O.fastba(st.poses, st.patches, st.intrinsics[0], st.target, st.weight, st.lmbda, st.ii, st.jj, st.kk,
+                         st.t0, st.n, 2, np.float64)
+    got = up.poses.cpu().numpy()
+    lo = max(st.t0 - 12, 0)     # the free poses and the fixed ones before them (so that the alignment is well posed)
+    ate = metrics.ate_rmse(p_o[lo:st.n], got[lo:st.n])
+    moved = metrics.ate_rmse(st.poses[lo:st.n], got[lo:st.n])
+    assert ate < 1e-4, ate
+    assert moved > 10 * ate     # the update did move the trajectory by much more than the two disagree
+
+
 def test_single_pixel_patches():
     """P = 1 patches (the structure-only caller of the classic loop closure passes 1x1 patches, long_term.py:118-135):
     reprojection, BA and the fused helpers take the centre-pixel code path"""

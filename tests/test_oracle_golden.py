@@ -91,3 +91,30 @@ def test_fastba_matches_ba_py_where_gates_coincide():
     ok = (X1[:, 2, 0, 0] > 1.001e-3) & (X1[:, 2, 0, 0] < 9.99)
     assert ok.sum() >= 0.7 * len(ok)
     assert np.allclose(X1[ok], X2[ok], atol=1e-9)
+
+
+def test_ate_metric_umeyama():
+    """metrics.ate_rmse (evaluate_tartan.py:63-70): a trajectory moved by a known Sim(3) aligns back exactly; noise on the
+    camera centres comes out as its RMS; without scale correction a scaled copy does not align"""
+    from cdv_slam_amd import metrics
+    rng = np.random.default_rng(2)
+    n = 50
+    q = rng.normal(size=(n, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    poses = np.concatenate([rng.normal(size=(n, 3)), q], 1)
+    c0 = metrics.camera_centres(poses)
+    # centres of identity-rotation poses are -t
+    ident = np.concatenate([rng.normal(size=(n, 3)), np.tile([0, 0, 0, 1.0], (n, 1))], 1)
+    assert np.allclose(metrics.camera_centres(ident), -ident[:, :3])
+    # a similarity applied to the camera centres: rebuild poses with identity rotations at the moved centres
+    A = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+    A *= np.sign(np.linalg.det(A))
+    moved = 2.5 * (A @ c0.T).T + np.array([1.0, -2.0, 0.5])
+    ref = np.concatenate([-c0, np.tile([0, 0, 0, 1.0], (n, 1))], 1)
+    est = np.concatenate([-moved, np.tile([0, 0, 0, 1.0], (n, 1))], 1)
+    assert metrics.ate_rmse(ref, est) < 1e-12
+    assert metrics.ate_rmse(ref, est, with_scale=False) > 0.1
+    R, t, c = metrics.umeyama_alignment(c0.T, moved.T)
+    assert np.allclose(R, A) and np.allclose(t, [1.0, -2.0, 0.5]) and abs(c - 2.5) < 1e-12
+    noisy = np.concatenate([-(c0 + rng.normal(0, 1e-3, c0.shape)), np.tile([0, 0, 0, 1.0], (n, 1))], 1)
+    e = metrics.ate_rmse(ref, noisy)
+    assert 1.2e-3 < e < 2.2e-3     # sqrt(3) * 1e-3, minus what the alignment absorbs
