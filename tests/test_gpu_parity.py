@@ -695,14 +695,23 @@ def test_ate_against_the_oracle_trajectory(name):
     up = UpdatePath(st, torch.device(DEV))
     up.step()
     torch.cuda.synchronize()
-    p_o, _, _ = O.fastba(st.poses, st.patches, st.intrinsics[0], st.target, st.weight, st.lmbda, st.ii, st.jj, st.kk,
-                         st.t0, st.n, 2, np.float64)
+    p_o, x_o, _ = O.fastba(st.poses, st.patches, st.intrinsics[0], st.target, st.weight, st.lmbda, st.ii, st.jj, st.kk,
+                           st.t0, st.n, 2, np.float64)
     got = up.poses.cpu().numpy()
     lo = max(st.t0 - 12, 0)     # the free poses and the fixed ones before them (so that the alignment is well posed)
     ate = metrics.ate_rmse(p_o[lo:st.n], got[lo:st.n])
     moved = metrics.ate_rmse(st.poses[lo:st.n], got[lo:st.n])
     assert ate < 1e-4, ate
     assert moved > 10 * ate     # the update did move the trajectory by much more than the two disagree
+    if name == "default":
+        # ten more updates on both sides (bundle adjustment on the evolving state, fixed targets): no drift apart
+        p, pat = p_o, x_o
+        for _ in range(10):
+            up.step()
+            p, pat, _ = O.fastba(p, pat, st.intrinsics[0], st.target, st.weight, st.lmbda, st.ii, st.jj, st.kk, st.t0, st.n,
+                                 2, np.float64)
+        torch.cuda.synchronize()
+        assert metrics.ate_rmse(p[lo:st.n], up.poses.cpu().numpy()[lo:st.n]) < 1e-4
 
 
 def test_single_pixel_patches():
