@@ -1379,7 +1379,12 @@ __global__ __launch_bounds__(256) void ba_big_backstep_kernel(float* __restrict_
 
 // dZ = Q (u - E^T dX), inverse-depth update, and re-zeroing of this patch's E column / C / u so that the
 // next iteration (or call) accumulates into zeros.
-__global__ __launch_bounds__(64) void ba_retract_kernel(float* __restrict__ poses, int t0, int pose_retr,
+constexpr int RET_RG = 4;   // waves per retract workgroup: each sweeps every fourth pose's rows of the chunk's E columns
+
+// Workgroup = one chunk of 64 patches (lane = patch) x RET_RG waves; wave g sweeps the rows of poses b = g, g + RET_RG, ..
+// of the chunk's E columns (a column is 6 N entries long: one wave alone walked it in 6 N / 6 dependent round trips --
+// 22 at N = 22, 299 in a global BA), the partial sums meet in LDS and wave 0 finishes the patches.
+__global__ __launch_bounds__(64 * RET_RG) void ba_retract_kernel(float* __restrict__ poses, int t0, int pose_retr,
                                                         float* __restrict__ patches, int P, int N,
                                                         const int32_t* __restrict__ gmeta,
                                                         const int64_t* __restrict__ kx, float* __restrict__ Cg,
@@ -1391,6 +1396,7 @@ __global__ __launch_bounds__(64) void ba_retract_kernel(float* __restrict__ pose
                                                         int n_chunks) {
   if (gmeta[GM_ERROR] || info[1]) return;
   const int U = gmeta[GM_U];
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
   // global-BA path: a workgroup is one chunk of 64 patches; its panel mask says which 32-pose panels of E are non-zero
   // (the rest of the column is zero and stays zero: not read, not rewritten); the mask is consumed here
   uint32_t pmask = 0xffffffffu;
@@ -1399,10 +1405,10 @@ __global__ __launch_bounds__(64) void ba_retract_kernel(float* __restrict__ pose
     __syncthreads();
     if (threadIdx.x == 0 && (int)blockIdx.x < n_chunks) cmask[blockIdx.x] = 0u;
   }
-  // pose_retr_kernel (ba_cuda.cu:178-206) for the small-system solver: T <- Exp(dX_i) T, one lane per free pose, in the
-  // last workgroup (the first ones carry the longest E-column sweeps)
-  const int gid_rev = (int)(gridDim.x * blockDim.x) - 1 - (int)(blockIdx.x * blockDim.x + threadIdx.x);
-  if (pose_retr && gid_rev < N) {
+  // pose_retr_kernel (ba_cuda.cu:178-206): T <- Exp(dX_i) T, one lane per free pose, in wave 0 of the last workgroups
+  // (the first ones carry the longest E-column sweeps)
+  const int gid_rev = (int)(gridDim.x * 64) - 1 - (int)(blockIdx.x * 64 + lane);
+  if (pose_retr && g == 0 && gid_rev < N) {
     const int pi = gid_rev;
     float* p = poses + 7 * (size_t)(t0 + pi);
     float tt[3] = {p[0], p[1], p[2]}, qq[4] = {p[3], p[4], p[5], p[6]}, tn[3], qn[4], xi[6];
@@ -1413,10 +1419,12 @@ __global__ __launch_bounds__(64) void ba_retract_kernel(float* __restrict__ pose
     p[3] = qn[0]; p[4] = qn[1]; p[5] = qn[2]; p[6] = qn[3];
   }
   const int PP = P * P;
-  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < U; r += gridDim.x * blockDim.x) {
-    // u - E^T dX  (ba_cuda.cu:592); six independent partial sums keep six loads in flight
-    float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int b = 0; b < N; b++) {
+  __shared__ float part[RET_RG][64];
+  const int r = (int)blockIdx.x * 64 + lane;   // the launch has one workgroup per 64 patches
+  // u - E^T dX  (ba_cuda.cu:592); six independent partial sums keep six loads in flight
+  float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (r < U) {
+    for (int b = g; b < N; b += RET_RG) {
       if (!((pmask >> (b >> 5)) & 1u)) continue;
 #pragma unroll
       for (int c = 0; c < 6; c++) {
@@ -1427,19 +1435,25 @@ __global__ __launch_bounds__(64) void ba_retract_kernel(float* __restrict__ pose
         s[c] += ev * dXg[6 * b + c];
       }
     }
-    const float cv = Cg[r], uv = ug[r];
-    const float qv = lmbda_q ? 1.0f / (cv + lmbda_q[0]) : qg[r];
-    const float dz = qv * (uv - (((s[0] + s[1]) + (s[2] + s[3])) + (s[4] + s[5])));
-    if (dbgp) { dbgp[r] = dz; dbgp[U_stride + r] = cv; dbgp[2 * (size_t)U_stride + r] = uv; }
-    Cg[r] = 0.f;
-    ug[r] = 0.f;
-    float* pk = patches + kx[r] * 3 * PP + 2 * PP;
-    float d = pk[0];                 // patch_retr_kernel reads pixel [0][0]   ba_cuda.cu:218
-    d = d + dz;
-    d = (d > 20.f) ? 1.0f : d;
-    d = fmaxf(d, 1e-4f);
-    for (int a = 0; a < PP; a++) pk[a] = d;
   }
+  part[g][lane] = ((s[0] + s[1]) + (s[2] + s[3])) + (s[4] + s[5]);
+  __syncthreads();
+  if (g != 0 || r >= U) return;
+  float tot = part[0][lane];
+#pragma unroll
+  for (int w = 1; w < RET_RG; w++) tot += part[w][lane];
+  const float cv = Cg[r], uv = ug[r];
+  const float qv = lmbda_q ? 1.0f / (cv + lmbda_q[0]) : qg[r];
+  const float dz = qv * (uv - tot);
+  if (dbgp) { dbgp[r] = dz; dbgp[U_stride + r] = cv; dbgp[2 * (size_t)U_stride + r] = uv; }
+  Cg[r] = 0.f;
+  ug[r] = 0.f;
+  float* pk = patches + kx[r] * 3 * PP + 2 * PP;
+  float d = pk[0];                 // patch_retr_kernel reads pixel [0][0]   ba_cuda.cu:218
+  d = d + dz;
+  d = (d > 20.f) ? 1.0f : d;
+  d = fmaxf(d, 1e-4f);
+  for (int a = 0; a < PP; a++) pk[a] = d;
 }
 
 }  // namespace
@@ -1575,7 +1589,7 @@ extern "C" int cdv_ba_forward(float* poses, float* patches, const float* intrins
     // dbg layout: [S n6^2 | y n6 | dX n6 | dZ U_stride | C U_stride | u U_stride | E n6*U_stride]
     float* dbgp = d ? d + (size_t)n6i * n6i + 2 * n6i : nullptr;
     const int pose_retr = (N > 0 && (6 * N <= SN || big)) ? 1 : 0;
-    hipLaunchKernelGGL(ba_retract_kernel, dim3(rb), dim3(64), 0, s, poses, t0, pose_retr, patches, P, N, gv.meta, gv.kx,
+    hipLaunchKernelGGL(ba_retract_kernel, dim3(rb), dim3(64 * RET_RG), 0, s, poses, t0, pose_retr, patches, P, N, gv.meta, gv.kx,
                        Cg, ug, qg, Edg, (int)L.U_stride, dXg, dbgp, info, big ? lmbda : (const float*)nullptr, cmask,
                        n_chunks);
     CDV_LAUNCH_CHECK();
