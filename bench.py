@@ -216,6 +216,7 @@ def main():
             res["ate_vs_oracle"] = res["cpu_baseline"].pop("ate_vs_oracle")
         else:
             res["cpu_baseline"] = None
+            res["ate_vs_oracle"] = None
         print(json.dumps(res))
     grp.close()
 
