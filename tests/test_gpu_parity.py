@@ -3,8 +3,9 @@ seeded inputs, plus the golden fixtures captured from the reference's Python fil
 
 Tolerances: reprojected coords atol 1e-3 px; corr f16 path
 |d| <= 2^-8 max|corr| + 2^-10 vs the float64 truth; S/y/C/u/E rtol 1e-4 (of the matrix scale);
-poses after 2 GN iterations atol 1e-5 (t) / 1e-6 (q) vs the float64 oracle on well-conditioned
-graphs; inverse depth rtol 1e-4; BIT-EXACT for kx, ku, neighbors.
+poses after 2 GN iterations atol 1e-5 (t) / 1e-6 (q) and inverse depth rtol 1e-4 vs the float64
+oracle on the window graphs (small, default, stress); explicit per-config numbers plus gauge-free bounds for the
+weak-gauge graphs (init, pr1, global): tests/ba_checks.py; BIT-EXACT for kx, ku, neighbors.
 """
 import os
 
@@ -14,6 +15,7 @@ import torch
 
 from cdv_slam_amd import ops, synth
 from oracle import oracle as O
+from tests import ba_checks
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -234,11 +236,15 @@ def _gpu_coords(st):
                          T(st.kk), layout_e2pp=True)
 
 
-@pytest.mark.parametrize("name", ["tiny", "small"])
+@pytest.mark.parametrize("name", ["tiny", "small", "default", "stress"])
 def test_corr_fused_vs_oracle(name):
+    """the fused two-level correlation against the float64 oracle -- on the benchmark workload too (default: E = 47,712,
+    stress: E = 97,412), both as a direct call (planar tiles) and as the launch bench.py times: UpdatePath.step() with
+    pixel-major tiles, the prologue's coordinates and the XCD dealing of the edge list"""
     from cdv_slam_amd.update import UpdatePath
     st = synth.make_state(name)
     up = UpdatePath(st, torch.device(DEV))
+    big = st.E > 20000
     # the channels-last rings hold exactly the reference-layout maps
     assert torch.equal(ops.fmap_interior(up.fmap1).permute(0, 3, 1, 2).cpu(), torch.as_tensor(st.fmap1))
     # the zero margins stay zero
@@ -248,20 +254,84 @@ def test_corr_fused_vs_oracle(name):
     coords = _gpu_coords(st)
     import ctypes
     perm = torch.randperm(st.E, device=DEV).to(torch.int32)
+    fmap2 = ops.fmap_interior(up.fmap2).permute(0, 3, 1, 2).contiguous().cpu().numpy()  # what the kernel reads
+    c = coords[0].cpu().numpy()
+    truth = O.slam_corr(st.gmap, st.fmap1, fmap2, c, st.ii1, st.jj1, 3, "truth")
+    tol = _corr_tol(truth)
     for order in (None, perm):
         optr = None if order is None else ctypes.c_void_p(order.data_ptr())
         out = ops.corr_fused(up.gmap, up.fmap1, up.fmap2, coords, up.kk, up.jj, kmod=up.kmod, jmod=up.jmod,
                              order_ptr=optr)
         got = out[0].float().cpu().numpy()
-        c = coords[0].cpu().numpy()
-        fmap2 = ops.fmap_interior(up.fmap2).permute(0, 3, 1, 2).contiguous().cpu().numpy()  # what the kernel reads
-        truth = O.slam_corr(st.gmap, st.fmap1, fmap2, c, st.ii1, st.jj1, 3, "truth")
         assert got.shape == truth.shape == (st.E, 882)
-        assert np.abs(got - truth).max() <= _corr_tol(truth)
-        # and the reference-faithful half-precision emulation sits inside the same envelope
-        ref = O.slam_corr(st.gmap, st.fmap1, fmap2, c, st.ii1, st.jj1, 3, "ref").astype(np.float64)
-        assert np.abs(ref - truth).max() <= 4 * _corr_tol(truth)
-        assert np.abs(got - ref).max() <= 4 * _corr_tol(truth)
+        assert np.abs(got - truth).max() <= tol
+        if not big:
+            # and the reference-faithful half-precision emulation sits inside the same envelope
+            ref = O.slam_corr(st.gmap, st.fmap1, fmap2, c, st.ii1, st.jj1, 3, "ref").astype(np.float64)
+            assert np.abs(ref - truth).max() <= 4 * tol
+            assert np.abs(got - ref).max() <= 4 * tol
+    direct = out
+    # the launch bench.py times
+    res = up.step(iterations=0)
+    torch.cuda.synchronize()
+    assert torch.equal(res["coords"], coords)          # the prologue's reprojection is the same code
+    got = res["corr"][0].float().cpu().numpy()
+    assert np.abs(got - truth).max() <= tol
+    assert torch.equal(res["corr"], direct)            # layouts, dealing and fusion change loads, not results
+    # mean error well inside the bound: the bound is not met by luck at one element
+    assert np.abs(got - truth).mean() <= 0.1 * tol
+
+
+def test_reference_call_sequence_through_the_dropin_names():
+    """The reference's own sequence for one update -- SLAM.reproject / SLAM.corr (slam.py:316-329), Update's
+    fastba.neighbors (net_cdv.py:102), fastba.BA (slam.py:512-515, fastba/ba.py:8) -- written against the module names it
+    imports (cuda_corr, cuda_ba, lietorch_backends, registered by install_dropin()) and the reference's state layouts
+    (planar feature rings [1,mem,C,h,w], gmap [1,pmem*M,C,3,3]), on the benchmark workload; equal to UpdatePath.step():
+    coordinates, correlation and neighbors bit for bit, poses / depths after BA to float32 summation order."""
+    import importlib
+    import cdv_slam_amd
+    from cdv_slam_amd.update import UpdatePath
+    from cdv_slam_amd import projective_ops as pops
+    from cdv_slam_amd.lietorch import SE3
+    cdv_slam_amd.install_dropin()
+    cuda_corr, cuda_ba = importlib.import_module("cuda_corr"), importlib.import_module("cuda_ba")
+    st = synth.make_state("default")
+    dev = torch.device(DEV)
+    up = UpdatePath(st, dev)
+    want = up.step()
+    torch.cuda.synchronize()
+    # reference-shaped state
+    M, mem, pmem = st.cfg.M, st.cfg.mem, st.cfg.pmem
+    N = st.cfg.buffer_size
+    poses_ = T(st.poses).clone()
+    patches_ = T(st.patches).clone()
+    poses, patches = poses_.view(1, N, 7), patches_.view(1, N * M, 3, 3, 3)
+    intrinsics = T(st.intrinsics).view(1, N, 4)
+    pyramid = (T(st.fmap1)[None].contiguous(), T(st.fmap2)[None].contiguous())
+    pyramid[1].copy_(ops.fmap_interior(up.fmap2).permute(0, 3, 1, 2)[None])   # the level-1 map the ingest pooled
+    gmap = T(st.gmap).view(1, pmem * M, st.cfg.C, 3, 3)
+    ii, jj, kk = T(st.ii), T(st.jj), T(st.kk)
+    # SLAM.reproject
+    coords = pops.transform(SE3(poses), patches, intrinsics, ii, jj, kk).permute(0, 1, 4, 2, 3).contiguous()
+    assert torch.equal(coords, want["coords"])
+    # SLAM.corr
+    ii1, jj1 = kk % (M * pmem), jj % mem
+    corr1, = cuda_corr.forward(gmap, pyramid[0], coords / 1, ii1, jj1, 3)
+    corr2, = cuda_corr.forward(gmap, pyramid[1], coords / 4, ii1, jj1, 3)
+    corr = torch.stack([corr1, corr2], -1).view(1, len(ii), -1)
+    assert corr.shape == want["corr"].shape and torch.equal(corr, want["corr"])
+    # Update.forward
+    ix, jx = cuda_ba.neighbors(kk, jj)
+    assert torch.equal(ix, want["ix"]) and torch.equal(jx, want["jx"])
+    # fastba.BA
+    lmbda = torch.as_tensor([1e-4], device=DEV)
+    res = cuda_ba.forward(poses.data, patches, intrinsics, T(st.target)[None], T(st.weight)[None], lmbda, ii, jj, kk, M,
+                          st.t0, st.n, 2, False)
+    torch.cuda.synchronize()
+    assert res == []
+    assert float((poses_ - up.poses).abs().max()) <= 1e-6
+    assert float((patches_ - up.patches).abs().max()) <= 1e-5
+    assert not torch.equal(poses_, T(st.poses))
 
 
 def test_corr_pixel_major_tiles_bit_identical():
@@ -452,16 +522,9 @@ def test_ba_intermediates_vs_oracle(name):
                            ("u", dbg["u"][:U], o["u"]), ("E", dbg["E"][:, :U], o["E"])):
         got = got.cpu().numpy()
         assert np.abs(got - want).max() <= 1e-4 * np.abs(want).max(), key
-    # The solve amplifies float32 rounding of S = B - E Q E^T (weakly constrained gauge at start-up); the float32
-    # oracle measures that conditioning: the kernel may differ from float64 by 2e-3 relative, or by no more than
-    # twice what the reference arithmetic in float32 (sequential sums) differs by, whichever is larger.
-    _, _, _, o32 = O.fastba(st.poses, st.patches, st.intrinsics[0], st.target, st.weight, st.lmbda, st.ii, st.jj,
-                            st.kk, st.t0, st.n, 1, np.float32, debug=True)
-    for key in ("dX", "dZ"):
-        got = dbg[key].cpu().numpy()
-        got = got[:U] if key == "dZ" else got
-        tol = max(2e-3 * max(1e-3, np.abs(o[key]).max()), 2.0 * np.abs(o32[key].astype(np.float64) - o[key]).max())
-        assert np.abs(got - o[key]).max() <= tol, key
+    # dX, dZ: stated bounds (tests/ba_checks.py) -- the error of dX inside the well-determined
+    # eigen-subspace of S, along the weak (scale) directions, the backward error of the kernel's own solve, dZ
+    ba_checks.check_iteration0(name, {k: v.cpu().numpy() for k, v in dbg.items()}, o)
 
 
 @pytest.mark.parametrize("name", ["small", "init", "pr1", "default", "stress"])
@@ -471,14 +534,9 @@ def test_ba_two_iterations_vs_oracle(name):
     p64, x64, info = O.fastba(st.poses, st.patches, st.intrinsics[0], st.target, st.weight, st.lmbda, st.ii, st.jj,
                               st.kk, st.t0, st.n, 2, np.float64)
     assert info == 0
-    # the float32 oracle bounds how much of the difference is float32 conditioning, not the kernel
-    p32, x32, _ = O.fastba(st.poses, st.patches, st.intrinsics[0], st.target, st.weight, st.lmbda, st.ii, st.jj,
-                           st.kk, st.t0, st.n, 2, np.float32)
-    slack = max(1.0, np.abs(p32 - p64).max() / 1e-6)
-    assert np.abs(poses[:, :3] - p64[:, :3]).max() <= 1e-5 * slack * 3
-    assert np.abs(poses[:, 3:] - p64[:, 3:]).max() <= 1e-6 * slack * 3
-    d, d64 = patches[:, 2, 0, 0], x64[:, 2, 0, 0]
-    assert np.abs(d - d64).max() <= 1e-4 * slack * np.maximum(np.abs(d64), 1e-2).max()
+    # explicit per-config bounds (tests/ba_checks.py = BASELINE.md section 5): raw poses / depths, and the gauge-free
+    # quantities (Sim(3)-aligned ATE, reprojection cost) that carry the claim on the weak-gauge graphs init / pr1
+    ba_checks.check_end_state(name, st, poses, patches, p64, x64)
     # fixed poses and untouched patches are bit-identical to the input
     assert np.array_equal(poses[:st.t0], st.poses[:st.t0])
     untouched = np.setdiff1d(np.arange(len(st.patches)), np.unique(st.kk))
@@ -506,29 +564,16 @@ def test_global_ba_vs_oracle(name):
     for key, got, want in (("y", dbg["y"], o["y"]), ("C", dbg["C"][:U], o["C"]), ("u", dbg["u"][:U], o["u"]),
                            ("E", dbg["E"][:, :U], o["E"])):
         assert np.abs(got.cpu().numpy() - want).max() <= 1e-4 * np.abs(want).max(), key
-    _, _, _, o32 = O.fastba(st.poses, st.patches, st.intrinsics[0], st.target, st.weight, st.lmbda, st.ii, st.jj,
-                            st.kk, st.t0, st.n, 1, np.float32, debug=True)
-    for key in ("dX", "dZ"):
-        got = dbg[key].cpu().numpy()
-        got = got[:U] if key == "dZ" else got
-        tol = max(2e-3 * max(1e-3, np.abs(o[key]).max()), 2.0 * np.abs(o32[key].astype(np.float64) - o[key]).max())
-        assert np.abs(got - o[key]).max() <= tol, key
+    ba_checks.check_iteration0(name, {k: v.cpu().numpy() for k, v in dbg.items()}, o)
     # two iterations, end state; the dense-path call signature with eff_impl=True goes the same way
     poses, patches, _ = _run_ba(st, iterations=2)
     p64, x64, info = O.fastba(st.poses, st.patches, st.intrinsics[0], st.target, st.weight, st.lmbda, st.ii, st.jj,
                               st.kk, st.t0, st.n, 2, np.float64)
-    p32, x32, _ = O.fastba(st.poses, st.patches, st.intrinsics[0], st.target, st.weight, st.lmbda, st.ii, st.jj,
-                           st.kk, st.t0, st.n, 2, np.float32)
-    slack = max(1.0, np.abs(p32 - p64).max() / 1e-6)
-    assert np.abs(poses[:, :3] - p64[:, :3]).max() <= 1e-5 * slack * 3
-    assert np.abs(poses[:, 3:] - p64[:, 3:]).max() <= 1e-6 * slack * 3
-    d, d64 = patches[:, 2, 0, 0], x64[:, 2, 0, 0]
-    assert np.abs(d - d64).max() <= 1e-4 * slack * np.maximum(np.abs(d64), 1e-2).max()
+    ba_checks.check_end_state(name, st, poses, patches, p64, x64)
     assert np.array_equal(poses[:st.t0], st.poses[:st.t0])
     # a second call on the same workspace (accumulators re-zeroed by their consumers) gives the same answer
     poses2, patches2, _ = _run_ba(st, iterations=2)
-    # (float atomics: the summation order, hence the last bits, differ from run to run -- same bound as against the oracle)
-    assert np.abs(poses2 - poses).max() <= 1e-5 * slack * 3 and np.abs(patches2 - patches).max() <= 3e-4 * slack
+    ba_checks.check_end_state(name, st, poses2, patches2, p64, x64)
 
 
 @pytest.mark.parametrize("tag", ["fc", "win"])
@@ -729,12 +774,9 @@ def test_single_pixel_patches():
                    T(st.ii), T(st.jj), T(st.kk), st.cfg.M, st.t0, st.n, 2, False)
     p64, x64, info = O.fastba(st.poses, p1, st.intrinsics[0], st.target, st.weight, st.lmbda, st.ii, st.jj, st.kk, st.t0,
                               st.n, 2, np.float64)
-    p32, _, _ = O.fastba(st.poses, p1, st.intrinsics[0], st.target, st.weight, st.lmbda, st.ii, st.jj, st.kk, st.t0, st.n,
-                         2, np.float32)
-    slack = max(1.0, np.abs(p32 - p64).max() / 1e-6)
-    assert np.abs(poses.cpu().numpy()[:, :3] - p64[:, :3]).max() <= 1e-5 * slack * 3
-    d, d64 = patches.cpu().numpy()[:, 2, 0, 0], x64[:, 2, 0, 0]
-    assert np.abs(d - d64).max() <= 1e-4 * slack * np.maximum(np.abs(d64), 1e-2).max()
+    st1 = synth.make_state("small", features=False)
+    st1.patches = p1
+    ba_checks.check_end_state("small", st1, poses.cpu().numpy(), patches.cpu().numpy(), p64, x64)
     flow, val = pops.flow_mag(SE3(T(st.poses)[None]), T(p1)[None], T(st.intrinsics)[None], T(st.ii), T(st.jj), T(st.kk))
     assert flow.shape == (1, st.E, 1, 1) and bool(torch.isfinite(flow).all())
 
