@@ -9,9 +9,12 @@ The Update network is replaced by fixed delta / weight tensors.  All inputs are 
 the timed region.
 
     python bench.py --gpus N --steps K --warmup W
-(N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`;
- every rank runs an independent sequence -- the path does not shard inside a sequence, SURVEY.md 8(e) --
- and the per-rank [pose checksum, fps] pairs are gathered with one RCCL all_gather: cdv_slam_amd/replicas.py.)
+N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (the ranks
+read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment) or run plainly -- then this process starts the N
+rank processes itself, before it touches any GPU, and exits with their status.  Every rank runs an independent
+sequence -- the path does not shard inside a sequence, SURVEY.md 8(e) -- and the per-rank [pose checksum, fps] pairs
+are gathered with one RCCL all_gather: cdv_slam_amd/replicas.py.  The line is only printed if the gathered world
+really has N ranks.
 """
 import argparse
 import json
@@ -89,11 +92,62 @@ def cpu_baseline(st, max_seconds=30.0, gpu_poses=None):
         "ba_py_pr1": {"value": 1.0 / t_bapy, "unit": "BA(2 it)/s", "edges": int(pr.E), "seconds": t_bapy,
                       "what": "oracle/ba_py.py (restated cdvslam/ba.py) on BASELINE.json configs[0], numpy f32"},
         "value": 1.0 / total, "unit": "frames/s", "cores": O.num_threads(), "kind": "port",
-        "sample": "1 update of the bench workload (E=%d): reproject + neighbors + BA(2 it) on all edges, "
-                  "correlation timed on the first %d edges and scaled to E; oracle/cdv_oracle.c, %d thread(s)"
-                  % (n, sample, O.num_threads()),
+        "sample": "1 update of the bench workload (E=%d): reproject + neighbors + BA(2 it) on all edges; "
+                  "2-level correlation (reference half arithmetic) %s; oracle/cdv_oracle.c, %d thread(s)"
+                  % (n, "on all edges" if sample >= n else "timed on the first %d edges and scaled to E" % sample,
+                     O.num_threads()),
         "seconds_per_update": total,
     }
+
+
+def dry_run(args):
+    """the N-rank plumbing of main() without a GPU: same group calls, a trivial step"""
+    import numpy as np
+    import torch
+    from cdv_slam_amd.replicas import ReplicaGroup, aggregate_rate, summarise
+    grp = ReplicaGroup(backend="gloo", device=torch.device("cpu"))
+    if grp.world != args.gpus:
+        raise SystemExit("process group has %d ranks, --gpus says %d" % (grp.world, args.gpus))
+    x = np.random.default_rng(grp.sequence_seed()).standard_normal(1 << 16)
+    for _ in range(args.warmup):
+        x = np.roll(x, 1)
+    grp.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        x = np.roll(x, 1)
+    grp.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed_max = grp.max_over_ranks(elapsed)
+    per_rank = grp.gather_metrics([float(np.abs(x).sum()), args.steps / elapsed])
+    if len(per_rank) != args.gpus:
+        raise SystemExit("gathered %d rows, --gpus says %d" % (len(per_rank), args.gpus))
+    if grp.rank == 0:
+        print(json.dumps({"metric": "dry run (no GPU, not a measurement)", "dry_run": True, "n_gpus": grp.world,
+                          "value": aggregate_rate(args.steps, elapsed_max, grp.world), "unit": "steps/s",
+                          "steps": args.steps, "warmup": args.warmup, "per_rank": per_rank,
+                          "per_rank_summary": summarise(per_rank)}))
+    grp.close()
+
+
+def spawn_ranks(n, argv):
+    """`bench.py --gpus N` run plainly: start the N rank processes (one per GPU, rendezvous on 127.0.0.1) from a parent
+    that never touches a GPU, forward rank 0's JSON line, exit with the worst status."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
 
 
 def main():
@@ -109,7 +163,12 @@ def main():
     ap.add_argument("--overlap", action="store_true", help="build the patch-graph index on a side stream under the "
                     "correlation (measured: no gain, the dispatcher does not interleave the small kernels)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--no-dropin", action="store_true", help="skip timing the reference-shaped drop-in call sequence")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU: the launch / rendezvous / gather plumbing only, on "
+                    "gloo with a trivial step (tests/test_replicas_gloo.py); the line says dry_run and is not a measurement")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     import numpy as np
     import torch
@@ -121,12 +180,16 @@ def main():
 
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world_env and world_env > 1:
+    if args.gpus != world_env:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world_env))
+    if args.dry_run:
+        return dry_run(args)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     grp = ReplicaGroup(backend="nccl", device=dev)  # "nccl" is RCCL on ROCm: xGMI between the GPUs of the node
     rank, world = grp.rank, grp.world
+    if world != args.gpus:
+        raise SystemExit("process group has %d ranks, --gpus says %d" % (world, args.gpus))
 
     # every rank tracks its own sequence: same config, its own seed
     st = synth.make_state(args.config, buffer_size=64, seed=grp.sequence_seed())
@@ -165,8 +228,31 @@ def main():
     # per-stage breakdown (informative)
     stages = up.stage_times(reps=20)
 
+    # ---- the same update the way an UNCHANGED slam.py issues it: planar rings written with torch ops, two
+    # cuda_corr.forward calls + torch.stack, cuda_ba.neighbors, cuda_ba.forward, all through the drop-in module names
+    # (cdv_slam_amd.update.DropinPath; tests/test_gpu_parity.py::test_reference_call_sequence_through_the_dropin_names
+    # shows it gives the same bits as UpdatePath) -- timed like the headline number, reported next to it
+    dropin = None
+    if st.fmap1 is not None and not args.no_dropin:
+        from cdv_slam_amd.update import DropinPath
+        dp = DropinPath(st, dev)
+        nd = max(10, min(args.steps, 100))
+        for _ in range(5):
+            dp.step()
+        torch.cuda.synchronize()
+        td = time.perf_counter()
+        for _ in range(nd):
+            dp.step()
+        torch.cuda.synchronize()
+        td = time.perf_counter() - td
+        dropin = {"value": nd / td, "unit": "frames/s", "ms_per_step": 1e3 * td / nd, "steps": nd,
+                  "what": "reference-shaped call sequence through install_dropin() names on reference state layouts"}
+        del dp
+
     # ---- gather per-rank metrics: [pose checksum, fps] (trajectory-metric gather of SURVEY.md 8(e)) ---
     per_rank = grp.gather_metrics([float(up.poses.double().abs().sum().item()), args.steps / elapsed])
+    if len(per_rank) != args.gpus:
+        raise SystemExit("gathered %d rows, --gpus says %d" % (len(per_rank), args.gpus))
 
     if rank == 0:
         traffic = None
@@ -205,6 +291,7 @@ def main():
                 "kernel": "corr_fused2_kernel<24, 2>", "avg_launch_ms": corr_ms, "algorithmic_bytes": corr_bytes,
             },
             "stages_us": stages,
+            "dropin_fps": dropin,
             "per_rank": per_rank,
             "per_rank_summary": summarise(per_rank),
         }

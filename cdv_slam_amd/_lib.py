@@ -19,6 +19,8 @@ SIGNATURES = {
     "cdv_corr_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "cdv_fmap_padded_elems": (_sz, [_i64, _i32, _i32, _i32]),
     "cdv_fmap_to_nhwc": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i64, _i64, _vp]),
+    "cdv_fmap_sync_workspace_bytes": (_sz, [_i64]),
+    "cdv_fmap_sync_nhwc": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _i32, _vp]),
     "cdv_fmap_ingest": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "cdv_corr_fused": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32,
                               _f32, _f32, _i32, _i64, _i64, _i32, _vp]),
@@ -42,6 +44,7 @@ SIGNATURES = {
     "cdv_graph_workspace_bytes": (_sz, [_i64, _i64]),
     "cdv_graph_build": (_i32, [_vp, _vp, _i64, _vp, _sz, _i64, _i64, _vp]),
     "cdv_graph_build_neighbors": (_i32, [_vp, _vp, _i64, _vp, _sz, _i64, _i64, _vp, _vp, _vp]),
+    "cdv_graph_build_edges": (_i32, [_vp, _vp, _vp, _i64, _vp, _sz, _i64, _i64, _vp, _vp, _vp]),
     "cdv_update_prologue": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i64, _i64, _i64,
                                    _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _sz, _i64, _i64, _vp, _vp, _vp]),
     "cdv_graph_read_meta_host": (_i32, [_vp, _vp, _vp]),
@@ -50,6 +53,8 @@ SIGNATURES = {
     "cdv_ba_workspace_bytes": (_sz, [_i64, _i64, _i32]),
     "cdv_ba_forward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _sz,
                               _i64, _vp, _vp]),
+    "cdv_ba_status": (_i32, [_vp, _vp, _vp]),
+    "cdv_ba_bind_status_counters": (_i32, [_vp, _vp]),
     "cdv_lie_op": (_i32, [_i32, _i32, _i32, _i64, _vp, _vp, _vp, _vp]),
 }
 

@@ -24,8 +24,7 @@
 #include <mutex>
 #include <unordered_map>
 
-#include "cdv_common.h"
-#include "cdv_graph.h"
+#include "cdv_ba.h"
 #include "cdv_se3.h"
 
 using namespace cdv;
@@ -34,12 +33,8 @@ CDV_STAMP_TU(ba)
 
 namespace {
 
-constexpr int BA_CHUNK = 64;      // unique patches per workgroup (= lanes of a wave)
-constexpr int BA_NMAX = 32;       // free poses supported by the single-workgroup solver
-constexpr int BA_NBIG = 1024;     // free poses supported by the global-BA path (dense E in HBM, blocked Cholesky)
 constexpr int BIG_PB = 32;        // poses per panel of the panel-sparse Schur products (192 rows; <= 32 panels: one mask word)
 constexpr int BIG_PR = 6 * BIG_PB;
-constexpr int CNB = 64;           // block size of the multi-workgroup Cholesky
 constexpr int XLD = 17;           // floats per residual row in the Gram staging buffer (16 + 1 pad)
 constexpr int PAIR_LDS_FLOATS = 128 * XLD + 64;  // per wave: [128][XLD] rows + 64 per-edge pair keys
 constexpr int ELD = BA_CHUNK + 4; // row stride of the chunk's E block in LDS (2-way bank conflicts at most)
@@ -48,41 +43,6 @@ constexpr int ASM_WAVES = 1;      // waves per assemble workgroup, one target sl
 constexpr int ASM_SG = 32;        // slot groups (workgroups) per chunk of 64 patches: 32 slots per pass (48, one pass for every patch of the
                                   // steady-state graph, measured: no change)
 constexpr int ASM_THREADS = 64 * ASM_WAVES;
-constexpr int BA_REPL = 4;        // copies of [S | y] the assemble / schur workgroups spread their atomics over
-                                  // (the memory-side atomic units serialise adds to one address); summed by the solve
-
-struct BaLayout {
-  size_t sy, C, u, Ed, cmask, zero_bytes, q, dX, info, Abig, total;
-  int64_t npad;                         // global-BA path: 6 N rounded up to the Cholesky block (0: not used)
-  int64_t U_max, U_stride, sy_stride;   // sy_stride: floats between two copies of [S | y]
-  int N_max;
-};
-
-inline BaLayout ba_layout(int64_t U_max, int N_max) {
-  BaLayout L;
-  L.U_max = U_max; L.N_max = N_max;
-  L.U_stride = (U_max + BA_CHUNK - 1) / BA_CHUNK * BA_CHUNK;
-  const size_t n6 = 6 * (size_t)N_max;
-  size_t o = 0;
-  // accumulators: zeroed once, then kept zero by their consumers
-  L.sy_stride = (int64_t)((n6 * n6 + n6 + 1023) / 1024 * 1024);   // 4 KB multiples: copies start on different channels
-  L.sy = o;   o = align256(o + sizeof(float) * (size_t)L.sy_stride * BA_REPL);
-  L.C = o;    o = align256(o + sizeof(float) * (size_t)L.U_stride);
-  L.u = o;    o = align256(o + sizeof(float) * (size_t)L.U_stride);
-  L.Ed = o;   o = align256(o + sizeof(float) * n6 * (size_t)L.U_stride);
-  L.cmask = o; o = align256(o + sizeof(uint32_t) * (size_t)(L.U_stride / BA_CHUNK));   // active pose panels per chunk
-  L.zero_bytes = o;
-  L.q = o;    o = align256(o + sizeof(float) * (size_t)L.U_stride);
-  L.dX = o;   o = align256(o + sizeof(float) * (n6 + 8));
-  L.info = o; o = align256(o + sizeof(int32_t) * 16 + sizeof(uint64_t) * 64);   // 16 words + the 64 dX granules of the solve -> retract hand-off
-  L.npad = 0; L.Abig = o;
-  if (N_max > BA_NMAX) {   // working copy of [S ; y^T] for the blocked Cholesky, padded with identity to 64-blocks
-    L.npad = (int64_t)((n6 + CNB - 1) / CNB * CNB);
-    o = align256(o + sizeof(float) * (size_t)(L.npad + 1) * (size_t)L.npad);
-  }
-  L.total = o;
-  return L;
-}
 
 struct WsState {
   bool valid;
@@ -92,10 +52,9 @@ struct WsState {
 };
 std::mutex g_ws_mutex;
 std::unordered_map<const void*, WsState> g_ws_state;
+std::unordered_map<const void*, int32_t*> g_ws_counters;   // cdv_ba_bind_status_counters
 
-struct EdgeJ {
-  float r[2], w[2], Jz[2], Ji[12], Jj[12];
-};
+typedef EdgeFactor EdgeJ;   // residual, weights and Jacobian rows of one edge (cdv_se3.h: fastba_factor)
 
 // Inputs of one edge, fetched ahead of use (the slot loop is software-pipelined: indices two slots
 // ahead, inputs one slot ahead, so the global-load round trips overlap the Gram / E work).
@@ -135,54 +94,8 @@ __device__ __forceinline__ EdgeIn load_in(const float* __restrict__ poses, const
   return o;
 }
 
-// ba_cuda.cu:261-342: residual, validity mask and the two Jacobian rows of one edge
 __device__ __forceinline__ void ba_edge(const EdgeIn& in, float fx, float fy, float cx, float cy, EdgeJ& o) {
-  float Xi[4], Xj[4];
-  Xi[0] = (in.px - cx) / fx;
-  Xi[1] = (in.py - cy) / fy;
-  Xi[2] = 1.0f;
-  Xi[3] = in.pd;
-  float tij[3], qij[4];
-  fb_relSE3(in.pi, in.pi + 3, in.pj, in.pj + 3, tij, qij);
-  fb_actSE3(tij, qij, Xi, Xj);
-  const float X = Xj[0], Y = Xj[1], Z = Xj[2], W = Xj[3];
-  const float d = (Z >= 0.2f) ? 1.0f / Z : 0.0f;
-  const float d2 = d * d;
-  const float x1 = fx * (X / Z) + cx;
-  const float y1 = fy * (Y / Z) + cy;
-  const float rx = in.tx - x1;
-  const float ry = in.ty - y1;
-  const bool in_bounds = (sqrtf(rx * rx + ry * ry) < 128.f) && (Z > 0.2f) && (x1 > -64.f) && (y1 > -64.f) &&
-                         (x1 < 2 * cx + 64.f) && (y1 < 2 * cy + 64.f);
-  const float mask = in_bounds ? 1.0f : 0.0f;
-  o.r[0] = rx;
-  o.w[0] = mask * in.wx;
-  o.Jz[0] = fx * (tij[0] * d - tij[2] * X * d2);
-  o.Jj[0] = fx * W * d;
-  o.Jj[1] = 0.0f;
-  o.Jj[2] = -fx * X * W * d2;
-  o.Jj[3] = -fx * X * Y * d2;
-  o.Jj[4] = fx * (1.0f + X * X * d2);
-  o.Jj[5] = -fx * Y * d;
-  o.r[1] = ry;
-  o.w[1] = mask * in.wy;
-  o.Jz[1] = fy * (tij[1] * d - tij[2] * Y * d2);
-  o.Jj[6] = 0.0f;
-  o.Jj[7] = fy * W * d;
-  o.Jj[8] = -fy * Y * W * d2;
-  o.Jj[9] = -fy * (1.0f + Y * Y * d2);
-  o.Jj[10] = fy * X * Y * d2;
-  o.Jj[11] = fy * X * d;
-  fb_adjSE3(tij, qij, o.Jj, o.Ji);
-  fb_adjSE3(tij, qij, o.Jj + 6, o.Ji + 6);
-}
-
-// LDS hand-off between the lanes of ONE wave: the LDS unit executes a wave's DS instructions in order, so only the
-// compiler has to be kept from moving accesses across this point.  (A workgroup-scope release fence would also drain
-// vmcnt, i.e. wait for the wave's outstanding global atomics: ~3000 cycles each time.)
-__device__ __forceinline__ void wave_lds_sync() {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
+  fastba_factor(in.pi, in.pj, in.px, in.py, in.pd, in.tx, in.ty, in.wx, in.wy, fx, fy, cx, cy, o);
 }
 
 // one entry (row, col) of the 13x13 Gram matrix G = sum_k w_k X[k] X[k]^T, X[k] = [Ji | Jj | r]
@@ -217,6 +130,8 @@ struct AsmArgs {
   int U_stride, U_max;
   int32_t* info;
   uint32_t* cmask;
+  int32_t* counters;   // optional host-visible event counters of the workspace (may be NULL)
+  int first;           // first iteration of a call
 };
 
 __device__ __forceinline__ void assemble_body(const AsmArgs& A, int bid, float* smem) {
@@ -240,12 +155,10 @@ __device__ __forceinline__ void assemble_body(const AsmArgs& A, int bid, float* 
   const int U_stride = A.U_stride, U_max = A.U_max;
   int32_t* __restrict__ info = A.info;
   uint32_t* __restrict__ cmask = A.cmask;
-  if (gmeta[GM_ERROR]) return;
+  const int gerr = gmeta[GM_ERROR];
   const int U = gmeta[GM_U];
-  if (U > U_max) {  // workspace too small: BA is skipped
-    if (threadIdx.x == 0 && bid == 0) info[1] = 1;
-    return;
-  }
+  if (threadIdx.x == 0 && bid == 0) ba_begin_status(info, A.counters, A.first, gerr, U > U_max);
+  if (gerr || U > U_max) return;   // no index / workspace too small: BA is skipped, the status words say so
   // workgroup = (chunk of 64 unique patches, slot group): wave w takes target slot t = 8 sg + w (+ 32 per pass)
   const int chunk = bid / ASM_SG, sg = bid - chunk * ASM_SG;
   const int r0 = chunk * BA_CHUNK;
@@ -715,321 +628,21 @@ __global__ __launch_bounds__(1024) void ba_solve_kernel(float* __restrict__ pose
     dXg[t] = z[t];
     if (dbg) dbg[n * n + n + t] = z[t];
   }
-  if (t == 0) info[0] = s_bad;
-  // pose_retr_kernel (ba_cuda.cu:178-206)
+  if (t == 0 && s_bad) ba_flag(info, BI_CHOL, s_bad);
+  // pose retraction T <- Exp(dX_i) T (ba_cuda.cu:178-206 semantics)
   if (t < N) {
     float* p = poses + 7 * (size_t)(t0 + t);
-    float tt[3] = {p[0], p[1], p[2]}, qq[4] = {p[3], p[4], p[5], p[6]}, tn[3], qn[4], xi[6];
+    float pose[7], xi[6];
+#pragma unroll
+    for (int c = 0; c < 7; c++) pose[c] = p[c];
 #pragma unroll
     for (int c = 0; c < 6; c++) xi[c] = z[6 * t + c];
-    fb_retrSE3(xi, tt, qq, tn, qn);
-    p[0] = tn[0]; p[1] = tn[1]; p[2] = tn[2];
-    p[3] = qn[0]; p[4] = qn[1]; p[5] = qn[2]; p[6] = qn[3];
+    se3_retract_raw(xi, pose);
+#pragma unroll
+    for (int c = 0; c < 7; c++) p[c] = pose[c];
   }
   CDV_STAMP(ba, sslot, 4);
 }
-
-// ---------------------------------------------------------------------------------------------------------
-// Small systems (N <= 10 free poses: the default optimisation window): the whole factorisation in the registers
-// of ONE wave.  Lane r holds row r of [S ; y^T] (lane 60 = the right-hand side, so the forward substitution is
-// free); column step k broadcasts L[c][k] with v_readlane (an SGPR operand of the following FMA), two
-// instructions per matrix entry, no barrier and no LDS traffic inside the factorisation.  The system is padded
-// with identity rows / columns up to 60, so one instantiation serves every N <= 10.
-// ---------------------------------------------------------------------------------------------------------
-constexpr int SN = 60;    // unknowns of the single-wave solver
-constexpr int SLD = 68;   // LDS row stride (floats): rows 16-byte aligned; b128 row reads and b32 column reads conflict-free
-
-__device__ __forceinline__ float readlane_f(float v, int l) {
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
-}
-
-// publish != nullptr: dX is handed to the retract workgroups of the SAME launch (ba_solve60_retract_kernel) as tagged
-// 8-byte granules (below).
-__device__ __forceinline__ void solve60_body(float* __restrict__ poses, float* __restrict__ sy, int sy_stride,
-                                             float* __restrict__ dXg, int t0, int N,
-                                             const int32_t* __restrict__ gmeta, float* __restrict__ dbg,
-                                             int32_t* __restrict__ info, uint64_t* publish) {
-  __shared__ __attribute__((aligned(16))) float A[(SN + 1) * SLD];
-  __shared__ float xs[64];
-  const int n = 6 * N;
-  const int T = 256, t = threadIdx.x;
-  CDV_IF_STAMPS(const int sslot = 4096 + (t >> 6);)
-  CDV_STAMP(ba, sslot, 0);
-  typedef float cdv_float2 __attribute__((ext_vector_type(2)));
-  cdv_float2 a2[SN / 2];
-  const bool direct = (n == SN);
-  if (!direct && (gmeta[GM_ERROR] || info[1])) return;
-  if (direct) {
-    // Full system (N = 10, the steady state): lane r of wave 0 loads row r of every copy of [S | y] (row 60 = the
-    // right-hand side) straight into its registers -- 60 independent 16-byte loads, ONE memory round trip, no LDS
-    // staging, no index arithmetic -- sums them and damps its own diagonal entry (ba_cuda.cu:589).  The other three
-    // waves re-zero the copies for the next iteration once wave 0 holds them.
-    const int row = min(t, SN);
-    cdv_float4 v[BA_REPL][SN / 4];
-    if (t < 64) {
-      const float* rp = sy + (size_t)row * SN;
-#pragma unroll
-      for (int rep = 0; rep < BA_REPL; rep++)
-#pragma unroll
-        for (int c4 = 0; c4 < SN / 4; c4++)
-          v[rep][c4] = *reinterpret_cast<const cdv_float4*>(rp + (size_t)rep * sy_stride + 4 * c4);
-    }
-    // the error words are looked at AFTER the loads are on their way (one round trip instead of two; the loads are
-    // harmless either way); uniform over the workgroup
-    if (gmeta[GM_ERROR] || info[1]) return;
-    if (t < 64) {
-#pragma unroll
-      for (int c4 = 0; c4 < SN / 4; c4++) {
-        cdv_float4 sum = v[0][c4];
-#pragma unroll
-        for (int rep = 1; rep < BA_REPL; rep++) sum += v[rep][c4];
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-          float sv = sum[c];
-          if (row == 4 * c4 + c) sv += 1e-4f * sv + 1.0f;      // S += I * (1e-4 * S + 1.0)   ba_cuda.cu:589
-          sum[c] = sv;
-        }
-        if (dbg && t <= SN) *reinterpret_cast<cdv_float4*>(dbg + (size_t)row * SN + 4 * c4) = sum;
-        a2[2 * c4] = cdv_float2{sum[0], sum[1]};
-        a2[2 * c4 + 1] = cdv_float2{sum[2], sum[3]};
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every copy is in registers before the barrier releases the zeroing
-    }
-    __syncthreads();
-    if (t >= 64) {
-      const int total4 = (SN * SN + SN) / 4;   // 915
-      const cdv_float4 z4 = {0.f, 0.f, 0.f, 0.f};
-      for (int i4 = t - 64; i4 < total4; i4 += T - 64)
-#pragma unroll
-        for (int rep = 0; rep < BA_REPL; rep++)
-          *reinterpret_cast<cdv_float4*>(sy + (size_t)rep * sy_stride + 4 * i4) = z4;
-      return;
-    }
-  } else
-  // [S | y]: the BA_REPL copies are summed on the way in (one memory round trip: all loads of a thread are issued
-  // before the first use), re-zeroed for the next iteration, damped (ba_cuda.cu:589) and laid out as rows in LDS.
-  {
-    const int total = n * n + n;
-    const float inv_n = 1.0f / (float)n;   // idx / n for idx < 2^23 via one multiply
-    const int total4 = (total + 3) / 4;    // <= 915: one batch of 4 float4 per thread
-    const cdv_float4 z4 = {0.f, 0.f, 0.f, 0.f};
-    cdv_float4 v[4][BA_REPL];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int i4 = i * T + t;
-#pragma unroll
-      for (int rep = 0; rep < BA_REPL; rep++)
-        v[i][rep] = (i4 < total4) ? *reinterpret_cast<const cdv_float4*>(sy + (size_t)rep * sy_stride + 4 * i4) : z4;
-    }
-    // identity padding (rows / columns n .. 59), zero right-hand side
-    for (int idx = t; idx < (SN + 1) * SLD; idx += T) {
-      const int row = (int)(((float)idx + 0.5f) * (1.0f / (float)SLD)), col = idx - row * SLD;   // exact for idx < 2^22
-      A[idx] = (row == col && row < SN) ? 1.0f : 0.0f;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int i4 = i * T + t;
-      if (i4 < total4) {
-        cdv_float4 sum = v[i][0];
-#pragma unroll
-        for (int rep = 1; rep < BA_REPL; rep++) sum += v[i][rep];
-#pragma unroll
-        for (int rep = 0; rep < BA_REPL; rep++)
-          *reinterpret_cast<cdv_float4*>(sy + (size_t)rep * sy_stride + 4 * i4) = z4;
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-          const int idx = 4 * i4 + c;
-          if (idx < total) {
-            float sv = sum[c];
-            const int a = (int)(((float)idx + 0.5f) * inv_n), b = idx - a * n;   // a == n: the y row
-            if (a == b) sv += 1e-4f * sv + 1.0f;      // S += I * (1e-4 * S + 1.0)   ba_cuda.cu:589
-            A[(a == n ? SN : a) * SLD + b] = sv;
-            if (dbg) dbg[idx] = sv;
-          }
-        }
-      }
-    }
-  }
-  if (!direct) __syncthreads();
-  CDV_STAMP(ba, sslot, 1);
-  if (t >= 64) return;   // one wave from here on (no block-wide barrier below)
-  const int lane = t;
-  const int myrow = min(lane, SN);   // lanes 61..63 shadow the right-hand-side row
-  // the row as 30 float2 registers: the rank-1 updates of a column step run two columns per v_pk_fma_f32
-  if (!direct) {
-#pragma unroll
-    for (int c4 = 0; c4 < SN / 4; c4++) {
-      const cdv_float4 q = *reinterpret_cast<const cdv_float4*>(&A[myrow * SLD + 4 * c4]);
-      a2[2 * c4] = cdv_float2{q[0], q[1]};
-      a2[2 * c4 + 1] = cdv_float2{q[2], q[3]};
-    }
-  }
-  int badk = 0;
-#pragma unroll
-  for (int k = 0; k < SN; k++) {
-    float ak = a2[k >> 1][k & 1];
-    const float piv = readlane_f(ak, k);
-    if (!(piv > 0.f) && badk == 0) badk = k / 6 + 1;   // wave-uniform
-    const float inv = __builtin_amdgcn_rsqf(piv);
-    ak *= inv;                                           // column k of L (rows >= k), z_k in lane 60
-    a2[k >> 1][k & 1] = ak;
-    if ((k & 1) == 0) a2[k >> 1][1] = fmaf(-ak, readlane_f(ak, k + 1), a2[k >> 1][1]);   // the partner column of an even k
-    // all broadcasts of the step first, then the FMAs: a v_readlane result needs two wait states before a VALU
-    // instruction may read it, which back-to-back (readlane, fma) pairs would pay as an s_nop every time
-    const cdv_float2 nak = {-ak, -ak};
-    cdv_float2 sb[SN / 2];
-#pragma unroll
-    for (int p = (k >> 1) + 1; p < SN / 2; p++) sb[p] = cdv_float2{readlane_f(ak, 2 * p), readlane_f(ak, 2 * p + 1)};
-#pragma unroll
-    for (int p = (k >> 1) + 1; p < SN / 2; p++) a2[p] = __builtin_elementwise_fma(nak, sb[p], a2[p]);
-  }
-  float a[SN];
-#pragma unroll
-  for (int c = 0; c < SN; c++) a[c] = a2[c >> 1][c & 1];
-  CDV_STAMP(ba, sslot, 2);
-  // L back to LDS (zeros above the diagonal), then lane k picks up COLUMN k: col[r] = L[r][k]
-  wave_lds_sync();
-  if (lane <= SN) {
-#pragma unroll
-    for (int c4 = 0; c4 < SN / 4; c4++) {
-      cdv_float4 q;
-#pragma unroll
-      for (int j = 0; j < 4; j++) q[j] = (4 * c4 + j <= lane) ? a[4 * c4 + j] : 0.f;
-      *reinterpret_cast<cdv_float4*>(&A[lane * SLD + 4 * c4]) = q;
-    }
-  }
-  wave_lds_sync();
-  const int kc = min(lane, SN - 1);
-  float col[SN];
-#pragma unroll
-  for (int r = 0; r < SN; r++) col[r] = A[r * SLD + kc];
-  float z = A[SN * SLD + kc];                       // z = L^-1 y
-  const float invd = 1.0f / A[kc * SLD + kc];
-  // back substitution L^T x = z: x_r = z_r / L[r][r] once every x_j, j > r, has been folded into z
-  float x = 0.f;
-#pragma unroll
-  for (int r = SN - 1; r >= 0; r--) {
-    const float xr = readlane_f(z * invd, r);
-    x = (lane == r) ? xr : x;
-    z = fmaf(-col[r], xr, z);
-  }
-  CDV_STAMP(ba, sslot, 3);
-  if (lane < n) {
-    // the data IS the flag: one 8-byte {tag = 1, value} granule per unknown, written through (an agent-scope atomic
-    // store); the retract workgroups poll the tags of the granules they read -- no drain, no separate flag word, and
-    // their poll is the load of dX (CDNA programming guide, Guideline 16, recipe R2)
-    if (publish)
-      __hip_atomic_store(&publish[lane], (1ull << 32) | (uint64_t)(uint32_t)__float_as_int(x), __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
-    dXg[lane] = x;
-    if (dbg) dbg[n * n + n + lane] = x;
-  }
-  if (lane == 0) info[0] = badk;
-  // the pose retraction (sin / cos of the update) runs in ba_retract_kernel, next to the depth updates, instead of
-  // lengthening this single-wave critical path
-  (void)poses; (void)t0; (void)xs;
-  CDV_STAMP(ba, sslot, 4);
-}
-
-__global__ __launch_bounds__(256) void ba_solve60_kernel(float* __restrict__ poses, float* __restrict__ sy,
-                                                         int sy_stride, float* __restrict__ dXg, int t0, int N,
-                                                         const int32_t* __restrict__ gmeta, float* __restrict__ dbg,
-                                                         int32_t* __restrict__ info) {
-  solve60_body(poses, sy, sy_stride, dXg, t0, N, gmeta, dbg, info, nullptr);   // looks at the error words itself
-}
-
-// Solve + retract in ONE launch (N <= 10).  Workgroup 0 is the single-wave solver; workgroups 1.. are the retract
-// workgroups: while the solver runs they load their patches' E columns, C, u, q and depth into registers and re-zero
-// the accumulators, then poll the tagged dX granules (one wave per workgroup, bounded), and finish with 60 FMAs per
-// patch.  The retract launch's start-up latency and its memory round trips hide under the solver instead of following
-// it.  All workgroups are co-resident (a few dozen on 256 CUs), so the wait cannot deadlock; the granules are reset by
-// the preceding schur launch.
-__global__ __launch_bounds__(256) void ba_solve60_retract_kernel(float* __restrict__ poses, float* __restrict__ sy,
-                                                                 int sy_stride, float* __restrict__ dXg, int t0, int N,
-                                                                 const int32_t* __restrict__ gmeta, float* __restrict__ dbg,
-                                                                 int32_t* __restrict__ info, uint64_t* __restrict__ gran,
-                                                                 float* __restrict__ patches, int P,
-                                                                 const int64_t* __restrict__ kx, float* __restrict__ Cg,
-                                                                 float* __restrict__ ug, const float* __restrict__ qg,
-                                                                 float* __restrict__ Edg, int U_stride,
-                                                                 float* __restrict__ dbgp) {
-  if (blockIdx.x == 0) {
-    solve60_body(poses, sy, sy_stride, dXg, t0, N, gmeta, dbg, info, gran);   // looks at the error words itself
-    return;
-  }
-  if (gmeta[GM_ERROR] || info[1]) return;
-  __shared__ float sdx[64];
-  const int U = gmeta[GM_U];
-  const int PP = P * P;
-  const int t = threadIdx.x;
-  const int r = ((int)blockIdx.x - 1) * 256 + t;
-  const bool live = r < U;
-  // ---- before dX exists: everything of this patch that does not depend on it -------------------------
-  float ev[SN];
-#pragma unroll
-  for (int b = 0; b < SN / 6; b++) {
-#pragma unroll
-    for (int c = 0; c < 6; c++) {
-      float v = 0.f;
-      if (live && b < N) {
-        float* ep = &Edg[(size_t)(6 * b + c) * U_stride + r];
-        v = *ep;
-        if (dbgp) dbgp[3 * (size_t)U_stride + (size_t)(6 * b + c) * U_stride + r] = v;
-        *ep = 0.f;
-      }
-      ev[6 * b + c] = v;
-    }
-  }
-  float cv = 0.f, uv = 0.f, qv = 0.f, d0 = 0.f;
-  float* pk = nullptr;
-  if (live) {
-    cv = Cg[r]; uv = ug[r]; qv = qg[r];
-    Cg[r] = 0.f; ug[r] = 0.f;
-    pk = patches + kx[r] * 3 * PP + 2 * PP;
-    d0 = pk[0];                      // patch_retr_kernel reads pixel [0][0]   ba_cuda.cu:218
-  }
-  // ---- wait for the solver (bounded: a lost hand-off must not hang the device) ------------------------
-  if (t < 64) {   // wave 0: lane t polls the granule of unknown t until its tag shows up; the poll is the load of dX
-    float xv = 0.f;
-    bool ok = t >= 6 * N;
-    for (int spins = 0; spins < (1 << 22); spins++) {
-      if (!ok) {
-        const uint64_t g = __hip_atomic_load(&gran[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((uint32_t)(g >> 32) == 1u) { xv = __int_as_float((int)(uint32_t)g); ok = true; }
-      }
-      if (__all(ok)) break;
-      __builtin_amdgcn_s_sleep(2);
-    }
-    if (!ok) info[2] = 1;   // bounded: a lost hand-off must not hang the device
-    sdx[t] = xv;
-  }
-  __syncthreads();
-  // ---- pose_retr_kernel (ba_cuda.cu:178-206): the last workgroup's first N lanes --------------------------
-  if (blockIdx.x == gridDim.x - 1 && t < N) {
-    float* p = poses + 7 * (size_t)(t0 + t);
-    float tt[3] = {p[0], p[1], p[2]}, qq[4] = {p[3], p[4], p[5], p[6]}, tn[3], qn[4], xi[6];
-#pragma unroll
-    for (int c = 0; c < 6; c++) xi[c] = sdx[6 * t + c];
-    fb_retrSE3(xi, tt, qq, tn, qn);
-    p[0] = tn[0]; p[1] = tn[1]; p[2] = tn[2];
-    p[3] = qn[0]; p[4] = qn[1]; p[5] = qn[2]; p[6] = qn[3];
-  }
-  if (!live) return;
-  // u - E^T dX  (ba_cuda.cu:592), six partial sums as in ba_retract_kernel
-  float sacc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int b = 0; b < SN / 6; b++)
-#pragma unroll
-    for (int c = 0; c < 6; c++) sacc[c] += ev[6 * b + c] * sdx[6 * b + c];
-  const float dz = qv * (uv - (((sacc[0] + sacc[1]) + (sacc[2] + sacc[3])) + (sacc[4] + sacc[5])));
-  if (dbgp) { dbgp[r] = dz; dbgp[U_stride + r] = cv; dbgp[2 * (size_t)U_stride + r] = uv; }
-  float d = d0 + dz;
-  d = (d > 20.f) ? 1.0f : d;
-  d = fmaxf(d, 1e-4f);
-  for (int a = 0; a < PP; a++) pk[a] = d;
-}
-
 
 // =========================================================================================================
 // Global bundle adjustment (N > 32 free poses; slam.py:460-478 calls fastba.BA(..., eff_impl=True) over the active
@@ -1252,7 +865,7 @@ __global__ __launch_bounds__(64) void ba_big_panel_kernel(float* __restrict__ A,
     }
   }
   if (blockIdx.x == 0) {
-    if (lane == 0 && bad && info[0] == 0) info[0] = kb + 1;
+    if (lane == 0 && bad && info[BI_CHOL] == 0) ba_flag(info, BI_CHOL, kb + 1);
     return;
   }
   wave_lds_sync();
@@ -1411,12 +1024,14 @@ __global__ __launch_bounds__(64 * RET_RG) void ba_retract_kernel(float* __restri
   if (pose_retr && g == 0 && gid_rev < N) {
     const int pi = gid_rev;
     float* p = poses + 7 * (size_t)(t0 + pi);
-    float tt[3] = {p[0], p[1], p[2]}, qq[4] = {p[3], p[4], p[5], p[6]}, tn[3], qn[4], xi[6];
+    float pose[7], xi[6];
+#pragma unroll
+    for (int c = 0; c < 7; c++) pose[c] = p[c];
 #pragma unroll
     for (int c = 0; c < 6; c++) xi[c] = dXg[6 * pi + c];
-    fb_retrSE3(xi, tt, qq, tn, qn);
-    p[0] = tn[0]; p[1] = tn[1]; p[2] = tn[2];
-    p[3] = qn[0]; p[4] = qn[1]; p[5] = qn[2]; p[6] = qn[3];
+    se3_retract_raw(xi, pose);
+#pragma unroll
+    for (int c = 0; c < 7; c++) p[c] = pose[c];
   }
   const int PP = P * P;
   __shared__ float part[RET_RG][64];
@@ -1465,6 +1080,7 @@ extern "C" void cdv_workspace_forget(const void* ws) {
   {
     std::lock_guard<std::mutex> lk(g_ws_mutex);
     g_ws_state.erase(ws);
+    g_ws_counters.erase(ws);
   }
   cdv_graph_forget(ws);
 }
@@ -1512,15 +1128,38 @@ extern "C" int cdv_ba_forward(float* poses, float* patches, const float* intrins
   // The accumulators are zeroed once per (workspace, U_max, N): afterwards the solve / retract kernels leave
   // them zero, so the steady-state call enqueues no memset.
   bool fresh;
+  int32_t* counters = nullptr;
   {
     std::lock_guard<std::mutex> lk(g_ws_mutex);
     WsState& st = g_ws_state[ba_ws];
     fresh = !(st.valid && st.U_max == U_max && st.N == N && st.bytes == ba_ws_bytes);
     st = WsState{true, U_max, N, ba_ws_bytes};
+    auto it = g_ws_counters.find(ba_ws);
+    if (it != g_ws_counters.end()) counters = it->second;
   }
+  const bool window = N >= 1 && N <= WIN_N;   // the optimisation-window path (ba_win.hip): two launches per iteration
   if (fresh) {
-    CDV_HIP_CHECK(hipMemsetAsync(b + L.sy, 0, L.zero_bytes, s));
+    if (!window) CDV_HIP_CHECK(hipMemsetAsync(b + L.sy, 0, L.zero_bytes, s));   // the window path keeps no accumulators
     CDV_HIP_CHECK(hipMemsetAsync(info, 0, sizeof(int32_t) * 16 + sizeof(uint64_t) * 64, s));
+  }
+  if (window) {
+    BaWinArgs wa;
+    wa.poses = poses; wa.patches = patches; wa.intr = intrinsics; wa.target = target; wa.weight = weight; wa.lmbda = lmbda;
+    wa.ii = ii; wa.P = P; wa.t0 = t0; wa.N = N;
+    wa.gmeta = gv.meta; wa.prec = gv.prec; wa.koff_u = gv.koff_u; wa.kx = gv.kx;
+    wa.slabs = (float*)(b + L.slabs); wa.ared = (float*)(b + L.ared);
+    wa.arrive = (int32_t*)(b + L.hand);
+    wa.granX = reinterpret_cast<uint64_t*>(info + 16);
+    wa.Cg = Cg; wa.ug = ug; wa.qg = qg; wa.Edg = Edg; wa.dXg = dXg;
+    wa.U_stride = (int)L.U_stride; wa.U_max = (int)L.U_max; wa.n_ck_cap = (int)L.n_ck;
+    wa.info = info; wa.counters = counters;
+    for (int itr = 0; itr < iterations; itr++) {
+      wa.dbg = (dbg && itr == 0) ? dbg : nullptr;
+      wa.first = itr == 0 ? 1 : 0;
+      const int rc = cdv_ba_window_iteration(wa, s);
+      if (rc != CDV_OK) return rc;
+    }
+    return CDV_OK;
   }
 
   const int n_chunks = cdv_div_up(L.U_max, BA_CHUNK);
@@ -1552,7 +1191,7 @@ extern "C" int cdv_ba_forward(float* poses, float* patches, const float* intrins
   for (int itr = 0; itr < iterations; itr++) {
     float* d = (dbg && itr == 0) ? dbg : nullptr;
     const AsmArgs aa{poses, patches, intrinsics, target, weight, ii, jj, kk, P, t0, N, gv.meta, gv.pcsr, gv.koff_u, sy,
-                     (int)L.sy_stride, Cg, ug, Edg, (int)L.U_stride, (int)L.U_max, info, cmask};
+                     (int)L.sy_stride, Cg, ug, Edg, (int)L.U_stride, (int)L.U_max, info, cmask, counters, itr == 0 ? 1 : 0};
     const SchurArgs sa{lmbda, N, gv.meta, sy, (int)L.sy_stride, Cg, ug, qg, Edg, (int)L.U_stride, info};
     hipLaunchKernelGGL(ba_assemble_kernel, dim3(n_chunks * ASM_SG), dim3(ASM_THREADS), smem_asm, s, aa);
     if (big) {
@@ -1574,25 +1213,61 @@ extern "C" int cdv_ba_forward(float* poses, float* patches, const float* intrins
       // one wave per lower-triangular tile pair of [Ed; u] (10 at N = 10): the pairs run side by side
       const int t16 = (n6i + 1 + 15) / 16, sch_waves = t16 * (t16 + 1) / 2 < 16 ? t16 * (t16 + 1) / 2 : 16;
       hipLaunchKernelGGL(ba_schur_kernel, dim3(n_chunks), dim3(64 * (sch_waves < 4 ? 4 : sch_waves)), smem_sch, s, sa);
-      if (N > 0 && 6 * N <= SN) {
-        // solve + retract in one launch (dbg layout as below)
-        float* dbgq = d ? d + (size_t)n6i * n6i + 2 * n6i : nullptr;
-        hipLaunchKernelGGL(ba_solve60_retract_kernel, dim3(1 + cdv_div_up(L.U_max, 256)), dim3(256), 0, s, poses, sy,
-                           (int)L.sy_stride, dXg, t0, N, gv.meta, d, info, reinterpret_cast<uint64_t*>(info + 16), patches, P, gv.kx, Cg, ug, qg, Edg,
-                           (int)L.U_stride, dbgq);
-        CDV_LAUNCH_CHECK();
-        continue;
-      } else if (N > 0)
+      if (N > 0)
         hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(1024), smem_sol, s, poses, sy, (int)L.sy_stride, dXg, t0, N,
                            gv.meta, d, info);
     }
     // dbg layout: [S n6^2 | y n6 | dX n6 | dZ U_stride | C U_stride | u U_stride | E n6*U_stride]
     float* dbgp = d ? d + (size_t)n6i * n6i + 2 * n6i : nullptr;
-    const int pose_retr = (N > 0 && (6 * N <= SN || big)) ? 1 : 0;
+    const int pose_retr = big ? 1 : 0;   // N <= 32: the solve kernel retracts the poses itself
     hipLaunchKernelGGL(ba_retract_kernel, dim3(rb), dim3(64 * RET_RG), 0, s, poses, t0, pose_retr, patches, P, N, gv.meta, gv.kx,
                        Cg, ug, qg, Edg, (int)L.U_stride, dXg, dbgp, info, big ? lmbda : (const float*)nullptr, cmask,
                        n_chunks);
     CDV_LAUNCH_CHECK();
+  }
+  return CDV_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// status of a workspace
+// ---------------------------------------------------------------------------------------------------------
+
+extern "C" int cdv_ba_bind_status_counters(void* ba_ws, int32_t* counters) {
+  CDV_REQUIRE(ba_ws != nullptr, CDV_ERR_ARG, "cdv_ba_bind_status_counters: workspace is NULL");
+  std::lock_guard<std::mutex> lk(g_ws_mutex);
+  if (counters) g_ws_counters[ba_ws] = counters;
+  else g_ws_counters.erase(ba_ws);
+  return CDV_OK;
+}
+
+extern "C" int cdv_ba_status(const void* ba_ws, int32_t* info_host, void* stream) {
+  CDV_REQUIRE(ba_ws != nullptr && info_host != nullptr, CDV_ERR_ARG, "cdv_ba_status: NULL argument");
+  WsState st;
+  {
+    std::lock_guard<std::mutex> lk(g_ws_mutex);
+    auto it = g_ws_state.find(ba_ws);
+    CDV_REQUIRE(it != g_ws_state.end() && it->second.valid, CDV_ERR_ARG, "cdv_ba_status: no cdv_ba_forward has run on this workspace");
+    st = it->second;
+  }
+  const BaLayout L = ba_layout(st.U_max, st.N > 0 ? st.N : 1);
+  CDV_HIP_CHECK(hipMemcpyAsync(info_host, (const char*)ba_ws + L.info, 4 * sizeof(int32_t), hipMemcpyDeviceToHost,
+                               (hipStream_t)stream));
+  CDV_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+  if (info_host[BI_GRAPH]) {
+    cdv_set_error(CDV_ERR_GRAPH_RANGE, "bundle adjustment skipped: the patch-graph index reported a patch-id range beyond its capacity");
+    return CDV_ERR_GRAPH_RANGE;
+  }
+  if (info_host[BI_OVERFLOW]) {
+    cdv_set_error(CDV_ERR_BA_OVERFLOW, "bundle adjustment skipped: more unique patches than U_max");
+    return CDV_ERR_BA_OVERFLOW;
+  }
+  if (info_host[BI_HANDOFF]) {
+    cdv_set_error(CDV_ERR_BA_HANDOFF, "bundle adjustment: an in-launch hand-off timed out, the update was not applied");
+    return CDV_ERR_BA_HANDOFF;
+  }
+  if (info_host[BI_CHOL]) {
+    cdv_set_error(CDV_ERR_BA_NOT_SPD, "bundle adjustment: the reduced system is not positive definite (Cholesky pivot <= 0)");
+    return CDV_ERR_BA_NOT_SPD;
   }
   return CDV_OK;
 }

@@ -1,0 +1,135 @@
+// cdv_ba.h -- internal: workspace layout and launch interface shared by ba.hip (dispatch, larger systems) and
+// ba_win.hip (the optimisation-window path, N <= 10 free poses).
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include "cdv_common.h"
+#include "cdv_graph.h"
+
+namespace cdv {
+
+constexpr int BA_CHUNK = 64;      // unique patches per workgroup of the N > 10 path (= lanes of a wave)
+constexpr int BA_NMAX = 32;       // free poses supported by the single-workgroup solver
+constexpr int BA_NBIG = 1024;     // free poses supported by the global-BA path (dense E in HBM, blocked Cholesky)
+constexpr int CNB = 64;           // block size of the multi-workgroup Cholesky
+constexpr int BA_REPL = 4;        // copies of [S | y] the N > 10 assemble / schur workgroups spread their atomics over
+
+// ---- window path (N <= 10): no float atomics anywhere, bitwise reproducible ---------------------------------
+constexpr int WIN_N = 10;                        // free poses
+constexpr int WIN_SN = 6 * WIN_N;                // unknowns
+constexpr int WIN_TRI = WIN_SN * (WIN_SN + 1) / 2;   // packed lower triangle of S
+constexpr int WIN_SLAB = 1896;                   // floats per partial system: TRI + 60 (y), padded to a multiple of 8
+constexpr int WIN_CK = 16;                       // unique patches per chunk workgroup
+constexpr int WIN_MAX_GRID = 1024;               // chunk workgroups per launch (grid-stride over the chunks beyond)
+constexpr int WIN_MAX_RW = 32;                   // reduce / retract workgroups of the finish launch
+
+// status words of a workspace (int32 info[16] on the device; cdv_ba_status reads the first four)
+enum { BI_CHOL = 0, BI_OVERFLOW = 1, BI_HANDOFF = 2, BI_GRAPH = 3 };
+
+struct BaLayout {
+  size_t sy, C, u, Ed, cmask, zero_bytes, q, dX, info, Abig, slabs, ared, hand, total;
+  int64_t npad;                         // global-BA path: 6 N rounded up to the Cholesky block (0: not used)
+  int64_t U_max, U_stride, sy_stride;   // sy_stride: floats between two copies of [S | y]
+  int64_t n_ck;                         // window path: chunk slabs
+  int N_max;
+};
+
+inline BaLayout ba_layout(int64_t U_max, int N_max) {
+  BaLayout L;
+  L.U_max = U_max; L.N_max = N_max;
+  L.U_stride = (U_max + BA_CHUNK - 1) / BA_CHUNK * BA_CHUNK;
+  const size_t n6 = 6 * (size_t)N_max;
+  size_t o = 0;
+  // accumulators of the N > 10 path: zeroed once, then kept zero by their consumers
+  L.sy_stride = (int64_t)((n6 * n6 + n6 + 1023) / 1024 * 1024);   // 4 KB multiples: copies start on different channels
+  L.sy = o;   o = align256(o + sizeof(float) * (size_t)L.sy_stride * BA_REPL);
+  L.C = o;    o = align256(o + sizeof(float) * (size_t)L.U_stride);
+  L.u = o;    o = align256(o + sizeof(float) * (size_t)L.U_stride);
+  L.Ed = o;   o = align256(o + sizeof(float) * n6 * (size_t)L.U_stride);
+  L.cmask = o; o = align256(o + sizeof(uint32_t) * (size_t)(L.U_stride / BA_CHUNK));   // active pose panels per chunk
+  L.zero_bytes = o;
+  L.q = o;    o = align256(o + sizeof(float) * (size_t)L.U_stride);
+  L.dX = o;   o = align256(o + sizeof(float) * (n6 + 8));
+  L.info = o; o = align256(o + sizeof(int32_t) * 16 + sizeof(uint64_t) * 64);   // 16 words + the 64 dX granules of the solve -> retract hand-off
+  L.npad = 0; L.Abig = o;
+  if (N_max > BA_NMAX) {   // working copy of [S ; y^T] for the blocked Cholesky, padded with identity to 64-blocks
+    L.npad = (int64_t)((n6 + CNB - 1) / CNB * CNB);
+    o = align256(o + sizeof(float) * (size_t)(L.npad + 1) * (size_t)L.npad);
+  }
+  // window path: one partial system per chunk of 16 patches, the reduced system, the arrival counter
+  L.n_ck = 0; L.slabs = o; L.ared = o; L.hand = o;
+  if (N_max >= 1 && N_max <= WIN_N) {
+    L.n_ck = (U_max + WIN_CK - 1) / WIN_CK;
+    L.slabs = o; o = align256(o + sizeof(float) * (size_t)WIN_SLAB * (size_t)L.n_ck);
+    L.ared = o;  o = align256(o + sizeof(float) * (size_t)WIN_SLAB);
+    L.hand = o;  o = align256(o + 64);
+  }
+  L.total = o;
+  return L;
+}
+
+struct BaWinArgs {
+  float* poses;
+  float* patches;
+  const float *intr, *target, *weight, *lmbda;
+  const int64_t* ii;                 // only read when the graph's CSR records carry no source frames
+  int P, t0, N;
+  const int32_t* gmeta;
+  const int32_t *prec, *koff_u;
+  const int64_t* kx;
+  float *slabs, *ared;
+  int32_t* arrive;                   // arrival counter of the reduce workgroups
+  uint64_t* granX;                   // dX granules {tag, value}
+  float *Cg, *ug, *qg, *Edg, *dXg;
+  int U_stride, U_max, n_ck_cap;
+  int32_t* info;
+  int32_t* counters;                 // optional host-visible event counters (cdv_ba_bind_status_counters), may be NULL
+  float* dbg;                        // iteration-0 dump (see cdv_ba_forward), may be NULL
+  int first;                         // first iteration of a call: clears the sticky status words
+};
+
+// one Gauss-Newton iteration of the window path: two launches on `s`
+int cdv_ba_window_iteration(const BaWinArgs& a, hipStream_t s);
+
+// LDS hand-off between the lanes of ONE wave: the LDS unit executes a wave's DS instructions in order, so only the
+// compiler has to be kept from moving accesses across this point.  (A workgroup-scope release fence would also drain
+// vmcnt, i.e. wait for the wave's outstanding global memory operations: ~3000 cycles each time.)
+__device__ __forceinline__ void wave_lds_sync() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ float readlane_f(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+// The first launch of every iteration publishes the (optional) host-visible event counters of the workspace in the
+// info block, so that every later kernel can count a failure without another argument.
+__device__ __forceinline__ void ba_publish_counters(int32_t* info, int32_t* counters) {
+  *reinterpret_cast<int32_t**>(info + 8) = counters;
+}
+
+// a failure event: the sticky word of this call and, when bound, the host-visible counter
+__device__ __forceinline__ void ba_flag(int32_t* info, int which, int value) {
+  info[which] = value;
+  int32_t* counters = *reinterpret_cast<int32_t* const*>(info + 8);
+  if (counters) {   // host-visible memory: a system-scope load and store (no PCIe atomic needed; events are rare and a lost
+                    // increment between two simultaneous reporters only under-counts)
+    const int32_t c = __hip_atomic_load(&counters[which], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&counters[which], c + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// status handling of the first launch of an iteration (one thread): sticky words cleared by the first iteration of a
+// call; overflow / graph error rewritten by every iteration, so a workspace recovers on the next well-sized call
+__device__ __forceinline__ void ba_begin_status(int32_t* info, int32_t* counters, int first, int gerr, bool overflow) {
+  ba_publish_counters(info, counters);
+  if (first) { info[BI_CHOL] = 0; info[BI_HANDOFF] = 0; }
+  info[BI_GRAPH] = 0;
+  info[BI_OVERFLOW] = 0;
+  if (gerr) ba_flag(info, BI_GRAPH, 1);
+  else if (overflow) ba_flag(info, BI_OVERFLOW, 1);
+}
+
+}  // namespace cdv

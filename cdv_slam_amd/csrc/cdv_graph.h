@@ -15,6 +15,7 @@ enum {
   GM_ERROR = 6,    // != 0: the patch-id range exceeded the workspace capacity (index contents undefined)
   GM_E = 7,
   GM_KRANGE = 8,   // kmax - kmin + 1 of the LAST successful build (0 if none): the range to re-zero
+  GM_HAS_II = 9,   // != 0: the CSR records carry the source frame of every edge (the build was given ii)
   GM_STAGE = 16,   // arrival counter of the histogram launch (its last workgroup does the scan); zero between builds
   GM_WORDS = 64
 };
@@ -23,7 +24,7 @@ constexpr int GRAPH_MAX_BLOCKS = 1024;   // workgroups of the per-edge kernels (
 
 struct GraphLayout {
   int64_t E_max, k_range;
-  size_t meta, stage, khist, kcount, kcursor, krank, koff_u, kx, ku, pcsr_tmp, pcsr, nprev, nnext, total;
+  size_t meta, stage, khist, kcount, kcursor, krank, koff_u, kx, ku, pcsr_tmp, pcsr, prec, nprev, nnext, total;
 };
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -44,6 +45,7 @@ static inline GraphLayout graph_layout(int64_t E_max, int64_t k_range) {
   L.ku = o;       o = align256(o + sizeof(int32_t) * (size_t)E_max);
   L.pcsr_tmp = o; o = align256(o + sizeof(int32_t) * (size_t)E_max);
   L.pcsr = o;     o = align256(o + sizeof(int32_t) * (size_t)E_max);
+  L.prec = o;     o = align256(o + sizeof(int32_t) * 4 * (size_t)E_max);   // CSR records {edge, ii, jj, 0} in pcsr order
   L.nprev = o;    o = align256(o + sizeof(int32_t) * (size_t)E_max);   // neighbors: previous / next edge of the same patch in time
   L.nnext = o;    o = align256(o + sizeof(int32_t) * (size_t)E_max);
   L.total = o;
@@ -52,7 +54,7 @@ static inline GraphLayout graph_layout(int64_t E_max, int64_t k_range) {
 
 struct GraphView {
   int32_t* meta;
-  int32_t *stage, *khist, *kcount, *kcursor, *krank, *koff_u, *ku, *pcsr_tmp, *pcsr, *nprev, *nnext;
+  int32_t *stage, *khist, *kcount, *kcursor, *krank, *koff_u, *ku, *pcsr_tmp, *pcsr, *prec, *nprev, *nnext;
   int64_t* kx;
 };
 
@@ -70,6 +72,7 @@ static inline GraphView graph_view(void* ws, const GraphLayout& L) {
   v.ku = (int32_t*)(b + L.ku);
   v.pcsr_tmp = (int32_t*)(b + L.pcsr_tmp);
   v.pcsr = (int32_t*)(b + L.pcsr);
+  v.prec = (int32_t*)(b + L.prec);
   v.nprev = (int32_t*)(b + L.nprev);
   v.nnext = (int32_t*)(b + L.nnext);
   return v;
@@ -86,5 +89,6 @@ void cdv_graph_forget(const void* ws);
 namespace cdv { struct HistArgs; }
 int cdv_graph_prepare(const int64_t* jj, const int64_t* kk, int64_t E, void* ws, size_t ws_bytes, int64_t E_max,
                       int64_t k_range, int64_t* ix, int64_t* jx, void* stream, cdv::HistArgs* hist, int* hist_blocks);
-int cdv_graph_finish(const int64_t* jj, const int64_t* kk, int64_t E, void* ws, int64_t E_max, int64_t k_range,
-                     int hist_blocks, int64_t* ix, int64_t* jx, void* stream);
+// ii (optional, may be NULL): the source frame of every edge, copied into the CSR records for the bundle adjustment
+int cdv_graph_finish(const int64_t* ii, const int64_t* jj, const int64_t* kk, int64_t E, void* ws, int64_t E_max,
+                     int64_t k_range, int hist_blocks, int64_t* ix, int64_t* jx, void* stream);

@@ -4,8 +4,9 @@
 //  * lt_*  : lietorch semantics (cdvslam/lietorch/include/so3.h, se3.h): every load of a group
 //            element re-normalises the quaternion (so3.h:30-37); used by pops.transform and the
 //            lietorch_backends ops.
-//  * fb_*  : fastba's own float helpers (cdvslam/fastba/ba_cuda.cu:36-174): no normalisation,
-//            its own Taylor thresholds.
+//  * fastba semantics (se3_between_raw, se3_row_times_adj_raw, se3_retract_raw, fastba_factor): group elements
+//            are used as stored (no normalisation), fastba's own series thresholds (ba_cuda.cu:97,140); written on
+//            the same primitives as the lt_* family.
 // Data layout: SE3 = (tx,ty,tz, qx,qy,qz,qw); tangent = (tau[3], phi[3]).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -271,101 +272,101 @@ __device__ __forceinline__ void lt_se3_log(const T* X, T* xi) {  // se3.h:124-13
   xi[3] = phi[0]; xi[4] = phi[1]; xi[5] = phi[2];
 }
 
-// ---- fastba family (float only) ------------------------------------------------------------------
+// ---- fastba semantics, on the primitives above (float only) -----------------------------------------------
+// fastba differs from lietorch in conventions, not in geometry: group elements are used as
+// stored -- NO quaternion re-normalisation anywhere (ba_cuda.cu:74-85 vs so3.h:30-37) -- the exponential switches to
+// its series at theta^2 < 1e-8 and adds the translation's rotation coupling only for theta > 1e-4 (ba_cuda.cu:97,140).
+// Everything below is the lt_* arithmetic (cross3 / lt_rot / lt_quat_mul / lt_act4_loaded) with those conventions.
 
-__device__ __forceinline__ void fb_actSO3(const float* q, const float* X, float* Y) {  // ba_cuda.cu:36-46
-  float uv[3];
-  uv[0] = 2.0f * (q[1] * X[2] - q[2] * X[1]);
-  uv[1] = 2.0f * (q[2] * X[0] - q[0] * X[2]);
-  uv[2] = 2.0f * (q[0] * X[1] - q[1] * X[0]);
-  float y0 = X[0] + q[3] * uv[0] + (q[1] * uv[2] - q[2] * uv[1]);
-  float y1 = X[1] + q[3] * uv[1] + (q[2] * uv[0] - q[0] * uv[2]);
-  float y2 = X[2] + q[3] * uv[2] + (q[0] * uv[1] - q[1] * uv[0]);
-  Y[0] = y0; Y[1] = y1; Y[2] = y2;
+// G_ij = G_j G_i^-1 of two stored poses (t, q_xyzw), raw
+__device__ __forceinline__ void se3_between_raw(const float* Pi, const float* Pj, float* t, float* q) {
+  const float qi_conj[4] = {-Pi[3], -Pi[4], -Pi[5], Pi[6]};
+  lt_quat_mul(Pj + 3, qi_conj, q);
+  float moved[3];
+  lt_rot(q, Pi, moved);               // where G_ij's rotation takes camera i's translation
+#pragma unroll
+  for (int a = 0; a < 3; a++) t[a] = Pj[a] - moved[a];
 }
 
-__device__ __forceinline__ void fb_actSE3(const float* t, const float* q, const float* X, float* Y) {  // :48-55
-  fb_actSO3(q, X, Y);
-  Y[3] = X[3];
-  Y[0] += X[3] * t[0];
-  Y[1] += X[3] * t[1];
-  Y[2] += X[3] * t[2];
+// row vector (lin, ang) times Adj(t, q):  (R^T lin, R^T (ang + lin x t)); R^T v = rotation by the conjugate
+__device__ __forceinline__ void se3_row_times_adj_raw(const float* t, const float* q, const float* row, float* out) {
+  const float qc[4] = {-q[0], -q[1], -q[2], q[3]};
+  float coupled[3];
+  cross3(row, t, coupled);
+#pragma unroll
+  for (int a = 0; a < 3; a++) coupled[a] += row[3 + a];
+  lt_rot(qc, row, out);
+  lt_rot(qc, coupled, out + 3);
 }
 
-__device__ __forceinline__ void fb_adjSE3(const float* t, const float* q, const float* X, float* Y) {  // :57-72
-  float qinv[4] = {-q[0], -q[1], -q[2], q[3]};
-  fb_actSO3(qinv, &X[0], &Y[0]);
-  fb_actSO3(qinv, &X[3], &Y[3]);
-  float u[3], v[3];
-  u[0] = t[2] * X[1] - t[1] * X[2];
-  u[1] = t[0] * X[2] - t[2] * X[0];
-  u[2] = t[1] * X[0] - t[0] * X[1];
-  fb_actSO3(qinv, u, v);
-  Y[3] += v[0];
-  Y[4] += v[1];
-  Y[5] += v[2];
-}
-
-__device__ __forceinline__ void fb_relSE3(const float* ti, const float* qi, const float* tj, const float* qj,
-                                          float* tij, float* qij) {  // :74-85
-  qij[0] = -qj[3] * qi[0] + qj[0] * qi[3] - qj[1] * qi[2] + qj[2] * qi[1];
-  qij[1] = -qj[3] * qi[1] + qj[1] * qi[3] - qj[2] * qi[0] + qj[0] * qi[2];
-  qij[2] = -qj[3] * qi[2] + qj[2] * qi[3] - qj[0] * qi[1] + qj[1] * qi[0];
-  qij[3] = qj[3] * qi[3] + qj[0] * qi[0] + qj[1] * qi[1] + qj[2] * qi[2];
-  fb_actSO3(qij, ti, tij);
-  tij[0] = tj[0] - tij[0];
-  tij[1] = tj[1] - tij[1];
-  tij[2] = tj[2] - tij[2];
-}
-
-__device__ __forceinline__ void fb_expSO3(const float* phi, float* q) {  // :89-112
-  float theta_sq = phi[0] * phi[0] + phi[1] * phi[1] + phi[2] * phi[2];
-  float theta_p4 = theta_sq * theta_sq;
-  float theta = sqrtf(theta_sq);
-  float imag, real;
-  if (theta_sq < 1e-8f) {
-    imag = 0.5f - (1.0f / 48.0f) * theta_sq + (1.0f / 3840.0f) * theta_p4;
-    real = 1.0f - (1.0f / 8.0f) * theta_sq + (1.0f / 384.0f) * theta_p4;
-  } else {
-    imag = sinf(0.5f * theta) / theta;
-    real = cosf(0.5f * theta);
+// pose retraction T <- Exp(xi) T, xi = (tau, phi), in place on a stored pose (ba_cuda.cu:178-206 semantics)
+__device__ __forceinline__ void se3_retract_raw(const float* xi, float* P) {
+  const float* tau = xi;
+  const float* phi = xi + 3;
+  const float th2 = phi[0] * phi[0] + phi[1] * phi[1] + phi[2] * phi[2];
+  const float th = sqrtf(th2);
+  // unit quaternion of the rotation vector phi: (sin(th/2)/th * phi, cos(th/2)), series below theta^2 = 1e-8
+  const bool tiny = th2 < 1e-8f;
+  const float th4 = th2 * th2;
+  const float sv = tiny ? 0.5f - th2 * (1.0f / 48.0f) + th4 * (1.0f / 3840.0f) : sinf(0.5f * th) / th;
+  const float cw = tiny ? 1.0f - th2 * (1.0f / 8.0f) + th4 * (1.0f / 384.0f) : cosf(0.5f * th);
+  const float dq[4] = {sv * phi[0], sv * phi[1], sv * phi[2], cw};
+  // translation of Exp: V tau = tau + a (phi x tau) + b (phi x (phi x tau)); the coupling terms only for theta > 1e-4
+  float dt[3] = {tau[0], tau[1], tau[2]};
+  if (th > 1e-4f) {
+    float w1[3], w2[3];
+    cross3(phi, tau, w1);
+    cross3(phi, w1, w2);
+    const float a = (1.0f - cosf(th)) / th2, b = (th - sinf(th)) / (th * th2);
+#pragma unroll
+    for (int c = 0; c < 3; c++) dt[c] += a * w1[c] + b * w2[c];
   }
-  q[0] = imag * phi[0]; q[1] = imag * phi[1]; q[2] = imag * phi[2]; q[3] = real;
+  float qn[4], tn[3];
+  lt_quat_mul(dq, P + 3, qn);
+  lt_rot(dq, P, tn);
+#pragma unroll
+  for (int c = 0; c < 3; c++) P[c] = tn[c] + dt[c];
+#pragma unroll
+  for (int c = 0; c < 4; c++) P[3 + c] = qn[c];
 }
 
-__device__ __forceinline__ void fb_crossInplace(const float* a, float* b) {  // :114-125
-  float x[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
-  b[0] = x[0]; b[1] = x[1]; b[2] = x[2];
-}
+// One reprojection factor of fastba (ba_cuda.cu:261-342 semantics): the patch centre (px, py, inverse depth pd) of a
+// patch in frame i seen in frame j through the pinhole (fx, fy, cx, cy).
+//   residual r = target - pi(X_j);  valid: |r| < 128, Z > 0.2, projection inside the image grown by 64 px
+//   g_r  = d pi_r / d X_j = (f d, 0, -f X d^2) resp. (0, f d, -f Y d^2),  d = 1/Z (0 below Z = 0.2)
+//   X_j moves by  w tau + phi x X_j  under a left perturbation (tau, phi) of G_j  (w = inverse depth)
+//     => J_j = [ w g | X_j x g ],   J_i = -(J_j Adj(G_ij))  (the sign is applied where J_i is used),   J_z = g . t_ij
+struct EdgeFactor {
+  float r[2], w[2], Jz[2], Ji[12], Jj[12];
+};
 
-__device__ __forceinline__ void fb_expSE3(const float* xi, float* t, float* q) {  // :127-154
-  fb_expSO3(xi + 3, q);
-  float tau[3] = {xi[0], xi[1], xi[2]};
-  float phi[3] = {xi[3], xi[4], xi[5]};
-  float theta_sq = phi[0] * phi[0] + phi[1] * phi[1] + phi[2] * phi[2];
-  float theta = sqrtf(theta_sq);
-  t[0] = tau[0]; t[1] = tau[1]; t[2] = tau[2];
-  if (theta > 1e-4f) {
-    float a = (1 - cosf(theta)) / theta_sq;
-    fb_crossInplace(phi, tau);
-    t[0] += a * tau[0]; t[1] += a * tau[1]; t[2] += a * tau[2];
-    float b = (theta - sinf(theta)) / (theta * theta_sq);
-    fb_crossInplace(phi, tau);
-    t[0] += b * tau[0]; t[1] += b * tau[1]; t[2] += b * tau[2];
+__device__ __forceinline__ void fastba_factor(const float* Pi, const float* Pj, float px, float py, float pd, float tx,
+                                              float ty, float wx, float wy, float fx, float fy, float cx, float cy,
+                                              EdgeFactor& o) {
+  float t[3], q[4];
+  se3_between_raw(Pi, Pj, t, q);
+  const float ray[4] = {(px - cx) / fx, (py - cy) / fy, 1.0f, pd};
+  float Xj[4];
+  lt_act4_loaded(t, q, ray, Xj);
+  const float Z = Xj[2];
+  const float d = (Z >= 0.2f) ? 1.0f / Z : 0.0f;
+  const float u = fx * (Xj[0] / Z) + cx, v = fy * (Xj[1] / Z) + cy;
+  o.r[0] = tx - u;
+  o.r[1] = ty - v;
+  const bool ok = (sqrtf(o.r[0] * o.r[0] + o.r[1] * o.r[1]) < 128.f) && (Z > 0.2f) && (u > -64.f) && (v > -64.f) &&
+                  (u < 2 * cx + 64.f) && (v < 2 * cy + 64.f);
+  o.w[0] = ok ? wx : 0.0f;
+  o.w[1] = ok ? wy : 0.0f;
+  const float g[2][3] = {{fx * d, 0.0f, -fx * Xj[0] * d * d}, {0.0f, fy * d, -fy * Xj[1] * d * d}};
+#pragma unroll
+  for (int row = 0; row < 2; row++) {
+    float* Jj = o.Jj + 6 * row;
+#pragma unroll
+    for (int a = 0; a < 3; a++) Jj[a] = Xj[3] * g[row][a];
+    cross3(Xj, g[row], Jj + 3);
+    se3_row_times_adj_raw(t, q, Jj, o.Ji + 6 * row);
+    o.Jz[row] = g[row][0] * t[0] + g[row][1] * t[1] + g[row][2] * t[2];
   }
-}
-
-__device__ __forceinline__ void fb_retrSE3(const float* xi, const float* t, const float* q, float* t1,
-                                           float* q1) {  // :157-174
-  float dt[3] = {0, 0, 0};
-  float dq[4] = {0, 0, 0, 1};
-  fb_expSE3(xi, dt, dq);
-  q1[0] = dq[3] * q[0] + dq[0] * q[3] + dq[1] * q[2] - dq[2] * q[1];
-  q1[1] = dq[3] * q[1] + dq[1] * q[3] + dq[2] * q[0] - dq[0] * q[2];
-  q1[2] = dq[3] * q[2] + dq[2] * q[3] + dq[0] * q[1] - dq[1] * q[0];
-  q1[3] = dq[3] * q[3] - dq[0] * q[0] - dq[1] * q[1] - dq[2] * q[2];
-  fb_actSO3(dq, t, t1);
-  t1[0] += dt[0]; t1[1] += dt[1]; t1[2] += dt[2];
 }
 
 }  // namespace cdv

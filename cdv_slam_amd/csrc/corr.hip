@@ -791,6 +791,60 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const _Float16* __res
   }
 }
 
+// ---- a planar ring whose writer is somebody else (the reference's slam.py writes fmap1_[:, n % mem] with torch ops) kept
+// in step with its channels-last shadow WITHOUT converting all of it every frame: pass 1 fingerprints every slot of the
+// planar ring (a read of the ring: 21 MB at level 0), pass 2 converts only the slots whose fingerprint differs from
+// the one taken at the previous sync (normally ONE).  Fingerprint = FP_PARTS position-keyed 64-bit sums per slot.
+constexpr int FP_PARTS = 16;      // workgroups (and partial sums) per slot
+
+__global__ __launch_bounds__(256) void fmap_fingerprint_kernel(const uint32_t* __restrict__ src, int64_t words_per_slot,
+                                                               uint64_t* __restrict__ fp) {
+  const int slot = (int)blockIdx.x / FP_PARTS, part = (int)blockIdx.x % FP_PARTS;
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4* p = reinterpret_cast<const u32x4*>(src + (size_t)slot * words_per_slot);
+  const int64_t n4 = words_per_slot / 4;        // slots are multiples of 16 bytes (C % 8 == 0)
+  uint64_t acc = 0;
+  for (int64_t i = (int64_t)part * 256 + threadIdx.x; i < n4; i += (int64_t)FP_PARTS * 256) {
+    const u32x4 v = p[i];
+    const uint64_t key = 0x9E3779B97F4A7C15ull + 2ull * (uint64_t)i;           // odd, different for every position
+    acc += ((uint64_t)v[0] | ((uint64_t)v[1] << 32)) * key;
+    acc += ((uint64_t)v[2] | ((uint64_t)v[3] << 32)) * (key ^ 0xD6E8FEB86659FD92ull);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  __shared__ uint64_t sw[4];
+  if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) fp[(size_t)slot * FP_PARTS + part] = (sw[0] + sw[1]) + (sw[2] + sw[3]) + 1ull;   // never 0 = "no fingerprint yet"
+}
+
+__global__ __launch_bounds__(256) void nchw_to_nhwc_dirty_kernel(const _Float16* __restrict__ src,
+                                                                 _Float16* __restrict__ dst, int C, int H, int W,
+                                                                 const uint64_t* __restrict__ fp_new,
+                                                                 const uint64_t* __restrict__ fp_old, int wg_per_slot,
+                                                                 int32_t* __restrict__ n_dirty) {
+  const int64_t nslot = (int)blockIdx.x / wg_per_slot;
+  const int wg = (int)blockIdx.x % wg_per_slot;
+  bool same = true;
+#pragma unroll
+  for (int i = 0; i < FP_PARTS; i++) same = same && fp_new[nslot * FP_PARTS + i] == fp_old[nslot * FP_PARTS + i];
+  if (same) return;                                  // workgroup-uniform
+  if (wg == 0 && threadIdx.x == 0 && n_dirty) atomicAdd(n_dirty, 1);
+  const int G = C / 8;
+  const int64_t total = (int64_t)H * W * G;
+  for (int64_t idx = (int64_t)wg * 256 + threadIdx.x; idx < total; idx += (int64_t)wg_per_slot * 256) {
+    int64_t t = idx;
+    const int xw = (int)(t % W); t /= W;
+    const int gq = (int)(t % G); t /= G;
+    const int yh = (int)t;
+    cdv_half8 v;
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = src[((nslot * C + 8 * gq + j) * H + yh) * W + xw];
+    *reinterpret_cast<cdv_half8*>(dst + ((nslot * (H + 2 * PADY) + yh + PADY) * (W + 2 * PADX) + xw + PADX) * C +
+                                  8 * gq) = v;
+  }
+}
+
 __global__ __launch_bounds__(256) void gmap_pm_kernel(const _Float16* __restrict__ src, _Float16* __restrict__ dst,
                                                       int64_t first, int64_t count, int C) {
   cdv::gmap_pm_convert(src, dst, first, count, C, (int64_t)blockIdx.x * blockDim.x + threadIdx.x,
@@ -993,6 +1047,30 @@ extern "C" int cdv_fmap_to_nhwc(const void* src_nchw, void* dst_nhwc, int64_t N,
   const int blocks = cdv_div_up(total, 256) < 16384 ? cdv_div_up(total, 256) : 16384;
   hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)src_nchw,
                      (_Float16*)dst_nhwc, first, count, C, H, W);
+  CDV_LAUNCH_CHECK();
+  return CDV_OK;
+}
+
+extern "C" size_t cdv_fmap_sync_workspace_bytes(int64_t N) {
+  return (size_t)(2 * (N > 0 ? N : 1) * FP_PARTS) * sizeof(uint64_t) + 64;
+}
+
+extern "C" int cdv_fmap_sync_nhwc(const void* src_nchw, void* dst_nhwc, int64_t N, int C, int H, int W, void* ws,
+                                  int parity, void* stream) {
+  CDV_REQUIRE(C % 8 == 0 && C > 0, CDV_ERR_ARG, "cdv_fmap_sync_nhwc: C must be a multiple of 8");
+  CDV_REQUIRE(src_nchw && dst_nhwc && ws && N >= 0 && H > 0 && W > 0, CDV_ERR_ARG, "cdv_fmap_sync_nhwc: bad argument");
+  if (N == 0) return CDV_OK;
+  uint64_t* fp = (uint64_t*)ws;
+  uint64_t* fp_new = fp + (size_t)(parity & 1) * N * FP_PARTS;
+  const uint64_t* fp_old = fp + (size_t)((parity & 1) ^ 1) * N * FP_PARTS;
+  int32_t* n_dirty = (int32_t*)(fp + 2 * (size_t)N * FP_PARTS);
+  const int64_t words = (int64_t)C * H * W / 2;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(fmap_fingerprint_kernel, dim3((unsigned)(N * FP_PARTS)), dim3(256), 0, s, (const uint32_t*)src_nchw,
+                     words, fp_new);
+  const int wg_per_slot = (int)(cdv_div_up((int64_t)H * W * (C / 8), 256) < 64 ? cdv_div_up((int64_t)H * W * (C / 8), 256) : 64);
+  hipLaunchKernelGGL(nchw_to_nhwc_dirty_kernel, dim3((unsigned)(N * wg_per_slot)), dim3(256), 0, s, (const _Float16*)src_nchw,
+                     (_Float16*)dst_nhwc, C, H, W, fp_new, fp_old, wg_per_slot, n_dirty);
   CDV_LAUNCH_CHECK();
   return CDV_OK;
 }

@@ -100,15 +100,22 @@ __global__ __launch_bounds__(256) void graph_fill_kernel(const int64_t* __restri
 // Deterministic order inside every patch segment: rank by (jj, edge id) == std::stable_sort by jj over an
 // ascending index list (ba.cpp:84-86).  O(d^2) per segment, d ~ 25 in a SLAM graph.  The same sweep yields the
 // edge's neighbours in time (ba.cpp:88-94): the largest key below its own and the smallest key above.
-__global__ __launch_bounds__(256) void graph_segsort_kernel(const int64_t* __restrict__ jj,
+__global__ __launch_bounds__(256) void graph_segsort_kernel(const int64_t* __restrict__ ii,
+                                                            const int64_t* __restrict__ jj,
                                                             const int64_t* __restrict__ kk, int32_t E,
-                                                            const int32_t* __restrict__ meta,
+                                                            int32_t* __restrict__ meta,
                                                             const int32_t* __restrict__ kcount,
                                                             const int32_t* __restrict__ pcsr_tmp,
-                                                            int32_t* __restrict__ pcsr, int32_t* __restrict__ nprev,
+                                                            int32_t* __restrict__ pcsr, int32_t* __restrict__ prec,
+                                                            int32_t* __restrict__ nprev,
                                                             int32_t* __restrict__ nnext, int32_t* __restrict__ kcursor,
                                                             int64_t* __restrict__ ix, int64_t* __restrict__ jx) {
-  if (meta[GM_ERROR]) return;
+  if (meta[GM_ERROR]) {   // no index: the neighbor lists say "none" instead of staying uninitialised
+    if (ix)
+      for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) { ix[e] = -1; jx[e] = -1; }
+    return;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) meta[GM_HAS_II] = ii ? 1 : 0;
   const int kmin = meta[GM_KMIN], krange = meta[GM_KRANGE];
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t <= krange; t += gridDim.x * blockDim.x)
     kcursor[t] = 0;   // the fill cursors of this build: zero again for the next one
@@ -139,6 +146,8 @@ __global__ __launch_bounds__(256) void graph_segsort_kernel(const int64_t* __res
     const bool hasp = r > 0, hasn = lo + r + 1 < hi;
     const int pe = hasp ? (int)(uint32_t)pk : -1, ne = hasn ? (int)(uint32_t)nk : -1;
     pcsr[lo + r] = e;
+    // the record the bundle adjustment walks: edge id, source frame, target frame in ONE 16-byte load
+    *reinterpret_cast<int4*>(prec + 4 * (size_t)(lo + r)) = make_int4(e, ii ? (int)ii[e] : -1, (int)(ke >> 32), 0);
     nprev[e] = pe;             // kept in the workspace for a later cdv_neighbors
     nnext[e] = ne;
     if (ix) {
@@ -152,8 +161,9 @@ __global__ __launch_bounds__(256) void graph_neighbors_kernel(int32_t E, const i
                                                               const int32_t* __restrict__ nprev,
                                                               const int32_t* __restrict__ nnext,
                                                               int64_t* __restrict__ ix, int64_t* __restrict__ jx) {
-  if (meta[GM_ERROR]) return;
+  const bool bad = meta[GM_ERROR] != 0;   // no index: "none" everywhere instead of uninitialised memory
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) {
+    if (bad) { ix[e] = -1; jx[e] = -1; continue; }
     ix[e] = (int64_t)nprev[e];   // previous edge in time (-1: none)
     jx[e] = (int64_t)nnext[e];   // next edge in time
   }
@@ -235,8 +245,8 @@ int cdv_graph_prepare(const int64_t* jj, const int64_t* kk, int64_t E, void* ws,
   return CDV_OK;
 }
 
-int cdv_graph_finish(const int64_t* jj, const int64_t* kk, int64_t E, void* ws, int64_t E_max, int64_t k_range,
-                     int hist_blocks, int64_t* ix, int64_t* jx, void* stream) {
+int cdv_graph_finish(const int64_t* ii, const int64_t* jj, const int64_t* kk, int64_t E, void* ws, int64_t E_max,
+                     int64_t k_range, int hist_blocks, int64_t* ix, int64_t* jx, void* stream) {
   const GraphLayout L = graph_layout(E_max, k_range);
   const GraphView v = graph_view(ws, L);
   hipStream_t s = (hipStream_t)stream;
@@ -249,21 +259,27 @@ int cdv_graph_finish(const int64_t* jj, const int64_t* kk, int64_t E, void* ws, 
   if (E > 0) {
     hipLaunchKernelGGL(graph_fill_kernel, dim3(fb), dim3(tb), 0, s, kk, En, v.meta, v.kcount, v.kcursor, v.krank,
                        v.koff_u, v.kx, v.ku, v.pcsr_tmp);
-    hipLaunchKernelGGL(graph_segsort_kernel, dim3(fb), dim3(tb), 0, s, jj, kk, En, v.meta, v.kcount, v.pcsr_tmp,
-                       v.pcsr, v.nprev, v.nnext, v.kcursor, ix, jx);
+    hipLaunchKernelGGL(graph_segsort_kernel, dim3(fb), dim3(tb), 0, s, ii, jj, kk, En, v.meta, v.kcount, v.pcsr_tmp,
+                       v.pcsr, v.prec, v.nprev, v.nnext, v.kcursor, ix, jx);
   }
   CDV_LAUNCH_CHECK();
   return CDV_OK;
 }
 
-extern "C" int cdv_graph_build_neighbors(const int64_t* jj, const int64_t* kk, int64_t E, void* ws, size_t ws_bytes,
-                                         int64_t E_max, int64_t k_range, int64_t* ix, int64_t* jx, void* stream) {
+extern "C" int cdv_graph_build_edges(const int64_t* ii, const int64_t* jj, const int64_t* kk, int64_t E, void* ws,
+                                     size_t ws_bytes, int64_t E_max, int64_t k_range, int64_t* ix, int64_t* jx,
+                                     void* stream) {
   cdv::HistArgs h;
   int hb = 0;
   const int rc = cdv_graph_prepare(jj, kk, E, ws, ws_bytes, E_max, k_range, ix, jx, stream, &h, &hb);
   if (rc != CDV_OK) return rc;
   if (hb > 0) hipLaunchKernelGGL(graph_hist_kernel, dim3(hb), dim3(256), 0, (hipStream_t)stream, h);
-  return cdv_graph_finish(jj, kk, E, ws, E_max, k_range, hb, ix, jx, stream);
+  return cdv_graph_finish(ii, jj, kk, E, ws, E_max, k_range, hb, ix, jx, stream);
+}
+
+extern "C" int cdv_graph_build_neighbors(const int64_t* jj, const int64_t* kk, int64_t E, void* ws, size_t ws_bytes,
+                                         int64_t E_max, int64_t k_range, int64_t* ix, int64_t* jx, void* stream) {
+  return cdv_graph_build_edges(nullptr, jj, kk, E, ws, ws_bytes, E_max, k_range, ix, jx, stream);
 }
 
 extern "C" int cdv_graph_read_meta_host(const void* ws, int64_t* meta_host, void* stream) {

@@ -60,5 +60,5 @@ extern "C" int cdv_update_prologue(
   hipLaunchKernelGGL(update_prologue_kernel, dim3(n_ing + n_tf + n_hist), dim3(256), 0, (hipStream_t)stream, ing, n_ing,
                      tf, n_tf, hist, n_hist);
   CDV_LAUNCH_CHECK();
-  return cdv_graph_finish(jj, kk, E, graph_ws, E_max, k_range, n_hist, ix, jx, stream);
+  return cdv_graph_finish(ii, jj, kk, E, graph_ws, E_max, k_range, n_hist, ix, jx, stream);
 }

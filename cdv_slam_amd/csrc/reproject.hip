@@ -14,6 +14,8 @@ __global__ __launch_bounds__(256) void transform_kernel(cdv::TfArgs A) {
   cdv::transform_body<P>(A, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
 }
 
+// cuda_ba.reproject: the projection fastba's residuals use -- stored (not re-normalised) poses, the intrinsics of row 0,
+// no depth clamp (ba_cuda.cu:408-458 semantics) -- for every pixel of the patch; one lane per edge
 template <int P>
 __global__ __launch_bounds__(256) void fastba_reproject_kernel(const float* __restrict__ poses,
                                                                const float* __restrict__ patches,
@@ -22,28 +24,24 @@ __global__ __launch_bounds__(256) void fastba_reproject_kernel(const float* __re
                                                                const int64_t* __restrict__ jj,
                                                                const int64_t* __restrict__ kk, int64_t E,
                                                                float* __restrict__ coords) {
-  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= E) return;
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
   constexpr int PP = P * P;
-  const float fx = intr[0], fy = intr[1], cx = intr[2], cy = intr[3];  // ba_cuda.cu:417-423
-  const int64_t ix = ii[n], jx = jj[n], kx = kk[n];
-  float ti[3], tj[3], qi[4], qj[4], tij[3], qij[4];
+  float Pi[7], Pj[7], t[3], q[4];
 #pragma unroll
-  for (int a = 0; a < 3; a++) { ti[a] = poses[7 * ix + a]; tj[a] = poses[7 * jx + a]; }
-#pragma unroll
-  for (int a = 0; a < 4; a++) { qi[a] = poses[7 * ix + 3 + a]; qj[a] = poses[7 * jx + 3 + a]; }
-  cdv::fb_relSE3(ti, qi, tj, qj, tij, qij);
-  const float* pk = patches + kx * 3 * PP;
+  for (int a = 0; a < 7; a++) { Pi[a] = poses[7 * ii[e] + a]; Pj[a] = poses[7 * jj[e] + a]; }
+  cdv::se3_between_raw(Pi, Pj, t, q);
+  const float fx = intr[0], fy = intr[1], cx = intr[2], cy = intr[3];
+  const float* xs = patches + kk[e] * 3 * PP;
+  const float *ys = xs + PP, *ds = ys + PP;
+  float* ou = coords + e * 2 * PP;
 #pragma unroll
   for (int a = 0; a < PP; a++) {
-    float Xi[4], Xj[4];
-    Xi[0] = (pk[a] - cx) / fx;
-    Xi[1] = (pk[PP + a] - cy) / fy;
-    Xi[2] = 1.0f;
-    Xi[3] = pk[2 * PP + a];
-    cdv::fb_actSE3(tij, qij, Xi, Xj);
-    coords[(n * 2 + 0) * PP + a] = fx * (Xj[0] / Xj[2]) + cx;
-    coords[(n * 2 + 1) * PP + a] = fy * (Xj[1] / Xj[2]) + cy;
+    const float ray[4] = {(xs[a] - cx) / fx, (ys[a] - cy) / fy, 1.0f, ds[a]};
+    float X[4];
+    cdv::lt_act4_loaded(t, q, ray, X);
+    ou[a] = fx * (X[0] / X[2]) + cx;
+    ou[PP + a] = fy * (X[1] / X[2]) + cy;
   }
 }
 

@@ -68,10 +68,11 @@ class GraphIndex:
         self.ws_bytes = nbytes
         self._key = None
 
-    def build(self, jj, kk, force=False, with_neighbors=False):
+    def build(self, jj, kk, force=False, with_neighbors=False, ii=None):
         """Enqueue the index build for (jj, kk).  Re-used when called again with the same, unmodified
         tensor objects (neighbors() and BA() of one update share one build).  with_neighbors: the build also
-        produces fastba.neighbors(kk, jj) (picked up by neighbors() without another launch)."""
+        produces fastba.neighbors(kk, jj) (picked up by neighbors() without another launch).  ii (optional): the
+        source frames, copied into the per-patch edge records the bundle adjustment walks."""
         _need_cuda(jj, kk)
         if jj.dtype != torch.int64 or kk.dtype != torch.int64:
             raise TypeError("index tensors must be int64")
@@ -85,17 +86,19 @@ class GraphIndex:
             raise ValueError("jj and kk must have the same length")
         self._reserve(E)
         self._nbr = None
+        if ii is not None:
+            _need_cuda(ii)
+            if ii.dtype != torch.int64 or ii.numel() != E:
+                raise TypeError("ii must be int64 with one entry per edge")
+            ii = ii.contiguous()
+        ix = jx = None
         if with_neighbors and E > 0:
             ix = torch.empty(E, dtype=torch.int64, device=self.device)
             jx = torch.empty(E, dtype=torch.int64, device=self.device)
-            rc = self.lib.cdv_graph_build_neighbors(_p(jj), _p(kk), E, _p(self.ws), self.ws_bytes, self.E_cap,
-                                                    self.k_range, _p(ix), _p(jx), _stream())
-            _lib.check(rc, "cdv_graph_build_neighbors")
             self._nbr = (ix, jx)
-        else:
-            rc = self.lib.cdv_graph_build(_p(jj), _p(kk), E, _p(self.ws), self.ws_bytes, self.E_cap, self.k_range,
-                                          _stream())
-            _lib.check(rc, "cdv_graph_build")
+        rc = self.lib.cdv_graph_build_edges(_p(ii), _p(jj), _p(kk), E, _p(self.ws), self.ws_bytes, self.E_cap,
+                                            self.k_range, _p(ix), _p(jx), _stream())
+        _lib.check(rc, "cdv_graph_build_edges")
         self._key = key  # strong refs pin the tensors so that identity implies content
         self.E = E
         if _sync_check():
@@ -161,13 +164,13 @@ def update_prologue(graph, fmap_chw, fmap1_nhwc, fmap2_nhwc, slot, gmap, gmap_pm
 _graphs = {}
 
 
-def graph_for(jj, kk, **kw):
+def graph_for(jj, kk, ii=None, **kw):
     """Per-device shared GraphIndex, (re)built for (jj, kk)."""
     dev = kk.device
     g = _graphs.get(dev)
     if g is None:
         g = _graphs[dev] = GraphIndex(dev, **kw)
-    return g.build(jj, kk)
+    return g.build(jj, kk, ii=ii)
 
 
 def neighbors(kk, jj):
@@ -244,7 +247,9 @@ def fmap_interior(ring):
 
 
 class NhwcCache:
-    """padded channels-last shadows of planar feature rings, refreshed when the source tensor's version moves."""
+    """padded channels-last shadows of planar feature rings somebody else writes (the reference's slam.py).  When the
+    ring's version counter has moved, the shadow is re-synchronised by cdv_fmap_sync_nhwc: a fingerprint pass over the
+    ring, then a conversion of only the slots that changed (slam.py:679-682 writes ONE slot per frame)."""
 
     def __init__(self, max_entries=4):
         self.entries = []
@@ -252,26 +257,40 @@ class NhwcCache:
 
     def get(self, fmap):
         for ent in self.entries:
-            if ent[0] is fmap:
-                if ent[1] != fmap._version:
-                    self._convert(fmap, ent[2])
-                    ent[1] = fmap._version
-                return ent[2]
-        C, H, W = fmap.shape[-3:]
-        shadow = torch.zeros(fmap.shape[:-3] + (H + 2 * FMAP_PADY, W + 2 * FMAP_PADX, C),
-                             dtype=fmap.dtype, device=fmap.device)
-        self._convert(fmap, shadow)
-        self.entries.append([fmap, fmap._version, shadow])
-        if len(self.entries) > self.max_entries:
-            self.entries.pop(0)
-        return shadow
-
-    @staticmethod
-    def _convert(fmap, shadow):
-        lib = _lib.load()
+            if ent["src"] is fmap:
+                if ent["version"] != fmap._version:
+                    self._sync(ent)
+                return ent["shadow"]
         C, H, W = fmap.shape[-3:]
         N = fmap.numel() // (C * H * W)
-        _lib.check(lib.cdv_fmap_to_nhwc(_p(fmap), _p(shadow), N, C, H, W, 0, N, _stream()), "cdv_fmap_to_nhwc")
+        lib = _lib.load()
+        ent = {"src": fmap, "version": None, "parity": 0,
+               "shadow": torch.zeros(fmap.shape[:-3] + (H + 2 * FMAP_PADY, W + 2 * FMAP_PADX, C), dtype=fmap.dtype,
+                                     device=fmap.device),
+               "ws": torch.zeros(lib.cdv_fmap_sync_workspace_bytes(N), dtype=torch.uint8, device=fmap.device)}
+        self._sync(ent)
+        self.entries.append(ent)
+        if len(self.entries) > self.max_entries:
+            self.entries.pop(0)
+        return ent["shadow"]
+
+    @staticmethod
+    def _sync(ent):
+        lib = _lib.load()
+        fmap = ent["src"]
+        C, H, W = fmap.shape[-3:]
+        N = fmap.numel() // (C * H * W)
+        _lib.check(lib.cdv_fmap_sync_nhwc(_p(fmap), _p(ent["shadow"]), N, C, H, W, _p(ent["ws"]), ent["parity"], _stream()),
+                   "cdv_fmap_sync_nhwc")
+        ent["parity"] ^= 1
+        ent["version"] = fmap._version
+
+    def converted_slots(self, fmap):
+        """diagnostics: slots converted so far for this ring (synchronises)"""
+        for ent in self.entries:
+            if ent["src"] is fmap:
+                return int(ent["ws"][-64:-60].view(torch.int32).item())
+        return 0
 
 
 _nhwc = NhwcCache()
@@ -476,6 +495,10 @@ def point_cloud(poses, patches, intrinsics, ix):
 # ---------------------------------------------------------------------------------------------------
 
 _ba_ws = {}
+_ba_counters = {}     # device -> pinned int32[4] event counters the kernels bump (cdv_ba_bind_status_counters)
+_ba_seen = {}         # device -> counts already reported
+BA_EVENTS = ("reduced system not positive definite", "more unique patches than U_max (update skipped)",
+             "in-launch hand-off timed out (update not applied)", "patch-graph index in its range-error state (update skipped)")
 
 
 def _ba_workspace(dev, E, U_max, N):
@@ -485,7 +508,48 @@ def _ba_workspace(dev, E, U_max, N):
     if ws is None or ws.numel() < need:
         ws = _ba_ws[dev] = torch.empty(int(need * 1.25) + 4096, dtype=torch.uint8, device=dev)
         lib.cdv_workspace_forget(_p(ws))             # a fresh allocation may reuse the address of a dead workspace
+        cnt = _ba_counters.get(dev)
+        if cnt is None:
+            cnt = _ba_counters[dev] = torch.zeros(4, dtype=torch.int32).pin_memory()
+            _ba_seen[dev] = [0, 0, 0, 0]
+        _lib.check(lib.cdv_ba_bind_status_counters(_p(ws), ctypes.c_void_p(cnt.data_ptr())), "cdv_ba_bind_status_counters")
     return ws
+
+
+def ba_event_counts(device=None):
+    """Failure events the BA kernels have counted on `device` since start-up, WITHOUT synchronising: a list of four
+    ints in the order of BA_EVENTS.  (The counters live in pinned host memory the kernels write to.)"""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    cnt = _ba_counters.get(dev)
+    return [0, 0, 0, 0] if cnt is None else [int(v) for v in cnt.tolist()]
+
+
+def ba_status(device=None, raise_on_error=True):
+    """Status words of the last BA on `device` (cdv_ba_status; synchronises the current stream):
+    (cholesky, overflow, hand-off, graph).  Raises CdvError naming the failure unless raise_on_error is False."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    ws = _ba_ws.get(dev)
+    if ws is None:
+        return (0, 0, 0, 0)
+    info = (ctypes.c_int32 * 4)()
+    rc = _lib.load().cdv_ba_status(_p(ws), info, _stream())
+    if rc != 0 and raise_on_error:
+        _lib.check(rc, "bundle adjustment")
+    return tuple(int(v) for v in info)
+
+
+def _ba_report_events(dev):
+    """non-blocking: warn about failure events counted since the last look (the update they belong to is an earlier one)"""
+    cnt = _ba_counters.get(dev)
+    if cnt is None:
+        return
+    now, seen = cnt.tolist(), _ba_seen[dev]
+    for i in range(4):
+        if now[i] > seen[i]:
+            import warnings
+            warnings.warn("cdv_slam_amd BA on %s: %s -- %d new event(s); ops.ba_status() / CDV_CHECK=1 raise at the call"
+                          % (dev, BA_EVENTS[i], now[i] - seen[i]), RuntimeWarning, stacklevel=3)
+            seen[i] = now[i]
 
 
 def ba_forward(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, PPF, t0, t1, iterations,
@@ -511,7 +575,8 @@ def ba_forward(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, PP
         lmbda = torch.tensor([float(lmbda)], dtype=torch.float32, device=dev)
     lmbda = lmbda.reshape(-1).float().contiguous().to(dev)
     ii, jj, kk = ii.contiguous(), jj.contiguous(), kk.contiguous()
-    g = graph.build(jj, kk) if graph is not None else graph_for(jj, kk)
+    g = graph.build(jj, kk, ii=ii) if graph is not None else graph_for(jj, kk, ii=ii)
+    _ba_report_events(dev)
     if U_max is None:
         U_max = min(E, patches.numel() // (3 * P * P))
     ws = _ba_workspace(dev, E, U_max, N)
@@ -524,7 +589,7 @@ def ba_forward(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, PP
                             _p(dbg), _stream())
     _lib.check(rc, "cdv_ba_forward")
     if _sync_check():
-        g.meta()
+        ba_status(dev)        # raises CdvError: not positive definite / U_max exceeded / hand-off lost / graph range
     if debug:
         n6, Us = 6 * N, (U_max + 63) // 64 * 64
         o = 0

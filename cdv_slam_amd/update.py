@@ -94,10 +94,10 @@ class UpdatePath:
             if self.overlap:
                 self._aux.wait_stream(main)      # the previous BA still reads the index this build overwrites
                 with torch.cuda.stream(self._aux):
-                    self.graph.build(self.jj, self.kk, force=rebuild_graph, with_neighbors=True)
+                    self.graph.build(self.jj, self.kk, force=rebuild_graph, with_neighbors=True, ii=self.ii)
                     out["ix"], out["jx"] = self.graph.neighbors()
             else:
-                self.graph.build(self.jj, self.kk, force=rebuild_graph, with_neighbors=True)
+                self.graph.build(self.jj, self.kk, force=rebuild_graph, with_neighbors=True, ii=self.ii)
                 out["ix"], out["jx"] = self.graph.neighbors()
             if self.has_features and ingest:
                 ops.fmap_ingest(self.new_frame, self.fmap1, self.fmap2, self.new_slot, gmap=self.gmap,
@@ -148,7 +148,7 @@ class UpdatePath:
                                                           gmap_first=self.new_tiles, gmap_count=self.M))
         res["reproject"] = timed(lambda: ops.transform(self.poses[None], self.patches[None], self.intrinsics[None],
                                                        self.ii, self.jj, self.kk, layout_e2pp=True))
-        res["graph_build"] = timed(lambda: self.graph.build(self.jj, self.kk, force=True, with_neighbors=True))
+        res["graph_build"] = timed(lambda: self.graph.build(self.jj, self.kk, force=True, with_neighbors=True, ii=self.ii))
         if self.has_features:
             res["corr"] = timed(lambda: self.corr_only(coords))
         res["neighbors"] = timed(lambda: self.graph.neighbors())
@@ -161,3 +161,66 @@ class UpdatePath:
                 self.M, self.poses, self.patches, self.intrinsics, self.ii, self.jj, self.kk), self.graph.neighbors()))
         res["step"] = timed(lambda: self.step())
         return res
+
+
+class DropinPath:
+    """The SAME update written the way the reference writes it -- SLAM.reproject / SLAM.corr (slam.py:316-329), the
+    per-frame ring writes (slam.py:679-682), Update's fastba.neighbors (net_cdv.py:102) and fastba.BA (slam.py:512-515,
+    fastba/ba.py:8) -- against the module names it imports (cuda_corr, cuda_ba, lietorch_backends, registered by
+    install_dropin()) and on the reference's state layouts (planar rings [1,mem,C,h,w], gmap [1,pmem*M,C,3,3]).  What an
+    unchanged slam.py gets; tests compare it with UpdatePath.step(), bench.py times it as `dropin_fps`."""
+
+    def __init__(self, st, device):
+        import importlib
+        import cdv_slam_amd
+        from . import projective_ops as pops
+        from .lietorch import SE3
+        cdv_slam_amd.install_dropin()
+        self.cuda_corr, self.cuda_ba = importlib.import_module("cuda_corr"), importlib.import_module("cuda_ba")
+        self.pops, self.SE3 = pops, SE3
+        t = lambda a: torch.as_tensor(a, device=device)
+        cfg = st.cfg
+        self.M, self.mem, self.pmem, self.n, self.t0 = cfg.M, cfg.mem, cfg.pmem, st.n, st.t0
+        N = cfg.buffer_size
+        self.poses_ = t(st.poses).clone()
+        self.patches_ = t(st.patches).clone()
+        self.poses = self.poses_.view(1, N, 7)
+        self.patches = self.patches_.view(1, N * self.M, 3, 3, 3)
+        self.intrinsics = t(st.intrinsics).view(1, N, 4)
+        self.ii, self.jj, self.kk = t(st.ii), t(st.jj), t(st.kk)
+        self.target, self.weight = t(st.target)[None].contiguous(), t(st.weight)[None].contiguous()
+        self.lmbda = torch.as_tensor([st.lmbda], dtype=torch.float32, device=device)
+        self.fmap1_ = t(st.fmap1)[None].contiguous()                       # [1, mem, C, h, w]
+        self.fmap2_ = torch.nn.functional.avg_pool2d(self.fmap1_[0], 4, 4)[None].contiguous()
+        self.pyramid = (self.fmap1_, self.fmap2_)
+        self.gmap = t(st.gmap).view(1, self.pmem * self.M, cfg.C, 3, 3)
+        self.new_frame = self.fmap1_[0, (st.n - 1) % self.mem].clone()
+        self._poses0, self._patches0 = self.poses_.clone(), self.patches_.clone()
+
+    def reset(self):
+        self.poses_.copy_(self._poses0)
+        self.patches_.copy_(self._patches0)
+
+    def step(self, ingest=True, iterations=2, pooled=None):
+        """pooled: the new frame's level-1 map, if the caller wants a particular rounding of the 4x4 average (tests);
+        default torch's avg_pool2d as slam.py:682"""
+        out = {}
+        if ingest:   # slam.py:679-682
+            slot = (self.n - 1) % self.mem
+            self.fmap1_[:, slot] = self.new_frame
+            self.fmap2_[:, slot] = torch.nn.functional.avg_pool2d(self.new_frame[None], 4, 4)[0] if pooled is None else pooled
+        # SLAM.reproject
+        coords = self.pops.transform(self.SE3(self.poses), self.patches, self.intrinsics, self.ii, self.jj, self.kk)
+        coords = coords.permute(0, 1, 4, 2, 3).contiguous()
+        # SLAM.corr
+        ii1, jj1 = self.kk % (self.M * self.pmem), self.jj % self.mem
+        corr1, = self.cuda_corr.forward(self.gmap, self.pyramid[0], coords / 1, ii1, jj1, 3)
+        corr2, = self.cuda_corr.forward(self.gmap, self.pyramid[1], coords / 4, ii1, jj1, 3)
+        out["corr"] = torch.stack([corr1, corr2], -1).view(1, len(self.ii), -1)
+        out["coords"] = coords
+        # Update.forward
+        out["ix"], out["jx"] = self.cuda_ba.neighbors(self.kk, self.jj)
+        # fastba.BA
+        out["ba"] = self.cuda_ba.forward(self.poses.data, self.patches, self.intrinsics, self.target, self.weight,
+                                         self.lmbda, self.ii, self.jj, self.kk, self.M, self.t0, self.n, iterations, False)
+        return out

@@ -37,6 +37,12 @@ extern "C" {
 #define CDV_ERR_ARG (-2)         /* invalid argument / unsupported shape */
 #define CDV_ERR_WORKSPACE (-3)   /* workspace too small */
 #define CDV_ERR_UNSUPPORTED (-4) /* group / dtype / configuration not implemented */
+/* returned by cdv_ba_status only (the enqueueing calls cannot know): what went wrong inside the last bundle adjustment */
+#define CDV_ERR_BA_NOT_SPD (-5)  /* a Cholesky pivot was not positive: the update is garbage / NaN (the reference ignores
+                                    cholesky_ex's info, ba_cuda.cu:576,590) */
+#define CDV_ERR_BA_OVERFLOW (-6) /* more unique patches than U_max: the update was SKIPPED */
+#define CDV_ERR_BA_HANDOFF (-7)  /* an in-launch hand-off timed out: the update was NOT applied */
+#define CDV_ERR_GRAPH_RANGE (-8) /* the patch-graph index had reported a patch-id range beyond k_range: update skipped */
 
 #define CDV_F16 0
 #define CDV_F32 1
@@ -86,6 +92,20 @@ size_t cdv_fmap_padded_elems(int64_t slots, int C, int H, int W);
  */
 int cdv_fmap_to_nhwc(const void* src_nchw, void* dst_nhwc, int64_t N, int C, int H, int W, int64_t first,
                      int64_t count, void* stream);
+
+/*
+ * Keep a padded channels-last shadow in step with a planar ring that SOMEBODY ELSE writes (the unchanged reference writes
+ * fmap1_[:, n % mem] = fmap with torch ops, slam.py:679-682, and hands the whole ring to cuda_corr.forward): pass 1
+ * fingerprints every slot of the planar ring (16 position-keyed 64-bit sums per slot: one read of the ring), pass 2
+ * converts only the slots whose fingerprint differs from the previous sync's -- normally one -- instead of all N.
+ *   ws: cdv_fmap_sync_workspace_bytes(N) bytes, zeroed once by the caller (zero = "no fingerprint yet": the first sync
+ *   converts every slot); parity: 0, 1, 0, 1, ... on successive calls for one (ring, shadow) pair.  The int32 behind the
+ *   two fingerprint arrays counts converted slots (diagnostics).  A changed slot goes undetected only if all of its 16
+ *   64-bit sums collide.
+ */
+size_t cdv_fmap_sync_workspace_bytes(int64_t N);
+int cdv_fmap_sync_nhwc(const void* src_nchw, void* dst_nhwc, int64_t N, int C, int H, int W, void* ws, int parity,
+                       void* stream);
 
 /*
  * Per-frame ingest of one new feature frame (slam.py:681-682): fmap [C][H][W] f16 (planar) is
@@ -191,6 +211,12 @@ int cdv_graph_build(const int64_t* jj, const int64_t* kk, int64_t E, void* ws, s
 int cdv_graph_build_neighbors(const int64_t* jj, const int64_t* kk, int64_t E, void* ws, size_t ws_bytes,
                               int64_t E_max, int64_t k_range, int64_t* ix, int64_t* jx, void* stream);
 
+/* cdv_graph_build_neighbors given the source frames ii [E] as well (what cdv_update_prologue does): the per-patch edge
+ * records then carry (edge id, ii, jj), so cdv_ba_forward walks them with one 16-byte load per edge instead of a dependent
+ * chain of index loads.  ii == NULL: identical to cdv_graph_build_neighbors (the BA then reads ii itself). */
+int cdv_graph_build_edges(const int64_t* ii, const int64_t* jj, const int64_t* kk, int64_t E, void* ws, size_t ws_bytes,
+                          int64_t E_max, int64_t k_range, int64_t* ix, int64_t* jx, void* stream);
+
 int cdv_graph_read_meta_host(const void* ws, int64_t* meta_host, void* stream);
 
 /* copy out torch::_unique results (kx needs U from cdv_graph_read_meta_host to size it) */
@@ -223,14 +249,35 @@ size_t cdv_ba_workspace_bytes(int64_t E_max, int64_t U_max, int N_max);
  *   dbg (optional, NULL): receives iteration-0 values, with n = 6N and Us = round_up(U_max, 64):
  *             [S n*n (damped) | y n | dX n | dZ Us | C Us | u Us | E n*Us]
  *             (N > 32: only the lower triangle of S is accumulated)
- * N = t1 - t0 <= 10: one-wave register Cholesky; <= 32: single-workgroup LDS Cholesky; <= 1024 (global BA,
- * slam.py:460-478): Schur products per (64-patch chunk, pair of 32-pose panels with non-zero E), blocked
- * multi-workgroup Cholesky.  More: CDV_ERR_UNSUPPORTED.
+ * 1 <= N = t1 - t0 <= 10 (the optimisation window): two launches per iteration, no float atomics -- results are
+ * bitwise reproducible; <= 32: single-workgroup LDS Cholesky; <= 1024 (global BA, slam.py:460-478): Schur products per
+ * (64-patch chunk, pair of 32-pose panels with non-zero E), blocked multi-workgroup Cholesky.  More: CDV_ERR_UNSUPPORTED.
+ * Failures inside the launches (not positive definite, U_max exceeded, ...) are reported by cdv_ba_status.
  */
 int cdv_ba_forward(float* poses, float* patches, const float* intrinsics, const float* target, const float* weight,
                    const float* lmbda, const int64_t* ii, const int64_t* jj, const int64_t* kk, int64_t E, int P,
                    int t0, int t1, int iterations, const void* graph_ws, void* ba_ws, size_t ba_ws_bytes,
                    int64_t U_max, float* dbg, void* stream);
+
+/*
+ * Status of the last cdv_ba_forward on a workspace.  The reference ignores cholesky_ex's info (ba_cuda.cu:576,590: NaNs
+ * propagate silently) and exits the process on its own capacity errors (block_e.cu:20-27); here every failure is a word:
+ *   info_host[4] <- { cholesky: 0 or 1 + the pose block whose pivot was not positive,
+ *                     overflow: 1 = more unique patches than U_max, the update was skipped,
+ *                     hand-off: 1 = an in-launch hand-off timed out, the update was not applied,
+ *                     graph:    1 = the graph index was in its range-error state, the update was skipped }
+ * The words are reset by the next cdv_ba_forward on the workspace (a workspace recovers by itself).  Synchronises
+ * `stream`.  Returns CDV_OK or the CDV_ERR_BA_* / CDV_ERR_GRAPH_RANGE code of the first non-zero word.
+ */
+int cdv_ba_status(const void* ba_ws, int32_t* info_host, void* stream);
+
+/*
+ * Non-blocking alternative: bind four event counters {not positive definite, overflow, hand-off, graph} to a workspace.
+ * `counters` must be memory both the host and the device can address (hipHostMalloc / a pinned torch tensor); the kernels
+ * add 1 (system-scope load + store) whenever the event happens in an iteration and never reset them, so a host thread can
+ * watch them without synchronising any stream.  NULL unbinds.
+ */
+int cdv_ba_bind_status_counters(void* ba_ws, int32_t* counters);
 
 /* altcorr.patchify(net, coords, radius, mode) -- correlation.py:51-71 -- in one launch: the gather of
  * patchify_forward plus the blend the reference composes from four slice products.

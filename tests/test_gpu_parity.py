@@ -283,55 +283,40 @@ def test_corr_fused_vs_oracle(name):
 
 
 def test_reference_call_sequence_through_the_dropin_names():
-    """The reference's own sequence for one update -- SLAM.reproject / SLAM.corr (slam.py:316-329), Update's
-    fastba.neighbors (net_cdv.py:102), fastba.BA (slam.py:512-515, fastba/ba.py:8) -- written against the module names it
-    imports (cuda_corr, cuda_ba, lietorch_backends, registered by install_dropin()) and the reference's state layouts
-    (planar feature rings [1,mem,C,h,w], gmap [1,pmem*M,C,3,3]), on the benchmark workload; equal to UpdatePath.step():
-    coordinates, correlation and neighbors bit for bit, poses / depths after BA to float32 summation order."""
-    import importlib
-    import cdv_slam_amd
-    from cdv_slam_amd.update import UpdatePath
-    from cdv_slam_amd import projective_ops as pops
-    from cdv_slam_amd.lietorch import SE3
-    cdv_slam_amd.install_dropin()
-    cuda_corr, cuda_ba = importlib.import_module("cuda_corr"), importlib.import_module("cuda_ba")
+    """The reference's own sequence for one update -- SLAM.reproject / SLAM.corr (slam.py:316-329), the ring writes
+    (slam.py:679-682), Update's fastba.neighbors (net_cdv.py:102), fastba.BA (slam.py:512-515, fastba/ba.py:8) -- written
+    against the module names it imports (cuda_corr, cuda_ba, lietorch_backends, registered by install_dropin()) and the
+    reference's state layouts (cdv_slam_amd.update.DropinPath), on the benchmark workload; equal to UpdatePath.step():
+    coordinates, correlation, neighbors AND the state after the bundle adjustment bit for bit (nothing on the path sums in
+    an order that depends on timing)."""
+    from cdv_slam_amd.update import DropinPath, UpdatePath
     st = synth.make_state("default")
     dev = torch.device(DEV)
     up = UpdatePath(st, dev)
     want = up.step()
+    dp = DropinPath(st, dev)
+    level1 = lambda: ops.fmap_interior(up.fmap2).permute(0, 3, 1, 2).contiguous()   # the 4x4 averages as the ingest rounds them
+    assert float((dp.fmap2_[0].float() - level1().float()).abs().max()) <= 2.0 ** -10  # torch's pooling: same up to f16 rounding
+    dp.fmap2_.copy_(level1()[None])
+    got = dp.step(pooled=level1()[up.new_slot])
     torch.cuda.synchronize()
-    # reference-shaped state
-    M, mem, pmem = st.cfg.M, st.cfg.mem, st.cfg.pmem
-    N = st.cfg.buffer_size
-    poses_ = T(st.poses).clone()
-    patches_ = T(st.patches).clone()
-    poses, patches = poses_.view(1, N, 7), patches_.view(1, N * M, 3, 3, 3)
-    intrinsics = T(st.intrinsics).view(1, N, 4)
-    pyramid = (T(st.fmap1)[None].contiguous(), T(st.fmap2)[None].contiguous())
-    pyramid[1].copy_(ops.fmap_interior(up.fmap2).permute(0, 3, 1, 2)[None])   # the level-1 map the ingest pooled
-    gmap = T(st.gmap).view(1, pmem * M, st.cfg.C, 3, 3)
-    ii, jj, kk = T(st.ii), T(st.jj), T(st.kk)
-    # SLAM.reproject
-    coords = pops.transform(SE3(poses), patches, intrinsics, ii, jj, kk).permute(0, 1, 4, 2, 3).contiguous()
-    assert torch.equal(coords, want["coords"])
-    # SLAM.corr
-    ii1, jj1 = kk % (M * pmem), jj % mem
-    corr1, = cuda_corr.forward(gmap, pyramid[0], coords / 1, ii1, jj1, 3)
-    corr2, = cuda_corr.forward(gmap, pyramid[1], coords / 4, ii1, jj1, 3)
-    corr = torch.stack([corr1, corr2], -1).view(1, len(ii), -1)
-    assert corr.shape == want["corr"].shape and torch.equal(corr, want["corr"])
-    # Update.forward
-    ix, jx = cuda_ba.neighbors(kk, jj)
-    assert torch.equal(ix, want["ix"]) and torch.equal(jx, want["jx"])
-    # fastba.BA
-    lmbda = torch.as_tensor([1e-4], device=DEV)
-    res = cuda_ba.forward(poses.data, patches, intrinsics, T(st.target)[None], T(st.weight)[None], lmbda, ii, jj, kk, M,
-                          st.t0, st.n, 2, False)
+    assert got["ba"] == []
+    assert torch.equal(got["coords"], want["coords"])
+    assert got["corr"].shape == want["corr"].shape and torch.equal(got["corr"], want["corr"])
+    assert torch.equal(got["ix"], want["ix"]) and torch.equal(got["jx"], want["jx"])
+    assert torch.equal(dp.poses_, up.poses) and torch.equal(dp.patches_, up.patches)
+    assert not torch.equal(dp.poses_, T(st.poses))
+    # a second frame: only the ring slot that was written is converted again (fingerprint-gated shadow sync)
+    before = ops._nhwc.converted_slots(dp.fmap1_)
+    assert before == st.cfg.mem                       # the first sync converted every slot
+    dp.new_frame = (dp.new_frame.float() * 0.5 + 0.125).half()
+    up.new_frame = dp.new_frame.clone()
+    want = up.step()
+    got = dp.step(pooled=level1()[up.new_slot])
     torch.cuda.synchronize()
-    assert res == []
-    assert float((poses_ - up.poses).abs().max()) <= 1e-6
-    assert float((patches_ - up.patches).abs().max()) <= 1e-5
-    assert not torch.equal(poses_, T(st.poses))
+    assert ops._nhwc.converted_slots(dp.fmap1_) == before + 1
+    assert torch.equal(got["corr"], want["corr"])
+    assert torch.equal(dp.poses_, up.poses) and torch.equal(dp.patches_, up.patches)
 
 
 def test_corr_pixel_major_tiles_bit_identical():
@@ -794,6 +779,97 @@ def test_ba_structure_only_and_gates():
     d, d64 = patches[:, 2, 0, 0], x64[:, 2, 0, 0]
     assert np.abs(d - d64).max() <= 2e-4 * np.maximum(np.abs(d64), 1e-2).max()
     assert d.min() >= 1e-4
+
+
+def test_ba_window_is_bitwise_reproducible():
+    """the optimisation-window path (N <= 10) sums everything in a fixed order: two runs give identical bits -- also
+    when other kernels have run in between and when the workspace was used for another graph meanwhile"""
+    for name in ("default", "pr1"):
+        st = synth.make_state(name, features=False)
+        p1, x1, _ = _run_ba(st, iterations=2)
+        other = synth.make_state("small", features=False)
+        _run_ba(other, iterations=1)
+        p2, x2, _ = _run_ba(st, iterations=2)
+        assert np.array_equal(p1, p2) and np.array_equal(x1, x2), name
+        assert not np.array_equal(p1, st.poses)
+
+
+def test_ba_window_irregular_graph():
+    """edge lists the front-end never builds but the API admits: a random third of the edges dropped (ragged patch
+    degrees, chunks whose lanes belong to different frame pairs), the edge order shuffled, a few DUPLICATED edges and a
+    few self edges (i == j) of free frames"""
+    st = synth.make_state("small", features=False)
+    rng = np.random.default_rng(17)
+    keep = rng.random(st.E) > 0.33
+    sel = np.flatnonzero(keep)
+    sel = np.concatenate([sel, sel[rng.integers(0, len(sel), 40)]])      # duplicates
+    rng.shuffle(sel)
+    st.ii, st.jj, st.kk = st.ii[sel].copy(), st.jj[sel].copy(), st.kk[sel].copy()
+    st.target, st.weight = st.target[sel].copy(), st.weight[sel].copy()
+    assert (st.ii == st.jj).any() and ((st.ii == st.jj) & (st.ii >= st.t0)).any()
+    _, _, dbg = _run_ba(st, iterations=1, debug=True)
+    _, _, info, o = O.fastba(st.poses, st.patches, st.intrinsics[0], st.target, st.weight, st.lmbda, st.ii, st.jj,
+                             st.kk, st.t0, st.n, 1, np.float64, debug=True)
+    U = len(o["kx"])
+    for key, got, want in (("S", dbg["S"], o["S"]), ("y", dbg["y"], o["y"]), ("C", dbg["C"][:U], o["C"]),
+                           ("u", dbg["u"][:U], o["u"]), ("E", dbg["E"][:, :U], o["E"])):
+        assert np.abs(got.cpu().numpy() - want).max() <= 1e-4 * np.abs(want).max(), key
+    poses, patches, _ = _run_ba(st, iterations=2)
+    p64, x64, _ = O.fastba(st.poses, st.patches, st.intrinsics[0], st.target, st.weight, st.lmbda, st.ii, st.jj, st.kk,
+                           st.t0, st.n, 2, np.float64)
+    ba_checks.check_end_state("small", st, poses, patches, p64, x64)
+
+
+def test_ba_status_is_reported():
+    """the failure words of the BA launches reach the caller (the reference ignores cholesky_ex's info, ba_cuda.cu:576,590,
+    and exits on capacity errors, block_e.cu:20-27): U_max too small -> the update is skipped and says so; a system that
+    is not positive definite -> said so; the next well-formed call on the same workspace works"""
+    from cdv_slam_amd import _lib
+    st = synth.make_state("small", features=False)
+    dev = torch.device(DEV)
+    args = lambda po, pa, w: (po, pa, T(st.intrinsics), T(st.target), w, torch.tensor([st.lmbda], device=DEV), T(st.ii),
+                              T(st.jj), T(st.kk), st.cfg.M, st.t0, st.n, 2, False)
+    poses, patches = T(st.poses).clone(), T(st.patches).clone()
+    before = ops.ba_event_counts(dev)
+    os.environ["CDV_CHECK"] = "0"
+    try:
+        # 1. U_max smaller than the number of unique patches
+        ops.ba_forward(*args(poses, patches, T(st.weight)), U_max=8)
+        torch.cuda.synchronize()
+        assert torch.equal(poses, T(st.poses)) and torch.equal(patches, T(st.patches))      # skipped, not garbage
+        info = ops.ba_status(dev, raise_on_error=False)
+        assert info[1] == 1 and info[0] == 0
+        with pytest.raises(_lib.CdvError, match="U_max"):
+            ops.ba_status(dev)
+        assert ops.ba_event_counts(dev)[1] == before[1] + 2                                 # one event per iteration
+        os.environ["CDV_CHECK"] = "1"
+        with pytest.raises(_lib.CdvError, match="U_max"):
+            ops.ba_forward(*args(poses, patches, T(st.weight)), U_max=8)
+        os.environ["CDV_CHECK"] = "0"
+        # 2. negative weights: B is negative definite, the damped system has negative pivots
+        ops.ba_forward(*args(poses.clone(), patches.clone(), -100.0 * T(st.weight)))
+        info = ops.ba_status(dev, raise_on_error=False)
+        assert info[0] != 0 and info[1] == 0
+        with pytest.raises(_lib.CdvError, match="positive definite"):
+            ops.ba_status(dev)
+        assert ops.ba_event_counts(dev)[0] > before[0]
+        # 3. the workspace recovers by itself
+        ops.ba_forward(*args(poses, patches, T(st.weight)))
+        assert ops.ba_status(dev) == (0, 0, 0, 0)
+        p64, x64, _ = O.fastba(st.poses, st.patches, st.intrinsics[0], st.target, st.weight, st.lmbda, st.ii, st.jj,
+                               st.kk, st.t0, st.n, 2, np.float64)
+        ba_checks.check_end_state("small", st, poses.cpu().numpy(), patches.cpu().numpy(), p64, x64)
+        # 4. a graph whose patch ids exceed the index capacity: neighbors say "none", BA is skipped and says so
+        g = ops.GraphIndex(dev, E_cap=st.E, k_range=8)
+        g.build(T(st.jj), T(st.kk), with_neighbors=True)
+        ix, jx = g.neighbors()
+        assert bool((ix == -1).all()) and bool((jx == -1).all())
+        ops.ba_forward(*args(poses.clone(), patches.clone(), T(st.weight)), graph=g)
+        assert ops.ba_status(dev, raise_on_error=False)[3] == 1
+        with pytest.raises(_lib.CdvError, match="range"):
+            ops.ba_status(dev)
+    finally:
+        os.environ["CDV_CHECK"] = "1"
 
 
 def test_ba_dropin_inplace_contract():

@@ -82,3 +82,22 @@ def test_single_replica_needs_no_process_group(monkeypatch):
     assert grp.max_over_ranks(3.0) == 3.0 and grp.shard([7, 8]) == [7, 8]
     grp.barrier()
     grp.close()
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` run PLAINLY (no torch.distributed.run, no WORLD_SIZE): the parent starts two rank
+    processes before touching any GPU and the gathered line says n_gpus 2 (dry run: gloo on CPU, trivial step -- the
+    launch / rendezvous / gather plumbing of the N-GPU bench, not a measurement)"""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1",
+                          "--dry-run"], env=env, capture_output=True, timeout=300)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    line = json.loads(out.stdout.decode().strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["dry_run"] is True
+    assert len(line["per_rank"]) == 2 and line["per_rank"][0][0] != line["per_rank"][1][0]   # two different sequences
+    # a world that does not match --gpus is an error, not a silent 1-GPU run
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"],
+                         env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, timeout=120)
+    assert bad.returncode != 0
