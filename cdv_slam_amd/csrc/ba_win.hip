@@ -8,9 +8,11 @@
 //                        target slots), four waves, so one or two rounds cover a patch's ~25 edges.
 //                          - the chunk owns its patches' E columns, C and u completely: built in LDS / registers, no
 //                            accumulation across workgroups; q = 1 / (C + lambda) on the spot;
-//                          - B and v: per wave the 13 x 13 Gram matrices of [Ji | Jj | r] per frame pair as f32 MFMA
-//                            tiles (K = the pair's residual rows), added into the wave's PRIVATE packed-triangular
-//                            copy of [S | y] in LDS;
+//                          - B and v: every lane forms the 90 distinct products of its edge (the lower triangles of
+//                            Ji^T w Ji and Jj^T w Jj, Ji^T w Jj, the two right-hand sides); the 16 patches of a target
+//                            slot share their frame pair, so the pair's sums are wavefront shuffle reductions (DPP
+//                            row rotations, as a transpose-reduce: 45 instructions per 16 values, lane l ends up
+//                            owning one sum) added into the wave's PRIVATE packed-triangular copy of [S | y] in LDS;
 //                          - the chunk's Schur products [E; u] diag(q) [E; u]^T (K = 16 patches) as MFMA tiles; the tile
 //                            owner adds the four wave copies in fixed order, subtracts and stores ONE partial system
 //                            per chunk (a "slab": packed lower triangle of S + y, 7.6 KB) with plain stores;
@@ -30,42 +32,119 @@
 
 using namespace cdv;
 
+CDV_STAMP_TU(baw)
+
 namespace {
+
+// workgroup barrier over LDS only: waits for this wave's LDS operations, NOT for its outstanding global loads (which
+// __syncthreads() would drain: the next level of a dependent load chain then starts a memory round trip late)
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 constexpr int CK = WIN_CK;
 constexpr int CKW = 4;                     // waves per chunk workgroup
 constexpr int SN = WIN_SN;
 constexpr int TRI = WIN_TRI;
 constexpr int SLAB = WIN_SLAB;
-constexpr int XLD = 17;                    // floats per residual row in the Gram staging buffer (16 + 1 pad)
-constexpr int XW = 128 * XLD + 64;         // per wave: [128][XLD] rows + 64 per-edge pair keys
 constexpr int EDL = CK + 1;                // row stride of the chunk's [E; u] block in LDS
-constexpr int LDS_CHUNK_FLOATS = CKW * XW + CKW * SLAB + 64 * EDL + CKW * 8 * CK + 2 * CK;
+constexpr int LDS_CHUNK_FLOATS = CKW * SLAB + 64 * EDL + CKW * 8 * CK + 2 * CK;
+constexpr int NV = 90;                     // distinct sums of one frame pair: 21 + 6 (B_ii, v_i) + 21 + 6 (B_jj, v_j) + 36 (B_ij)
 
 __device__ __forceinline__ int tri_index(int R, int Cc) { return ((R * (R + 1)) >> 1) + Cc; }
 
-// one entry (row, col) of the 13 x 13 Gram matrix G = sum_k w_k X[k] X[k]^T, X[k] = [Ji | Jj | r], of frame pair
-// (ci, cj) (free-pose indices or -1) into the wave's packed copy: B[ii] += w Ji Ji^T, B[jj] += w Jj Jj^T,
-// B[ij] -= w Ji Jj^T, v[i] -= w r Ji, v[j] += w r Jj (ba_cuda.cu:364-377,393-398 semantics), lower triangle only.
-// quad < 0: every entry; otherwise only the entries of Gram quadrant `quad` (row >= 6, col in [6, 12)).
-__device__ __forceinline__ void tri_emit(float val, int row, int col, int ci, int cj, float* __restrict__ Sw, int quad) {
-  if (row >= 12 || col >= 13) return;                 // row 12 duplicates column 12; (12, 12) = sum w r^2
-  const bool ri = row < 6;
-  const bool isv = col == 12;
-  const bool cib = col < 6;
-  if (quad >= 0 && quad != ((ri ? 0 : 2) + ((isv || cib) ? 0 : 1))) return;
-  const int rb = ri ? ci : cj;
-  if (rb < 0) return;
-  const int R = 6 * rb + (ri ? row : row - 6);
-  if (isv) {
-    Sw[TRI + R] += ri ? -val : val;
-    return;
-  }
-  const int cb = cib ? ci : cj;
-  if (cb < 0) return;
-  const int Cc = 6 * cb + (cib ? col : col - 6);
-  if (Cc > R) return;                                  // the mirrored Gram entry lands in the lower triangle
-  Sw[tri_index(R, Cc)] += (ri != cib) ? -val : val;
+// ds_add_f32 without return: issued and forgotten (a read-modify-write through registers would expose an LDS round trip
+// per entry).  Used on data only this wave touches, one lane per address inside an instruction: no contention, and the
+// LDS unit executes a wave's instructions in order, so successive adds to one address apply in program order.
+__device__ __forceinline__ void lds_add(float* p, float v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// ---- the sums of one frame pair (i, j) over the edges of a target slot ---------------------------------------------------
+// Flat order of the NV = 90 values (signs included, ba_cuda.cu:364-377,393-398 semantics):
+//   [0, 21)   B_ii += w Ji Ji^T   lower triangle, (a, b) with a >= b in row-major order
+//   [21, 27)  v_i  -= w r Ji
+//   [27, 48)  B_jj += w Jj Jj^T   lower triangle
+//   [48, 54)  v_j  += w r Jj
+//   [54, 90)  B_ij -= w Ji Jj^T   all 36, (a, b) row-major
+// code of a value: kind << 6 | a << 3 | b, kind 7 = padding
+__device__ __forceinline__ int pair_code(int vi) {
+  auto tri_unrank = [](int t, int& a, int& b) {
+    a = 0;
+    while (((a + 1) * (a + 2)) / 2 <= t) a++;
+    b = t - (a * (a + 1)) / 2;
+  };
+  int a = 0, b = 0, kind = 7;
+  if (vi < 21) { kind = 0; tri_unrank(vi, a, b); }
+  else if (vi < 27) { kind = 1; a = vi - 21; }
+  else if (vi < 48) { kind = 2; tri_unrank(vi - 27, a, b); }
+  else if (vi < 54) { kind = 3; a = vi - 48; }
+  else if (vi < NV) { kind = 4; a = (vi - 54) / 6; b = (vi - 54) - 6 * a; }
+  return (kind << 6) | (a << 3) | b;
+}
+
+__device__ __forceinline__ void pair_products(const EdgeFactor& J, float w0, float w1, float (&val)[96]) {
+  const float* Ji0 = J.Ji; const float* Ji1 = J.Ji + 6;
+  const float* Jj0 = J.Jj; const float* Jj1 = J.Jj + 6;
+  float wi0[6], wi1[6], wj0[6], wj1[6];
+#pragma unroll
+  for (int a = 0; a < 6; a++) { wi0[a] = w0 * Ji0[a]; wi1[a] = w1 * Ji1[a]; wj0[a] = w0 * Jj0[a]; wj1[a] = w1 * Jj1[a]; }
+  int vi = 0;
+#pragma unroll
+  for (int a = 0; a < 6; a++)
+#pragma unroll
+    for (int b = 0; b <= a; b++) val[vi++] = fmaf(wi1[a], Ji1[b], wi0[a] * Ji0[b]);
+#pragma unroll
+  for (int a = 0; a < 6; a++) val[vi++] = -fmaf(wi1[a], J.r[1], wi0[a] * J.r[0]);
+#pragma unroll
+  for (int a = 0; a < 6; a++)
+#pragma unroll
+    for (int b = 0; b <= a; b++) val[vi++] = fmaf(wj1[a], Jj1[b], wj0[a] * Jj0[b]);
+#pragma unroll
+  for (int a = 0; a < 6; a++) val[vi++] = fmaf(wj1[a], J.r[1], wj0[a] * J.r[0]);
+#pragma unroll
+  for (int a = 0; a < 6; a++)
+#pragma unroll
+    for (int b = 0; b < 6; b++) val[vi++] = -fmaf(wi1[a], Jj1[b], wi0[a] * Jj0[b]);
+#pragma unroll
+  for (; vi < 96; vi++) val[vi] = 0.f;
+}
+
+// value of lane (l + n) or (l - n) mod 16 of the same DPP row (row_ror:n); the reduction below works with either
+template <int N>
+__device__ __forceinline__ float row_ror(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xf, 0xf, false));
+}
+
+// Transpose-reduce: 16 values per lane, summed over the 16 lanes of each DPP row; lane l of the row ends up with the
+// total of value 8 b0(l) + 4 b1(l) + 2 b2(l) + b3(l).  Step d in {1, 2, 4, 8}: a lane keeps the half of its values that
+// its bit log2(d) selects and adds the same half of the lane d away (whose bit log2(d) is the opposite one and whose
+// lower bits -- hence its value set -- are the same): 8 + 4 + 2 + 1 adds, a fixed summation tree.
+__device__ __forceinline__ float transpose_reduce16(const float* v, int c16) {
+  const bool b0 = (c16 & 1) != 0, b1 = (c16 & 2) != 0, b2 = (c16 & 4) != 0, b3 = (c16 & 8) != 0;
+  float u8[8], u4[4], u2[2];
+#pragma unroll
+  for (int i = 0; i < 8; i++) u8[i] = (b0 ? v[i + 8] : v[i]) + row_ror<1>(b0 ? v[i] : v[i + 8]);
+#pragma unroll
+  for (int i = 0; i < 4; i++) u4[i] = (b1 ? u8[i + 4] : u8[i]) + row_ror<2>(b1 ? u8[i] : u8[i + 4]);
+#pragma unroll
+  for (int i = 0; i < 2; i++) u2[i] = (b2 ? u4[i + 2] : u4[i]) + row_ror<4>(b2 ? u4[i] : u4[i + 2]);
+  return (b3 ? u2[1] : u2[0]) + row_ror<8>(b3 ? u2[0] : u2[1]);
+}
+
+// one reduced value of frame pair (ci, cj) (free-pose indices or -1) into the wave's packed copy of [S | y]
+__device__ __forceinline__ void pair_emit(float total, int code, int ci, int cj, bool row_on, float* __restrict__ Sw) {
+  const int kind = code >> 6, a = (code >> 3) & 7, b = code & 7;
+  const bool isv = (kind == 1) || (kind == 3);
+  const int rp = (kind == 2 || kind == 3) ? cj : ci;     // pose of the row index
+  const int cp = (kind == 0) ? ci : cj;                  // pose of the column index (unused for v)
+  const bool ok = row_on && kind != 7 && rp >= 0 && (isv || cp >= 0);
+  const int R = 6 * rp + a, Cc = 6 * cp + b;
+  const int hi = max(R, Cc), lo = min(R, Cc);            // B_ij lands in the block of the lower triangle
+  const int idx = isv ? TRI + R : tri_index(hi, lo);
+  // a self pair (i == j) folds B_ij and its transpose onto one block: the diagonal receives both
+  const float v = (kind == 4 && ci == cj && a == b) ? 2.0f * total : total;
+  if (ok) lds_add(&Sw[idx], v);
 }
 
 struct EdgeRec {
@@ -97,8 +176,7 @@ __device__ __forceinline__ EdgeIn load_in(const BaWinArgs& A, const EdgeRec& x) 
 
 __global__ __launch_bounds__(64 * CKW) void ba_chunk_kernel(BaWinArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Xall = smem;                         // [CKW][XW]   Gram staging rows + pair keys, per wave
-  float* Sc = Xall + CKW * XW;                // [CKW][SLAB] per-wave packed copies of [S | y] (B and v parts)
+  float* Sc = smem;                           // [CKW][SLAB] per-wave packed copies of [S | y] (B and v parts)
   float* Ed = Sc + CKW * SLAB;                // [64][EDL]   rows 0..59 E, row 60 u, rows 61..63 zero
   float* part = Ed + 64 * EDL;                // [CKW][8][CK] per-wave partial sums: 6 rows of E_i, C, u
   float* qs = part + CKW * 8 * CK;            // [CK]
@@ -125,16 +203,24 @@ __global__ __launch_bounds__(64 * CKW) void ba_chunk_kernel(BaWinArgs A) {
   const float lm = A.lmbda[0];
   const int p = lane & 15, sub = lane >> 4;
   const int c16 = lane & 15, g4 = lane >> 4;
-  float* X = Xall + wave * XW;
-  int* keys = reinterpret_cast<int*>(X + 128 * XLD);
   float* Sw = Sc + wave * SLAB;
+  // which of a frame pair's 90 sums this lane owns after the reductions: value 16 g + brev4(c16) of group g
+  int codes[6];
+  {
+    const int br = ((c16 & 1) << 3) | ((c16 & 2) << 1) | ((c16 & 4) >> 1) | ((c16 & 8) >> 3);
+#pragma unroll
+    for (int g = 0; g < 6; g++) codes[g] = pair_code(16 * g + br);
+  }
   const int n_chunks = (U + CK - 1) / CK;
 
+  CDV_IF_STAMPS(const int sslot = (int)blockIdx.x * CKW + wave; unsigned long long t_fac = 0, t_ej = 0, t_xw = 0, t_rd = 0, t_mf = 0, t_em = 0, t_x;)
+  CDV_STAMP(baw, sslot, 0);
+  CDV_STAMP_RT(baw, sslot, 14);
   for (int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
     const int r0 = chunk * CK;
     const int r = r0 + p;
     const bool live = r < U;
-    // ---- level 1: this lane's patch ----
+    // ---- level 1: this lane's patch (r <= U_max: inside the index arrays whatever U is) ----
     const int plo = live ? A.koff_u[r] : 0;
     const int deg = live ? A.koff_u[r + 1] - plo : 0;
     const int64_t kxr = live ? A.kx[r] : 0;
@@ -145,11 +231,11 @@ __global__ __launch_bounds__(64 * CKW) void ba_chunk_kernel(BaWinArgs A) {
       for (int i = tid; i < CKW * SLAB / 4; i += 64 * CKW) s4[i] = z4;
       for (int i = tid; i < 64 * EDL; i += 64 * CKW) Ed[i] = 0.f;
     }
-    int maxdeg = deg;
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, o));   // over the 16 patches (all sub rows alike)
-    maxdeg = __builtin_amdgcn_readfirstlane(maxdeg);
-    // ---- level 2: patch centre, and the source frame every edge of this patch shares (ii = ix[kk], slam.py:331-337)
+    // ---- level 2 (all of it depends on level 1 only): this lane's first edge record, the record of the patch's first
+    // edge (the source frame every edge of a patch shares: ii = ix[kk], slam.py:331-337), the patch centre
+    const int step = 4 * CKW;
+    int tb = 4 * wave;
+    EdgeRec rec = load_rec(A, (live && tb + sub < deg) ? plo + tb + sub : 0, has_ii);
     float px = 0.f, py = 0.f, pd = 0.f;
     int ix_patch = -1;
     if (deg > 0) {
@@ -157,23 +243,28 @@ __global__ __launch_bounds__(64 * CKW) void ba_chunk_kernel(BaWinArgs A) {
       px = pk[centre]; py = pk[PP + centre]; pd = pk[2 * PP + centre];
       ix_patch = load_rec(A, plo, has_ii).ix;
     }
+    // ---- level 3: the first round's poses, target, weight
+    EdgeIn in = load_in(A, rec);
+    int maxdeg = deg;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, o));   // over the 16 patches (all sub rows alike)
+    maxdeg = __builtin_amdgcn_readfirstlane(maxdeg);
     const int a0 = ix_patch - t0;
     const int ixf_patch = (deg > 0 && a0 >= 0 && a0 < N) ? a0 : -1;
-    __syncthreads();   // accumulators are zero
+    lds_barrier();   // accumulators are zero (LDS only: the loads above stay in flight)
+    CDV_STAMP(baw, sslot, 1);
 
     float Cacc = 0.f, uacc = 0.f;
     float eiacc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const int step = 4 * CKW;
-    int tb = 4 * wave;
-    EdgeRec rec = load_rec(A, (live && tb + sub < deg) ? plo + tb + sub : 0, has_ii);
-    EdgeIn in = load_in(A, rec);
     for (; tb < maxdeg; tb += step) {
       const bool active = live && (tb + sub) < deg;
       const bool more = tb + step < maxdeg;      // wave-uniform
       const EdgeRec cur = rec;
       if (more) rec = load_rec(A, (live && tb + step + sub < deg) ? plo + tb + step + sub : 0, has_ii);
+      CDV_IF_STAMPS(t_x = cdv_now();)
       EdgeFactor J;
       fastba_factor(in.pi, in.pj, px, py, pd, in.tx, in.ty, in.wx, in.wy, fx, fy, cx, cy, J);
+      CDV_IF_STAMPS(asm volatile("v_nop" :: "v"(J.Ji[11] + J.Jz[1])); { const unsigned long long t_y = cdv_now(); t_fac += t_y - t_x; t_x = t_y; })
       if (more) in = load_in(A, rec);            // the next round's inputs travel under this round's Gram
       int ixf = -1, jxf = -1;
       if (active) {
@@ -208,70 +299,35 @@ __global__ __launch_bounds__(64 * CKW) void ba_chunk_kernel(BaWinArgs A) {
           for (int c = 0; c < 6; c++) atomicAdd(&Ed[(6 * jxf + c) * EDL + p], ej[c]);
         }
       }
-      // ---- B and v of this wave's frame pairs: Gram matrices on the matrix cores ----
+      CDV_IF_STAMPS({ const unsigned long long t_y = cdv_now(); t_ej += t_y - t_x; t_x = t_y; })
+      // ---- B and v: the 16 patches of a target slot (one DPP row) normally share their frame pair (i, j); every pass
+      // takes, per row, the pair of its lowest unprocessed lane and sums the lanes of that pair (an irregular edge list
+      // costs more passes, nothing else) ----
       const int key = (ixf + 1) * (N + 1) + (jxf + 1);
-      keys[lane] = active ? key : 0;
-#pragma unroll
-      for (int row = 0; row < 2; row++) {
-        float* xr = X + (2 * lane + row) * XLD;
-#pragma unroll
-        for (int c = 0; c < 6; c++) {
-          xr[c] = active ? J.Ji[6 * row + c] : 0.f;
-          xr[6 + c] = active ? J.Jj[6 * row + c] : 0.f;
-        }
-        xr[12] = active ? J.r[row] : 0.f;
-        xr[13] = 0.f;
-        xr[14] = 0.f;
-        xr[15] = active ? J.w[row] : 0.f;
-      }
-      wave_lds_sync();
       unsigned long long todo = __ballot(active && key != 0);
-      if (todo) {
-        // this lane's MFMA operands of all 32 k-steps, read once (unconditional, batched LDS reads): column c16 of
-        // row k = 4 st + g4, with the row's weight and its edge's pair key
-        float xa[32], xw[32];
-        int xk[32];
+      while (todo) {
+        const unsigned rowbits = (unsigned)(todo >> (16 * sub)) & 0xffffu;
+        const bool row_on = rowbits != 0;
+        const int leader = 16 * sub + (row_on ? __ffs((int)rowbits) - 1 : 0);
+        const int kcur = __shfl(key, leader);
+        const int ci = __shfl(ixf, leader), cj = __shfl(jxf, leader);
+        const bool match = active && row_on && key == kcur;
+        float val[96];
+        pair_products(J, match ? J.w[0] : 0.f, match ? J.w[1] : 0.f, val);
+        CDV_IF_STAMPS({ asm volatile("v_nop" :: "v"(val[0] + val[89])); const unsigned long long t_y = cdv_now(); t_xw += t_y - t_x; t_x = t_y; })
+        float tot[6];
 #pragma unroll
-        for (int st = 0; st < 32; st++) {
-          const int k = 4 * st + g4;
-          xa[st] = X[k * XLD + c16];
-          xw[st] = X[k * XLD + 15];
-          xk[st] = keys[k >> 1];
-        }
-        while (todo) {
-          const int leader = __ffsll((long long)todo) - 1;
-          const int kcur = __shfl(key, leader);
-          const int ci = __shfl(ixf, leader), cj = __shfl(jxf, leader);
-          cdv_float4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-          const unsigned long long match = __ballot(active && key == kcur);
+        for (int g = 0; g < 6; g++) tot[g] = transpose_reduce16(val + 16 * g, c16);
+        CDV_IF_STAMPS({ asm volatile("v_nop" :: "v"(tot[0] + tot[5])); const unsigned long long t_y = cdv_now(); t_mf += t_y - t_x; t_x = t_y; })
 #pragma unroll
-          for (int st = 0; st < 32; st += 2) {
-            // k-steps st, st + 1 hold the rows of edges (lanes) 2 st .. 2 st + 3: skipped when none is of this pair
-            if (((match >> (2 * st)) & 15ull) == 0) continue;
-            const float w0 = (xk[st] == kcur) ? xw[st] : 0.f;
-            const float w1 = (xk[st + 1] == kcur) ? xw[st + 1] : 0.f;
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[st], w0 * xa[st], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[st + 1], w1 * xa[st + 1], acc1, 0, 0, 0);
-          }
-          // D layout: col = lane & 15, row = 4 * (lane >> 4) + reg.  One owner lane per destination inside a pass;
-          // a self pair (i == j) folds its four Gram quadrants onto one block: four sequential sub-steps
-          if (ci == cj && ci >= 0) {
-#pragma unroll
-            for (int quad = 0; quad < 4; quad++) {
-#pragma unroll
-              for (int q = 0; q < 4; q++) tri_emit(acc0[q] + acc1[q], 4 * g4 + q, c16, ci, cj, Sw, quad);
-              wave_lds_sync();
-            }
-          } else {
-#pragma unroll
-            for (int q = 0; q < 4; q++) tri_emit(acc0[q] + acc1[q], 4 * g4 + q, c16, ci, cj, Sw, -1);
-          }
-          wave_lds_sync();   // the next pass of this wave may touch the same entries
-          todo &= ~match;
-        }
+        for (int g = 0; g < 6; g++) pair_emit(tot[g], codes[g], ci, cj, row_on, Sw);
+        CDV_IF_STAMPS({ const unsigned long long t_y = cdv_now(); t_em += t_y - t_x; t_x = t_y; })
+        todo &= ~__ballot(match);
       }
-      wave_lds_sync();  // the next round overwrites X
     }
+    CDV_STAMP(baw, sslot, 2);
+    CDV_STAMP_VAL(baw, sslot, 8, t_fac); CDV_STAMP_VAL(baw, sslot, 9, t_ej); CDV_STAMP_VAL(baw, sslot, 10, t_xw);
+    CDV_STAMP_VAL(baw, sslot, 11, t_rd); CDV_STAMP_VAL(baw, sslot, 12, t_mf); CDV_STAMP_VAL(baw, sslot, 13, t_em);
     // ---- the wave's partial E_i, C, u: over its four target slots in fixed order, then published ----
     {
       float v[8] = {eiacc[0], eiacc[1], eiacc[2], eiacc[3], eiacc[4], eiacc[5], Cacc, uacc};
@@ -283,7 +339,7 @@ __global__ __launch_bounds__(64 * CKW) void ba_chunk_kernel(BaWinArgs A) {
       }
       if (wave == 0 && sub == 0) ixp[p] = ixf_patch;
     }
-    __syncthreads();
+    lds_barrier();
     if (tid < 6 * CK) {          // E_i rows of every patch: the four wave partials in fixed order, onto the E_j entries
       const int c = tid / CK, pp = tid - c * CK;
       const float tot = (part[(0 * 8 + c) * CK + pp] + part[(1 * 8 + c) * CK + pp]) +
@@ -309,6 +365,7 @@ __global__ __launch_bounds__(64 * CKW) void ba_chunk_kernel(BaWinArgs A) {
       }
     }
     __syncthreads();
+    CDV_STAMP(baw, sslot, 3);
     // ---- the chunk's E columns for the retraction (complete values, plain stores) ----
     for (int i = tid; i < n6 * CK; i += 64 * CKW) {
       const int row = i / CK, pp = i - row * CK;
@@ -318,6 +375,7 @@ __global__ __launch_bounds__(64 * CKW) void ba_chunk_kernel(BaWinArgs A) {
     }
     // ---- Schur products of the chunk, [E; u] diag(q) [E; u]^T on the matrix cores (K = 16 patches), and the chunk's
     // partial system: slab = (wave copies of B, v in fixed order) - products; each entry has exactly one owner ----
+    CDV_STAMP(baw, sslot, 4);
     float* slab = A.slabs + (size_t)chunk * SLAB;
     if (tid < SLAB - (TRI + SN)) slab[TRI + SN + tid] = 0.f;
     for (int pidx = wave; pidx < 10; pidx += CKW) {
@@ -341,8 +399,11 @@ __global__ __launch_bounds__(64 * CKW) void ba_chunk_kernel(BaWinArgs A) {
         slab[idx] = bsum - acc[q];
       }
     }
+    CDV_STAMP(baw, sslot, 5);
     __syncthreads();   // a grid-stride successor chunk re-zeroes the accumulators
   }
+  CDV_STAMP(baw, sslot, 6);
+  CDV_STAMP_RT(baw, sslot, 15);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -362,6 +423,9 @@ __device__ __forceinline__ void solve_wave(const BaWinArgs& A, int RW) {
   __shared__ __attribute__((aligned(16))) float Lt[(SN + 1) * 68]; // L for the back substitution (row stride 68)
   const int lane = threadIdx.x;
   const int n = 6 * A.N;
+  CDV_IF_STAMPS(const int sslot = 4000;)
+  CDV_STAMP(baw, sslot, 0);
+  CDV_STAMP_RT(baw, sslot, 14);
   // ---- wait for the reduce workgroups (bounded: a lost hand-off must not hang the device) ----
   bool ok = false;
   for (int spins = 0; spins < (1 << 20); spins++) {
@@ -373,18 +437,33 @@ __device__ __forceinline__ void solve_wave(const BaWinArgs& A, int RW) {
     if (lane == 0) ba_flag(A.info, BI_HANDOFF, 1);
     return;   // the retract workgroups time out on the dX granules and leave the state untouched
   }
-  // ---- my row, write-through loads.  The packed rows follow each other in memory, so a row is read at full length:
-  // its tail (the head of the next rows) sits where the upper triangle would be, which lane r computes on but nobody
-  // ever reads (a pivot is lane k's own a[k][k], a broadcast value lane c's a[c][k], c > k) ----
+  CDV_STAMP(baw, sslot, 1);
+  // ---- the reduced system: coalesced 8-byte write-through loads (every lane 15 of them, one memory round trip) into
+  // LDS, then my row from there.  The packed rows follow each other, so a row is read at full length: its tail (the
+  // head of the next rows) sits where the upper triangle would be, which lane r computes on but nobody ever reads (a
+  // pivot is lane k's own a[k][k], a broadcast value lane c's a[c][k], c > k) ----
+  {
+    uint64_t v[SLAB / 128 + 1];
+    const uint64_t* src = reinterpret_cast<const uint64_t*>(A.ared);
+#pragma unroll
+    for (int i = 0; i < SLAB / 128 + 1; i++)
+      v[i] = (64 * i + lane < SLAB / 2) ? __hip_atomic_load(src + 64 * i + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    uint64_t* dst = reinterpret_cast<uint64_t*>(Lt);   // (SN + 1) * 68 floats >= SLAB
+#pragma unroll
+    for (int i = 0; i < SLAB / 128 + 1; i++)
+      if (64 * i + lane < SLAB / 2) dst[64 * i + lane] = v[i];
+  }
+  wave_lds_sync();
   const int row = min(lane, SN);
-  const float* rp = A.ared + ((row < SN) ? tri_index(row, 0) : TRI);
+  const float* rp = Lt + ((row < SN) ? tri_index(row, 0) : TRI);
   cdv_float2 a2[SN / 2];     // the row as 30 float2 registers: rank-1 updates run two columns per v_pk_fma_f32
 #pragma unroll
   for (int c = 0; c < SN; c++) {
-    float v = ld_agent(rp + c);
+    float v = rp[c];
     if (c == row) v += 1e-4f * v + 1.0f;             // S += I (1e-4 S + 1.0)  (ba_cuda.cu:589 semantics); rows >= 6 N: identity
     a2[c >> 1][c & 1] = v;
   }
+  wave_lds_sync();   // Lt is reused for L below
   if (A.dbg && lane <= SN) {                          // damped S (both triangles) and y of iteration 0
 #pragma unroll
     for (int c = 0; c < SN; c++) {
@@ -393,6 +472,8 @@ __device__ __forceinline__ void solve_wave(const BaWinArgs& A, int RW) {
       if (lane == SN && c < n) A.dbg[(size_t)n * n + c] = v;
     }
   }
+  CDV_IF_STAMPS(asm volatile("v_nop" :: "v"(a2[29][1] + a2[0][0]));)
+  CDV_STAMP(baw, sslot, 2);
   // ---- right-looking Cholesky, column k broadcast through LDS one column ahead of its rank-1 update ----
   int badk = 0;
   float Lk;
@@ -415,7 +496,9 @@ __device__ __forceinline__ void solve_wave(const BaWinArgs& A, int RW) {
     float Ln = 0.f;
     if (k + 1 < SN) {
       // column k + 1 first: its one update from column k, pivot, scale, broadcast request
-      float an = fmaf(-Lk, bcur[(k + 1) >> 1][(k + 1) & 1], a2[(k + 1) >> 1][(k + 1) & 1]);
+      // L[k+1][k] straight from lane k + 1 (the LDS copy of column k only feeds the rest of the update: the chain
+      // pivot -> scale -> next pivot never waits for an LDS round trip)
+      float an = fmaf(-Lk, readlane_f(Lk, k + 1), a2[(k + 1) >> 1][(k + 1) & 1]);
       const float piv = readlane_f(an, k + 1);
       if (!(piv > 0.f) && badk == 0) badk = (k + 1) / 6 + 1;        // wave-uniform
       Ln = an * __builtin_amdgcn_rsqf(piv);
@@ -441,6 +524,7 @@ __device__ __forceinline__ void solve_wave(const BaWinArgs& A, int RW) {
   float a[SN];
 #pragma unroll
   for (int c = 0; c < SN; c++) a[c] = a2[c >> 1][c & 1];
+  CDV_STAMP(baw, sslot, 3);
   // ---- L back to LDS, then lane k picks up COLUMN k: col[r] = L[r][k].  Entries above the diagonal (r < k) are
   // whatever the row held there: lane k folds them into its z only AFTER x_k has been taken from it ----
   wave_lds_sync();
@@ -465,6 +549,7 @@ __device__ __forceinline__ void solve_wave(const BaWinArgs& A, int RW) {
     x = (lane == r) ? xr : x;
     z = fmaf(-col[r], xr, z);
   }
+  CDV_STAMP(baw, sslot, 4);
   if (lane < n) {
     // the data IS the flag: one 8-byte {tag = 1, value} granule per unknown, written through; the retract workgroups
     // poll the tags of the granules they read (CDNA programming guide, Guideline 16, recipe R2)
@@ -474,6 +559,8 @@ __device__ __forceinline__ void solve_wave(const BaWinArgs& A, int RW) {
     if (A.dbg) A.dbg[(size_t)n * n + n + lane] = x;
   }
   if (lane == 0 && badk) ba_flag(A.info, BI_CHOL, badk);
+  CDV_STAMP(baw, sslot, 5);
+  CDV_STAMP_RT(baw, sslot, 15);
 }
 
 __global__ __launch_bounds__(256) void ba_finish_kernel(BaWinArgs A) {
@@ -487,12 +574,15 @@ __global__ __launch_bounds__(256) void ba_finish_kernel(BaWinArgs A) {
     return;
   }
   const int b = (int)blockIdx.x - 1;
+  CDV_IF_STAMPS(const int sslot = 4100 + b * 4 + (tid >> 6);)
+  CDV_STAMP(baw, sslot, 0);
+  CDV_STAMP_RT(baw, sslot, 14);
   // ---- 1. reduce the chunk slabs: thread = (16-byte column, one of G interleaved slab subsets).  G depends on the
   //         number of slabs only and the butterfly over the subsets is fixed, so the sum is the same whatever the
   //         launch geometry (U_max, number of workgroups): reproducible bits ----
   {
     const int nsl = (U + CK - 1) / CK;
-    const int G = nsl <= 256 ? 4 : (nsl <= 1024 ? 8 : 16);
+    const int G = nsl <= 1024 ? 8 : 16;
     const int cols_per_wg = 256 / G;
     const int g = tid % G;
     for (int col = b * cols_per_wg + tid / G; col - tid / G < SLAB / 4; col += RW * cols_per_wg) {   // workgroup-uniform trip count
@@ -500,12 +590,17 @@ __global__ __launch_bounds__(256) void ba_finish_kernel(BaWinArgs A) {
       const bool mine = col < SLAB / 4;
       if (mine) {
         const cdv_float4* src = reinterpret_cast<const cdv_float4*>(A.slabs) + col;
-        int sidx = g;
-        for (; sidx + 3 * G < nsl; sidx += 4 * G) {   // four independent loads in flight per trip
+        // 32 loads in flight per thread (one memory round trip covers 32 G slabs = 4,096 patches), summed in slab order
+        for (int s0 = g; s0 < nsl; s0 += 32 * G) {
+          cdv_float4 v[32];
 #pragma unroll
-          for (int u = 0; u < 4; u++) acc[u] += src[(size_t)(sidx + u * G) * (SLAB / 4)];
+          for (int u = 0; u < 32; u++) {
+            const int sidx = s0 + u * G;
+            v[u] = (sidx < nsl) ? src[(size_t)sidx * (SLAB / 4)] : cdv_float4{0.f, 0.f, 0.f, 0.f};
+          }
+#pragma unroll
+          for (int u = 0; u < 32; u++) acc[u & 3] += v[u];
         }
-        for (int u = 0; sidx < nsl; sidx += G, u++) acc[u] += src[(size_t)sidx * (SLAB / 4)];
       }
       cdv_float4 tot = (acc[0] + acc[1]) + (acc[2] + acc[3]);
       for (int o = 1; o < G; o <<= 1) {
@@ -525,8 +620,9 @@ __global__ __launch_bounds__(256) void ba_finish_kernel(BaWinArgs A) {
     __syncthreads();
     if (tid == 0) __hip_atomic_fetch_add(A.arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  CDV_STAMP(baw, sslot, 1);
   // ---- 2. before dX exists: everything of this thread's patch that does not depend on it ----
-  __shared__ float sdx[64];
+  __shared__ __attribute__((aligned(16))) float sdx[64];
   const int P = A.P, PP = P * P, N = A.N;
   int r = b * 256 + tid;
   bool livep = r < U;
@@ -540,6 +636,8 @@ __global__ __launch_bounds__(256) void ba_finish_kernel(BaWinArgs A) {
     pk = A.patches + A.kx[r] * 3 * PP + 2 * PP;
     d0 = pk[0];                      // the depth is read from pixel [0][0]   (ba_cuda.cu:218 semantics)
   }
+  CDV_IF_STAMPS(asm volatile("v_nop" :: "v"(ev[0] + ev[59] + d0));)
+  CDV_STAMP(baw, sslot, 2);
   // ---- 3. wait for the solver (bounded) ----
   __shared__ int s_ok;
   if (tid < 64) {   // wave 0: lane t polls the granule of unknown t until its tag shows up; the poll is the load of dX
@@ -559,6 +657,7 @@ __global__ __launch_bounds__(256) void ba_finish_kernel(BaWinArgs A) {
     sdx[tid] = xv;
   }
   __syncthreads();
+  CDV_STAMP(baw, sslot, 3);
   if (!s_ok) return;   // no update without a solution: poses and depths stay as they were
   // ---- 4. pose retraction T <- Exp(dX_i) T: the last workgroup's first N lanes ----
   if ((int)blockIdx.x == (int)gridDim.x - 1 && tid < N) {
@@ -575,12 +674,14 @@ __global__ __launch_bounds__(256) void ba_finish_kernel(BaWinArgs A) {
   // ---- 5. dZ = Q (u - E^T dX), inverse-depth update (ba_cuda.cu:592,209-229 semantics) ----
   for (;;) {
     if (livep) {
-      float sacc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      float sacc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int bb = 0; bb < SN / 6; bb++)
+      for (int c4 = 0; c4 < SN / 4; c4++) {
+        const cdv_float4 x4 = *reinterpret_cast<const cdv_float4*>(&sdx[4 * c4]);
 #pragma unroll
-        for (int c = 0; c < 6; c++) sacc[c] += ev[6 * bb + c] * sdx[6 * bb + c];
-      const float dz = qv * (uv - (((sacc[0] + sacc[1]) + (sacc[2] + sacc[3])) + (sacc[4] + sacc[5])));
+        for (int j = 0; j < 4; j++) sacc[j] += ev[4 * c4 + j] * x4[j];
+      }
+      const float dz = qv * (uv - ((sacc[0] + sacc[1]) + (sacc[2] + sacc[3])));
       if (A.dbg) A.dbg[(size_t)36 * N * N + 12 * N + r] = dz;
       float d = d0 + dz;
       d = (d > 20.f) ? 1.0f : d;
@@ -589,7 +690,7 @@ __global__ __launch_bounds__(256) void ba_finish_kernel(BaWinArgs A) {
     }
     // more patches than one pass of the retract workgroups covers: the next block of 256 (loaded now, dX is known)
     r += RW * 256;
-    if (r - tid >= U) break;          // workgroup-uniform
+    if (r - tid >= U) { CDV_STAMP(baw, sslot, 4); CDV_STAMP_RT(baw, sslot, 15); break; }          // workgroup-uniform
     livep = r < U;
 #pragma unroll
     for (int i = 0; i < SN; i++) ev[i] = (livep && i < 6 * N) ? A.Edg[(size_t)i * A.U_stride + r] : 0.f;
@@ -611,10 +712,10 @@ int cdv::cdv_ba_window_iteration(const BaWinArgs& a, hipStream_t s) {
   CDV_HIP_CHECK(attr_err);
   const int n_ck = a.n_ck_cap < WIN_MAX_GRID ? a.n_ck_cap : WIN_MAX_GRID;
   hipLaunchKernelGGL(ba_chunk_kernel, dim3(n_ck), dim3(64 * CKW), sizeof(float) * LDS_CHUNK_FLOATS, s, a);
-  // reduce / retract workgroups: one per 256 patches of capacity, at least 8 (the reduce wants the parallelism), at
+  // reduce / retract workgroups: one per 256 patches of capacity, at least 16 (the reduce wants the parallelism), at
   // most WIN_MAX_RW (they all poll the solver)
   int RW = cdv_div_up(a.U_max, 256);
-  RW = RW < 8 ? 8 : (RW > WIN_MAX_RW ? WIN_MAX_RW : RW);
+  RW = RW < 16 ? 16 : (RW > WIN_MAX_RW ? WIN_MAX_RW : RW);
   hipLaunchKernelGGL(ba_finish_kernel, dim3(1 + RW), dim3(256), 0, s, a);
   CDV_LAUNCH_CHECK();
   return CDV_OK;

@@ -588,7 +588,7 @@ def ba_forward(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, PP
                             _p(kk), E, P, int(t0), int(t1), int(iterations), _p(g.ws), _p(ws), ws.numel(), U_max,
                             _p(dbg), _stream())
     _lib.check(rc, "cdv_ba_forward")
-    if _sync_check():
+    if _sync_check() and iterations > 0:
         ba_status(dev)        # raises CdvError: not positive definite / U_max exceeded / hand-off lost / graph range
     if debug:
         n6, Us = 6 * N, (U_max + 63) // 64 * 64

@@ -78,9 +78,8 @@ def check_iteration0(name, dbg, o64):
     coef = V.T @ (dX - o64["dX"].reshape(-1))
     e_strong = np.abs(coef[strong]).max()
     e_weak = np.abs(coef[~strong]).max() if (~strong).any() else 0.0
-    S = dbg["S"].astype(np.float64)
-    if np.abs(np.triu(S, 1)).max() == 0.0:          # the global-BA path accumulates the lower triangle only
-        S = S + np.tril(S, -1).T
+    S = np.tril(dbg["S"].astype(np.float64))       # the lower triangle is what every path accumulates and factors
+    S = S + np.tril(S, -1).T
     y = dbg["y"].astype(np.float64)
     res = np.linalg.norm(S @ dX - y) / np.linalg.norm(y)
     U = len(o64["dZ"])
