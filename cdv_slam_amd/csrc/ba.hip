@@ -1147,6 +1147,8 @@ extern "C" int cdv_ba_forward(float* poses, float* patches, const float* intrins
     wa.poses = poses; wa.patches = patches; wa.intr = intrinsics; wa.target = target; wa.weight = weight; wa.lmbda = lmbda;
     wa.ii = ii; wa.P = P; wa.t0 = t0; wa.N = N;
     wa.gmeta = gv.meta; wa.prec = gv.prec; wa.koff_u = gv.koff_u; wa.kx = gv.kx;
+    wa.pell = gv.pell; wa.ell_chunks = (int)GL.ell_chunks;
+    wa.has_ii = cdv_graph_has_ii(graph_ws) ? 1 : 0;
     wa.slabs = (float*)(b + L.slabs); wa.ared = (float*)(b + L.ared);
     wa.arrive = (int32_t*)(b + L.hand);
     wa.granX = reinterpret_cast<uint64_t*>(info + 16);

@@ -27,6 +27,8 @@
 //                        substitution for free); column k is broadcast through LDS (one ds_write, then 16-byte
 //                        broadcast reads) one column AHEAD of the rank-1 updates that consume it, so the LDS round
 //                        trip and the rsqrt chain of column k + 1 hide under the packed FMAs of column k.
+#include <utility>
+
 #include "cdv_ba.h"
 #include "cdv_se3.h"
 
@@ -43,7 +45,8 @@ __device__ __forceinline__ void lds_barrier() {
 }
 
 constexpr int CK = WIN_CK;
-constexpr int CKW = 4;                     // waves per chunk workgroup
+constexpr int CKW = 8;                     // waves per chunk workgroup: two per SIMD (a lone wave issues a vector
+                                           // instruction every 4 cycles, two alternate at 2), 32 target slots per round
 constexpr int SN = WIN_SN;
 constexpr int TRI = WIN_TRI;
 constexpr int SLAB = WIN_SLAB;
@@ -68,46 +71,61 @@ __device__ __forceinline__ void lds_add(float* p, float v) {
 //   [48, 54)  v_j  += w r Jj
 //   [54, 90)  B_ij -= w Ji Jj^T   all 36, (a, b) row-major
 // code of a value: kind << 6 | a << 3 | b, kind 7 = padding
-__device__ __forceinline__ int pair_code(int vi) {
-  auto tri_unrank = [](int t, int& a, int& b) {
+constexpr int pair_code(int vi) {
+  int a = 0, b = 0, kind = 7, t = 0;
+  if (vi < 21) { kind = 0; t = vi; }
+  else if (vi < 27) { kind = 1; a = vi - 21; }
+  else if (vi < 48) { kind = 2; t = vi - 27; }
+  else if (vi < 54) { kind = 3; a = vi - 48; }
+  else if (vi < NV) { kind = 4; a = (vi - 54) / 6; b = (vi - 54) - 6 * a; }
+  if (kind == 0 || kind == 2) {   // (a, b) of the t-th entry of a lower triangle in row-major order
     a = 0;
     while (((a + 1) * (a + 2)) / 2 <= t) a++;
     b = t - (a * (a + 1)) / 2;
-  };
-  int a = 0, b = 0, kind = 7;
-  if (vi < 21) { kind = 0; tri_unrank(vi, a, b); }
-  else if (vi < 27) { kind = 1; a = vi - 21; }
-  else if (vi < 48) { kind = 2; tri_unrank(vi - 27, a, b); }
-  else if (vi < 54) { kind = 3; a = vi - 48; }
-  else if (vi < NV) { kind = 4; a = (vi - 54) / 6; b = (vi - 54) - 6 * a; }
+  }
   return (kind << 6) | (a << 3) | b;
 }
 
-__device__ __forceinline__ void pair_products(const EdgeFactor& J, float w0, float w1, float (&val)[96]) {
-  const float* Ji0 = J.Ji; const float* Ji1 = J.Ji + 6;
-  const float* Jj0 = J.Jj; const float* Jj1 = J.Jj + 6;
+// the weighted Jacobian rows every product starts from
+struct PairW {
   float wi0[6], wi1[6], wj0[6], wj1[6];
+};
+__device__ __forceinline__ PairW pair_weights(const EdgeFactor& J, float w0, float w1) {
+  PairW P;
 #pragma unroll
-  for (int a = 0; a < 6; a++) { wi0[a] = w0 * Ji0[a]; wi1[a] = w1 * Ji1[a]; wj0[a] = w0 * Jj0[a]; wj1[a] = w1 * Jj1[a]; }
-  int vi = 0;
+  for (int a = 0; a < 6; a++) {
+    P.wi0[a] = w0 * J.Ji[a]; P.wi1[a] = w1 * J.Ji[6 + a];
+    P.wj0[a] = w0 * J.Jj[a]; P.wj1[a] = w1 * J.Jj[6 + a];
+  }
+  return P;
+}
+
+// value VI of the flat order above.  Generated 16 at a time, right before their reduction, so that at most 16 of the 90
+// are alive.
+template <int VI>
+__device__ __forceinline__ float pair_value(const EdgeFactor& J, const PairW& P) {
+  constexpr int code = pair_code(VI);
+  constexpr int kind = code >> 6, a = (code >> 3) & 7, b = code & 7;
+  if constexpr (kind == 0) return fmaf(P.wi1[a], J.Ji[6 + b], P.wi0[a] * J.Ji[b]);
+  else if constexpr (kind == 1) return -fmaf(P.wi1[a], J.r[1], P.wi0[a] * J.r[0]);
+  else if constexpr (kind == 2) return fmaf(P.wj1[a], J.Jj[6 + b], P.wj0[a] * J.Jj[b]);
+  else if constexpr (kind == 3) return fmaf(P.wj1[a], J.r[1], P.wj0[a] * J.r[0]);
+  else if constexpr (kind == 4) return -fmaf(P.wi1[a], J.Jj[6 + b], P.wi0[a] * J.Jj[b]);
+  else return 0.f;
+}
+
+template <int G, int... I>
+__device__ __forceinline__ void pair_group(const EdgeFactor& J, const PairW& P, float (&v)[16], std::integer_sequence<int, I...>) {
+  ((v[I] = pair_value<16 * G + I>(J, P)), ...);
+}
+
+// the code of value 16 g + br (br known at run time only: the lane's bit-reversed index)
+__device__ __forceinline__ int pair_code_rt(int g, int br) {
+  int code = pair_code(95);
 #pragma unroll
-  for (int a = 0; a < 6; a++)
-#pragma unroll
-    for (int b = 0; b <= a; b++) val[vi++] = fmaf(wi1[a], Ji1[b], wi0[a] * Ji0[b]);
-#pragma unroll
-  for (int a = 0; a < 6; a++) val[vi++] = -fmaf(wi1[a], J.r[1], wi0[a] * J.r[0]);
-#pragma unroll
-  for (int a = 0; a < 6; a++)
-#pragma unroll
-    for (int b = 0; b <= a; b++) val[vi++] = fmaf(wj1[a], Jj1[b], wj0[a] * Jj0[b]);
-#pragma unroll
-  for (int a = 0; a < 6; a++) val[vi++] = fmaf(wj1[a], J.r[1], wj0[a] * J.r[0]);
-#pragma unroll
-  for (int a = 0; a < 6; a++)
-#pragma unroll
-    for (int b = 0; b < 6; b++) val[vi++] = -fmaf(wi1[a], Jj1[b], wi0[a] * Jj0[b]);
-#pragma unroll
-  for (; vi < 96; vi++) val[vi] = 0.f;
+  for (int vi = 0; vi < 96; vi++)
+    if (vi == 16 * g + br) code = pair_code(vi);
+  return code;
 }
 
 // value of lane (l + n) or (l - n) mod 16 of the same DPP row (row_ror:n); the reduction below works with either
@@ -154,13 +172,17 @@ struct EdgeIn {
   float pi[7], pj[7], tx, ty, wx, wy;
 };
 
-__device__ __forceinline__ EdgeRec load_rec(const BaWinArgs& A, int pos, bool has_ii) {
-  const int4 r = *reinterpret_cast<const int4*>(A.prec + 4 * (size_t)pos);
-  EdgeRec o;
-  o.e = r.x;
-  o.ix = has_ii ? r.y : (int)A.ii[r.x];
-  o.jx = r.z;
-  return o;
+// A record becomes usable once the patch's degree is known: a slot that does not exist (its memory may hold anything)
+// is replaced by `safe` (CSR record 0, always valid) BEFORE any of its fields is used as an index -- by selects.  A
+// graph built without source frames (HAS_II false) gets them from ii here: one more dependent load.
+template <bool HAS_II>
+__device__ __forceinline__ EdgeRec settle_rec(const BaWinArgs& A, int4 raw, bool exists, const EdgeRec& safe) {
+  EdgeRec r;
+  r.e = exists ? raw.x : safe.e;
+  r.jx = exists ? raw.z : safe.jx;
+  if (HAS_II) r.ix = exists ? raw.y : safe.ix;
+  else r.ix = (int)A.ii[r.e];
+  return r;
 }
 
 __device__ __forceinline__ EdgeIn load_in(const BaWinArgs& A, const EdgeRec& x) {
@@ -174,6 +196,7 @@ __device__ __forceinline__ EdgeIn load_in(const BaWinArgs& A, const EdgeRec& x) 
   return o;
 }
 
+template <bool HAS_II>
 __global__ __launch_bounds__(64 * CKW) void ba_chunk_kernel(BaWinArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Sc = smem;                           // [CKW][SLAB] per-wave packed copies of [S | y] (B and v parts)
@@ -186,7 +209,6 @@ __global__ __launch_bounds__(64 * CKW) void ba_chunk_kernel(BaWinArgs A) {
   const int32_t* __restrict__ gmeta = A.gmeta;
   const int gerr = gmeta[GM_ERROR];
   const int U = gmeta[GM_U];
-  const bool has_ii = gmeta[GM_HAS_II] != 0;
   if (blockIdx.x == 0) {
     if (tid == 0) {
       ba_begin_status(A.info, A.counters, A.first, gerr, U > A.U_max);
@@ -199,8 +221,6 @@ __global__ __launch_bounds__(64 * CKW) void ba_chunk_kernel(BaWinArgs A) {
   const int n6 = 6 * N;
   const int PP = P * P;
   const int centre = (P > 1) ? (P + 1) : 0;
-  const float fx = A.intr[0], fy = A.intr[1], cx = A.intr[2], cy = A.intr[3];   // row 0 only (ba_cuda.cu:253-259)
-  const float lm = A.lmbda[0];
   const int p = lane & 15, sub = lane >> 4;
   const int c16 = lane & 15, g4 = lane >> 4;
   float* Sw = Sc + wave * SLAB;
@@ -209,7 +229,7 @@ __global__ __launch_bounds__(64 * CKW) void ba_chunk_kernel(BaWinArgs A) {
   {
     const int br = ((c16 & 1) << 3) | ((c16 & 2) << 1) | ((c16 & 4) >> 1) | ((c16 & 8) >> 3);
 #pragma unroll
-    for (int g = 0; g < 6; g++) codes[g] = pair_code(16 * g + br);
+    for (int g = 0; g < 6; g++) codes[g] = pair_code_rt(g, br);
   }
   const int n_chunks = (U + CK - 1) / CK;
 
@@ -220,10 +240,25 @@ __global__ __launch_bounds__(64 * CKW) void ba_chunk_kernel(BaWinArgs A) {
     const int r0 = chunk * CK;
     const int r = r0 + p;
     const bool live = r < U;
-    // ---- level 1: this lane's patch (r <= U_max: inside the index arrays whatever U is) ----
-    const int plo = live ? A.koff_u[r] : 0;
-    const int deg = live ? A.koff_u[r + 1] - plo : 0;
-    const int64_t kxr = live ? A.kx[r] : 0;
+    // ---- level 1, every load unconditional on a clamped index and all of them issued together: the records of this
+    // lane's first-round slot and of the patch's first edge from the chunk-slot copy (addresses that need no CSR
+    // offset), the patch's CSR offsets and id
+    const int step = 4 * CKW;
+    int tb = 4 * wave;
+    const bool use_ell = chunk < A.ell_chunks;               // workgroup-uniform; false only beyond 65,536 patches
+    // (no branch around these loads: a chunk without a chunk-slot copy reads CSR record 0 here and the real ones below)
+    const int4* cell = use_ell ? reinterpret_cast<const int4*>(A.pell) + (size_t)chunk * ELL_SLOTS * 16
+                               : reinterpret_cast<const int4*>(A.prec);
+    int4 raw = cell[use_ell ? (tb + sub) * 16 + p : 0];
+    int4 raw0 = cell[use_ell ? p : 0];
+    const int rs = live ? r : 0;
+    const int plo_raw = A.koff_u[rs], phi_raw = A.koff_u[rs + 1];
+    const int64_t kx_raw = A.kx[rs];
+    // the wave-uniform inputs travel with level 1 as well (read here, not before the loop: nothing waits for them
+    // before the loads above are out): intrinsics of row 0 (ba_cuda.cu:253-259), lambda, CSR record 0
+    const float fx = A.intr[0], fy = A.intr[1], cx = A.intr[2], cy = A.intr[3];
+    const float lm = A.lmbda[0];
+    const EdgeRec safe = {A.prec[0], A.prec[1], A.prec[2]};   // stands in for slots that do not exist
     // zero the workgroup's accumulators (the previous chunk of a grid-stride loop is done with them: barrier below)
     {
       const cdv_float4 z4 = {0.f, 0.f, 0.f, 0.f};
@@ -231,19 +266,21 @@ __global__ __launch_bounds__(64 * CKW) void ba_chunk_kernel(BaWinArgs A) {
       for (int i = tid; i < CKW * SLAB / 4; i += 64 * CKW) s4[i] = z4;
       for (int i = tid; i < 64 * EDL; i += 64 * CKW) Ed[i] = 0.f;
     }
-    // ---- level 2 (all of it depends on level 1 only): this lane's first edge record, the record of the patch's first
-    // edge (the source frame every edge of a patch shares: ii = ix[kk], slam.py:331-337), the patch centre
-    const int step = 4 * CKW;
-    int tb = 4 * wave;
-    EdgeRec rec = load_rec(A, (live && tb + sub < deg) ? plo + tb + sub : 0, has_ii);
-    float px = 0.f, py = 0.f, pd = 0.f;
-    int ix_patch = -1;
-    if (deg > 0) {
-      const float* pk = A.patches + kxr * 3 * PP;
-      px = pk[centre]; py = pk[PP + centre]; pd = pk[2 * PP + centre];
-      ix_patch = load_rec(A, plo, has_ii).ix;
+    const int plo = live ? plo_raw : 0;
+    const int deg = live ? phi_raw - plo_raw : 0;
+    const int64_t kxr = live ? kx_raw : 0;
+    if (!use_ell) {   // beyond the chunk-slot copy: the CSR records, one round trip later
+      const int4* csr = reinterpret_cast<const int4*>(A.prec);
+      raw = csr[(tb + sub < deg) ? plo + tb + sub : 0];
+      raw0 = csr[plo];
     }
-    // ---- level 3: the first round's poses, target, weight
+    // a slot beyond the patch's degree holds anything: replaced by CSR record 0 (always valid) before use (selects)
+    EdgeRec rec = settle_rec<HAS_II>(A, raw, tb + sub < deg, safe);
+    const EdgeRec rec0 = settle_rec<HAS_II>(A, raw0, deg > 0, safe);
+    // ---- level 2: the patch centre (patch 0 for a lane without a patch), the first round's poses, target, weight
+    const float* pk = A.patches + kxr * 3 * PP;
+    const float px = pk[centre], py = pk[PP + centre], pd = pk[2 * PP + centre];
+    const int ix_patch = deg > 0 ? rec0.ix : -1;
     EdgeIn in = load_in(A, rec);
     int maxdeg = deg;
 #pragma unroll
@@ -257,15 +294,19 @@ __global__ __launch_bounds__(64 * CKW) void ba_chunk_kernel(BaWinArgs A) {
     float Cacc = 0.f, uacc = 0.f;
     float eiacc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (; tb < maxdeg; tb += step) {
-      const bool active = live && (tb + sub) < deg;
-      const bool more = tb + step < maxdeg;      // wave-uniform
+      const bool active = (tb + sub) < deg;
+      const bool more = tb + step < maxdeg;      // wave-uniform; only patches with more than 4 CKW = 32 edges
       const EdgeRec cur = rec;
-      if (more) rec = load_rec(A, (live && tb + step + sub < deg) ? plo + tb + step + sub : 0, has_ii);
+      int4 raw_nxt = {0, 0, 0, 0};
+      if (more) raw_nxt = reinterpret_cast<const int4*>(A.prec)[(tb + step + sub < deg) ? plo + tb + step + sub : 0];
       CDV_IF_STAMPS(t_x = cdv_now();)
       EdgeFactor J;
       fastba_factor(in.pi, in.pj, px, py, pd, in.tx, in.ty, in.wx, in.wy, fx, fy, cx, cy, J);
       CDV_IF_STAMPS(asm volatile("v_nop" :: "v"(J.Ji[11] + J.Jz[1])); { const unsigned long long t_y = cdv_now(); t_fac += t_y - t_x; t_x = t_y; })
-      if (more) in = load_in(A, rec);            // the next round's inputs travel under this round's Gram
+      if (more) {   // rare: this wave's next round (its record was requested above)
+        rec = settle_rec<HAS_II>(A, raw_nxt, tb + step + sub < deg, safe);
+        in = load_in(A, rec);
+      }
       int ixf = -1, jxf = -1;
       if (active) {
         const int a = cur.ix - t0, b = cur.jx - t0;
@@ -312,12 +353,18 @@ __global__ __launch_bounds__(64 * CKW) void ba_chunk_kernel(BaWinArgs A) {
         const int kcur = __shfl(key, leader);
         const int ci = __shfl(ixf, leader), cj = __shfl(jxf, leader);
         const bool match = active && row_on && key == kcur;
-        float val[96];
-        pair_products(J, match ? J.w[0] : 0.f, match ? J.w[1] : 0.f, val);
-        CDV_IF_STAMPS({ asm volatile("v_nop" :: "v"(val[0] + val[89])); const unsigned long long t_y = cdv_now(); t_xw += t_y - t_x; t_x = t_y; })
+        const PairW PW = pair_weights(J, match ? J.w[0] : 0.f, match ? J.w[1] : 0.f);
         float tot[6];
-#pragma unroll
-        for (int g = 0; g < 6; g++) tot[g] = transpose_reduce16(val + 16 * g, c16);
+        {
+          constexpr auto seq = std::make_integer_sequence<int, 16>{};
+          float v16[16];
+          pair_group<0>(J, PW, v16, seq); tot[0] = transpose_reduce16(v16, c16);
+          pair_group<1>(J, PW, v16, seq); tot[1] = transpose_reduce16(v16, c16);
+          pair_group<2>(J, PW, v16, seq); tot[2] = transpose_reduce16(v16, c16);
+          pair_group<3>(J, PW, v16, seq); tot[3] = transpose_reduce16(v16, c16);
+          pair_group<4>(J, PW, v16, seq); tot[4] = transpose_reduce16(v16, c16);
+          pair_group<5>(J, PW, v16, seq); tot[5] = transpose_reduce16(v16, c16);
+        }
         CDV_IF_STAMPS({ asm volatile("v_nop" :: "v"(tot[0] + tot[5])); const unsigned long long t_y = cdv_now(); t_mf += t_y - t_x; t_x = t_y; })
 #pragma unroll
         for (int g = 0; g < 6; g++) pair_emit(tot[g], codes[g], ci, cj, row_on, Sw);
@@ -340,18 +387,28 @@ __global__ __launch_bounds__(64 * CKW) void ba_chunk_kernel(BaWinArgs A) {
       if (wave == 0 && sub == 0) ixp[p] = ixf_patch;
     }
     lds_barrier();
+    // the wave copies of B, v summed in fixed order into copy 0 (each thread its own 16-byte columns)
+    {
+      cdv_float4* s4 = reinterpret_cast<cdv_float4*>(Sc);
+      for (int i = tid; i < SLAB / 4; i += 64 * CKW) {
+        cdv_float4 t = s4[i];
+#pragma unroll
+        for (int w = 1; w < CKW; w++) t += s4[w * (SLAB / 4) + i];
+        s4[i] = t;
+      }
+    }
     if (tid < 6 * CK) {          // E_i rows of every patch: the four wave partials in fixed order, onto the E_j entries
       const int c = tid / CK, pp = tid - c * CK;
-      const float tot = (part[(0 * 8 + c) * CK + pp] + part[(1 * 8 + c) * CK + pp]) +
-                        (part[(2 * 8 + c) * CK + pp] + part[(3 * 8 + c) * CK + pp]);
+      float tot = 0.f;
+#pragma unroll
+      for (int w = 0; w < CKW; w++) tot += part[(w * 8 + c) * CK + pp];
       const int ib = ixp[pp];
       if (ib >= 0) Ed[(6 * ib + c) * EDL + pp] += tot;
     } else if (tid < 7 * CK) {   // C, u, q of every patch
       const int pp = tid - 6 * CK;
-      const float Ct = (part[(0 * 8 + 6) * CK + pp] + part[(1 * 8 + 6) * CK + pp]) +
-                       (part[(2 * 8 + 6) * CK + pp] + part[(3 * 8 + 6) * CK + pp]);
-      const float ut = (part[(0 * 8 + 7) * CK + pp] + part[(1 * 8 + 7) * CK + pp]) +
-                       (part[(2 * 8 + 7) * CK + pp] + part[(3 * 8 + 7) * CK + pp]);
+      float Ct = 0.f, ut = 0.f;
+#pragma unroll
+      for (int w = 0; w < CKW; w++) { Ct += part[(w * 8 + 6) * CK + pp]; ut += part[(w * 8 + 7) * CK + pp]; }
       const int rr = r0 + pp;
       const float q = (rr < U) ? 1.0f / (Ct + lm) : 0.f;      // Q = 1 / (C + lambda)   (ba_cuda.cu:548 semantics)
       qs[pp] = q;
@@ -373,8 +430,10 @@ __global__ __launch_bounds__(64 * CKW) void ba_chunk_kernel(BaWinArgs A) {
       A.Edg[(size_t)row * A.U_stride + r0 + pp] = v;
       if (A.dbg) A.dbg[(size_t)n6 * n6 + 2 * n6 + 3 * (size_t)A.U_stride + (size_t)row * A.U_stride + r0 + pp] = v;
     }
-    // ---- Schur products of the chunk, [E; u] diag(q) [E; u]^T on the matrix cores (K = 16 patches), and the chunk's
-    // partial system: slab = (wave copies of B, v in fixed order) - products; each entry has exactly one owner ----
+    // ---- Schur products of the chunk, [E; u] diag(q) [E; u]^T on the matrix cores (K = 16 patches), subtracted from
+    // the combined copy of B, v: the chunk's partial system; each entry has exactly one owner lane, which stores it
+    // (a pass of 16-byte stores behind one more barrier was measured: slower -- every wave then waits for the two that
+    // own two tile pairs) ----
     CDV_STAMP(baw, sslot, 4);
     float* slab = A.slabs + (size_t)chunk * SLAB;
     if (tid < SLAB - (TRI + SN)) slab[TRI + SN + tid] = 0.f;
@@ -395,8 +454,7 @@ __global__ __launch_bounds__(64 * CKW) void ba_chunk_kernel(BaWinArgs A) {
         const int R = 16 * ti + 4 * g4 + q, Cc = 16 * tj + c16;
         if (R > SN || Cc >= SN || (R < SN && Cc > R)) continue;   // row 60 = y; column 60 only duplicates it
         const int idx = (R < SN) ? tri_index(R, Cc) : TRI + Cc;
-        const float bsum = (Sc[idx] + Sc[SLAB + idx]) + (Sc[2 * SLAB + idx] + Sc[3 * SLAB + idx]);
-        slab[idx] = bsum - acc[q];
+        slab[idx] = Sc[idx] - acc[q];
       }
     }
     CDV_STAMP(baw, sslot, 5);
@@ -417,6 +475,10 @@ __device__ __forceinline__ float ld_agent(const float* p) {   // global_load_dwo
                                                __HIP_MEMORY_SCOPE_AGENT));
 }
 
+// (Measured and rejected: a second wave on another SIMD applying the published columns to columns [34, 60) until the
+// chain wave gets there -- half the rank-1 work per wave -- left the factorisation at 14.4k cycles: a lone wave issues a
+// v_pk_fma_f32 every 8 cycles and a ds_read_b128 every ~8, and the ~30 instructions of a column step, chain included,
+// are paid per column whoever does the bulk of the update.)
 // The 60 x 60 system in the registers of ONE wave.  Lane r holds row r of [S ; y^T] (lane 60 = the right-hand side).
 __device__ __forceinline__ void solve_wave(const BaWinArgs& A, int RW) {
   __shared__ __attribute__((aligned(16))) float colb[64];          // the column being broadcast
@@ -603,9 +665,15 @@ __global__ __launch_bounds__(256) void ba_finish_kernel(BaWinArgs A) {
         }
       }
       cdv_float4 tot = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-      for (int o = 1; o < G; o <<= 1) {
+      // the G partials sit in adjacent lanes: lane g = 0 collects them with DPP row shifts (a fixed tree)
 #pragma unroll
-        for (int j = 0; j < 4; j++) tot[j] += __shfl_xor(tot[j], o);
+      for (int j = 0; j < 4; j++) {
+        float t = tot[j];
+        t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x101, 0xf, 0xf, true));   // row_shl:1
+        t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x102, 0xf, 0xf, true));   // row_shl:2
+        t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x104, 0xf, 0xf, true));   // row_shl:4
+        if (G == 16) t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x108, 0xf, 0xf, true));   // row_shl:8
+        tot[j] = t;
       }
       if (mine && g == 0) {
         // written through (8-byte agent-scope stores): the solver reads them past its L1
@@ -706,12 +774,18 @@ __global__ __launch_bounds__(256) void ba_finish_kernel(BaWinArgs A) {
 
 int cdv::cdv_ba_window_iteration(const BaWinArgs& a, hipStream_t s) {
   static hipError_t attr_err = [] {
-    return hipFuncSetAttribute((const void*)ba_chunk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)(sizeof(float) * LDS_CHUNK_FLOATS));
+    hipError_t e1 = hipFuncSetAttribute((const void*)ba_chunk_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)(sizeof(float) * LDS_CHUNK_FLOATS));
+    hipError_t e2 = hipFuncSetAttribute((const void*)ba_chunk_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)(sizeof(float) * LDS_CHUNK_FLOATS));
+    return e1 != hipSuccess ? e1 : e2;
   }();
   CDV_HIP_CHECK(attr_err);
   const int n_ck = a.n_ck_cap < WIN_MAX_GRID ? a.n_ck_cap : WIN_MAX_GRID;
-  hipLaunchKernelGGL(ba_chunk_kernel, dim3(n_ck), dim3(64 * CKW), sizeof(float) * LDS_CHUNK_FLOATS, s, a);
+  if (a.has_ii)
+    hipLaunchKernelGGL(ba_chunk_kernel<true>, dim3(n_ck), dim3(64 * CKW), sizeof(float) * LDS_CHUNK_FLOATS, s, a);
+  else
+    hipLaunchKernelGGL(ba_chunk_kernel<false>, dim3(n_ck), dim3(64 * CKW), sizeof(float) * LDS_CHUNK_FLOATS, s, a);
   // reduce / retract workgroups: one per 256 patches of capacity, at least 16 (the reduce wants the parallelism), at
   // most WIN_MAX_RW (they all poll the solver)
   int RW = cdv_div_up(a.U_max, 256);

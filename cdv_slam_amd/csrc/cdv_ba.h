@@ -77,6 +77,8 @@ struct BaWinArgs {
   int P, t0, N;
   const int32_t* gmeta;
   const int32_t *prec, *koff_u;
+  const int32_t* pell;               // chunk-slot copy of the records (cdv_graph.h: ELL_SLOTS, ELL_CHUNKS)
+  int ell_chunks;
   const int64_t* kx;
   float *slabs, *ared;
   int32_t* arrive;                   // arrival counter of the reduce workgroups
@@ -87,6 +89,7 @@ struct BaWinArgs {
   int32_t* counters;                 // optional host-visible event counters (cdv_ba_bind_status_counters), may be NULL
   float* dbg;                        // iteration-0 dump (see cdv_ba_forward), may be NULL
   int first;                         // first iteration of a call: clears the sticky status words
+  int has_ii;                        // the graph's records carry the source frames (it was built with ii)
 };
 
 // one Gauss-Newton iteration of the window path: two launches on `s`

@@ -21,10 +21,16 @@ enum {
 };
 
 constexpr int GRAPH_MAX_BLOCKS = 1024;   // workgroups of the per-edge kernels (one min/max staging slot each)
+// "chunk-slot" copy of the edge records for the window bundle adjustment: record of the t-th edge (in (jj, edge id)
+// order) of the patch with unique rank u at [(u / 16) * ELL_SLOTS + t][u % 16] -- addressable without the CSR offsets, so
+// the BA's first memory round trip already fetches records.  Kept for t < ELL_SLOTS and u < 16 * ELL_CHUNKS (beyond: CSR).
+constexpr int ELL_SLOTS = 32;
+constexpr int ELL_CHUNKS = 4096;
 
 struct GraphLayout {
   int64_t E_max, k_range;
-  size_t meta, stage, khist, kcount, kcursor, krank, koff_u, kx, ku, pcsr_tmp, pcsr, prec, nprev, nnext, total;
+  size_t meta, stage, khist, kcount, kcursor, krank, koff_u, kx, ku, pcsr_tmp, pcsr, prec, pell, nprev, nnext, total;
+  int64_t ell_chunks;
 };
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -46,6 +52,8 @@ static inline GraphLayout graph_layout(int64_t E_max, int64_t k_range) {
   L.pcsr_tmp = o; o = align256(o + sizeof(int32_t) * (size_t)E_max);
   L.pcsr = o;     o = align256(o + sizeof(int32_t) * (size_t)E_max);
   L.prec = o;     o = align256(o + sizeof(int32_t) * 4 * (size_t)E_max);   // CSR records {edge, ii, jj, 0} in pcsr order
+  L.ell_chunks = (U_max + 15) / 16 < ELL_CHUNKS ? (U_max + 15) / 16 : ELL_CHUNKS;
+  L.pell = o;     o = align256(o + sizeof(int32_t) * 4 * 16 * (size_t)ELL_SLOTS * (size_t)L.ell_chunks);
   L.nprev = o;    o = align256(o + sizeof(int32_t) * (size_t)E_max);   // neighbors: previous / next edge of the same patch in time
   L.nnext = o;    o = align256(o + sizeof(int32_t) * (size_t)E_max);
   L.total = o;
@@ -54,7 +62,7 @@ static inline GraphLayout graph_layout(int64_t E_max, int64_t k_range) {
 
 struct GraphView {
   int32_t* meta;
-  int32_t *stage, *khist, *kcount, *kcursor, *krank, *koff_u, *ku, *pcsr_tmp, *pcsr, *prec, *nprev, *nnext;
+  int32_t *stage, *khist, *kcount, *kcursor, *krank, *koff_u, *ku, *pcsr_tmp, *pcsr, *prec, *pell, *nprev, *nnext;
   int64_t* kx;
 };
 
@@ -73,6 +81,7 @@ static inline GraphView graph_view(void* ws, const GraphLayout& L) {
   v.pcsr_tmp = (int32_t*)(b + L.pcsr_tmp);
   v.pcsr = (int32_t*)(b + L.pcsr);
   v.prec = (int32_t*)(b + L.prec);
+  v.pell = (int32_t*)(b + L.pell);
   v.nprev = (int32_t*)(b + L.nprev);
   v.nnext = (int32_t*)(b + L.nnext);
   return v;
@@ -84,6 +93,9 @@ static inline GraphView graph_view(void* ws, const GraphLayout& L) {
 bool cdv_graph_lookup(const void* ws, cdv::GraphLayout* out);
 
 void cdv_graph_forget(const void* ws);
+
+// was the last build on this workspace given the source frames ii (they are then part of the edge records)?
+bool cdv_graph_has_ii(const void* ws);
 
 // the index build in two halves (graph.hip), for cdv_update_prologue
 namespace cdv { struct HistArgs; }

@@ -37,6 +37,7 @@ namespace {
 struct RegEntry {
   GraphLayout L;
   bool initialised;
+  bool has_ii;
 };
 std::mutex g_reg_mutex;
 std::unordered_map<const void*, RegEntry> g_registry;
@@ -107,6 +108,8 @@ __global__ __launch_bounds__(256) void graph_segsort_kernel(const int64_t* __res
                                                             const int32_t* __restrict__ kcount,
                                                             const int32_t* __restrict__ pcsr_tmp,
                                                             int32_t* __restrict__ pcsr, int32_t* __restrict__ prec,
+                                                            int32_t* __restrict__ pell, int ell_chunks,
+                                                            const int32_t* __restrict__ krank,
                                                             int32_t* __restrict__ nprev,
                                                             int32_t* __restrict__ nnext, int32_t* __restrict__ kcursor,
                                                             int64_t* __restrict__ ix, int64_t* __restrict__ jx) {
@@ -147,7 +150,11 @@ __global__ __launch_bounds__(256) void graph_segsort_kernel(const int64_t* __res
     const int pe = hasp ? (int)(uint32_t)pk : -1, ne = hasn ? (int)(uint32_t)nk : -1;
     pcsr[lo + r] = e;
     // the record the bundle adjustment walks: edge id, source frame, target frame in ONE 16-byte load
-    *reinterpret_cast<int4*>(prec + 4 * (size_t)(lo + r)) = make_int4(e, ii ? (int)ii[e] : -1, (int)(ke >> 32), 0);
+    const int4 record = make_int4(e, ii ? (int)ii[e] : -1, (int)(ke >> 32), 0);
+    *reinterpret_cast<int4*>(prec + 4 * (size_t)(lo + r)) = record;
+    const int u = krank[d];                    // unique rank of the patch
+    if (r < ELL_SLOTS && (u >> 4) < ell_chunks)
+      *reinterpret_cast<int4*>(pell + 4 * ((size_t)((u >> 4) * ELL_SLOTS + r) * 16 + (u & 15))) = record;
     nprev[e] = pe;             // kept in the workspace for a later cdv_neighbors
     nnext[e] = ne;
     if (ix) {
@@ -198,6 +205,12 @@ bool cdv_graph_lookup(const void* ws, GraphLayout* out) {
   return true;
 }
 
+bool cdv_graph_has_ii(const void* ws) {
+  std::lock_guard<std::mutex> lk(g_reg_mutex);
+  auto it = g_registry.find(ws);
+  return it != g_registry.end() && it->second.has_ii;
+}
+
 // forget what is known about a workspace address (see cdv_workspace_forget in the header)
 void cdv_graph_forget(const void* ws) {
   std::lock_guard<std::mutex> lk(g_reg_mutex);
@@ -234,7 +247,7 @@ int cdv_graph_prepare(const int64_t* jj, const int64_t* kk, int64_t E, void* ws,
     auto it = g_registry.find(ws);
     need_init = it == g_registry.end() || !it->second.initialised || it->second.L.E_max != E_max ||
                 it->second.L.k_range != k_range;
-    g_registry[ws] = RegEntry{L, true};
+    g_registry[ws] = RegEntry{L, true, false};
   }
   const GraphView v = graph_view(ws, L);
   if (need_init)
@@ -249,6 +262,11 @@ int cdv_graph_finish(const int64_t* ii, const int64_t* jj, const int64_t* kk, in
                      int64_t k_range, int hist_blocks, int64_t* ix, int64_t* jx, void* stream) {
   const GraphLayout L = graph_layout(E_max, k_range);
   const GraphView v = graph_view(ws, L);
+  {
+    std::lock_guard<std::mutex> lk(g_reg_mutex);
+    auto it = g_registry.find(ws);
+    if (it != g_registry.end()) it->second.has_ii = ii != nullptr && E > 0;
+  }
   hipStream_t s = (hipStream_t)stream;
   const int32_t En = (int32_t)E;
   const int tb = 256;
@@ -260,7 +278,7 @@ int cdv_graph_finish(const int64_t* ii, const int64_t* jj, const int64_t* kk, in
     hipLaunchKernelGGL(graph_fill_kernel, dim3(fb), dim3(tb), 0, s, kk, En, v.meta, v.kcount, v.kcursor, v.krank,
                        v.koff_u, v.kx, v.ku, v.pcsr_tmp);
     hipLaunchKernelGGL(graph_segsort_kernel, dim3(fb), dim3(tb), 0, s, ii, jj, kk, En, v.meta, v.kcount, v.pcsr_tmp,
-                       v.pcsr, v.prec, v.nprev, v.nnext, v.kcursor, ix, jx);
+                       v.pcsr, v.prec, v.pell, (int)L.ell_chunks, v.krank, v.nprev, v.nnext, v.kcursor, ix, jx);
   }
   CDV_LAUNCH_CHECK();
   return CDV_OK;

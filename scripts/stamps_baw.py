@@ -9,6 +9,7 @@ from cdv_slam_amd.update import UpdatePath
 lib = _lib.load()
 dev = torch.device("cuda:0")
 cfg = sys.argv[1] if len(sys.argv) > 1 else "default"
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 1     # 2: the stamps show the SECOND iteration (caches warm)
 st = synth.make_state(cfg)
 up = UpdatePath(st, dev)
 for _ in range(5):
@@ -23,11 +24,12 @@ up.step(iterations=0)
 torch.cuda.synchronize()
 buf.zero_()
 ops.ba_forward(up.poses, up.patches, up.intrinsics, up.target, up.weight, up.lmbda, up.ii, up.jj, up.kk, up.M, up.t0, up.n,
-               1, False, U_max=up.U_max, graph=up.graph)
+               iters, False, U_max=up.U_max, graph=up.graph)
 torch.cuda.synchronize()
 b = buf.cpu().numpy().astype(np.float64)
 ck = b[:4000]
 ck = ck[ck[:, 0] > 0]
+print("iteration %d of %d after a full prologue + correlation" % (iters, iters))
 print("chunk kernel: %d waves stamped" % len(ck))
 names = ["loads L1-L3 issue + zero + barrier", "rounds (factor, E, gram)", "partials + finalize", "Edg store", "schur + slab"]
 for i, nme in enumerate(names):
