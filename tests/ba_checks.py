@@ -15,6 +15,9 @@ so the bounds that carry the parity claim there are the gauge-free ones (all at 
 Sim(3)-aligned ATE, the reprojection cost after the update, the error of dX inside the well-determined eigen-subspace
 of S, and the backward error of the solve.
 """
+import json
+import os
+
 import numpy as np
 
 from cdv_slam_amd import metrics
@@ -26,20 +29,30 @@ BA_TOL = {
     "small":    dict(t=1e-5, q=1e-6, d=1e-4, ate=1e-6, cost=1e-6),
     "default":  dict(t=1e-5, q=1e-6, d=1e-4, ate=1e-6, cost=1e-6),
     "stress":   dict(t=1e-5, q=1e-6, d=1e-4, ate=1e-6, cost=1e-6),
-    "init":     dict(t=2e-4, q=1e-6, d=1e-3, ate=2e-6, cost=1e-6),
-    "pr1":      dict(t=1e-4, q=1e-6, d=5e-4, ate=2e-6, cost=1e-6),
-    "global":   dict(t=2e-4, q=5e-6, d=1e-3, ate=5e-6, cost=1e-6),
-    "global_l": dict(t=2e-4, q=5e-6, d=1e-3, ate=1e-5, cost=1e-6),
-    "global_xl": dict(t=3e-4, q=1e-5, d=1e-3, ate=2e-5, cost=1e-6),
+    "init":     dict(t=5e-5, q=1e-6, d=2e-4, ate=1e-6, cost=1e-6),
+    "pr1":      dict(t=3e-5, q=1e-6, d=1e-4, ate=1e-6, cost=1e-6),
+    "global":   dict(t=1e-4, q=5e-6, d=2e-4, ate=5e-6, cost=1e-6),
+    "global_l": dict(t=1e-4, q=5e-6, d=2e-4, ate=1e-5, cost=1e-6),
+    "global_xl": dict(t=2e-4, q=1e-5, d=5e-4, ate=2e-5, cost=1e-6),
 }
 # iteration 0: dX error inside the eigen-subspace of S with eigenvalue >= 1e-2 of the largest (absolute, rad / scene
 # units; |dX| is 3e-3 .. 3e-2), and the relative residual of the solve |S dX - y| / |y| with the kernel's own S, y, dX
 DX_STRONG_TOL = 5e-6
-DX_WEAK_TOL = {"small": 1e-5, "default": 1e-5, "stress": 2e-5, "init": 5e-4, "pr1": 2e-4, "global": 1e-3, "global_l": 1e-3,
+DX_WEAK_TOL = {"small": 1e-5, "default": 1e-5, "stress": 2e-5, "init": 1e-4, "pr1": 5e-5, "global": 5e-4, "global_l": 5e-4,
                "global_xl": 1e-3}
 SOLVE_RESIDUAL_TOL = 2e-5
-DZ_TOL = {"small": 1e-5, "default": 1e-5, "stress": 1e-5, "init": 1e-3, "pr1": 5e-4, "global": 1e-3, "global_l": 1e-3,
-          "global_xl": 1e-3}
+DZ_TOL = {"small": 1e-5, "default": 1e-5, "stress": 1e-5, "init": 2.5e-4, "pr1": 1e-4, "global": 1e-4, "global_l": 1e-4,
+          "global_xl": 5e-4}
+
+
+def _log(kind, name, got, tol):
+    """measured values next to their bounds, one JSON line per check, when CDV_TEST_LOG names a file (profiles/ keeps
+    the GPU box's)"""
+    path = os.environ.get("CDV_TEST_LOG")
+    if path:
+        with open(path, "a") as f:
+            f.write(json.dumps({"check": kind, "graph": name, "measured": {k: float(v) for k, v in got.items()},
+                                "bound": {k: float(v) for k, v in tol.items()}}) + "\n")
 
 
 def reprojection_cost(poses, patches, st):
@@ -64,6 +77,7 @@ def check_end_state(name, st, poses, patches, p64, x64):
     ec = abs(cg - c64) / c64
     got = dict(t=et, q=eq, d=ed, ate=ate, cost=ec)
     print("BA end state [%s]: " % name + "  ".join("%s %.2e (<= %.0e)" % (k, got[k], tol[k]) for k in got))
+    _log("end_state", name, got, tol)
     for k in got:
         assert got[k] <= tol[k], (name, k, got[k], tol[k])
     return got
@@ -86,6 +100,8 @@ def check_iteration0(name, dbg, o64):
     e_dz = np.abs(dbg["dZ"][:U].astype(np.float64) - o64["dZ"]).max()
     print("BA iteration 0 [%s]: dX strong %.2e (<= %.0e) weak %.2e (<= %.0e), solve residual %.2e (<= %.0e), dZ %.2e (<= %.0e)"
           % (name, e_strong, DX_STRONG_TOL, e_weak, DX_WEAK_TOL[name], res, SOLVE_RESIDUAL_TOL, e_dz, DZ_TOL[name]))
+    _log("iteration0", name, dict(dX_strong=e_strong, dX_weak=e_weak, solve_residual=res, dZ=e_dz),
+         dict(dX_strong=DX_STRONG_TOL, dX_weak=DX_WEAK_TOL[name], solve_residual=SOLVE_RESIDUAL_TOL, dZ=DZ_TOL[name]))
     assert e_strong <= DX_STRONG_TOL, (name, e_strong)
     assert e_weak <= DX_WEAK_TOL[name], (name, e_weak)
     assert res <= SOLVE_RESIDUAL_TOL, (name, res)
