@@ -16,8 +16,22 @@ from .edges import EdgeStore, frames_keyframe_shift
 
 class StreamRunner:
     def __init__(self, device, M=96, ht=384, wd=512, C=24, mem=36, pmem=36, buffer_size=512, patch_lifetime=13,
-                 removal_window=22, opt_window=10, keyframe_index=4, seed=1234):
+                 removal_window=22, opt_window=10, keyframe_index=4, seed=1234, loop_closure=False, max_edge_age=1000,
+                 global_opt_freq=15, backend_thresh=64.0, pose_init=None, record_global=False):
+        """loop_closure: the LOOP_CLOSURE configuration of the reference (default_cdvslam.yaml): the patch ring holds
+        MAX_EDGE_AGE frames (slam.py:66-68), proximity loop edges are added every GLOBAL_OPT_FREQ frames
+        (slam.py:699-705, patchgraph.py:71-97), edges that close loops survive the removal window (slam.py:453-457) and an
+        update with long-range edges runs the GLOBAL bundle adjustment over inactive + active edges (slam.py:460-478,507).
+        pose_init(n) -> 7 floats: the initial guess of frame n's pose (default: the previous pose moved forward)."""
         self.dev = device
+        self.lc, self.max_edge_age, self.gof, self.backend_thresh = loop_closure, max_edge_age, global_opt_freq, backend_thresh
+        self.last_global_ba = -1000
+        self.ran_global_ba = {}
+        self.n_global = 0
+        self.pose_init, self.record_global, self.last_global = pose_init, record_global, None
+        self.last_loop_edges = None    # the loop edges the latest frame appended (tests)
+        if loop_closure:
+            pmem = max_edge_age
         self.M, self.C, self.mem, self.pmem = M, C, mem, pmem
         self.h, self.w = ht // 4, wd // 4
         self.r, self.rw, self.ow, self.ki = patch_lifetime, removal_window, opt_window, keyframe_index
@@ -34,9 +48,10 @@ class StreamRunner:
         self.fmap2 = ops.alloc_fmap_ring(mem, C, self.h // 4, self.w // 4, device)
         self.gmap = torch.zeros((pmem * M, C, 3, 3), dtype=torch.float16, device=device)
         self.gmap_pm = torch.zeros((pmem * M, 9, C), dtype=torch.float16, device=device)
-        ecap = M * (removal_window + 6) * 2 * patch_lifetime
+        ecap = M * (removal_window + 6) * 2 * patch_lifetime + (M * 1000 if loop_closure else 0)
         self.edges = EdgeStore(device, capacity=ecap, net_dim=0, inactive_capacity=ecap + buffer_size * M * 2 * patch_lifetime)
         self.graph = ops.GraphIndex(device, E_cap=ecap, k_range=(removal_window + 8) * M + M * pmem)
+        self.graph_full = None     # index over inactive + active edges (global BA), built on demand
         self.lmbda = torch.tensor([1e-4], **f32)
         self.n = 0
         self.n_updates = 0
@@ -60,7 +75,9 @@ class StreamRunner:
         tiles = ops.patchify_blend(fmap[None], coords, 1, "bilinear")[0].half()       # [M,C,3,3]
         t0 = (n % self.pmem) * M
         self.gmap[t0:t0 + M] = tiles
-        if n > 0:   # constant-position initialisation plus a small forward motion
+        if self.pose_init is not None:
+            self.poses[n] = torch.as_tensor(self.pose_init(n), dtype=torch.float32, device=self.dev)
+        elif n > 0:   # constant-position initialisation plus a small forward motion
             self.poses[n] = self.poses[n - 1]
             self.poses[n, 0] += 0.05
         return fmap, t0
@@ -75,10 +92,40 @@ class StreamRunner:
         delta = 0.01 * torch.tanh(corr[0, :, :2].float())
         e.target[0].copy_(coords[0, :, :, 1, 1] + delta)
         e.weight[0].copy_(torch.sigmoid(corr[0, :, 2:4].float()))
-        t0 = max(1, n - self.ow)
-        ops.ba_forward(self.poses, self.patches, self.intrinsics, e.target, e.weight, self.lmbda, e.ii, e.jj, e.kk, M, t0, n,
-                       2, False, U_max=(self.rw + 8) * M, graph=self.graph)
+        if self.lc and bool((e.ii < n - self.rw - 1).any()) and not self.ran_global_ba.get(n, False):
+            self._global_ba()      # long-range edges exist: slam.py:507-510
+        else:
+            t0 = max(1, n - self.ow)
+            ops.ba_forward(self.poses, self.patches, self.intrinsics, e.target, e.weight, self.lmbda, e.ii, e.jj, e.kk, M, t0,
+                           n, 2, False, U_max=min(e.E, (self.rw + 8) * M + (1000 * M if self.lc else 0)), graph=self.graph)
         self.n_updates += 1
+
+    def normalize(self):
+        """PatchGraph.normalize (patchgraph.py:99-117): mean inverse depth 1, first pose the identity"""
+        from .lietorch import SE3
+        n, M = self.n, self.M
+        s = self.patches[:n * M, 2].mean()
+        self.patches[:n * M, 2] /= s
+        self.poses[:n, :3] *= s
+        self.poses[:n] = (SE3(self.poses[:n]) * SE3(self.poses[[0]]).inv()).data
+
+    def _global_ba(self):
+        """SLAM.__run_global_BA (slam.py:460-478): inactive + active edges, every pose from the oldest active source
+        frame on is free"""
+        e, n, M = self.edges, self.n, self.M
+        target, weight, ii, jj, kk = e.full_edges()
+        self.normalize()
+        t0 = int(e.ii.min().item())
+        if self.record_global:
+            self.last_global = dict(poses=self.poses.clone(), patches=self.patches.clone(), target=target[0].clone(),
+                                    weight=weight[0].clone(), ii=ii.clone(), jj=jj.clone(), kk=kk.clone(), t0=t0, n=n,
+                                    E_active=e.E, E_inactive=e.E_inac)
+        if self.graph_full is None or self.graph_full.E_cap < ii.numel():
+            self.graph_full = ops.GraphIndex(self.dev, E_cap=int(ii.numel() * 1.5) + 1024, k_range=self.N * M)
+        ops.ba_forward(self.poses, self.patches, self.intrinsics, target, weight, self.lmbda, ii, jj, kk, M, t0, n, 2, True,
+                       U_max=min(int(ii.numel()), n * M), graph=self.graph_full)
+        self.ran_global_ba[n] = True
+        self.n_global += 1
 
     def _keyframe(self, drop):
         M, n = self.M, self.n
@@ -87,7 +134,7 @@ class StreamRunner:
             frames_keyframe_shift([(self.poses, 0), (self.intrinsics, 0), (self.patches.view(self.N, -1), 0),
                                    (self.gmap.view(self.pmem, -1), self.pmem), (self.gmap_pm.view(self.pmem, -1), self.pmem),
                                    (self.fmap1, self.mem), (self.fmap2, self.mem)], k, n)
-        self.n = self.edges.keyframe(k, n, M, self.ix, self.rw, drop=drop)
+        self.n = self.edges.keyframe(k, n, M, self.ix, self.rw, loop_closure=self.lc, opt_window=self.ow, drop=drop)
 
     def frame(self, drop=False):
         """one incoming frame (slam.py:697-720 for an initialised system)"""
@@ -95,6 +142,17 @@ class StreamRunner:
             raise RuntimeError("StreamRunner: frame buffer full")
         fmap, tile0 = self._new_frame()
         self.n += 1
+        self.last_loop_edges = None
+        if self.lc and self.n - self.last_global_ba >= self.gof:      # proximity loop edges (slam.py:699-705)
+            from . import loop
+            lk, lj = loop.edges_loop(self.poses, self.patches, self.intrinsics, self.ix, self.n, self.M,
+                                     removal_window=self.rw, max_edge_age=self.max_edge_age, global_opt_freq=self.gof,
+                                     keyframe_index=self.ki, backend_thresh=self.backend_thresh)
+            if lk.numel() > 0:
+                self.last_global_ba = self.n
+                self.ran_global_ba[self.n] = False
+                self.edges.append_factors(lk, lj, self.ix)
+                self.last_loop_edges = (lk, lj)
         self.edges.append_frame(self.ix, self.n, self.M, self.r)
         if self.n >= 8:
             self._update(fmap, tile0)

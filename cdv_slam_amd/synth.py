@@ -48,6 +48,9 @@ CONFIGS = {
     # the same with three pose panels' worth of free poses in a wider graph: N = 139
     "global_l": GraphConfig(name="global_l", frames=140, M=12, ht=192, wd=256, buffer_size=160, removal_window=10 ** 6,
                             opt_window=10 ** 6),
+    # the global BA at the reference's scale (slam.py:460-478 with MAX_EDGE_AGE = 1000): N = 299 free poses, full-size
+    # frames, 96 patches per frame -> U = 28,800 patches, E = 0.7 M edges
+    "global_xl": GraphConfig(name="global_xl", frames=300, buffer_size=304, removal_window=10 ** 6, opt_window=10 ** 6),
 }
 
 

@@ -307,16 +307,31 @@ static int SUF(fb_ba)(REAL *poses, REAL *patches, const REAL *intr, const REAL *
     if (N == 0) {
       for (long k = 0; k < U; k++) dZ[k] = Q[k] * u[k]; /* ba_cuda.cu:550-560 */
     } else {
-      /* S = B - (E*Q) E^T ; y = v - (E*Q) u   (ba_cuda.cu:583-587) */
-      for (long a = 0; a < n6; a++) {
-        for (long b = 0; b < n6; b++) {
+      /* S = B - (E*Q) E^T ; y = v - (E*Q) u   (ba_cuda.cu:583-587).  The sums run over k in ascending order as a dense
+       * matmul row would; columns in which row a of E is exactly zero contribute exactly zero and are skipped (a pose
+       * sees a few hundred of the tens of thousands of patches of a global BA), rows run in parallel under OpenMP. */
+#ifdef _OPENMP
+#pragma omp parallel
+#endif
+      {
+        long *nz = (long *)malloc(sizeof(long) * (size_t)(U + 1));
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 4)
+#endif
+        for (long a = 0; a < n6; a++) {
+          long nnz = 0;
+          for (long k = 0; k < U; k++)
+            if (Em[a * U + k] != 0) nz[nnz++] = k;
+          for (long b = 0; b < n6; b++) {
+            REAL s = 0;
+            for (long t = 0; t < nnz; t++) { const long k = nz[t]; s += (Em[a * U + k] * Q[k]) * Em[b * U + k]; }
+            S[a * n6 + b] = B[a * n6 + b] - s;
+          }
           REAL s = 0;
-          for (long k = 0; k < U; k++) s += (Em[a * U + k] * Q[k]) * Em[b * U + k];
-          S[a * n6 + b] = B[a * n6 + b] - s;
+          for (long t = 0; t < nnz; t++) { const long k = nz[t]; s += (Em[a * U + k] * Q[k]) * u[k]; }
+          y[a] = v[a] - s;
         }
-        REAL s = 0;
-        for (long k = 0; k < U; k++) s += (Em[a * U + k] * Q[k]) * u[k];
-        y[a] = v[a] - s;
+        free(nz);
       }
       /* S += I * (1e-4 * S + 1.0)   (ba_cuda.cu:589) */
       for (long a = 0; a < n6; a++) S[a * n6 + a] += (REAL)1e-4 * S[a * n6 + a] + (REAL)1.0;

@@ -561,6 +561,130 @@ def test_global_ba_vs_oracle(name):
     ba_checks.check_end_state(name, st, poses2, patches2, p64, x64)
 
 
+def test_global_ba_at_the_reference_scale():
+    """the global bundle adjustment at the size slam.py:460-478 runs it with MAX_EDGE_AGE = 1000 (slam.py:66-71): 299 free
+    poses, 28,800 patches, 0.7 M edges (a 1794 x 1794 reduced system, a 1794 x 28,800 E) against the float64 oracle --
+    intermediates of iteration 0, dX split by the eigen-subspaces of S, the state after two iterations"""
+    st = synth.make_state("global_xl", features=False)
+    assert st.n - st.t0 == 299 and st.E > 700000
+    _, _, dbg = _run_ba(st, iterations=1, debug=True)
+    _, _, info, o = O.fastba(st.poses, st.patches, st.intrinsics[0], st.target, st.weight, st.lmbda, st.ii, st.jj,
+                             st.kk, st.t0, st.n, 1, np.float64, debug=True)
+    assert info == 0
+    U = len(o["kx"])
+    assert U == 28800
+    S = np.tril(dbg["S"].cpu().numpy())
+    assert np.abs(S - np.tril(o["S"])).max() <= 1e-4 * np.abs(o["S"]).max()
+    # y = v - E Q u sums ~2,400 signed terms of size 1e2 per entry into |y| ~ 1e3: float32 itself (the reference's
+    # arithmetic restated in float32, sequential sums) is off by 1.6e-4 of max |y| here, so the bound for y is 5e-4 at
+    # this scale; everything else keeps 1e-4
+    for key, got, want, tol in (("y", dbg["y"], o["y"], 5e-4), ("C", dbg["C"][:U], o["C"], 1e-4),
+                                ("u", dbg["u"][:U], o["u"], 1e-4), ("E", dbg["E"][:, :U], o["E"], 1e-4)):
+        assert np.abs(got.cpu().numpy() - want).max() <= tol * np.abs(want).max(), key
+    ba_checks.check_iteration0("global_xl", {k: v.cpu().numpy() for k, v in dbg.items() if k != "E"}, o)
+    del dbg
+    poses, patches, _ = _run_ba(st, iterations=2)
+    p64, x64, info = O.fastba(st.poses, st.patches, st.intrinsics[0], st.target, st.weight, st.lmbda, st.ii, st.jj,
+                              st.kk, st.t0, st.n, 2, np.float64)
+    ba_checks.check_end_state("global_xl", st, poses, patches, p64, x64)
+    assert ops.ba_status(torch.device(DEV)) == (0, 0, 0, 0)
+
+
+def _circle_pose(t, period=60.0, radius=0.5):
+    """camera t of a closed path: world-to-camera pose (t, q) of a camera at radius * (cos a, sin a, 0) looking along +z"""
+    a = 2 * np.pi * t / period
+    return [-radius * np.cos(a), -radius * np.sin(a), 0.0, 0.0, 0.0, 0.0, 1.0]
+
+
+def test_loop_closure_stream_runs_the_global_ba():
+    """configs[2]'s mechanics on a synthetic stream (no images: stub networks): LOOP_CLOSURE keeps the patch ring at
+    MAX_EDGE_AGE = 1000 frames (slam.py:66-71; the correlation indexes it with kk % (M * 1000)), edges_loop adds proximity
+    edges when the camera comes back to where it was (patchgraph.py:71-97, slam.py:699-705), those edges survive the
+    removal window (slam.py:453-457), and an update that sees long-range edges runs the GLOBAL bundle adjustment over
+    inactive + active edges (slam.py:460-478,507).  Checked: the edge bookkeeping -- active and inactive lists -- against
+    the numpy restatement of slam.py, bit for bit, after every frame; the global BA against the float64 oracle on the
+    very state it ran on."""
+    from cdv_slam_amd.stream import StreamRunner
+    from oracle.edges_py import EdgesPy
+    dev = torch.device(DEV)
+    M = 16
+    run = StreamRunner(dev, M=M, ht=192, wd=256, buffer_size=160, loop_closure=True, max_edge_age=1000, global_opt_freq=15,
+                       backend_thresh=64.0, pose_init=_circle_pose, record_global=True)
+    assert run.pmem == 1000 and run.gmap.shape[0] == 1000 * M and run.gmap_pm.shape[0] == 1000 * M
+    g = EdgesPy()
+    ix_np = np.repeat(np.arange(run.N), M)
+    checked_global = False
+    for f in range(110):
+        n_globals = run.n_global
+        run.frame(drop=False)
+        n = run.n
+        # the same frame through the numpy restatement (slam.py:699-709, then keyframe() without a drop)
+        if run.last_loop_edges is not None:
+            lk, lj = (t.cpu().numpy() for t in run.last_loop_edges)
+            assert len(lk) % M == 0 and ((lj - ix_np[lk]) >= 30).all()
+            g.append_factors(lk, lj, ix_np)
+        g.append_factors(*g.edges_forw(n, M, run.r), ix_np)
+        g.append_factors(*g.edges_back(n, M, run.r), ix_np)
+        if n >= 8:
+            g.keyframe(-1, n, M, ix_np, run.rw, drop=False, loop_closure=True, opt_window=run.ow)
+        e = run.edges
+        assert e.E == len(g.ii) and e.E_inac == len(g.ii_inac), (f, e.E, len(g.ii))
+        assert np.array_equal(e.ii.cpu().numpy(), g.ii) and np.array_equal(e.jj.cpu().numpy(), g.jj) \
+            and np.array_equal(e.kk.cpu().numpy(), g.kk)
+        assert np.array_equal(e.ii_inac[:e.E_inac].cpu().numpy(), g.ii_inac) and \
+            np.array_equal(e.kk_inac[:e.E_inac].cpu().numpy(), g.kk_inac)
+        if run.n_global > n_globals and not checked_global:
+            checked_global = True
+            rec = run.last_global
+            ii, jj, kk = (rec[k].cpu().numpy() for k in ("ii", "jj", "kk"))
+            assert rec["E_inactive"] > 0 and len(ii) == rec["E_inactive"] + rec["E_active"]
+            assert ((jj - ii) >= 30).any()                              # loop edges took part (reduce_edges admits j - i >= 30)
+            assert (ii < rec["n"] - run.rw - 1).any()                   # what triggered the global BA (slam.py:507)
+            assert rec["n"] - rec["t0"] > 32                            # the multi-workgroup solver path
+            p0, x0 = rec["poses"].cpu().numpy(), rec["patches"].cpu().numpy()
+            tg, wg = rec["target"].cpu().numpy(), rec["weight"].cpu().numpy()
+            intr = run.intrinsics.cpu().numpy()
+            p64, x64, info = O.fastba(p0, x0, intr[0], tg, wg, 1e-4, ii, jj, kk, rec["t0"], rec["n"], 2, np.float64)
+            assert info == 0
+
+            class _State:      # what ba_checks reads of a synthetic state
+                pass
+            s = _State()
+            s.intrinsics, s.ii, s.jj, s.kk, s.target, s.weight, s.n = intr, ii, jj, kk, tg, wg, rec["n"]
+            got_p, got_x = run.poses.cpu().numpy(), run.patches.cpu().numpy()   # nothing touched them since the BA
+            ba_checks.check_end_state("global", s, got_p, got_x, p64, x64)
+            assert not np.array_equal(got_p[rec["t0"]:rec["n"]], p0[rec["t0"]:rec["n"]])
+            assert ops.ba_status(dev) == (0, 0, 0, 0)
+    assert checked_global, "the stream never ran a global bundle adjustment"
+    assert run.n_global >= 2             # ... and did so again GLOBAL_OPT_FREQ frames later
+
+
+def test_corr_patch_ring_of_a_thousand_frames():
+    """the fused correlation with the LOOP_CLOSURE patch ring (pmem = MAX_EDGE_AGE = 1000, M = 96: kmod = 96,000 tiles,
+    slam.py:66-71,319): raw patch ids far beyond the ring, wrapped by the kernel's reciprocal-multiply modulus"""
+    rng = np.random.default_rng(33)
+    C, H, W, mem, Ng, E = 24, 24, 32, 4, 96000, 2000
+    f1 = (rng.standard_normal((mem, C, H, W)) / 4).astype(np.float16)
+    f2 = f1.reshape(mem, C, H // 4, 4, W // 4, 4).astype(np.float32).mean((3, 5)).astype(np.float16)
+    gmap = (rng.standard_normal((Ng, C, 3, 3)) / 4).astype(np.float16)
+    coords = np.empty((E, 2, 3, 3), np.float32)
+    cx, cy = rng.uniform(2, W - 2, E), rng.uniform(2, H - 2, E)
+    off = np.arange(3.0) - 1
+    coords[:, 0] = cx[:, None, None] + off[None, None, :]
+    coords[:, 1] = cy[:, None, None] + off[None, :, None]
+    kk = rng.integers(0, 40 * Ng, E).astype(np.int64)        # frames long gone by: ids up to 3.8 M
+    kk[:8] = [0, Ng - 1, Ng, Ng + 1, 2 * Ng - 1, 39 * Ng + 95999, 95999, 96000]
+    jj = rng.integers(0, 30 * mem, E).astype(np.int64)
+    dev = torch.device(DEV)
+    r1, r2 = ops.alloc_fmap_ring(mem, C, H, W, dev), ops.alloc_fmap_ring(mem, C, H // 4, W // 4, dev)
+    ops.fmap_interior(r1).copy_(T(f1).permute(0, 2, 3, 1))
+    ops.fmap_interior(r2).copy_(T(f2).permute(0, 2, 3, 1))
+    pm = ops.gmap_to_pixel_major(T(gmap))
+    out = ops.corr_fused(pm, r1, r2, T(coords)[None], T(kk), T(jj), kmod=Ng, jmod=mem, pixel_major=True)
+    truth = O.slam_corr(gmap, f1, f2, coords, kk % Ng, jj % mem, 3, "truth")
+    assert np.abs(out[0].float().cpu().numpy() - truth).max() <= _corr_tol(truth)
+
+
 @pytest.mark.parametrize("tag", ["fc", "win"])
 def test_ba_py_mirror_vs_reference_golden(golden_dir, tag):
     """cdv_slam_amd.ba.BA == the reference's own cdvslam/ba.py run on the same inputs (tests/golden/ba_py_*.npz,
