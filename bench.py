@@ -27,6 +27,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+VALU_ISSUE_PEAK_GINST = 1024 * 2.4 / 4.0   # 256 CUs x 4 SIMDs, one VALU wave-instruction per 4 cycles, 2.4 GHz: 614.4 G/s
 
 
 def corr_algorithmic_bytes(st):
@@ -255,13 +256,25 @@ def main():
         raise SystemExit("gathered %d rows, --gpus says %d" % (len(per_rank), args.gpus))
 
     if rank == 0:
-        traffic = None
+        traffic, pmc = None, {}
         tpath = os.path.join(ROOT, "profiles", "corr_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(args.config, {}).get("hbm_bytes_per_launch")
+                pmc = json.load(open(tpath)).get(args.config, {})
+                traffic = pmc.get("hbm_bytes_per_launch")
             except Exception:
-                traffic = None
+                traffic, pmc = None, {}
+        # second bound of the same kernel: vector-instruction issue.  Wave-instructions per launch from the PMC pass
+        # (SQ_INSTS_VALU, profiles/corr_traffic.json) over the launch time measured above, against one VALU
+        # wave-instruction per 4 cycles per SIMD (the issue cost of the guide's cycle table; 1,024 SIMDs at 2.4 GHz)
+        valu = pmc.get("valu_insts_per_launch")
+        roofline_valu = None
+        if valu:
+            a_v = valu / (corr_ms * 1e-3) / 1e9
+            roofline_valu = {"bound": "valu_issue", "achieved": a_v, "peak": VALU_ISSUE_PEAK_GINST, "unit": "G wave-instr/s",
+                             "frac": a_v / VALU_ISSUE_PEAK_GINST, "kernel": "corr_fused2_kernel<24, 2>",
+                             "insts_per_launch": valu, "avg_launch_ms": corr_ms,
+                             "source": "SQ_INSTS_VALU of profiles/%s_corr_pmc_%s.txt" % (pmc.get("round", "r2"), args.config)}
         res = {
             "metric": "frames/sec per GPU (CDVO update, 96 patches, win=10); ATE vs ref",
             "value": aggregate_rate(args.steps, elapsed_max, world),
@@ -290,6 +303,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "kernel": "corr_fused2_kernel<24, 2>", "avg_launch_ms": corr_ms, "algorithmic_bytes": corr_bytes,
             },
+            "roofline_valu": roofline_valu,
             "stages_us": stages,
             "dropin_fps": dropin,
             "per_rank": per_rank,

@@ -704,7 +704,7 @@ __device__ __forceinline__ void corr_edge(const CorrArgs2& a, int p, int e, int 
 }
 
 template <int CC, int NLEV>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void corr_fused2_kernel(const CorrArgs2 a) {
+__global__ __launch_bounds__(256) void corr_fused2_kernel(const CorrArgs2 a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

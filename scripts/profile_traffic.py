@@ -5,7 +5,7 @@ feature ring, a kernel of exactly known byte count used to check the FETCH_SIZE 
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from cdv_slam_amd import synth, ops
+from cdv_slam_amd import synth, ops, _lib
 from cdv_slam_amd.update import UpdatePath
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "default"
@@ -14,8 +14,10 @@ st = synth.make_state(cfg, buffer_size=64, seed=1234)
 up = UpdatePath(st, dev)
 planar = torch.as_tensor(st.fmap1, device=dev)
 shadow = torch.zeros_like(up.fmap1)
+lib = _lib.load()
+N, C, H, W = planar.shape[-4:]
 for _ in range(12):
     up.step()
-    ops.NhwcCache._convert(planar, shadow)
+    _lib.check(lib.cdv_fmap_to_nhwc(ops._p(planar), ops._p(shadow), N, C, H, W, 0, N, ops._stream()), "cdv_fmap_to_nhwc")
 torch.cuda.synchronize()
 print("known bytes of one ring conversion: read %d write %d" % (planar.numel() * 2, planar.numel() * 2))
