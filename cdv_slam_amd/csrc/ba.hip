@@ -1137,10 +1137,11 @@ extern "C" int cdv_ba_forward(float* poses, float* patches, const float* intrins
     auto it = g_ws_counters.find(ba_ws);
     if (it != g_ws_counters.end()) counters = it->second;
   }
-  const bool window = N >= 1 && N <= WIN_N;   // the optimisation-window path (ba_win.hip): two launches per iteration
+  // the slab paths: two launches per iteration, no float atomics (ba_win.hip up to 10 free poses, ba_mid.hip up to 32)
+  const bool window = N >= 1 && N <= MID_N;
   if (fresh) {
     if (!window) CDV_HIP_CHECK(hipMemsetAsync(b + L.sy, 0, L.zero_bytes, s));   // the window path keeps no accumulators
-    CDV_HIP_CHECK(hipMemsetAsync(info, 0, sizeof(int32_t) * 16 + sizeof(uint64_t) * 64, s));
+    CDV_HIP_CHECK(hipMemsetAsync(info, 0, sizeof(int32_t) * 16 + sizeof(uint64_t) * MID_GRAN, s));
   }
   if (window) {
     BaWinArgs wa;
@@ -1158,7 +1159,7 @@ extern "C" int cdv_ba_forward(float* poses, float* patches, const float* intrins
     for (int itr = 0; itr < iterations; itr++) {
       wa.dbg = (dbg && itr == 0) ? dbg : nullptr;
       wa.first = itr == 0 ? 1 : 0;
-      const int rc = cdv_ba_window_iteration(wa, s);
+      const int rc = N <= WIN_N ? cdv_ba_window_iteration(wa, s) : cdv_ba_mid_iteration(wa, s);
       if (rc != CDV_OK) return rc;
     }
     return CDV_OK;

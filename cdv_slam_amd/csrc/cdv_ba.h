@@ -24,6 +24,16 @@ constexpr int WIN_CK = 16;                       // unique patches per chunk wor
 constexpr int WIN_MAX_GRID = 1024;               // chunk workgroups per launch (grid-stride over the chunks beyond)
 constexpr int WIN_MAX_RW = 32;                   // reduce / retract workgroups of the finish launch
 
+// ---- the same design for 10 < N <= BA_NMAX free poses (ba_mid.hip): the slab is the packed triangle of a 6N x 6N system
+constexpr int MID_N = BA_NMAX;
+constexpr int MID_GRAN = 256;                    // dX granules of the solve -> retract hand-off (>= 6 MID_N)
+constexpr int MID_MAX_RW = 64;                   // retract workgroups of the mid finish launch
+inline int mid_tri(int N) { return 6 * N * (6 * N + 1) / 2; }
+inline int mid_slab(int N) { return (mid_tri(N) + 6 * N + 7) / 8 * 8; }   // floats per partial system
+// row stride of the dense system the mid solver works on: >= n, = 4 (mod 32) floats -- the 16-byte row reads and writes of
+// 8 consecutive rows then cover the 32 LDS banks once
+__host__ __device__ inline int solve_ld(int n) { return (n + 27) / 32 * 32 + 4; }
+
 // status words of a workspace (int32 info[16] on the device; cdv_ba_status reads the first four)
 enum { BI_CHOL = 0, BI_OVERFLOW = 1, BI_HANDOFF = 2, BI_GRAPH = 3 };
 
@@ -51,7 +61,7 @@ inline BaLayout ba_layout(int64_t U_max, int N_max) {
   L.zero_bytes = o;
   L.q = o;    o = align256(o + sizeof(float) * (size_t)L.U_stride);
   L.dX = o;   o = align256(o + sizeof(float) * (n6 + 8));
-  L.info = o; o = align256(o + sizeof(int32_t) * 16 + sizeof(uint64_t) * 64);   // 16 words + the 64 dX granules of the solve -> retract hand-off
+  L.info = o; o = align256(o + sizeof(int32_t) * 16 + sizeof(uint64_t) * MID_GRAN);   // 16 words + the dX granules of the solve -> retract hand-off
   L.npad = 0; L.Abig = o;
   if (N_max > BA_NMAX) {   // working copy of [S ; y^T] for the blocked Cholesky, padded with identity to 64-blocks
     L.npad = (int64_t)((n6 + CNB - 1) / CNB * CNB);
@@ -59,10 +69,13 @@ inline BaLayout ba_layout(int64_t U_max, int N_max) {
   }
   // window path: one partial system per chunk of 16 patches, the reduced system, the arrival counter
   L.n_ck = 0; L.slabs = o; L.ared = o; L.hand = o;
-  if (N_max >= 1 && N_max <= WIN_N) {
+  if (N_max >= 1 && N_max <= MID_N) {
+    const size_t slab = N_max <= WIN_N ? (size_t)WIN_SLAB : (size_t)mid_slab(N_max);
     L.n_ck = (U_max + WIN_CK - 1) / WIN_CK;
-    L.slabs = o; o = align256(o + sizeof(float) * (size_t)WIN_SLAB * (size_t)L.n_ck);
-    L.ared = o;  o = align256(o + sizeof(float) * (size_t)WIN_SLAB);
+    L.slabs = o; o = align256(o + sizeof(float) * slab * (size_t)L.n_ck);
+    // the reduced system: packed (window path) or as dense rows [6N + 1][solve_ld] (mid path)
+    const size_t ared = N_max <= WIN_N ? slab : (size_t)(6 * N_max + 1) * (size_t)solve_ld(6 * N_max);
+    L.ared = o;  o = align256(o + sizeof(float) * ared);
     L.hand = o;  o = align256(o + 64);
   }
   L.total = o;
@@ -94,6 +107,8 @@ struct BaWinArgs {
 
 // one Gauss-Newton iteration of the window path: two launches on `s`
 int cdv_ba_window_iteration(const BaWinArgs& a, hipStream_t s);
+// the same for 10 < N <= MID_N (ba_mid.hip)
+int cdv_ba_mid_iteration(const BaWinArgs& a, hipStream_t s);
 
 // LDS hand-off between the lanes of ONE wave: the LDS unit executes a wave's DS instructions in order, so only the
 // compiler has to be kept from moving accesses across this point.  (A workgroup-scope release fence would also drain

@@ -494,10 +494,22 @@ def _run_ba(st, iterations=2, debug=False, t0=None, t1=None):
     return poses.cpu().numpy(), patches.cpu().numpy(), res
 
 
-@pytest.mark.parametrize("name", ["small", "init", "pr1", "default"])
+# graphs of the 10 < N <= 32 path (ba_mid.hip): `stress` (N = 21, M = 196), and two variants of `small`: N = 15 (an odd
+# number of poses: the solver's last block is 6 wide) and N = 19 with 5 patches per frame (a chunk of 16 consecutive
+# patches spans four source frames: two passes over the chunk)
+MID_VARIANTS = {"mid15": dict(opt_window=15), "mid19_m5": dict(opt_window=19, M=5)}
+
+
+def _make(name):
+    if name in MID_VARIANTS:
+        return synth.make_state("small", features=False, **MID_VARIANTS[name]), "small"
+    return synth.make_state(name, features=False), name
+
+
+@pytest.mark.parametrize("name", ["small", "init", "pr1", "default", "stress", "mid15", "mid19_m5"])
 def test_ba_intermediates_vs_oracle(name):
     """iteration-0 S, y, C, u, E, dX, dZ against the float64 oracle"""
-    st = synth.make_state(name, features=False)
+    st, name = _make(name)
     _, _, dbg = _run_ba(st, iterations=1, debug=True)
     _, _, info, o = O.fastba(st.poses, st.patches, st.intrinsics[0], st.target, st.weight, st.lmbda, st.ii, st.jj,
                              st.kk, st.t0, st.n, 1, np.float64, debug=True)
@@ -512,9 +524,9 @@ def test_ba_intermediates_vs_oracle(name):
     ba_checks.check_iteration0(name, {k: v.cpu().numpy() for k, v in dbg.items()}, o)
 
 
-@pytest.mark.parametrize("name", ["small", "init", "pr1", "default", "stress"])
+@pytest.mark.parametrize("name", ["small", "init", "pr1", "default", "stress", "mid15", "mid19_m5"])
 def test_ba_two_iterations_vs_oracle(name):
-    st = synth.make_state(name, features=False)
+    st, name = _make(name)
     poses, patches, _ = _run_ba(st, iterations=2)
     p64, x64, info = O.fastba(st.poses, st.patches, st.intrinsics[0], st.target, st.weight, st.lmbda, st.ii, st.jj,
                               st.kk, st.t0, st.n, 2, np.float64)
@@ -906,10 +918,11 @@ def test_ba_structure_only_and_gates():
 
 
 def test_ba_window_is_bitwise_reproducible():
-    """the optimisation-window path (N <= 10) sums everything in a fixed order: two runs give identical bits -- also
-    when other kernels have run in between and when the workspace was used for another graph meanwhile"""
-    for name in ("default", "pr1"):
-        st = synth.make_state(name, features=False)
+    """the slab paths (N <= 10: ba_win.hip, N <= 32: ba_mid.hip) sum everything in a fixed order: two runs give
+    identical bits -- also when other kernels have run in between and when the workspace was used for another graph
+    meanwhile"""
+    for name in ("default", "pr1", "stress", "mid19_m5"):
+        st, _ = _make(name)
         p1, x1, _ = _run_ba(st, iterations=2)
         other = synth.make_state("small", features=False)
         _run_ba(other, iterations=1)
@@ -918,11 +931,12 @@ def test_ba_window_is_bitwise_reproducible():
         assert not np.array_equal(p1, st.poses)
 
 
-def test_ba_window_irregular_graph():
+@pytest.mark.parametrize("variant", ["small", "mid15", "mid19_m5"])
+def test_ba_window_irregular_graph(variant):
     """edge lists the front-end never builds but the API admits: a random third of the edges dropped (ragged patch
     degrees, chunks whose lanes belong to different frame pairs), the edge order shuffled, a few DUPLICATED edges and a
-    few self edges (i == j) of free frames"""
-    st = synth.make_state("small", features=False)
+    few self edges (i == j) of free frames; on the N <= 10 and on the N <= 32 path"""
+    st, _ = _make(variant)
     rng = np.random.default_rng(17)
     keep = rng.random(st.E) > 0.33
     sel = np.flatnonzero(keep)
