@@ -548,6 +548,12 @@ __device__ __forceinline__ void mid_solve(const BaWinArgs& A, float* smem) {
         if (lane == 0) __hip_atomic_fetch_add(&s_read, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
       CDV_IF_STAMPS(asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t_p0 = cdv_now(); t_pl += t_p0 - t_x;)
+      // Right-looking, per column k: all broadcasts L[m][k] (v_readlane, m > k) first, then the updates.  The empty asm
+      // statements pin that order: left to itself the compiler pairs broadcast and update (each pair then waits for the
+      // v_readlane result) or sinks all updates of a column to just before its pivot (276 broadcast values alive in
+      // SGPRs, spilled through v_writelane: 11,000 cycles per panel).  Measured alternatives, none faster than this
+      // (4,600 cycles per 24-column panel): the next column's pivot chain started before the bulk of the updates; the
+      // broadcasts as 16-byte LDS reads from a per-wave column buffer written one column ahead, as in ba_win.hip (6,900).
       float rs_k[NB];
 #pragma unroll
       for (int k = 0; k < NB; k++) {
@@ -557,10 +563,6 @@ __device__ __forceinline__ void mid_solve(const BaWinArgs& A, float* smem) {
         rs_k[k] = rs;
         const float Lk = a[k] * rs;
         a[k] = Lk;
-        // right-looking on purpose, and all broadcasts of the column issued before the first update: a v_readlane result
-        // reaches a dependent vector instruction only after ~30 cycles, and left to itself the compiler either pairs
-        // them (276 x 30 cycles per panel) or sinks the updates of column m to just before its pivot (276 broadcast values
-        // alive in SGPRs, spilled through v_writelane).  The empty asm statements pin both orders.
         float bc[NB];
 #pragma unroll
         for (int m = k + 1; m < NB; m++) {
@@ -654,31 +656,42 @@ __device__ __forceinline__ void mid_solve(const BaWinArgs& A, float* smem) {
   CDV_STAMP_VAL(bam, sslot, 12, t_ps);
   // ---- row n of A now holds z = L^-1 y.  Back substitution L^T x = z inside ONE wave, no barrier: lane l keeps
   // components l, 64 + l, 128 + l of z in three registers; from the last unknown down, x_k = z_k / L[k][k] is broadcast by
-  // v_readlane and row k of L (contiguous in LDS, requested one step ahead: it does not depend on the chain) folds it into
+  // v_readlane and row k of L (contiguous in LDS, requested a step ahead: it does not depend on the chain) folds it into
   // the components before it.  (Block by block with the other waves' help: two barriers per block, 6,000 cycles each.) ----
   float* z = Am + (size_t)n * LD;
   if (wv == 0) {
     float zr[3], xr[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int q = 0; q < 3; q++) zr[q] = (64 * q + lane < n) ? z[64 * q + lane] : 0.f;
-    float Lr[3], Ln[3];
+    // two unknowns per step (n and the group sizes are even): the chain fma -> v_readlane (~40 cycles to a dependent
+    // vector instruction) -> three scalar-operand instructions is paid once per pair
+    float La[3], Lb[3], Na[3], Nb[3];   // rows k, k - 1 in use; the next pair's, requested a step ahead
 #pragma unroll
-    for (int q = 0; q < 3; q++) Ln[q] = Am[(size_t)(n - 1) * LD + min(64 * q + lane, LD - 1)];
+    for (int q = 0; q < 3; q++) {
+      Na[q] = Am[(size_t)(n - 1) * LD + min(64 * q + lane, LD - 1)];
+      Nb[q] = Am[(size_t)(n - 2) * LD + min(64 * q + lane, LD - 1)];
+    }
 #pragma unroll
     for (int r = 2; r >= 0; r--) {
-      for (int k = min(n, 64 * (r + 1)) - 1; k >= 64 * r; k--) {
+      for (int k = min(n, 64 * (r + 1)) - 1; k >= 64 * r; k -= 2) {
 #pragma unroll
-        for (int q = 0; q < 3; q++) Lr[q] = Ln[q];
-        const int kn = max(k - 1, 0);
+        for (int q = 0; q < 3; q++) { La[q] = Na[q]; Lb[q] = Nb[q]; }
+        const int ka = max(k - 2, 0), kb2 = max(k - 3, 0);
 #pragma unroll
-        for (int q = 0; q < 3; q++) Ln[q] = Am[(size_t)kn * LD + min(64 * q + lane, LD - 1)];     // row k - 1, for the next step
+        for (int q = 0; q < 3; q++) {
+          Na[q] = Am[(size_t)ka * LD + min(64 * q + lane, LD - 1)];
+          Nb[q] = Am[(size_t)kb2 * LD + min(64 * q + lane, LD - 1)];
+        }
         const int lk = k - 64 * r;
-        const float dk = readlane_f(Lr[r], lk);            // inverted diagonal
-        const float xk = readlane_f(zr[r], lk) * dk;
-        xr[r] = (lane == lk) ? xk : xr[r];
-        // components >= k receive garbage here (the upper part of the row): their x is kept in xr, zr is done with them
+        const float dk = readlane_f(La[r], lk), dk1 = readlane_f(Lb[r], lk - 1);   // inverted diagonals
+        const float lkk1 = readlane_f(La[r], lk - 1);                              // L[k][k - 1]
+        const float zk = readlane_f(zr[r], lk), zk1 = readlane_f(zr[r], lk - 1);
+        const float xk = zk * dk;
+        const float xk1 = fmaf(-lkk1, xk, zk1) * dk1;
+        xr[r] = (lane == lk) ? xk : ((lane == lk - 1) ? xk1 : xr[r]);
+        // components >= k - 1 receive garbage here (the upper part of the rows): their x is kept in xr
 #pragma unroll
-        for (int q = 0; q <= r; q++) zr[q] = fmaf(-Lr[q], xk, zr[q]);
+        for (int q = 0; q <= r; q++) zr[q] = fmaf(-Lb[q], xk1, fmaf(-La[q], xk, zr[q]));
       }
     }
 #pragma unroll
