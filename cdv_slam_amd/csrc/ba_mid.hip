@@ -41,8 +41,7 @@ constexpr int FT = 512;                    // threads of a finish workgroup
 __host__ __device__ inline int fp_floats(int N) { return (54 + 99 * N + 3) / 4 * 4; }
 __host__ __device__ inline int ed_rows(int N) { return (6 * N + 1 + 15) / 16 * 16; }
 inline size_t chunk_lds_bytes(int N, int waves) {
-  return sizeof(float) * ((size_t)waves * fp_floats(N) + (size_t)ed_rows(N) * EDL + (size_t)waves * 8 * CK + 2 * CK + 8 +
-                          (size_t)ed_rows(N));
+  return sizeof(float) * ((size_t)waves * fp_floats(N) + (size_t)ed_rows(N) * EDL + (size_t)waves * 8 * CK + 2 * CK + 8);
 }
 
 // where value `code` of a frame pair goes inside a footprint: base + ms * (source slot) + mj * (target frame); need: bit 0
@@ -82,7 +81,6 @@ __global__ __launch_bounds__(64 * MKW) void ba_mid_chunk_kernel(BaWinArgs A) {
   float* qs = part + MKW * 8 * CK;             // [CK]
   int* ixp = reinterpret_cast<int*>(qs + CK);  // [CK] free-pose index of the patch's source frame (-1: fixed / none)
   uint32_t* smask = reinterpret_cast<uint32_t*>(ixp + CK);   // [2] free source frames of the chunk's edges (ping-pong)
-  int* t6 = reinterpret_cast<int*>(smask + 8);                // [ER] x -> x / 6, x % 6 and friends, packed (below)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: loops over a wave's share are uniform
@@ -111,13 +109,6 @@ __global__ __launch_bounds__(64 * MKW) void ba_mid_chunk_kernel(BaWinArgs A) {
   }
   const int n_chunks = (U + CK - 1) / CK;
   if (tid < 2) smask[tid] = 0u;
-  // matrix row / column x (< 6N; clamped beyond) -> pose f = x / 6, component a = x % 6, packed with what the slab stage
-  // needs of them: f | a << 6 | a (a + 1) / 2 << 9 | 9 f << 14 | 6 a << 23   (integer multiplies are slow: done once)
-  for (int x = tid; x < ER; x += 64 * MKW) {
-    const int xc = min(x, n6 - 1);
-    const int f = xc / 6, a = xc - 6 * f;
-    t6[x] = f | (a << 6) | (((a * (a + 1)) >> 1) << 9) | ((9 * f) << 14) | ((6 * a) << 23);
-  }
   __syncthreads();
 
   CDV_IF_STAMPS(const int sslot = (int)blockIdx.x * MKW + wave;)
@@ -321,16 +312,10 @@ __global__ __launch_bounds__(64 * MKW) void ba_mid_chunk_kernel(BaWinArgs A) {
           const float q = (rr < U) ? 1.0f / (Ct + lm) : 0.f;      // Q = 1 / (C + lambda)   (ba_cuda.cu:548 semantics)
           qs[pp] = q;
           Ed[n6 * EDL + pp] = (rr < U) ? ut : 0.f;
-          A.qg[rr] = q;
-          A.ug[rr] = (rr < U) ? ut : 0.f;
-          if (A.dbg) {
-            float* dbgp = A.dbg + (size_t)n6 * n6 + 2 * n6;
-            dbgp[A.U_stride + rr] = Ct;
-            dbgp[2 * (size_t)A.U_stride + rr] = ut;
-          }
+          part[6 * CK + pp] = Ct;      // (wave 0's slot, consumed above) kept for the stores at the end of the pass
         }
       }
-      __syncthreads();
+      lds_barrier();
       // ---- fold the source-frame parts onto the diagonal blocks of copy 0: F_jj[i_s] += F_ii[s], and a self pair
       // (i_s -> i_s) contributes B_ij + B_ij^T to its diagonal block ----
       if (tid < 54) {
@@ -347,24 +332,18 @@ __global__ __launch_bounds__(64 * MKW) void ba_mid_chunk_kernel(BaWinArgs A) {
           }
           Fw[54 + 27 * is + t] += add;
         }
+      } else if (tid >= 64 && tid < 100 && isrc0 >= 0 && isrc1 >= 0) {
+        // the chunk's two source frames see each other: block (i1, i0) is the transpose of block (i0, i1) of the lower
+        // triangle -- folded onto slot 0's copy, so that every slab entry has ONE addend below
+        const int ab = tid - 64, a = ab / 6, b = ab - 6 * a;
+        float* f0 = Fw + 54 + 27 * N + 36 * isrc1;
+        const float* f1 = Fw + 54 + 27 * N + 36 * (N + isrc0);
+        f0[ab] += f1[6 * b + a];
       }
-      __syncthreads();
+      lds_barrier();
       CDV_STAMP(bam, sslot, 3);
-      if (pass == 0) {
-        // ---- the chunk's E columns for the retraction (complete values; 16 bytes per lane: narrow stores are bound by
-        // the CU's store issue, not by bandwidth) ----
-        for (int i = tid; i < n6 * (CK / 4); i += 64 * MKW) {
-          const int row = i >> 2, p4 = (i & 3) * 4;
-          const float* e = Ed + row * EDL + p4;
-          const cdv_float4 v = {e[0], e[1], e[2], e[3]};
-          *reinterpret_cast<cdv_float4*>(A.Edg + (size_t)row * A.U_stride + r0 + p4) = v;
-          if (A.dbg)
-            *reinterpret_cast<cdv_float4*>(A.dbg + (size_t)n6 * n6 + 2 * n6 + 3 * (size_t)A.U_stride + (size_t)row * A.U_stride + r0 + p4) = v;
-        }
-      }
-      // ---- slab = B - E Q E^T, y = v - E Q u: Schur products of the chunk on the matrix cores (K = 16 patches) tile
-      // by tile; the B part of an entry is looked up in the folded footprint (most tiles hold none besides the diagonal
-      // blocks).  Each entry has exactly one owner lane. ----
+      // ---- slab = B - E Q E^T, y = v - E Q u: first the Schur products of the chunk on the matrix cores (K = 16 patches)
+      // tile by tile, each entry with exactly one owner lane ----
       // The entries are staged in LDS (the footprint copies 1.. are free now) and leave as 16-byte stores afterwards.
       float* Sd = Fw + FP;   // [slabf] <= (MKW - 1) FP (checked by the host)
       if (tid < slabf - (TRI_N + n6)) Sd[TRI_N + n6 + tid] = 0.f;
@@ -386,45 +365,68 @@ __global__ __launch_bounds__(64 * MKW) void ba_mid_chunk_kernel(BaWinArgs A) {
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[k], qs[k] * pb[k], acc, 0, 0, 0);
           }
         }
-        // the B part of this lane's four entries: three unconditional LDS reads each on clamped addresses (the diagonal
-        // block or v; the block row / column of source slot 0; of source slot 1), selected afterwards -- no branch
-        // around a read, no multiply or divide (the packed table)
         const int Cc = 16 * tj + c16;
-        const int wc = t6[Cc];
-        int wr[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) wr[q] = t6[16 * ti + 4 * g4 + q];
-        const int fc = wc & 63, b = (wc >> 6) & 7, f9c = (wc >> 14) & 511, b6 = (wc >> 23) & 31;
-        float f1[4], f2[4], f3[4];
-        bool u1[4], u2[4], u3[4];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const int R = 16 * ti + 4 * g4 + q;
-          const int fr = wr[q] & 63, a = (wr[q] >> 6) & 7, ta = (wr[q] >> 9) & 31, f9r = (wr[q] >> 14) & 511, a6 = (wr[q] >> 23) & 31;
-          const bool isy = R == n6, inside = R < n6;
-          const int a1 = isy ? 54 + 21 + 3 * f9c + b : 54 + 3 * f9r + ta + min(b, a);
-          u1[q] = isy || (inside && fr == fc);
-          const bool off = inside && fr != fc;
-          const bool r0 = fr == isrc0, r1 = fr == isrc1;
-          const int a2 = r0 ? 4 * f9c + a6 + b : 4 * f9r + b6 + a;
-          const int a3 = r1 ? 4 * f9c + a6 + b : 4 * f9r + b6 + a;
-          u2[q] = off && (r0 || fc == isrc0);
-          u3[q] = off && (r1 || fc == isrc1);
-          f1[q] = Fw[a1];
-          f2[q] = Fij0[a2];
-          f3[q] = Fij1[a3];
-        }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
           const int R = 16 * ti + 4 * g4 + q;
           if (R > n6 || Cc >= n6 || (R < n6 && Cc > R)) continue;   // row 6N = y; column 6N only duplicates it
-          const float bv = (u1[q] ? f1[q] : 0.f) + (u2[q] ? f2[q] : 0.f) + (u3[q] ? f3[q] : 0.f);
-          const int idx = (R < n6) ? tri_index(R, Cc) : TRI_N + Cc;
-          Sd[idx] = bv - acc[q];
+          Sd[(R < n6) ? tri_index(R, Cc) : TRI_N + Cc] = -acc[q];
+        }
+      }
+      lds_barrier();   // LDS only: the E stores above drain in the background
+      // ---- the B part: every entry of the folded footprint onto its slab entry.  Each slab entry has at most one addend
+      // (the diagonal blocks and v from F_jj; block (i_s, j) from F_ij[s][j], self pairs and the transposed pair of the
+      // two source frames having been folded away above): plain read-modify-write, one owner each.  A tile-side lookup
+      // of the same values cost 150 vector instructions per tile. ----
+      if (tid < 27 * 18) {
+        const int jl = tid / 27, t = tid - 27 * jl;
+        int a = 0, b = 0;
+        if (t < 21) {
+          while (((a + 1) * (a + 2)) / 2 <= t) a++;
+          b = t - (a * (a + 1)) / 2;
+        }
+        for (int j = jl; j < N; j += 18) {
+          const int idx = (t < 21) ? tri_index(6 * j + a, 6 * j + b) : TRI_N + 6 * j + (t - 21);
+          Sd[idx] += Fw[54 + 27 * j + t];
+        }
+      }
+      if (tid < 36 * 14) {
+        const int bl = tid / 36, ab = tid - 36 * bl;
+        const int a = ab / 6, b = ab - 6 * a;
+        for (int blk = bl; blk < 2 * N; blk += 14) {
+          const int sl = blk >= N ? 1 : 0, j = blk - N * sl;
+          const int is = sl ? isrc1 : isrc0;
+          // skipped: no such source frame; the self pair (folded onto the diagonal block); slot 1's view of slot 0
+          if (is < 0 || j == is || (sl == 1 && j == isrc0)) continue;
+          const int R = is > j ? 6 * is + a : 6 * j + b, Cc = is > j ? 6 * j + b : 6 * is + a;
+          Sd[tri_index(R, Cc)] += Fij0[36 * blk + ab];
         }
       }
       CDV_STAMP(bam, sslot, 4);
-      __syncthreads();
+      lds_barrier();
+      if (pass == 0) {
+        // ---- the chunk's E columns for the retraction (complete values; 16 bytes per lane: narrow stores are bound by
+        // the CU's store issue, not by bandwidth).  Issued here, after the tile loop: the compiler makes whoever reuses a
+        // store's data registers wait for the store (s_waitcnt vmcnt inside the tile loop: 2,000 cycles per tile) ----
+        if (tid < CK) {   // q, u (and C for the debug dump) of the chunk's patches
+          const int rr = r0 + tid;
+          A.qg[rr] = qs[tid];
+          A.ug[rr] = Ed[n6 * EDL + tid];
+          if (A.dbg) {
+            float* dbgp = A.dbg + (size_t)n6 * n6 + 2 * n6;
+            dbgp[A.U_stride + rr] = part[6 * CK + tid];
+            dbgp[2 * (size_t)A.U_stride + rr] = Ed[n6 * EDL + tid];
+          }
+        }
+        for (int i = tid; i < n6 * (CK / 4); i += 64 * MKW) {
+          const int row = i >> 2, p4 = (i & 3) * 4;
+          const float* e = Ed + row * EDL + p4;
+          const cdv_float4 v = {e[0], e[1], e[2], e[3]};
+          *reinterpret_cast<cdv_float4*>(A.Edg + (size_t)row * A.U_stride + r0 + p4) = v;
+          if (A.dbg)
+            *reinterpret_cast<cdv_float4*>(A.dbg + (size_t)n6 * n6 + 2 * n6 + 3 * (size_t)A.U_stride + (size_t)row * A.U_stride + r0 + p4) = v;
+        }
+      }
       {
         cdv_float4* dst = reinterpret_cast<cdv_float4*>(A.slabs + (size_t)chunk * slabf);
         const cdv_float4* src = reinterpret_cast<const cdv_float4*>(Sd);
