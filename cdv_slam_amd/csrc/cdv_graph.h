@@ -26,10 +26,14 @@ constexpr int GRAPH_MAX_BLOCKS = 1024;   // workgroups of the per-edge kernels (
 // the BA's first memory round trip already fetches records.  Kept for t < ELL_SLOTS and u < 16 * ELL_CHUNKS (beyond: CSR).
 constexpr int ELL_SLOTS = 32;
 constexpr int ELL_CHUNKS = 4096;
+// processing order of the fused correlation: edges grouped by target frame (jj mod ORD_BINS), so that the eighth of the
+// list an XCD works through touches three frames' feature maps instead of sixteen (counting sort riding the index build:
+// per-block counts from the histogram launch, positions and scatter in the fill launch)
+constexpr int ORD_BINS = 32;
 
 struct GraphLayout {
   int64_t E_max, k_range;
-  size_t meta, stage, khist, kcount, kcursor, krank, koff_u, kx, ku, pcsr_tmp, pcsr, prec, pell, nprev, nnext, total;
+  size_t meta, stage, khist, kcount, kcursor, krank, koff_u, kx, ku, pcsr_tmp, pcsr, prec, pell, nprev, nnext, ocnt, order, total;
   int64_t ell_chunks;
 };
 
@@ -56,13 +60,15 @@ static inline GraphLayout graph_layout(int64_t E_max, int64_t k_range) {
   L.pell = o;     o = align256(o + sizeof(int32_t) * 4 * 16 * (size_t)ELL_SLOTS * (size_t)L.ell_chunks);
   L.nprev = o;    o = align256(o + sizeof(int32_t) * (size_t)E_max);   // neighbors: previous / next edge of the same patch in time
   L.nnext = o;    o = align256(o + sizeof(int32_t) * (size_t)E_max);
+  L.ocnt = o;     o = align256(o + sizeof(int32_t) * ORD_BINS * GRAPH_MAX_BLOCKS);   // [block][bin] edges of the block per target bin
+  L.order = o;    o = align256(o + sizeof(int32_t) * (size_t)E_max);
   L.total = o;
   return L;
 }
 
 struct GraphView {
   int32_t* meta;
-  int32_t *stage, *khist, *kcount, *kcursor, *krank, *koff_u, *ku, *pcsr_tmp, *pcsr, *prec, *pell, *nprev, *nnext;
+  int32_t *stage, *khist, *kcount, *kcursor, *krank, *koff_u, *ku, *pcsr_tmp, *pcsr, *prec, *pell, *nprev, *nnext, *ocnt, *order;
   int64_t* kx;
 };
 
@@ -84,6 +90,8 @@ static inline GraphView graph_view(void* ws, const GraphLayout& L) {
   v.pell = (int32_t*)(b + L.pell);
   v.nprev = (int32_t*)(b + L.nprev);
   v.nnext = (int32_t*)(b + L.nnext);
+  v.ocnt = (int32_t*)(b + L.ocnt);
+  v.order = (int32_t*)(b + L.order);
   return v;
 }
 

@@ -184,6 +184,7 @@ struct HistArgs {
   int32_t* khist;
   int32_t R;
   int32_t *meta, *kcount, *krank;   // for the scan the last workgroup to finish performs
+  int32_t* ocnt;    // [blocks][ORD_BINS] this workgroup's edges per target bin (the correlation's processing order)
 };
 
 // One workgroup: publish meta, exclusive scan of the histogram in id order (bin of id kmin + i is (kmin + i) mod R)
@@ -312,8 +313,12 @@ __device__ __forceinline__ void graph_hist_body(const HistArgs& a, int bid, int 
   int kmin = IMAXV, kmax = IMINV, jmin = IMAXV, jmax = IMINV;
   const int R = a.R;
   const float rinv = 1.0f / (float)R;
+  __shared__ int s_obin[ORD_BINS];
+  if (tid < ORD_BINS) s_obin[tid] = 0;
+  __syncthreads();
   for (int e = bid * nthreads_per_block + tid; e < a.E; e += nblocks * nthreads_per_block) {
     const int k = (int)a.kk[e], j = (int)a.jj[e];
+    atomicAdd(&s_obin[j & (ORD_BINS - 1)], 1);
     kmin = min(kmin, k); kmax = max(kmax, k);
     jmin = min(jmin, j); jmax = max(jmax, j);
     if (k >= 0) {
@@ -334,6 +339,7 @@ __device__ __forceinline__ void graph_hist_body(const HistArgs& a, int bid, int 
   const int lane = tid & 63, wave = tid >> 6, nw = nthreads_per_block >> 6;
   if (lane == 0) { s_mm[wave][0] = kmin; s_mm[wave][1] = kmax; s_mm[wave][2] = jmin; s_mm[wave][3] = jmax; }
   __syncthreads();
+  if (tid < ORD_BINS) a.ocnt[bid * ORD_BINS + tid] = s_obin[tid];   // read by the fill launch
   if (tid == 0) {
     for (int w = 1; w < nw; w++) {
       kmin = min(kmin, s_mm[w][0]); kmax = max(kmax, s_mm[w][1]);

@@ -75,7 +75,61 @@ __global__ __launch_bounds__(256) void graph_fill_kernel(const int64_t* __restri
                                                          const int32_t* __restrict__ kcount, int32_t* kcursor,
                                                          const int32_t* __restrict__ krank,
                                                          int32_t* __restrict__ koff_u, int64_t* __restrict__ kx,
-                                                         int32_t* __restrict__ ku, int32_t* __restrict__ pcsr_tmp) {
+                                                         int32_t* __restrict__ ku, int32_t* __restrict__ pcsr_tmp,
+                                                         const int64_t* __restrict__ jj,
+                                                         const int32_t* __restrict__ ocnt, int nblk_hist,
+                                                         int32_t* __restrict__ order) {
+  // ---- the correlation's processing order (independent of the patch index and of its error state): a counting sort
+  // of the edges by target bin.  The histogram launch left every workgroup's count per bin; this workgroup handles the
+  // same edges, so its first position in bin b is (edges of the bins before b) + (edges of bin b in the workgroups
+  // before it) -- summed here from the whole table (6 K words, L2-resident: cheaper than a scan pass of its own), the
+  // rank inside the workgroup from an LDS counter.
+  const bool do_order = order && nblk_hist == (int)gridDim.x;
+  __shared__ int s_pos[ORD_BINS];
+  // this thread's first edge: requested before the order computation (whose barriers the loads would not cross)
+  const int t_first = blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t kk_first = t_first < E ? kk[t_first] : 0;
+  const int64_t jj_first = (do_order && t_first < E) ? jj[t_first] : 0;
+  if (do_order) {
+    __shared__ int s_tot[32][ORD_BINS + 1], s_pre[32][ORD_BINS + 1];
+    const int tid = threadIdx.x, bq = tid & 7, part = tid >> 3;   // 256 threads: 8 groups of four bins x 32 parts
+    int tot[4] = {0, 0, 0, 0}, pre[4] = {0, 0, 0, 0};
+    const int4* tab = reinterpret_cast<const int4*>(ocnt);
+    for (int b0 = part; b0 < nblk_hist; b0 += 32 * 4) {   // up to four 16-byte loads in flight
+      int4 c[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int b = b0 + 32 * u;
+        c[u] = (b < nblk_hist) ? tab[b * (ORD_BINS / 4) + bq] : int4{0, 0, 0, 0};
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const bool before = b0 + 32 * u < (int)blockIdx.x;
+        tot[0] += c[u].x; tot[1] += c[u].y; tot[2] += c[u].z; tot[3] += c[u].w;
+        pre[0] += before ? c[u].x : 0; pre[1] += before ? c[u].y : 0; pre[2] += before ? c[u].z : 0; pre[3] += before ? c[u].w : 0;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) { s_tot[part][4 * bq + q] = tot[q]; s_pre[part][4 * bq + q] = pre[q]; }
+    __syncthreads();
+    if (tid < ORD_BINS) {
+      int t = 0, p = 0;
+#pragma unroll
+      for (int q = 0; q < 32; q++) { t += s_tot[q][tid]; p += s_pre[q][tid]; }
+      int incl = t;   // inclusive scan of the bin totals over the 32 lanes
+#pragma unroll
+      for (int o = 1; o < ORD_BINS; o <<= 1) {
+        const int up = __shfl_up(incl, o);
+        if (tid >= o) incl += up;
+      }
+      s_pos[tid] = incl - t + p;
+    }
+    __syncthreads();
+    for (int e = t_first; e < E; e += gridDim.x * blockDim.x) {
+      const int b = (int)(e == t_first ? jj_first : jj[e]) & (ORD_BINS - 1);
+      order[atomicAdd(&s_pos[b], 1)] = e;
+    }
+  }
   if (meta[GM_ERROR]) return;
   const int krange = meta[GM_KRANGE], kmin = meta[GM_KMIN];
   const int n = max(E, krange + 1);
@@ -90,7 +144,7 @@ __global__ __launch_bounds__(256) void graph_fill_kernel(const int64_t* __restri
       }
     }
     if (t < E) {
-      const int d = (int)kk[t] - kmin;
+      const int d = (int)(t == t_first ? kk_first : kk[t]) - kmin;
       const int p = atomicAdd(&kcursor[d], 1);
       pcsr_tmp[kcount[d] + p] = t;
       ku[t] = krank[d];
@@ -253,7 +307,7 @@ int cdv_graph_prepare(const int64_t* jj, const int64_t* kk, int64_t E, void* ws,
   if (need_init)
     hipLaunchKernelGGL(graph_init_kernel, dim3(grid_for(k_range + 1 + GM_WORDS, 256, 2048)), dim3(256), 0,
                        (hipStream_t)stream, v.meta, v.khist, v.kcursor, k_range);
-  *hist = cdv::HistArgs{jj, kk, (int32_t)E, v.stage, v.khist, (int32_t)k_range, v.meta, v.kcount, v.krank};
+  *hist = cdv::HistArgs{jj, kk, (int32_t)E, v.stage, v.khist, (int32_t)k_range, v.meta, v.kcount, v.krank, v.ocnt};
   *hist_blocks = E > 0 ? grid_for(E, 256, GRAPH_MAX_BLOCKS) : 0;
   return CDV_OK;
 }
@@ -276,7 +330,7 @@ int cdv_graph_finish(const int64_t* ii, const int64_t* jj, const int64_t* kk, in
                        v.krank, En, k_range);
   if (E > 0) {
     hipLaunchKernelGGL(graph_fill_kernel, dim3(fb), dim3(tb), 0, s, kk, En, v.meta, v.kcount, v.kcursor, v.krank,
-                       v.koff_u, v.kx, v.ku, v.pcsr_tmp);
+                       v.koff_u, v.kx, v.ku, v.pcsr_tmp, jj, v.ocnt, hist_blocks, v.order);
     hipLaunchKernelGGL(graph_segsort_kernel, dim3(fb), dim3(tb), 0, s, ii, jj, kk, En, v.meta, v.kcount, v.pcsr_tmp,
                        v.pcsr, v.prec, v.pell, (int)L.ell_chunks, v.krank, v.nprev, v.nnext, v.kcursor, ix, jx);
   }
@@ -298,6 +352,12 @@ extern "C" int cdv_graph_build_edges(const int64_t* ii, const int64_t* jj, const
 extern "C" int cdv_graph_build_neighbors(const int64_t* jj, const int64_t* kk, int64_t E, void* ws, size_t ws_bytes,
                                          int64_t E_max, int64_t k_range, int64_t* ix, int64_t* jx, void* stream) {
   return cdv_graph_build_edges(nullptr, jj, kk, E, ws, ws_bytes, E_max, k_range, ix, jx, stream);
+}
+
+extern "C" const int32_t* cdv_graph_corr_order(const void* ws) {
+  GraphLayout L;
+  if (!cdv_graph_lookup(ws, &L)) return nullptr;
+  return graph_view((void*)ws, L).order;
 }
 
 extern "C" int cdv_graph_read_meta_host(const void* ws, int64_t* meta_host, void* stream) {

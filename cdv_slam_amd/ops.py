@@ -68,6 +68,12 @@ class GraphIndex:
         self.ws_bytes = nbytes
         self._key = None
 
+    def corr_order_ptr(self):
+        """device pointer (ctypes.c_void_p) of the correlation's processing order of the index currently in the
+        workspace (edges grouped by target frame; cdv_graph_corr_order), for ops.corr_fused(order_ptr=...)"""
+        p = self.lib.cdv_graph_corr_order(_p(self.ws))
+        return ctypes.c_void_p(p) if p else None
+
     def build(self, jj, kk, force=False, with_neighbors=False, ii=None):
         """Enqueue the index build for (jj, kk).  Re-used when called again with the same, unmodified
         tensor objects (neighbors() and BA() of one update share one build).  with_neighbors: the build also

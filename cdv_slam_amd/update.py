@@ -15,13 +15,14 @@ from . import ops
 
 
 class UpdatePath:
-    def __init__(self, st, device, overlap=False):
+    def __init__(self, st, device, overlap=False, sorted_corr=True):
         """st: synth.SynthState (numpy).  Uploads the state once; step() then runs entirely on device.
         overlap: build the patch-graph index and the neighbor lists (they depend on the edge lists only) on a
         second HIP stream while the main stream reprojects and correlates; the streams join before the BA."""
         self.cfg = st.cfg
         self.dev = device
         self.overlap = overlap
+        self.sorted_corr = sorted_corr   # correlation processes the edges grouped by target frame (ops.GraphIndex.corr_order_ptr)
         self.fused_prologue = True   # ingest + reproject + index histogram in one launch (cdv_update_prologue)
         self._aux = torch.cuda.Stream(device=device, priority=-1) if overlap else None  # high priority: tiny kernels
         t = lambda a, dt=None: torch.as_tensor(a, device=device) if dt is None else torch.as_tensor(a, dtype=dt, device=device)
@@ -122,8 +123,11 @@ class UpdatePath:
     # -- measurement helpers (bench.py) --------------------------------------------------------------
     def corr_only(self, coords):
         """just the fused correlation launch (dominant kernel) on the current stream"""
+        # processing order by target frame, a by-product of this update's index build (prologue): each XCD's share of
+        # the edges then works on ~3 frames' maps
         return ops.corr_fused(self.gmap_pm, self.fmap1, self.fmap2, coords, self.kk, self.jj, kmod=self.kmod,
-                              jmod=self.jmod, out=self.corr_out, pixel_major=True)
+                              jmod=self.jmod, out=self.corr_out, pixel_major=True,
+                              order_ptr=self.graph.corr_order_ptr() if self.sorted_corr else None)
 
     def stage_times(self, reps=20):
         """median microseconds per stage, each timed with HIP events on the current stream"""

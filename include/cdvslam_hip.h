@@ -219,6 +219,13 @@ int cdv_graph_build_edges(const int64_t* ii, const int64_t* jj, const int64_t* k
 
 int cdv_graph_read_meta_host(const void* ws, int64_t* meta_host, void* stream);
 
+/* A processing order for cdv_corr_fused that the index build produces on the side: the edge ids [E] (int32) grouped by target
+ * frame (jj mod 32), so that the share of the list one XCD works through touches ~3 frames' feature maps instead of ~16
+ * (the reference launches one thread block per edge in list order, correlation_kernel.cu:82-136; results do not depend on
+ * the order).  Device pointer into the workspace, valid after any cdv_graph_build* / cdv_update_prologue on it until the
+ * next build; NULL if the workspace holds no index. */
+const int32_t* cdv_graph_corr_order(const void* graph_ws);
+
 /* copy out torch::_unique results (kx needs U from cdv_graph_read_meta_host to size it) */
 int cdv_graph_get_unique(const void* ws, int64_t* kx, int64_t kx_capacity, int64_t* ku, int64_t E, void* stream);
 

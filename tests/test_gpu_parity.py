@@ -282,6 +282,34 @@ def test_corr_fused_vs_oracle(name):
     assert np.abs(got - truth).mean() <= 0.1 * tol
 
 
+@pytest.mark.parametrize("name", ["small", "default"])
+def test_corr_processing_order_from_the_index_build(name):
+    """the edge order the fused correlation works through (cdv_graph_corr_order, a counting sort by target frame riding
+    the index build): a permutation of the edges, grouped by jj mod 32; the correlation output does not depend on it"""
+    from cdv_slam_amd.update import UpdatePath
+    st = synth.make_state(name, buffer_size=64 if name == "default" else None) if name == "default" else synth.make_state(name)
+    up = UpdatePath(st, torch.device(DEV), sorted_corr=True)
+    res = up.step(iterations=0)
+    torch.cuda.synchronize()
+    ptr = up.graph.corr_order_ptr()
+    assert ptr is not None
+    order = torch.empty(st.E, dtype=torch.int32, device=DEV)
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    assert hip.hipMemcpy(ctypes.c_void_p(order.data_ptr()), ptr, 4 * st.E, 3) == 0     # device to device
+    o = order.cpu().numpy().astype(np.int64)
+    assert np.array_equal(np.sort(o), np.arange(st.E))
+    bins = (st.jj[o] & 31)
+    # grouped: the bin sequence along the order is non-decreasing
+    assert (np.diff(bins) >= 0).all()
+    sorted_out = res["corr"].clone()
+    up2 = UpdatePath(st, torch.device(DEV), sorted_corr=False)
+    res2 = up2.step(iterations=0)
+    assert torch.equal(sorted_out, res2["corr"])
+
+
+
 def test_reference_call_sequence_through_the_dropin_names():
     """The reference's own sequence for one update -- SLAM.reproject / SLAM.corr (slam.py:316-329), the ring writes
     (slam.py:679-682), Update's fastba.neighbors (net_cdv.py:102), fastba.BA (slam.py:512-515, fastba/ba.py:8) -- written
