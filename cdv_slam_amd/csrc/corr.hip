@@ -1153,6 +1153,8 @@ extern "C" int cdv_corr_fused(const void* gmap, const void* fmap0_nhwc, const vo
       hipLaunchKernelGGL((corr_fused2_kernel<24, 2>), dim3(blocks), dim3(256), smem, s, a);
     else if (nlev == 2)
       hipLaunchKernelGGL((corr_fused2_kernel<0, 2>), dim3(blocks), dim3(256), smem, s, a);
+    else if (C == 24)   // one level per call: what an unchanged slam.py issues (slam.py:316-323), twice per update
+      hipLaunchKernelGGL((corr_fused2_kernel<24, 1>), dim3(blocks), dim3(256), smem, s, a);
     else
       hipLaunchKernelGGL((corr_fused2_kernel<0, 1>), dim3(blocks), dim3(256), smem, s, a);
   } else {

@@ -87,7 +87,7 @@ class StreamRunner:
         coords = ops.update_prologue(self.graph, fmap, self.fmap1, self.fmap2, (n - 1) % self.mem, self.gmap, self.gmap_pm,
                                      tile0, M, self.poses, self.patches, self.intrinsics, e.ii, e.jj, e.kk)
         corr = ops.corr_fused(self.gmap_pm, self.fmap1, self.fmap2, coords, e.kk, e.jj, kmod=M * self.pmem, jmod=self.mem,
-                              pixel_major=True)
+                              pixel_major=True, order_ptr=self.graph.corr_order_ptr())   # edges grouped by target frame
         # stub of the update operator (net_cdv.py:66-107): a small correction that depends on the correlation
         delta = 0.01 * torch.tanh(corr[0, :, :2].float())
         e.target[0].copy_(coords[0, :, :, 1, 1] + delta)
