@@ -127,7 +127,7 @@ class UpdatePath:
         # the edges then works on ~3 frames' maps
         return ops.corr_fused(self.gmap_pm, self.fmap1, self.fmap2, coords, self.kk, self.jj, kmod=self.kmod,
                               jmod=self.jmod, out=self.corr_out, pixel_major=True,
-                              order_ptr=self.graph.corr_order_ptr() if self.sorted_corr else None)
+                              order_ptr=self.graph.corr_order_ptr() if (self.sorted_corr and not self.overlap) else None)
 
     def stage_times(self, reps=20):
         """median microseconds per stage, each timed with HIP events on the current stream"""

@@ -525,16 +525,22 @@ def _run_ba(st, iterations=2, debug=False, t0=None, t1=None):
 # graphs of the 10 < N <= 32 path (ba_mid.hip): `stress` (N = 21, M = 196), and two variants of `small`: N = 15 (an odd
 # number of poses: the solver's last block is 6 wide) and N = 19 with 5 patches per frame (a chunk of 16 consecutive
 # patches spans four source frames: two passes over the chunk)
-MID_VARIANTS = {"mid15": dict(opt_window=15), "mid19_m5": dict(opt_window=19, M=5)}
+MID_VARIANTS = {"mid15": dict(opt_window=15), "mid19_m5": dict(opt_window=19, M=5),
+                # the ends of the path's range: 11 and 32 free poses (the latter: the largest system the solver's LDS holds)
+                "mid11": dict(opt_window=11), "mid32": dict(frames=34, opt_window=32, removal_window=34, buffer_size=40)}
+
+
+# tolerance class (tests/ba_checks.py) of a variant: mid32 frees all poses but two, the weak-scale-gauge class of pr1
+MID_TOL = {"mid32": "pr1"}
 
 
 def _make(name):
     if name in MID_VARIANTS:
-        return synth.make_state("small", features=False, **MID_VARIANTS[name]), "small"
+        return synth.make_state("small", features=False, **MID_VARIANTS[name]), MID_TOL.get(name, "small")
     return synth.make_state(name, features=False), name
 
 
-@pytest.mark.parametrize("name", ["small", "init", "pr1", "default", "stress", "mid15", "mid19_m5"])
+@pytest.mark.parametrize("name", ["small", "init", "pr1", "default", "stress", "mid15", "mid19_m5", "mid11", "mid32"])
 def test_ba_intermediates_vs_oracle(name):
     """iteration-0 S, y, C, u, E, dX, dZ against the float64 oracle"""
     st, name = _make(name)
@@ -552,7 +558,7 @@ def test_ba_intermediates_vs_oracle(name):
     ba_checks.check_iteration0(name, {k: v.cpu().numpy() for k, v in dbg.items()}, o)
 
 
-@pytest.mark.parametrize("name", ["small", "init", "pr1", "default", "stress", "mid15", "mid19_m5"])
+@pytest.mark.parametrize("name", ["small", "init", "pr1", "default", "stress", "mid15", "mid19_m5", "mid11", "mid32"])
 def test_ba_two_iterations_vs_oracle(name):
     st, name = _make(name)
     poses, patches, _ = _run_ba(st, iterations=2)
