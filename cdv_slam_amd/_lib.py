@@ -24,6 +24,10 @@ SIGNATURES = {
     "cdv_fmap_ingest": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "cdv_corr_fused": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32,
                               _f32, _f32, _i32, _i64, _i64, _i32, _vp]),
+    "cdv_corr_fused_split": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32,
+                                    _f32, _f32, _i64, _i64, _i32, _vp]),
+    "cdv_corr_level_checked": (_i32, [_vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _i32, _i64, _i64, _i64, _i32, _i32, _i32, _f32,
+                                      _i64, _i64, _i32, _vp]),
     "cdv_gmap_to_pixel_major": (_i32, [_vp, _vp, _i64, _i32, _i64, _i64, _vp]),
     "cdv_frame_ingest": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i64, _i64, _i64, _vp]),
     "cdv_patchify_fwd": (_i32, [_vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),

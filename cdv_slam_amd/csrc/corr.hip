@@ -481,6 +481,15 @@ struct CorrArgs2 {
   int C;
   int gmap_pm;
   int exp;
+  // one-level launches only: output element (e, t) at out[e * out_pitch + t * out_stride + out_off] (inside the row of a
+  // two-level result), and edges whose coordinates equal coords_ref * ref_mul bit for bit are skipped (their values are
+  // in place already: cdv_corr_level_checked)
+  int out_stride, out_off, out_pitch;   // out_pitch: halves from one edge's row to the next
+  const float* coords_ref;
+  float ref_mul;
+  // two-level launches: != 0 keeps the levels apart, [E][2][442] halves (row 884 B: each level a contiguous run of 441 --
+  // what two separate one-level results look like to torch.stack) instead of [E][441][2]
+  int split;
 };
 
 constexpr uint32_t FBIAS = 0x4B000000u;   // bit pattern of 2^23
@@ -662,7 +671,11 @@ __device__ __forceinline__ void corr_edge(const CorrArgs2& a, int p, int e, int 
   // ---- stage the edge's output row [x][y][m][lev] in LDS, then 16-byte-per-lane stores ------------------------------
   wave_lds_sync();   // the row overwrites the raw volume: keep the stores behind the last blend's reads
   if (lane < 63 && !CDV_EXP(512)) {
-    if (NLEV == 2) {
+    if (NLEV == 2 && a.split) {
+      _Float16* o0 = outT + __mul24(bxo, 63) + bm;   // half (x, y, m) = 63 x + 9 y + m; level 1 starts 442 halfs on
+#pragma unroll
+      for (int yo = 0; yo < 7; yo++) { o0[yo * 9] = res0[yo]; o0[442 + yo * 9] = res1[yo]; }
+    } else if (NLEV == 2) {
       uint32_t* o32 = reinterpret_cast<uint32_t*>(outT) + __mul24(bxo, 63) + bm;   // dword (x, y, m) = 63 x + 9 y + m (24-bit multiply: full rate)
 #pragma unroll
       for (int yo = 0; yo < 7; yo++) {
@@ -681,7 +694,7 @@ __device__ __forceinline__ void corr_edge(const CorrArgs2& a, int p, int e, int 
       // 441 dwords: two 16-byte-per-lane stores (256 + 184 dwords) and one last dword.  The row starts on a 4-byte
       // boundary only (1764 B per edge); global memory takes the unaligned 16-byte accesses.
       const uint32_t* src = reinterpret_cast<const uint32_t*>(outT);
-      uint32_t* dst = reinterpret_cast<uint32_t*>(a.out) + (size_t)e * 441;
+      uint32_t* dst = reinterpret_cast<uint32_t*>(a.out) + (size_t)e * (a.split ? 442 : 441);
       typedef uint32_t cdv_u32x4 __attribute__((ext_vector_type(4)));
       typedef uint32_t cdv_u32x4u __attribute__((ext_vector_type(4), aligned(4)));
       const cdv_u32x4 v0 = *reinterpret_cast<const cdv_u32x4*>(src + 4 * lane);
@@ -691,12 +704,13 @@ __device__ __forceinline__ void corr_edge(const CorrArgs2& a, int p, int e, int 
         *reinterpret_cast<cdv_u32x4u*>(dst + 256 + 4 * lane) = v1;
       }
       if (lane == 63) dst[440] = src[440];
+      if (lane == 62 && a.split) dst[441] = src[441];
     } else {
-      _Float16* dst = a.out + (size_t)e * 441;
+      _Float16* dst = a.out + (size_t)e * a.out_pitch + a.out_off;
 #pragma unroll
       for (int i = 0; i < 7; i++) {
         const int t = i * 64 + lane;
-        if (t < 441) dst[t] = outT[t];
+        if (t < 441) dst[t * a.out_stride] = outT[t];
       }
     }
   }
@@ -718,6 +732,10 @@ __global__ __launch_bounds__(256) void corr_fused2_kernel(const CorrArgs2 a) {
   // ---- round trip 1: the 18 coordinates (one vector load) and the two indices (scalar loads) -----------------------
   const int e = a.order ? __builtin_amdgcn_readfirstlane(a.order[p0]) : p0;   // wave-uniform
   const int cval = __float_as_int(a.coords[(size_t)e * 18 + min(lane, 17)]);
+  if (NLEV == 1 && a.coords_ref) {   // this edge's level is in place if it was computed from these very coordinates
+    const float r = a.coords_ref[(size_t)e * 18 + min(lane, 17)] * a.ref_mul;
+    if (__all(lane >= 18 || __float_as_int(r) == cval)) return;
+  }
   corr_edge<CC, NLEV>(a, p0, e, cval, a.kk[e], a.jj[e], lane, raw, outT);
 }
 
@@ -1113,10 +1131,11 @@ extern "C" int cdv_gmap_to_pixel_major(const void* gmap_planar, void* gmap_pm, i
   return CDV_OK;
 }
 
-extern "C" int cdv_corr_fused(const void* gmap, const void* fmap0_nhwc, const void* fmap1_nhwc, const float* coords,
-                              const int64_t* kk, const int64_t* jj, const int32_t* order, void* out, int64_t E,
-                              int64_t Ng, int64_t slots, int C, int H0, int W0, int H1, int W1, float scale0,
-                              float scale1, int nlev, int64_t kmod, int64_t jmod, int gmap_pixel_major, void* stream) {
+static int corr_fused_impl(const void* gmap, const void* fmap0_nhwc, const void* fmap1_nhwc, const float* coords,
+                           const int64_t* kk, const int64_t* jj, const int32_t* order, void* out, int64_t E,
+                           int64_t Ng, int64_t slots, int C, int H0, int W0, int H1, int W1, float scale0,
+                           float scale1, int nlev, int64_t kmod, int64_t jmod, int gmap_pixel_major, void* stream,
+                           int out_stride, int out_off, int out_pitch, const float* coords_ref, float ref_mul, int split) {
   CDV_REQUIRE(nlev == 1 || nlev == 2, CDV_ERR_ARG, "cdv_corr_fused: nlev must be 1 or 2");
   CDV_REQUIRE(C % 8 == 0 && C > 0 && C <= 128, CDV_ERR_UNSUPPORTED, "cdv_corr_fused: C must be a multiple of 8, <= 128");
   CDV_REQUIRE(E >= 0 && E < ((int64_t)1 << 31), CDV_ERR_ARG, "cdv_corr_fused: E out of range");
@@ -1147,7 +1166,8 @@ extern "C" int cdv_corr_fused(const void* gmap, const void* fmap0_nhwc, const vo
     const CorrLevel A0 = level(fmap0_nhwc, H0, W0, scale0, 0);
     const CorrArgs2 a{coords, kk, jj, order, (int)E, (uint32_t)kmod, (uint32_t)jmod, kmagic, jmagic, (uint32_t)Ng,
                       (uint32_t)slots, (const char*)gmap, (_Float16*)out, A0,
-                      nlev == 2 ? level(fmap1_nhwc, H1, W1, scale1, ex1 - ex0) : A0, C, gmap_pixel_major, exp};
+                      nlev == 2 ? level(fmap1_nhwc, H1, W1, scale1, ex1 - ex0) : A0, C, gmap_pixel_major, exp,
+                      out_stride, out_off, out_pitch, coords_ref, ref_mul, split};
     const int blocks = 8 * (int)cdv_div_up(E, 32);   // a multiple of 8: the kernel deals contiguous eighths to the XCDs
     if (nlev == 2 && C == 24)
       hipLaunchKernelGGL((corr_fused2_kernel<24, 2>), dim3(blocks), dim3(256), smem, s, a);
@@ -1158,6 +1178,8 @@ extern "C" int cdv_corr_fused(const void* gmap, const void* fmap0_nhwc, const vo
     else
       hipLaunchKernelGGL((corr_fused2_kernel<0, 1>), dim3(blocks), dim3(256), smem, s, a);
   } else {
+    CDV_REQUIRE(out_stride == 1 && out_off == 0 && coords_ref == nullptr && !split, CDV_ERR_UNSUPPORTED,
+                "cdv_corr_fused: split levels / checked calls need C <= 32");
     LevelParams L0{(const _Float16*)fmap0_nhwc, H0, W0, 1.0f / scale0, 0};
     LevelParams L1{(const _Float16*)fmap1_nhwc, H1, W1, nlev == 2 ? 1.0f / scale1 : 1.0f, nlev == 2 ? ex1 - ex0 : 0};
     hipLaunchKernelGGL(corr_wide_kernel<4>, dim3(cdv_div_up(E, 4)), dim3(256), smem, s, (const _Float16*)gmap, L0, L1, coords,
@@ -1166,6 +1188,34 @@ extern "C" int cdv_corr_fused(const void* gmap, const void* fmap0_nhwc, const vo
   }
   CDV_LAUNCH_CHECK();
   return CDV_OK;
+}
+
+extern "C" int cdv_corr_fused(const void* gmap, const void* fmap0_nhwc, const void* fmap1_nhwc, const float* coords,
+                              const int64_t* kk, const int64_t* jj, const int32_t* order, void* out, int64_t E,
+                              int64_t Ng, int64_t slots, int C, int H0, int W0, int H1, int W1, float scale0,
+                              float scale1, int nlev, int64_t kmod, int64_t jmod, int gmap_pixel_major, void* stream) {
+  return corr_fused_impl(gmap, fmap0_nhwc, fmap1_nhwc, coords, kk, jj, order, out, E, Ng, slots, C, H0, W0, H1, W1, scale0,
+                         scale1, nlev, kmod, jmod, gmap_pixel_major, stream, 1, 0, 441, nullptr, 1.0f, 0);
+}
+
+extern "C" int cdv_corr_fused_split(const void* gmap, const void* fmap0_nhwc, const void* fmap1_nhwc, const float* coords,
+                                    const int64_t* kk, const int64_t* jj, const int32_t* order, void* out2, int64_t E,
+                                    int64_t Ng, int64_t slots, int C, int H0, int W0, int H1, int W1, float scale0,
+                                    float scale1, int64_t kmod, int64_t jmod, int gmap_pixel_major, void* stream) {
+  CDV_REQUIRE(C <= 32, CDV_ERR_UNSUPPORTED, "cdv_corr_fused_split: C must be <= 32");
+  return corr_fused_impl(gmap, fmap0_nhwc, fmap1_nhwc, coords, kk, jj, order, out2, E, Ng, slots, C, H0, W0, H1, W1, scale0,
+                         scale1, 2, kmod, jmod, gmap_pixel_major, stream, 1, 0, 884, nullptr, 1.0f, 1);
+}
+
+extern "C" int cdv_corr_level_checked(const void* gmap, const void* fmap_nhwc, const float* coords, const float* coords_ref,
+                                      float ref_mul, const int64_t* kk, const int64_t* jj, void* out2, int level, int64_t E,
+                                      int64_t Ng, int64_t slots, int C, int H, int W, float scale, int64_t kmod,
+                                      int64_t jmod, int gmap_pixel_major, void* stream) {
+  CDV_REQUIRE(level == 0 || level == 1, CDV_ERR_ARG, "cdv_corr_level_checked: level must be 0 or 1");
+  CDV_REQUIRE(coords_ref != nullptr && out2 != nullptr, CDV_ERR_ARG, "cdv_corr_level_checked: NULL argument");
+  CDV_REQUIRE(C <= 32, CDV_ERR_UNSUPPORTED, "cdv_corr_level_checked: C must be <= 32");
+  return corr_fused_impl(gmap, fmap_nhwc, nullptr, coords, kk, jj, nullptr, out2, E, Ng, slots, C, H, W, 0, 0, scale, 1.0f, 1,
+                         kmod, jmod, gmap_pixel_major, stream, 1, 442 * level, 884, coords_ref, ref_mul, 0);
 }
 
 extern "C" int cdv_patchify_fwd(const void* net, const float* coords, void* patches, int B, int64_t M, int C, int H,

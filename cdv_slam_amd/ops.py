@@ -368,6 +368,79 @@ def corr_fused(gmap, fmap0_nhwc, fmap1_nhwc, coords, kk, jj, kmod=0, jmod=0, sca
     return out
 
 
+class _LevelPairing:
+    """The reference calls cuda_corr.forward twice per update: pyramid[0] with coords, then pyramid[1] with coords / 4
+    (slam.py:321-322), and stacks the two results (slam.py:323).  Seen from here the second call repeats the per-edge
+    work of the first.  Once that pattern has been observed (two consecutive calls on the same patch tiles and index
+    tensors, on two rings whose sizes differ by a power of two), the call on the first ring computes BOTH levels in one
+    launch (cdv_corr_fused_split) into one buffer [E][2][442] and returns its level-0 view; the call that follows on the
+    second ring only checks, per edge and on the device, that its coords are the first call's divided by the same power
+    of two, recomputes the edges for which they are not (cdv_corr_level_checked), and returns the level-1 view.  Nothing
+    is assumed: a second call that never comes, or comes with other tensors, costs the speculative level and nothing
+    else.  drops `n_fused` += 1 per pair served this way."""
+
+    def __init__(self):
+        self.learned = {}      # data_ptr of ring A -> (weakref of ring B, ratio)
+        self.last = None       # signature of the previous call
+        self.pending = None
+        self.n_fused = 0
+
+    @staticmethod
+    def _sig(fmap1, fmap2, coords, ii, jj):
+        return (fmap1.data_ptr(), fmap1._version, ii.data_ptr(), jj.data_ptr(), ii.numel(), coords.shape[1])
+
+    def call(self, fmap1, fmap2, coords, ii, jj):
+        import weakref
+        lib = _lib.load()
+        sig = self._sig(fmap1, fmap2, coords, ii, jj)
+        E = coords.shape[1]
+        pend, self.pending = self.pending, None
+        # ---- the second call of a pair whose first call computed both levels
+        if (pend is not None and pend["sig"] == sig and pend["ringB"]() is fmap2 and pend["verB"] == fmap2._version
+                and E == ii.numel()):
+            shadow = _nhwc.get(fmap2)          # in step already (synchronised by the first call; the version has not moved)
+            N2, H2, W2 = fmap2.shape[1], fmap2.shape[3], fmap2.shape[4]
+            C = fmap1.shape[2]
+            g = fmap1[0].contiguous()
+            rc = lib.cdv_corr_level_checked(_p(g), _p(shadow[0]), _p(coords), _p(pend["coords"]), 1.0 / pend["ratio"],
+                                            _p(ii), _p(jj), _p(pend["buf"]), 1, E, g.numel() // (C * 9), N2, C, H2, W2, 1.0,
+                                            0, 0, 0, _stream())
+            _lib.check(rc, "cdv_corr_level_checked")
+            self.n_fused += 1
+            self.last = None
+            return pend["buf"][:, 1, :441].view(1, E, 7, 7, 3, 3)
+        # ---- a first call whose second is expected: both levels now
+        known = self.learned.get(fmap2.data_ptr())
+        ringB = known[0]() if known else None
+        if ringB is not None and ringB.is_contiguous() and ringB.dtype == torch.float16 and E == ii.numel() and E > 0:
+            ratio = known[1]
+            sa, sb = _nhwc.get(fmap2), _nhwc.get(ringB)
+            C = fmap1.shape[2]
+            g = fmap1[0].contiguous()
+            buf = torch.empty((E, 2, 442), dtype=torch.float16, device=g.device)     # levels kept apart: rows of 884 B
+            rc = lib.cdv_corr_fused_split(_p(g), _p(sa[0]), _p(sb[0]), _p(coords), _p(ii), _p(jj), None, _p(buf), E,
+                                          g.numel() // (C * 9), fmap2.shape[1], C, fmap2.shape[3], fmap2.shape[4],
+                                          ringB.shape[3], ringB.shape[4], 1.0, float(ratio), 0, 0, 0, _stream())
+            _lib.check(rc, "cdv_corr_fused_split")
+            self.pending = {"sig": sig, "ringB": weakref.ref(ringB), "verB": ringB._version, "coords": coords, "ratio": ratio,
+                            "buf": buf}
+            self.last = None
+            return buf[:, 0, :441].view(1, E, 7, 7, 3, 3)
+        # ---- an ordinary call: remember it, and learn the pairing from two in a row
+        if self.last is not None and self.last["sig"] == sig and self.last["ring"]() is not None:
+            ra = self.last["ring"]()
+            if ra is not fmap2 and ra.shape[:3] == fmap2.shape[:3]:
+                h, w, H, W = fmap2.shape[3], fmap2.shape[4], ra.shape[3], ra.shape[4]
+                ratio = H // h if h > 0 else 0
+                if ratio >= 2 and (ratio & (ratio - 1)) == 0 and h * ratio == H and w * ratio == W:
+                    self.learned[ra.data_ptr()] = (weakref.ref(fmap2), ratio)
+        self.last = {"sig": sig, "ring": weakref.ref(fmap2)}
+        return None
+
+
+_pairing = _LevelPairing()
+
+
 def corr_forward(fmap1, fmap2, coords, ii, jj, radius):
     """cuda_corr.forward (cdvslam/altcorr/correlation.cpp:35-42): fmap1 [B,N1,C,P,P], fmap2
     [B,N2,C,H2,W2], coords [B,M,2,P,P] f32 -> [B,M,2r+1 (x),2r+1 (y),P,P]."""
@@ -386,6 +459,10 @@ def corr_forward(fmap1, fmap2, coords, ii, jj, radius):
     fast = (fmap1.dtype == torch.float16 and radius == 3 and P == 3 and C % 8 == 0 and C <= 128
             and fmap2.is_contiguous())
     if fast:
+        if B == 1 and C <= 32:
+            o = _pairing.call(fmap1, fmap2, coords, ii, jj)
+            if o is not None:
+                return o
         shadow = _nhwc.get(fmap2)
         outs = []
         for b in range(B):

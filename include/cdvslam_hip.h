@@ -154,6 +154,25 @@ int cdv_corr_fused(const void* gmap, const void* fmap0_nhwc, const void* fmap1_n
                    int64_t slots, int C, int H0, int W0, int H1, int W1, float scale0, float scale1, int nlev,
                    int64_t kmod, int64_t jmod, int gmap_pixel_major, void* stream);
 
+/*
+ * The reference's two-call sequence (slam.py:321-322: cuda_corr.forward on pyramid[0] with coords, then on pyramid[1] with
+ * coords / 4, stacked by slam.py:323) served by one two-level launch and a check:
+ *   cdv_corr_fused_split   = cdv_corr_fused with the levels kept apart: out2 [E][2][442] halves (each level a contiguous
+ *                            run of 441, rows of 884 bytes), so that either level can be handed out as a tensor view;
+ *   cdv_corr_level_checked = the SECOND call, given that the first already produced both levels into out2: every edge whose
+ *                            coords equal coords_ref * ref_mul bit for bit keeps what is there, any other edge is
+ *                            recomputed from coords into out2[e][level].  ~5 us when all match instead of a second
+ *                            correlation.  C <= 32 only.
+ */
+int cdv_corr_fused_split(const void* gmap, const void* fmap0_nhwc, const void* fmap1_nhwc, const float* coords,
+                         const int64_t* kk, const int64_t* jj, const int32_t* order, void* out2, int64_t E, int64_t Ng,
+                         int64_t slots, int C, int H0, int W0, int H1, int W1, float scale0, float scale1, int64_t kmod,
+                         int64_t jmod, int gmap_pixel_major, void* stream);
+int cdv_corr_level_checked(const void* gmap, const void* fmap_nhwc, const float* coords, const float* coords_ref,
+                           float ref_mul, const int64_t* kk, const int64_t* jj, void* out2, int level, int64_t E,
+                           int64_t Ng, int64_t slots, int C, int H, int W, float scale, int64_t kmod, int64_t jmod,
+                           int gmap_pixel_major, void* stream);
+
 /* cuda_corr.patchify_forward(net, coords, radius) -- correlation.cpp:49-52, kernel :16-47.
  *   net [B][C][H][W] (f16 or f32), coords [B][M][2] f32 -> patches [B][M][C][D][D], zero when OOB */
 int cdv_patchify_fwd(const void* net, const float* coords, void* patches, int B, int64_t M, int C, int H, int W,

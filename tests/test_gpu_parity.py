@@ -282,6 +282,46 @@ def test_corr_fused_vs_oracle(name):
     assert np.abs(got - truth).mean() <= 0.1 * tol
 
 
+def test_dropin_corr_pairs_the_two_level_calls():
+    """cuda_corr.forward called the way slam.py:321-322 calls it (pyramid[0] with coords, pyramid[1] with coords / 4): from
+    the second update on the first call computes both levels and the second only checks its coords on the device
+    (ops._LevelPairing).  Results equal the unpaired calls bit for bit -- also when the second call's coords are NOT the
+    first's divided by four for some edges (those are recomputed)."""
+    st = synth.make_state("small")
+    dev = torch.device(DEV)
+    gmap = torch.as_tensor(st.gmap, device=dev)[None].contiguous()             # [1, Ng, C, 3, 3]
+    f1 = torch.as_tensor(st.fmap1, device=dev)[None].contiguous()              # [1, mem, C, H, W]
+    f2 = torch.as_tensor(st.fmap2, device=dev)[None].contiguous()
+    ii1 = torch.as_tensor(st.kk % (st.cfg.M * st.cfg.pmem), device=dev)
+    jj1 = torch.as_tensor(st.jj % st.cfg.mem, device=dev)
+    rng = np.random.default_rng(5)
+    h, w = f1.shape[-2], f1.shape[-1]
+    base = torch.as_tensor(np.stack([rng.uniform(4, w - 4, (st.E, 3, 3)), rng.uniform(4, h - 4, (st.E, 3, 3))], 1)[None]
+                           .astype(np.float32), device=dev)
+
+    def plain(ring, c):      # an unpaired call: a fresh pairing state sees one call only
+        saved, ops._pairing = ops._pairing, ops._LevelPairing()
+        try:
+            return ops.corr_forward(gmap, ring, c, ii1, jj1, 3).clone()
+        finally:
+            ops._pairing = saved
+
+    ops._pairing = ops._LevelPairing()
+    for it in range(3):
+        coords = base + 0.37 * it
+        c0, c1 = coords / 1, coords / 4
+        if it == 2:          # a caller that does something else on some edges
+            c1 = c1.clone()
+            c1[0, ::7] += 0.125
+        a = ops.corr_forward(gmap, f1, c0, ii1, jj1, 3)
+        b = ops.corr_forward(gmap, f2, c1, ii1, jj1, 3)
+        stacked = torch.stack([a, b], -1).view(1, st.E, -1)
+        assert torch.equal(a, plain(f1, c0)), it
+        assert torch.equal(b, plain(f2, c1)), it
+        assert stacked.shape[-1] == 882
+    assert ops._pairing.n_fused == 2          # updates 1 and 2; update 0 taught the pattern
+
+
 @pytest.mark.parametrize("name", ["small", "default"])
 def test_corr_processing_order_from_the_index_build(name):
     """the edge order the fused correlation works through (cdv_graph_corr_order, a counting sort by target frame riding
