@@ -1,27 +1,27 @@
 // ba_mid.hip -- fastba for 10 < N <= 32 free poses (a wider OPTIMIZATION_WINDOW, the start of a global optimisation),
 // gfx950.  The design of ba_win.hip -- one Gauss-Newton iteration of cuda_ba.forward (cdvslam/fastba/ba_cuda.cu:462-611)
-// as two launches, one owner and a fixed order for every sum, no float atomic in HBM -- for systems whose triangle no
-// longer fits a wave-private LDS copy (6N = 192: 75 KB):
+// with one owner and a fixed order for every sum, no float atomic in HBM -- for systems whose triangle no longer fits a
+// wave-private LDS copy (6N = 192: 75 KB).  Three launches per iteration:
 //
 //   1. ba_mid_chunk_kernel  workgroup = 16 unique patches x all their edges, as in ba_win.hip.  What a chunk adds to B
 //                           and v is sparse: the block diagonal (B_jj, v_j of every target frame), and the block rows
 //                           of its patches' SOURCE frames (B_ii, v_i, B_ij) -- one frame, two when the chunk straddles
 //                           a frame boundary.  Each wave keeps that footprint privately ([2][27] + [N][27] + [2][N][36]
-//                           floats, 8.9 KB at N = 22); the copies are summed in a fixed order, the source-frame parts
-//                           are folded onto the diagonal blocks, and the chunk's Schur complement E Q E^T (MFMA, K = 16
-//                           patches) is subtracted tile by tile on the way to the chunk's slab (packed lower triangle of
-//                           the 6N x 6N system + y): every word written once.  Source frames are found from a 32-bit
-//                           mask of the free frames the chunk's edges start from; a chunk with more than two (patches
-//                           of three frames among 16 consecutive ones: fewer than 8 patches per frame) takes one more
-//                           pass per further pair and adds its B part onto its own slab.
-//   2. ba_mid_finish_kernel workgroup 0 = the solver (8 waves), the others reduce the slabs in a fixed order, hand the
-//                           system over (write-through stores, arrival counter), preload their patches' E columns, wait
-//                           for dX (tagged granules) and retract.  Solver: [S ; y^T] dense in LDS, right-looking
-//                           Cholesky over blocks of two poses (12 columns): the diagonal block is factored by every row
-//                           thread in registers (no barrier between factor and panel solve), the trailing update runs
-//                           as 16 x 16 tiles on the matrix cores (K = 12).
-#include <cstdlib>
-
+//                           floats, 8.9 KB at N = 22); the copies are summed in a fixed order and the source-frame parts
+//                           folded onto the diagonal blocks.  The chunk's Schur complement E Q E^T (MFMA, K = 16 patches)
+//                           goes tile by tile into a packed triangle staged in the LDS the copies no longer need, the
+//                           folded footprint is scattered onto it (one addend per entry), and the slab (packed lower
+//                           triangle of the 6N x 6N system + y) leaves as 16-byte stores: every word written once.
+//                           Source frames are found from a 32-bit mask of the free frames the chunk's edges start from;
+//                           a chunk with more than two (fewer than 8 patches per frame) takes one more pass per further
+//                           pair and adds its B part onto its own slab.
+//   2. ba_mid_reduce_kernel the slabs summed in a fixed order by the whole chip (9.6 MB at N = 22, U = 4,312), written as
+//                           the damped dense system [6N + 1][LD].
+//   3. ba_mid_finish_kernel workgroup 0 = the solver (8 waves), the others preload their patches' E columns, wait for dX
+//                           (tagged granules) and retract.  Solver: [S ; y^T] dense in LDS, right-looking Cholesky over
+//                           panels of 24 columns factored inside single waves (one matrix row per lane, pivots and
+//                           L[m][k] by v_readlane), trailing update as 16 x 16 tiles on the matrix cores (K = 24), back
+//                           substitution inside one wave.
 #include "cdv_ba_pairs.h"
 
 using namespace cdv;
