@@ -1,26 +1,22 @@
-// ba.hip -- fastba: Schur-reduced Gauss-Newton bundle adjustment over the patch graph, gfx950.
+// ba.hip -- fastba: Schur-reduced Gauss-Newton bundle adjustment over the patch graph, gfx950: the entry point
+// cdv_ba_forward (replaces cuda_ba.forward, cdvslam/fastba/ba.cpp:31-45, ba_cuda.cu:462-611), the status words, and the
+// path for more than 32 free poses (the global optimisation, slam.py:460-478).
 //
-// Replaces cuda_ba.forward (cdvslam/fastba/ba.cpp:31-45, ba_cuda.cu:462-611, dense-E path) without
-// the reference's ~16 M contended global float atomics per iteration (ba_cuda.cu:350-402) and without
-// ATen's matmul / cholesky_ex / cholesky_solve launches (ba_cuda.cu:583-592).
-//
-// Per Gauss-Newton iteration, four launches (E, C, u and [S | y] are accumulators in the workspace: zero at
-// entry, re-zeroed by their consumers; S = B - E Q E^T, y = v - E Q u):
-//  1. ba_assemble_kernel: workgroup = (chunk of 64 unique patches, group of 8 target slots) through the patch
-//     CSR.  A wave owns ONE "target slot" t: lane = patch, edge = t-th edge of that patch in (jj, edge id)
-//     order.  Patches of one source frame share their target list, so the 64 edges of a wave belong to
-//     (almost always) ONE frame pair (i, j):
-//       - B blocks and v: the 13x13 Gram matrix of the wave's 128 residual rows [Ji | Jj | r], weighted
-//         by w, is ONE 16x16 f32 MFMA tile with K = 128 (32 x v_mfma_f32_16x16x4_f32, exact f32 fma chains);
-//         one atomic per entry per wave adds it into [S | y].
-//       - E, C, u: lanes are consecutive unique patches, so every atomic wave-instruction is one contiguous
-//         256-byte row segment of E (the shape the memory-side atomic units run at full rate).
-//  2. ba_schur_kernel: one workgroup per chunk of 64 patches, once E, C, u are complete: q = 1 / (C + lambda)
-//     and the Schur products as MFMA tiles, [Ed; u] diag(q) [Ed; u]^T with K = 64, subtracted from [S | y].
-//  3. ba_solve_kernel (one workgroup): damping (ba_cuda.cu:589), 6x6-block Cholesky in LDS with the right-hand
-//     side carried as an extra row (the forward substitution is free) and the trailing updates on the matrix
-//     cores, block back-substitution, pose retraction (ba_cuda.cu:178-206); re-zeroes [S | y].
-//  4. ba_retract_kernel: dZ = Q (u - E^T dX), inverse-depth update (ba_cuda.cu:209-229, 592); re-zeroes E, C, u.
+// Dispatch on the number of free poses N:
+//   1 <= N <= 10    ba_win.hip   two launches per iteration, no float atomics, bitwise reproducible
+//   10 < N <= 32    ba_mid.hip   three launches per iteration, the same properties
+//   N > 32 (<=1024) this file    dense E in HBM; per iteration:
+//     1. ba_assemble_kernel: workgroup = (chunk of 64 unique patches, group of target slots) through the patch CSR.  A wave
+//        owns ONE "target slot" t: lane = patch, edge = t-th edge of that patch in (jj, edge id) order.  Patches of one
+//        source frame share their target list, so the 64 edges of a wave belong to (almost always) ONE frame pair (i, j):
+//          - B blocks and v: the 13x13 Gram matrix of the wave's 128 residual rows [Ji | Jj | r], weighted by w, is ONE
+//            16x16 f32 MFMA tile with K = 128; one atomic per entry per wave adds it into one of four copies of [S | y];
+//          - E, C, u: lanes are consecutive unique patches, so every atomic wave-instruction is one contiguous 256-byte
+//            row segment of E (the shape the memory-side atomic units run at full rate).
+//     2. ba_big_schur_kernel: panel-sparse Schur products on the matrix cores; 3. fold + blocked multi-workgroup Cholesky +
+//        back substitution; 4. ba_retract_kernel: dZ = Q (u - E^T dX), depth and pose update (ba_cuda.cu:178-229, 592).
+//     (Float atomics: results agree with the oracle to the stated tolerances, not bit for bit between runs.)
+//   N = 0           assemble + ba_schur_kernel (q only) + retract: depths alone.
 #include <mutex>
 #include <unordered_map>
 
@@ -426,222 +422,6 @@ __global__ __launch_bounds__(1024) void ba_schur_kernel(SchurArgs A) {
   if (blockIdx.x == 0 && threadIdx.x < 64) reinterpret_cast<uint64_t*>(A.info + 16)[threadIdx.x] = 0ull;
   extern __shared__ float smem[];
   schur_body(A, (int)blockIdx.x, (int)blockDim.x, smem);
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// 6x6-block Cholesky in LDS.  The matrix is [S ; y^T]: the right-hand side is carried as an extra row, so the
-// forward substitution happens inside the factorisation.
-// ---------------------------------------------------------------------------------------------------------
-
-// lower Cholesky factor of a 6x6 block (row-major input, lower part used); the diagonal of L is returned
-// INVERTED (all later uses divide by it).  Returns false if a pivot is not positive.
-__device__ __forceinline__ bool chol6(const float* a, float* Lm) {
-  bool ok = true;
-#pragma unroll
-  for (int j = 0; j < 6; j++) {
-    float s = a[j * 6 + j];
-#pragma unroll
-    for (int k = 0; k < j; k++) s -= Lm[j * 6 + k] * Lm[j * 6 + k];
-    ok = ok && (s > 0.f);
-    const float inv = __builtin_amdgcn_rsqf(s);
-    Lm[j * 6 + j] = inv;
-#pragma unroll
-    for (int i = j + 1; i < 6; i++) {
-      float tt = a[i * 6 + j];
-#pragma unroll
-      for (int k = 0; k < j; k++) tt -= Lm[i * 6 + k] * Lm[j * 6 + k];
-      Lm[i * 6 + j] = tt * inv;
-    }
-  }
-  return ok;
-}
-
-// One workgroup (1024 threads).  Per block step: (1) one thread per matrix row below the diagonal block
-// factors the 6x6 block redundantly in registers (~400-cycle dependent chain) and forward-substitutes its own
-// row (the panel); (2) the trailing update runs as 16x16 tiles on the matrix cores.
-__global__ __launch_bounds__(1024) void ba_solve_kernel(float* __restrict__ poses, float* __restrict__ sy,
-                                                       int sy_stride, float* __restrict__ dXg, int t0, int N,
-                                                       const int32_t* __restrict__ gmeta, float* __restrict__ dbg,
-                                                       int32_t* __restrict__ info) {
-  if (gmeta[GM_ERROR] || info[1]) return;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int n = 6 * N;
-  const int LD = n + 2;                 // even: 6-float block rows stay 8-byte aligned
-  float* A = smem;                      // [n + 1][LD]: rows 0..n-1 = S (lower part used), row n = y^T
-  float* Dl = A + (size_t)(n + 1) * LD; // [N][36] diagonal factors (diagonal inverted)
-  const int T = blockDim.x, t = threadIdx.x;
-  CDV_IF_STAMPS(const int sslot = 4096 + (t >> 6); unsigned long long t_pan = 0, t_tr = 0, t_x;)
-  CDV_STAMP(ba, sslot, 0);
-  // [S | y] -> LDS.  All global loads of a thread are issued before the first use (one memory round trip).
-  {
-    const int total = n * n + n;
-    const float inv_n = 1.0f / (float)n;   // idx / n for idx < 2^23 via one multiply
-    // float4 loads of all BA_REPL copies; a copy is padded with (never written) zeros up to sy_stride
-    const int total4 = (total + 3) / 4;
-    const cdv_float4 z4 = {0.f, 0.f, 0.f, 0.f};
-    for (int base = 0; base < total4; base += 4 * T) {
-      cdv_float4 v[4][BA_REPL];
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const int i4 = base + i * T + t;
-#pragma unroll
-        for (int rep = 0; rep < BA_REPL; rep++)
-          v[i][rep] = (i4 < total4) ? *reinterpret_cast<const cdv_float4*>(sy + (size_t)rep * sy_stride + 4 * i4) : z4;
-      }
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const int i4 = base + i * T + t;
-        if (i4 < total4) {
-          cdv_float4 sum = v[i][0];
-#pragma unroll
-          for (int rep = 1; rep < BA_REPL; rep++) sum += v[i][rep];
-#pragma unroll
-          for (int rep = 0; rep < BA_REPL; rep++)   // ready for the next iteration / call
-            *reinterpret_cast<cdv_float4*>(sy + (size_t)rep * sy_stride + 4 * i4) = z4;
-#pragma unroll
-          for (int c = 0; c < 4; c++) {
-            const int idx = 4 * i4 + c;
-            if (idx < total) {
-              float s = sum[c];
-              const int a = (int)(((float)idx + 0.5f) * inv_n), b = idx - a * n;   // a == n: the y row
-              if (a == b) s += 1e-4f * s + 1.0f;        // S += I * (1e-4 * S + 1.0)   ba_cuda.cu:589
-              A[a * LD + b] = s;
-              if (dbg) dbg[idx] = s;
-            }
-          }
-        }
-      }
-    }
-  }
-  __shared__ int s_bad;
-  if (t == 0) s_bad = 0;
-  __syncthreads();
-
-  CDV_STAMP(ba, sslot, 1);
-  for (int kb = 0; kb < N; kb++) {
-    CDV_IF_STAMPS(t_x = cdv_now();)
-    const int R0 = 6 * (kb + 1);      // first matrix row below the diagonal block
-    const int nrows = n + 1 - R0;     // rows R0 .. n (row n = y)
-    if (t < nrows || t == 0) {
-      float a[36], Lm[36];
-#pragma unroll
-      for (int i = 0; i < 6; i++)
-#pragma unroll
-        for (int j = 0; j < 6; j += 2) {
-          const float2 v = *reinterpret_cast<const float2*>(&A[(6 * kb + i) * LD + 6 * kb + j]);
-          a[i * 6 + j] = v.x; a[i * 6 + j + 1] = v.y;
-        }
-      const bool ok = chol6(a, Lm);
-      if (t == 0) {
-        if (!ok && s_bad == 0) s_bad = kb + 1;
-#pragma unroll
-        for (int i = 0; i < 6; i++)
-#pragma unroll
-          for (int j = 0; j <= i; j++) Dl[kb * 36 + i * 6 + j] = Lm[i * 6 + j];
-      }
-      if (t < nrows) {  // panel row: solve  o L^T = row   (o[c] = (row[c] - sum_{j<c} o[j] L[c][j]) / L[c][c])
-        float* rp = &A[(R0 + t) * LD + 6 * kb];
-        float o[6];
-#pragma unroll
-        for (int j = 0; j < 6; j += 2) {
-          const float2 v = *reinterpret_cast<const float2*>(rp + j);
-          o[j] = v.x; o[j + 1] = v.y;
-        }
-#pragma unroll
-        for (int c = 0; c < 6; c++) {
-          float s = o[c];
-#pragma unroll
-          for (int j = 0; j < c; j++) s -= o[j] * Lm[c * 6 + j];
-          o[c] = s * Lm[c * 6 + c];
-        }
-#pragma unroll
-        for (int j = 0; j < 6; j += 2) *reinterpret_cast<float2*>(rp + j) = make_float2(o[j], o[j + 1]);
-      }
-    }
-    __syncthreads();
-    CDV_IF_STAMPS({ const unsigned long long t_y = cdv_now(); t_pan += t_y - t_x; t_x = t_y; })
-    // trailing update A[R0.., R0..] -= P P^T (P = the panel just formed, rows R0..n, 6 columns) as 16x16 tiles
-    // on the matrix cores: K = 6 padded to 8 = two v_mfma_f32_16x16x4_f32 per tile; lower tiles only, dealt
-    // round-robin to the 16 waves (up to 36 tiles per step at N = 22; with 4 waves the nine dependent
-    // LDS-read / MFMA / LDS-update rounds per wave were 73 % of the kernel).  The y row (row n) is simply the last
-    // panel row.
-    {
-      const int lane = t & 63, wv = t >> 6, c16 = lane & 15, g4 = lane >> 4;
-      const int T16 = (nrows + 15) >> 4;
-      const int ntile = T16 * (T16 + 1) / 2;
-      for (int pidx = wv; pidx < ntile; pidx += (T >> 6)) {
-        int ti = 0, acc_rows = 0;
-        while (acc_rows + ti + 1 <= pidx) { acc_rows += ti + 1; ti++; }
-        const int tj = pidx - acc_rows;
-        const int ra = 16 * ti + c16, rb = 16 * tj + c16;
-        const float* pa = &A[(R0 + min(ra, nrows - 1)) * LD + 6 * kb];
-        const float* pb = &A[(R0 + min(rb, nrows - 1)) * LD + 6 * kb];
-        // k = g4 (step 0) and 4 + g4 (step 1); k >= 6 is padding
-        const float a0 = (ra < nrows) ? pa[g4] : 0.f, b0 = (rb < nrows) ? pb[g4] : 0.f;
-        const float a1 = (ra < nrows && g4 < 2) ? pa[4 + (g4 & 1)] : 0.f;
-        const float b1 = (rb < nrows && g4 < 2) ? pb[4 + (g4 & 1)] : 0.f;
-        cdv_float4 acc = {0.f, 0.f, 0.f, 0.f};
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc, 0, 0, 0);
-        // D: row = 16 ti + 4 g4 + q, col = 16 tj + c16
-        const int cc = 16 * tj + c16;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const int rr = 16 * ti + 4 * g4 + q;
-          if (rr < nrows && cc < n - R0 && cc <= rr) A[(R0 + rr) * LD + R0 + cc] -= acc[q];
-        }
-      }
-    }
-    __syncthreads();
-    CDV_IF_STAMPS(t_tr += cdv_now() - t_x;)
-  }
-  CDV_STAMP(ba, sslot, 2);
-  CDV_STAMP_VAL(ba, sslot, 5, t_pan);
-  CDV_STAMP_VAL(ba, sslot, 6, t_tr);
-  // row n of A now holds z = L^-1 y.  Back substitution L^T x = z, block by block from the bottom.
-  float* z = A + (size_t)n * LD;
-  for (int kb = N - 1; kb >= 0; kb--) {
-    if (t == 0) {  // x_k: solve L_kk^T x = z_k (6 unknowns, in registers)
-      float x[6];
-#pragma unroll
-      for (int c = 5; c >= 0; c--) {
-        float s = z[6 * kb + c];
-#pragma unroll
-        for (int j = c + 1; j < 6; j++) s -= Dl[kb * 36 + j * 6 + c] * x[j];
-        x[c] = s * Dl[kb * 36 + c * 6 + c];
-      }
-#pragma unroll
-      for (int c = 0; c < 6; c++) z[6 * kb + c] = x[c];
-    }
-    __syncthreads();
-    // z_cb -= L[kb][cb]^T x_k for cb < kb  (one thread per component)
-    for (int idx = t; idx < 6 * kb; idx += T) {
-      float s = 0.f;
-#pragma unroll
-      for (int j = 0; j < 6; j++) s += A[(6 * kb + j) * LD + idx] * z[6 * kb + j];
-      z[idx] -= s;
-    }
-    __syncthreads();
-  }
-  CDV_STAMP(ba, sslot, 3);
-  if (t < n) {
-    dXg[t] = z[t];
-    if (dbg) dbg[n * n + n + t] = z[t];
-  }
-  if (t == 0 && s_bad) ba_flag(info, BI_CHOL, s_bad);
-  // pose retraction T <- Exp(dX_i) T (ba_cuda.cu:178-206 semantics)
-  if (t < N) {
-    float* p = poses + 7 * (size_t)(t0 + t);
-    float pose[7], xi[6];
-#pragma unroll
-    for (int c = 0; c < 7; c++) pose[c] = p[c];
-#pragma unroll
-    for (int c = 0; c < 6; c++) xi[c] = z[6 * t + c];
-    se3_retract_raw(xi, pose);
-#pragma unroll
-    for (int c = 0; c < 7; c++) p[c] = pose[c];
-  }
-  CDV_STAMP(ba, sslot, 4);
 }
 
 // =========================================================================================================
@@ -1168,7 +948,6 @@ extern "C" int cdv_ba_forward(float* poses, float* patches, const float* intrins
   const int n_chunks = cdv_div_up(L.U_max, BA_CHUNK);
   const size_t smem_asm = sizeof(float) * ASM_WAVES * (size_t)PAIR_LDS_FLOATS;
   const size_t smem_sch = sizeof(float) * ((size_t)((n6i + 1 + 15) / 16 * 16) * ELD + BA_CHUNK);
-  const size_t smem_sol = sizeof(float) * ((size_t)(n6i + 1) * (n6i + 2) + 36 * (size_t)(N > 0 ? N : 1) + 8);
   // raise the dynamic-LDS limits once (not a stream operation: kept out of the per-call path so that the
   // call sequence can be captured into a hipGraph)
   static std::once_flag attr_once;
@@ -1177,14 +956,11 @@ extern "C" int cdv_ba_forward(float* poses, float* patches, const float* intrins
     hipError_t e4 = hipFuncSetAttribute((const void*)ba_big_schur_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         112 * 1024);
     if (e4 != hipSuccess) { attr_err = e4; return; }
-    // worst cases at N = 32: assemble 71 KB (fixed), schur 57 KB, solve 155 KB (+ a few static bytes)
     hipError_t e1 = hipFuncSetAttribute((const void*)ba_assemble_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         96 * 1024);
     hipError_t e2 = hipFuncSetAttribute((const void*)ba_schur_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         64 * 1024);
-    hipError_t e3 = hipFuncSetAttribute((const void*)ba_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        158 * 1024);
-    attr_err = e1 != hipSuccess ? e1 : e2 != hipSuccess ? e2 : e3;
+    attr_err = e1 != hipSuccess ? e1 : e2;
   });
   CDV_HIP_CHECK(attr_err);
   const int rb = cdv_div_up(L.U_max > N ? L.U_max : N, 64);
@@ -1213,16 +989,12 @@ extern "C" int cdv_ba_forward(float* poses, float* patches, const float* intrins
         hipLaunchKernelGGL(ba_big_backstep_kernel, dim3(kb > 0 ? cdv_div_up(CNB * kb, 256) : 1), dim3(256), 0, s, Abig, npad,
                            n6i, kb, dXg, gv.meta, d, info);
     } else {
-      // one wave per lower-triangular tile pair of [Ed; u] (10 at N = 10): the pairs run side by side
-      const int t16 = (n6i + 1 + 15) / 16, sch_waves = t16 * (t16 + 1) / 2 < 16 ? t16 * (t16 + 1) / 2 : 16;
-      hipLaunchKernelGGL(ba_schur_kernel, dim3(n_chunks), dim3(64 * (sch_waves < 4 ? 4 : sch_waves)), smem_sch, s, sa);
-      if (N > 0)
-        hipLaunchKernelGGL(ba_solve_kernel, dim3(1), dim3(1024), smem_sol, s, poses, sy, (int)L.sy_stride, dXg, t0, N,
-                           gv.meta, d, info);
+      // only N = 0 gets here (no free pose: depths alone are refined): q = 1 / (C + lambda) per chunk
+      hipLaunchKernelGGL(ba_schur_kernel, dim3(n_chunks), dim3(256), smem_sch, s, sa);
     }
     // dbg layout: [S n6^2 | y n6 | dX n6 | dZ U_stride | C U_stride | u U_stride | E n6*U_stride]
     float* dbgp = d ? d + (size_t)n6i * n6i + 2 * n6i : nullptr;
-    const int pose_retr = big ? 1 : 0;   // N <= 32: the solve kernel retracts the poses itself
+    const int pose_retr = big ? 1 : 0;   // N = 0: no pose to retract
     hipLaunchKernelGGL(ba_retract_kernel, dim3(rb), dim3(64 * RET_RG), 0, s, poses, t0, pose_retr, patches, P, N, gv.meta, gv.kx,
                        Cg, ug, qg, Edg, (int)L.U_stride, dXg, dbgp, info, big ? lmbda : (const float*)nullptr, cmask,
                        n_chunks);
