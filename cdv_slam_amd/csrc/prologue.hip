@@ -4,8 +4,8 @@
 // and patch tiles go into the rings (slam.py:676-682), the patches are reprojected (slam.py:325-329), and the
 // patch-graph index of this update's edge lists is started (ba_cuda.cu:476-478 / ba.cpp:59-97).  Each is a few
 // microseconds of latency-bound work; as separate launches they cost the sum of their latencies, side by side in one
-// grid they cost the longest one.  Workgroups [0, n_ing) ingest, [n_ing, n_ing + n_tf) reproject, the rest
-// histogram the patch ids; then the rest of the index build (scan, fill, segment sort + neighbors) follows.
+// grid they cost the longest one.  Workgroups [0, n_hist) histogram the patch ids, the next n_ing ingest, the rest
+// reproject; then the rest of the index build (scan, fill, segment sort + neighbors) follows.
 #include "cdv_common.h"
 #include "cdv_graph.h"
 #include "cdv_parts.h"
@@ -14,18 +14,20 @@ namespace {
 
 __global__ __launch_bounds__(256) void update_prologue_kernel(cdv::IngestArgs ing, int n_ing, cdv::TfArgs tf, int n_tf,
                                                               cdv::HistArgs hist, int n_hist) {
+  // the histogram workgroups first: theirs is the longest dependent chain (atomics -> drain -> arrival count -> the last
+  // one scans), so they get the head start of the dispatch order
   int b = (int)blockIdx.x;
+  if (b < n_hist) {
+    cdv::graph_hist_body(hist, b, n_hist, 256, (int)threadIdx.x);
+    return;
+  }
+  b -= n_hist;
   if (b < n_ing) {
     cdv::ingest_body(ing, b, 256, (int)threadIdx.x);
     return;
   }
   b -= n_ing;
-  if (b < n_tf) {
-    cdv::transform_body<3>(tf, (int64_t)b * 256 + threadIdx.x);
-    return;
-  }
-  b -= n_tf;
-  cdv::graph_hist_body(hist, b, n_hist, 256, (int)threadIdx.x);
+  cdv::transform_body<3>(tf, (int64_t)b * 256 + threadIdx.x);
 }
 
 }  // namespace
