@@ -555,7 +555,9 @@ __device__ __forceinline__ void mid_solve(const BaWinArgs& A, float* smem) {
       // v_readlane result) or sinks all updates of a column to just before its pivot (276 broadcast values alive in
       // SGPRs, spilled through v_writelane: 11,000 cycles per panel).  Measured alternatives, none faster than this
       // (4,600 cycles per 24-column panel): the next column's pivot chain started before the bulk of the updates; the
-      // broadcasts as 16-byte LDS reads from a per-wave column buffer written one column ahead, as in ba_win.hip (6,900).
+      // broadcasts as 16-byte LDS reads from a per-wave column buffer written one column ahead, as in ba_win.hip (6,900);
+      // two halves of 12 columns with the rank-12 update between them from a 12 x 12 block in LDS (132 instead of 276
+      // v_readlane: 4,800) -- the cost is the pivot chain of each column, not the broadcasts.
       float rs_k[NB];
 #pragma unroll
       for (int k = 0; k < NB; k++) {
