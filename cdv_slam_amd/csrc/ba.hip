@@ -922,6 +922,7 @@ extern "C" int cdv_ba_forward(float* poses, float* patches, const float* intrins
   if (fresh) {
     if (!window) CDV_HIP_CHECK(hipMemsetAsync(b + L.sy, 0, L.zero_bytes, s));   // the window path keeps no accumulators
     CDV_HIP_CHECK(hipMemsetAsync(info, 0, sizeof(int32_t) * 16 + sizeof(uint64_t) * MID_GRAN, s));
+    if (window) CDV_HIP_CHECK(hipMemsetAsync(b + L.hand, 0, sizeof(int32_t) * HAND_WORDS, s));   // token 0, no flag set
   }
   if (window) {
     BaWinArgs wa;

@@ -18,11 +18,13 @@
 //                            per chunk (a "slab": packed lower triangle of S + y, 7.6 KB) with plain stores;
 //                          - E columns, q, u of the chunk go to HBM for the retraction (plain stores, complete values:
 //                            nothing has to be re-zeroed afterwards).
-//   2. ba_finish_kernel  workgroup 0 = the solver wave; workgroups 1.. first reduce the slabs (each thread a 16-byte
-//                        column over every G-th slab, butterfly over the G partials: fixed order), hand the reduced
-//                        system to the solver (write-through stores, drained, one arrival count per workgroup), then
-//                        preload their patches' E columns while the solver runs, wait for dX (tagged 8-byte granules:
-//                        the poll is the load), and retract depths and poses (ba_cuda.cu:178-229 semantics).
+//   2. ba_finish_kernel  workgroup 0 = the solver wave; workgroups 1.. (119: a CU streams ~10 B per cycle, the 1.5 MB of
+//                        slabs want many) first reduce the slabs -- thread = (16-byte column, one of 64 slab subsets),
+//                        DPP row shifts over 16 of them, the four waves' partials through LDS: a fixed order -- hand the
+//                        reduced system to the solver (write-through stores, drained, then the launch's token into the
+//                        workgroup's own flag word: no shared counter), and the first U / 256 of them preload their
+//                        patches' E columns while the solver runs, wait for dX (tagged 8-byte granules: the poll is the
+//                        load), and retract depths and poses (ba_cuda.cu:178-229 semantics).
 //                        Solver: lane r holds row r of [S ; y^T] in registers (the right-hand side as row 60: forward
 //                        substitution for free); column k is broadcast through LDS (one ds_write, then 16-byte
 //                        broadcast reads) one column AHEAD of the rank-1 updates that consume it, so the LDS round
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(64 * CKW) void ba_chunk_kernel(BaWinArgs A) {
   if (blockIdx.x == 0) {
     if (tid == 0) {
       ba_begin_status(A.info, A.counters, A.first, gerr, U > A.U_max);
-      *A.arrive = 0;                              // hand-off words of the finish launch that follows
+      A.arrive[1] = A.arrive[1] + 1;              // token of the finish launch that follows: its arrival flags carry it
     }
     if (tid < 64) A.granX[tid] = 0ull;
   }
@@ -351,11 +353,15 @@ __device__ __forceinline__ void solve_wave(const BaWinArgs& A, int RW) {
   CDV_IF_STAMPS(const int sslot = 4000;)
   CDV_STAMP(baw, sslot, 0);
   CDV_STAMP_RT(baw, sslot, 14);
-  // ---- wait for the reduce workgroups (bounded: a lost hand-off must not hang the device) ----
+  // ---- wait for the reduce workgroups: each stores the launch's token into its own flag word once its part of the
+  // reduced system is written through -- no shared counter (same-address atomics serialise, ~90 ns each).  Bounded: a
+  // lost hand-off must not hang the device. ----
+  const int token = A.arrive[1];
   bool ok = false;
   for (int spins = 0; spins < (1 << 20); spins++) {
-    const int v = __hip_atomic_load(A.arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (v >= RW) { ok = true; break; }
+    const int f0 = lane < RW ? __hip_atomic_load(&A.arrive[16 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : token;
+    const int f1 = lane + 64 < RW ? __hip_atomic_load(&A.arrive[16 + 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : token;
+    if (__all(f0 == token && f1 == token)) { ok = true; break; }
     __builtin_amdgcn_s_sleep(1);
   }
   if (!ok) {
@@ -502,55 +508,63 @@ __global__ __launch_bounds__(256) void ba_finish_kernel(BaWinArgs A) {
   CDV_IF_STAMPS(const int sslot = 4100 + b * 4 + (tid >> 6);)
   CDV_STAMP(baw, sslot, 0);
   CDV_STAMP_RT(baw, sslot, 14);
-  // ---- 1. reduce the chunk slabs: thread = (16-byte column, one of G interleaved slab subsets).  G depends on the
-  //         number of slabs only and the butterfly over the subsets is fixed, so the sum is the same whatever the
-  //         launch geometry (U_max, number of workgroups): reproducible bits ----
+  // ---- 1. reduce the chunk slabs.  A CU streams ~10 B per cycle, so the 1.5 MB of slabs want many CUs: a workgroup takes
+  //         FOUR 16-byte columns, thread = (column, one of 64 interleaved slab subsets: 16 in the lanes of a DPP row x the 4
+  //         waves).  Per-thread sums in slab order, the row's 16 partials by DPP row shifts, the four waves' partials in
+  //         LDS: a fixed tree that depends on nothing but the number of slabs -- reproducible bits whatever the launch
+  //         geometry. ----
   {
     const int nsl = (U + CK - 1) / CK;
-    const int G = nsl <= 1024 ? 8 : 16;
-    const int cols_per_wg = 256 / G;
-    const int g = tid % G;
-    for (int col = b * cols_per_wg + tid / G; col - tid / G < SLAB / 4; col += RW * cols_per_wg) {   // workgroup-uniform trip count
-      cdv_float4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const int g = tid & 15, cs = (tid >> 4) & 3, w = tid >> 6;
+    __shared__ cdv_float4 s_part[4][4];
+    const int token = A.arrive[1];
+    for (int col0 = b * 4; col0 < SLAB / 4; col0 += RW * 4) {   // workgroup-uniform trip count
+      const int col = col0 + cs;
       const bool mine = col < SLAB / 4;
+      cdv_float4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
       if (mine) {
         const cdv_float4* src = reinterpret_cast<const cdv_float4*>(A.slabs) + col;
-        // 32 loads in flight per thread (one memory round trip covers 32 G slabs = 4,096 patches), summed in slab order
-        for (int s0 = g; s0 < nsl; s0 += 32 * G) {
-          cdv_float4 v[32];
+        for (int s0 = g + 16 * w; s0 < nsl; s0 += 8 * 64) {   // 8 loads in flight: 512 slabs per memory round trip
+          cdv_float4 v[8];
 #pragma unroll
-          for (int u = 0; u < 32; u++) {
-            const int sidx = s0 + u * G;
+          for (int u = 0; u < 8; u++) {
+            const int sidx = s0 + 64 * u;
             v[u] = (sidx < nsl) ? src[(size_t)sidx * (SLAB / 4)] : cdv_float4{0.f, 0.f, 0.f, 0.f};
           }
 #pragma unroll
-          for (int u = 0; u < 32; u++) acc[u & 3] += v[u];
+          for (int u = 0; u < 8; u++) acc[u & 1] += v[u];
         }
       }
-      cdv_float4 tot = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-      // the G partials sit in adjacent lanes: lane g = 0 collects them with DPP row shifts (a fixed tree)
+      cdv_float4 tot = acc[0] + acc[1];
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
+      for (int j = 0; j < 4; j++) {   // lane g = 0 of the row collects the 16 partials with DPP row shifts
         float t = tot[j];
         t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x101, 0xf, 0xf, true));   // row_shl:1
         t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x102, 0xf, 0xf, true));   // row_shl:2
         t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x104, 0xf, 0xf, true));   // row_shl:4
-        if (G == 16) t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x108, 0xf, 0xf, true));   // row_shl:8
+        t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x108, 0xf, 0xf, true));   // row_shl:8
         tot[j] = t;
       }
-      if (mine && g == 0) {
+      if (g == 0) s_part[w][cs] = tot;
+      __syncthreads();
+      if (w == 0 && g == 0 && mine) {
+        const cdv_float4 t4 = ((s_part[0][cs] + s_part[1][cs]) + s_part[2][cs]) + s_part[3][cs];
         // written through (8-byte agent-scope stores): the solver reads them past its L1
         uint64_t* dst = reinterpret_cast<uint64_t*>(A.ared + 4 * col);
-        __hip_atomic_store(dst, ((uint64_t)(uint32_t)__float_as_int(tot[1]) << 32) | (uint32_t)__float_as_int(tot[0]),
+        __hip_atomic_store(dst, ((uint64_t)(uint32_t)__float_as_int(t4[1]) << 32) | (uint32_t)__float_as_int(t4[0]),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(dst + 1, ((uint64_t)(uint32_t)__float_as_int(tot[3]) << 32) | (uint32_t)__float_as_int(tot[2]),
+        __hip_atomic_store(dst + 1, ((uint64_t)(uint32_t)__float_as_int(t4[3]) << 32) | (uint32_t)__float_as_int(t4[2]),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
+      __syncthreads();
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains before the workgroup counts itself in
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the storing wave drains before the workgroup raises its flag
     __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_add(A.arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_store(&A.arrive[16 + b], token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  // only the first RT workgroups go on to the retraction (256 patches each per pass); the others were here for the reduce
+  const int RT = min(RW, max(1, (U + 255) / 256));
+  if (b >= RT) return;
   CDV_STAMP(baw, sslot, 1);
   // ---- 2. before dX exists: everything of this thread's patch that does not depend on it ----
   __shared__ __attribute__((aligned(16))) float sdx[64];
@@ -590,8 +604,8 @@ __global__ __launch_bounds__(256) void ba_finish_kernel(BaWinArgs A) {
   __syncthreads();
   CDV_STAMP(baw, sslot, 3);
   if (!s_ok) return;   // no update without a solution: poses and depths stay as they were
-  // ---- 4. pose retraction T <- Exp(dX_i) T: the last workgroup's first N lanes ----
-  if ((int)blockIdx.x == (int)gridDim.x - 1 && tid < N) {
+  // ---- 4. pose retraction T <- Exp(dX_i) T: the first retract workgroup's first N lanes ----
+  if (b == 0 && tid < N) {
     float* p = A.poses + 7 * (size_t)(A.t0 + tid);
     float pose[7], xi[6];
 #pragma unroll
@@ -620,7 +634,7 @@ __global__ __launch_bounds__(256) void ba_finish_kernel(BaWinArgs A) {
       for (int a = 0; a < PP; a++) pk[a] = d;
     }
     // more patches than one pass of the retract workgroups covers: the next block of 256 (loaded now, dX is known)
-    r += RW * 256;
+    r += RT * 256;
     if (r - tid >= U) { CDV_STAMP(baw, sslot, 4); CDV_STAMP_RT(baw, sslot, 15); break; }          // workgroup-uniform
     livep = r < U;
 #pragma unroll
@@ -649,10 +663,12 @@ int cdv::cdv_ba_window_iteration(const BaWinArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(ba_chunk_kernel<true>, dim3(n_ck), dim3(64 * CKW), sizeof(float) * LDS_CHUNK_FLOATS, s, a);
   else
     hipLaunchKernelGGL(ba_chunk_kernel<false>, dim3(n_ck), dim3(64 * CKW), sizeof(float) * LDS_CHUNK_FLOATS, s, a);
-  // reduce / retract workgroups: one per 256 patches of capacity, at least 16 (the reduce wants the parallelism), at
-  // most WIN_MAX_RW (they all poll the solver)
-  int RW = cdv_div_up(a.U_max, 256);
-  RW = RW < 16 ? 16 : (RW > WIN_MAX_RW ? WIN_MAX_RW : RW);
+  // reduce workgroups: one per four 16-byte columns of a slab (119), at least one per 256 patches of capacity for the
+  // retraction the first of them go on to, at most WIN_MAX_RW (their arrival flags)
+  int RW = cdv_div_up(WIN_SLAB / 4, 4);
+  const int rw_p = cdv_div_up(a.U_max, 256);
+  RW = RW < rw_p ? rw_p : RW;
+  RW = RW > WIN_MAX_RW ? WIN_MAX_RW : RW;
   hipLaunchKernelGGL(ba_finish_kernel, dim3(1 + RW), dim3(256), 0, s, a);
   CDV_LAUNCH_CHECK();
   return CDV_OK;

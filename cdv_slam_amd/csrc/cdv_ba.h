@@ -22,7 +22,8 @@ constexpr int WIN_TRI = WIN_SN * (WIN_SN + 1) / 2;   // packed lower triangle of
 constexpr int WIN_SLAB = 1896;                   // floats per partial system: TRI + 60 (y), padded to a multiple of 8
 constexpr int WIN_CK = 16;                       // unique patches per chunk workgroup
 constexpr int WIN_MAX_GRID = 1024;               // chunk workgroups per launch (grid-stride over the chunks beyond)
-constexpr int WIN_MAX_RW = 32;                   // reduce / retract workgroups of the finish launch
+constexpr int WIN_MAX_RW = 128;                  // reduce workgroups of the finish launch (the first few also retract)
+constexpr int HAND_WORDS = 16 + WIN_MAX_RW;      // hand-off words: [1] launch token, [16 + b] arrival flag of reduce workgroup b
 
 // ---- the same design for 10 < N <= BA_NMAX free poses (ba_mid.hip): the slab is the packed triangle of a 6N x 6N system
 constexpr int MID_N = BA_NMAX;
@@ -76,7 +77,7 @@ inline BaLayout ba_layout(int64_t U_max, int N_max) {
     // the reduced system: packed (window path) or as dense rows [6N + 1][solve_ld] (mid path)
     const size_t ared = N_max <= WIN_N ? slab : (size_t)(6 * N_max + 1) * (size_t)solve_ld(6 * N_max);
     L.ared = o;  o = align256(o + sizeof(float) * ared);
-    L.hand = o;  o = align256(o + 64);
+    L.hand = o;  o = align256(o + sizeof(int32_t) * HAND_WORDS);
   }
   L.total = o;
   return L;
@@ -94,7 +95,7 @@ struct BaWinArgs {
   int ell_chunks;
   const int64_t* kx;
   float *slabs, *ared;
-  int32_t* arrive;                   // arrival counter of the reduce workgroups
+  int32_t* arrive;                   // hand-off words (HAND_WORDS): token and arrival flags of the reduce workgroups
   uint64_t* granX;                   // dX granules {tag, value}
   float *Cg, *ug, *qg, *Edg, *dXg;
   int U_stride, U_max, n_ck_cap;

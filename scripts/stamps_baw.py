@@ -49,7 +49,7 @@ print("finish kernel, solver wave:")
 for i, nme in enumerate(["wait for the reduce", "row loads", "factor", "back substitution", "publish"]):
     print("  %-24s %8.0f cycles" % (nme, sol[i + 1] - sol[i]))
 srt = sol[14:16] / 100.0
-red = b[4100:4100 + 4 * 40]
+red = b[4100:4100 + 4 * 128]
 red = red[red[:, 0] > 0]
 print("finish kernel, %d reduce/retract waves:" % len(red))
 for i, nme in enumerate(["reduce + publish", "preload", "wait for dX", "retract"]):
