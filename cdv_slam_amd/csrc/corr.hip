@@ -499,7 +499,7 @@ __device__ __forceinline__ LevelParams level_params(const CorrLevel& L) {
 }
 
 // one edge; its first round trip (coordinates: lane l < 18 holds value l; indices) was issued by the caller
-template <int CC, int NLEV>
+template <int CC, int NLEV, bool SPLIT>
 __device__ __forceinline__ void corr_edge(const CorrArgs2& a, int p, int e, int cval, int64_t k64, int64_t j64, int lane,
                                           _Float16* __restrict__ raw, _Float16* __restrict__ outT) {
   CDV_STAMP(corr, p, 0);
@@ -671,7 +671,7 @@ __device__ __forceinline__ void corr_edge(const CorrArgs2& a, int p, int e, int 
   // ---- stage the edge's output row [x][y][m][lev] in LDS, then 16-byte-per-lane stores ------------------------------
   wave_lds_sync();   // the row overwrites the raw volume: keep the stores behind the last blend's reads
   if (lane < 63 && !CDV_EXP(512)) {
-    if (NLEV == 2 && a.split) {
+    if (NLEV == 2 && SPLIT) {
       _Float16* o0 = outT + __mul24(bxo, 63) + bm;   // half (x, y, m) = 63 x + 9 y + m; level 1 starts 442 halfs on
 #pragma unroll
       for (int yo = 0; yo < 7; yo++) { o0[yo * 9] = res0[yo]; o0[442 + yo * 9] = res1[yo]; }
@@ -694,7 +694,7 @@ __device__ __forceinline__ void corr_edge(const CorrArgs2& a, int p, int e, int 
       // 441 dwords: two 16-byte-per-lane stores (256 + 184 dwords) and one last dword.  The row starts on a 4-byte
       // boundary only (1764 B per edge); global memory takes the unaligned 16-byte accesses.
       const uint32_t* src = reinterpret_cast<const uint32_t*>(outT);
-      uint32_t* dst = reinterpret_cast<uint32_t*>(a.out) + (size_t)e * (a.split ? 442 : 441);
+      uint32_t* dst = reinterpret_cast<uint32_t*>(a.out) + (size_t)e * (SPLIT ? 442 : 441);
       typedef uint32_t cdv_u32x4 __attribute__((ext_vector_type(4)));
       typedef uint32_t cdv_u32x4u __attribute__((ext_vector_type(4), aligned(4)));
       const cdv_u32x4 v0 = *reinterpret_cast<const cdv_u32x4*>(src + 4 * lane);
@@ -704,7 +704,7 @@ __device__ __forceinline__ void corr_edge(const CorrArgs2& a, int p, int e, int 
         *reinterpret_cast<cdv_u32x4u*>(dst + 256 + 4 * lane) = v1;
       }
       if (lane == 63) dst[440] = src[440];
-      if (lane == 62 && a.split) dst[441] = src[441];
+      if (lane == 62 && SPLIT) dst[441] = src[441];
     } else {
       _Float16* dst = a.out + (size_t)e * a.out_pitch + a.out_off;
 #pragma unroll
@@ -717,7 +717,7 @@ __device__ __forceinline__ void corr_edge(const CorrArgs2& a, int p, int e, int 
   CDV_STAMP(corr, p, 8);
 }
 
-template <int CC, int NLEV>
+template <int CC, int NLEV, bool SPLIT = false>
 __global__ __launch_bounds__(256) void corr_fused2_kernel(const CorrArgs2 a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lane = threadIdx.x & 63;
@@ -736,7 +736,7 @@ __global__ __launch_bounds__(256) void corr_fused2_kernel(const CorrArgs2 a) {
     const float r = a.coords_ref[(size_t)e * 18 + min(lane, 17)] * a.ref_mul;
     if (__all(lane >= 18 || __float_as_int(r) == cval)) return;
   }
-  corr_edge<CC, NLEV>(a, p0, e, cval, a.kk[e], a.jj[e], lane, raw, outT);
+  corr_edge<CC, NLEV, SPLIT>(a, p0, e, cval, a.kk[e], a.jj[e], lane, raw, outT);
 }
 
 // ---- generic per-level kernel: planar layouts, any C / P / radius, f16 or f32 ----------------------
@@ -1169,7 +1169,11 @@ static int corr_fused_impl(const void* gmap, const void* fmap0_nhwc, const void*
                       nlev == 2 ? level(fmap1_nhwc, H1, W1, scale1, ex1 - ex0) : A0, C, gmap_pixel_major, exp,
                       out_stride, out_off, out_pitch, coords_ref, ref_mul, split};
     const int blocks = 8 * (int)cdv_div_up(E, 32);   // a multiple of 8: the kernel deals contiguous eighths to the XCDs
-    if (nlev == 2 && C == 24)
+    if (nlev == 2 && split) {   // levels kept apart (cdv_corr_fused_split): a variant of its own, so that the main kernel
+                              // keeps its 72 VGPRs (74 with the choice at run time: 6 instead of 7 waves per SIMD, +7 %)
+      if (C == 24) hipLaunchKernelGGL((corr_fused2_kernel<24, 2, true>), dim3(blocks), dim3(256), smem, s, a);
+      else hipLaunchKernelGGL((corr_fused2_kernel<0, 2, true>), dim3(blocks), dim3(256), smem, s, a);
+    } else if (nlev == 2 && C == 24)
       hipLaunchKernelGGL((corr_fused2_kernel<24, 2>), dim3(blocks), dim3(256), smem, s, a);
     else if (nlev == 2)
       hipLaunchKernelGGL((corr_fused2_kernel<0, 2>), dim3(blocks), dim3(256), smem, s, a);
