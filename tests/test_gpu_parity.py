@@ -282,6 +282,23 @@ def test_corr_fused_vs_oracle(name):
     assert np.abs(got - truth).mean() <= 0.1 * tol
 
 
+def test_corr_processing_order_beyond_one_trip():
+    """the same order on a graph whose per-edge launches loop (E = 705,024 > 1,024 workgroups x 256 edges): still a
+    permutation grouped by target bin"""
+    import ctypes
+    st = synth.make_state("global_xl", features=False)
+    g = ops.GraphIndex(torch.device(DEV), E_cap=st.E, k_range=len(st.patches))
+    g.build(T(st.jj), T(st.kk), force=True, with_neighbors=True, ii=T(st.ii))
+    torch.cuda.synchronize()
+    order = torch.empty(st.E, dtype=torch.int32, device=DEV)
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    assert hip.hipMemcpy(ctypes.c_void_p(order.data_ptr()), g.corr_order_ptr(), 4 * st.E, 3) == 0
+    o = order.cpu().numpy().astype(np.int64)
+    assert np.array_equal(np.sort(o), np.arange(st.E))
+    assert (np.diff(st.jj[o] & 31) >= 0).all()
+
+
 def test_dropin_corr_pairs_the_two_level_calls():
     """cuda_corr.forward called the way slam.py:321-322 calls it (pyramid[0] with coords, pyramid[1] with coords / 4): from
     the second update on the first call computes both levels and the second only checks its coords on the device
