@@ -556,11 +556,12 @@ __global__ __launch_bounds__(256) void ba_finish_kernel(BaWinArgs A) {
         __hip_atomic_store(dst + 1, ((uint64_t)(uint32_t)__float_as_int(t4[3]) << 32) | (uint32_t)__float_as_int(t4[2]),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      __syncthreads();
+      if (col0 + RW * 4 < SLAB / 4) __syncthreads();   // another trip reuses s_part (workgroup-uniform)
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the storing wave drains before the workgroup raises its flag
-    __syncthreads();
-    if (tid == 0) __hip_atomic_store(&A.arrive[16 + b], token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (w == 0) {   // wave 0 holds every store of this workgroup: it drains, then raises the flag (no barrier needed)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (tid == 0) __hip_atomic_store(&A.arrive[16 + b], token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   // only the first RT workgroups go on to the retraction (256 patches each per pass); the others were here for the reduce
   const int RT = min(RW, max(1, (U + 255) / 256));
