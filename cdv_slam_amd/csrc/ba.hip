@@ -585,8 +585,8 @@ __device__ __forceinline__ cdv_float4 tile64_xyt(const float* X, const float* Y,
 }
 
 // Block step kb, part 1.  One wave per workgroup, lane = matrix row.  Every workgroup factors the 64x64 diagonal block
-// in its registers (redundantly; the single-wave scheme of ba_solve60_kernel: v_readlane broadcasts, v_pk_fma_f32
-// rank-1 updates, no barrier) and parks L_kk in LDS; workgroup 0 writes it back; workgroup b > 0 solves its 64 rows of
+// in its registers (redundantly; the single-wave scheme of ba_win.hip's solver: columns broadcast through LDS one ahead,
+// v_pk_fma_f32 rank-1 updates, no barrier) and parks L_kk in LDS; workgroup 0 writes it back; workgroup b > 0 solves its 64 rows of
 // the panel, X L_kk^T = A, by forward substitution along the row (L entries as LDS broadcast reads, 16 bytes at a
 // time); the last workgroup does the same for the right-hand-side row.
 __global__ __launch_bounds__(64) void ba_big_panel_kernel(float* __restrict__ A, int npad, int kb,
@@ -610,22 +610,53 @@ __global__ __launch_bounds__(64) void ba_big_panel_kernel(float* __restrict__ A,
       a2[2 * c4 + 1] = cdv_float2{q[2], q[3]};
     }
   }
+  // right-looking Cholesky in the wave's registers, column k broadcast through LDS ONE COLUMN AHEAD of its rank-1 update
+  // (the scheme of ba_win.hip's solver: a v_readlane costs ~16 cycles of issue, so only the chain -- L[k+1][k] and the next
+  // pivot -- travels that way; 2 x 2,016 of them made this kernel 21.7 us)
+  __shared__ __attribute__((aligned(16))) float colb[CNB];
   bool bad = false;
+  float Lk;
+  {
+    const float piv = readlane_f(a2[0][0], 0);
+    bad = !(piv > 0.f);
+    Lk = a2[0][0] * __builtin_amdgcn_rsqf(piv);
+    a2[0][0] = Lk;
+    colb[lane] = Lk;
+  }
+  cdv_float2 bcur[CNB / 2], bnxt[CNB / 2];   // column k / column k + 1 of L, the same in every lane (pairs of columns)
+#pragma unroll
+  for (int c4 = 0; c4 < CNB / 4; c4++) {
+    const cdv_float4 v = *reinterpret_cast<const cdv_float4*>(&colb[4 * c4]);
+    bcur[2 * c4] = cdv_float2{v[0], v[1]};
+    bcur[2 * c4 + 1] = cdv_float2{v[2], v[3]};
+  }
 #pragma unroll
   for (int k = 0; k < CNB; k++) {
-    float ak = a2[k >> 1][k & 1];
-    const float piv = readlane_f(ak, k);
-    bad = bad || !(piv > 0.f);                          // wave-uniform
-    const float inv = __builtin_amdgcn_rsqf(piv);
-    ak *= inv;                                           // column k of L (rows >= k)
-    a2[k >> 1][k & 1] = ak;
-    if ((k & 1) == 0) a2[k >> 1][1] = fmaf(-ak, readlane_f(ak, k + 1), a2[k >> 1][1]);
-    const cdv_float2 nak = {-ak, -ak};
-    cdv_float2 sb[CNB / 2];
+    float Ln = 0.f;
+    if (k + 1 < CNB) {
+      // column k + 1 first: its one update from column k, pivot, scale, broadcast request
+      const float an = fmaf(-Lk, readlane_f(Lk, k + 1), a2[(k + 1) >> 1][(k + 1) & 1]);
+      const float piv = readlane_f(an, k + 1);
+      bad = bad || !(piv > 0.f);                          // wave-uniform
+      Ln = an * __builtin_amdgcn_rsqf(piv);
+      a2[(k + 1) >> 1][(k + 1) & 1] = Ln;
+      colb[lane] = Ln;      // in-order LDS: the reads of column k were issued before this write
 #pragma unroll
-    for (int p = (k >> 1) + 1; p < CNB / 2; p++) sb[p] = cdv_float2{readlane_f(ak, 2 * p), readlane_f(ak, 2 * p + 1)};
+      for (int c4 = (k + 2) / 4; c4 < CNB / 4; c4++) {
+        const cdv_float4 v = *reinterpret_cast<const cdv_float4*>(&colb[4 * c4]);
+        bnxt[2 * c4] = cdv_float2{v[0], v[1]};
+        bnxt[2 * c4 + 1] = cdv_float2{v[2], v[3]};
+      }
+    }
+    // the rest of column k's rank-1 update (columns k + 2 ..) runs while column k + 1 travels through LDS
+    if (((k + 2) & 1) && k + 2 < CNB)
+      a2[(k + 2) >> 1][1] = fmaf(-Lk, bcur[(k + 2) >> 1][1], a2[(k + 2) >> 1][1]);
+    const cdv_float2 nLk = {-Lk, -Lk};
 #pragma unroll
-    for (int p = (k >> 1) + 1; p < CNB / 2; p++) a2[p] = __builtin_elementwise_fma(nak, sb[p], a2[p]);
+    for (int pp = (k + 3) >> 1; pp < CNB / 2; pp++) a2[pp] = __builtin_elementwise_fma(nLk, bcur[pp], a2[pp]);
+    Lk = Ln;
+#pragma unroll
+    for (int pp = (k + 2) >> 1; pp < CNB / 2; pp++) bcur[pp] = bnxt[pp];
   }
   // L_kk -> LDS (zeros above the diagonal), and back to the matrix from workgroup 0
 #pragma unroll
