@@ -610,6 +610,15 @@ __global__ __launch_bounds__(64) void ba_big_panel_kernel(float* __restrict__ A,
       a2[2 * c4 + 1] = cdv_float2{q[2], q[3]};
     }
   }
+  // this workgroup's own row of the panel (unused by workgroup 0), requested now
+  const bool rhs = rb == nb;
+  float* rowp = A + (size_t)(rhs ? npad : CNB * min(rb, nb - 1) + lane) * lda + c0;
+  float x[CNB];
+#pragma unroll
+  for (int c4 = 0; c4 < CNB / 4; c4++) {
+    const cdv_float4 q = *reinterpret_cast<const cdv_float4*>(rowp + 4 * c4);
+    x[4 * c4] = q[0]; x[4 * c4 + 1] = q[1]; x[4 * c4 + 2] = q[2]; x[4 * c4 + 3] = q[3];
+  }
   // right-looking Cholesky in the wave's registers, column k broadcast through LDS ONE COLUMN AHEAD of its rank-1 update
   // (the scheme of ba_win.hip's solver: a v_readlane costs ~16 cycles of issue, so only the chain -- L[k+1][k] and the next
   // pivot -- travels that way; 2 x 2,016 of them made this kernel 21.7 us)
@@ -680,16 +689,9 @@ __global__ __launch_bounds__(64) void ba_big_panel_kernel(float* __restrict__ A,
     return;
   }
   wave_lds_sync();
-  // ---- this workgroup's rows of the panel: x L^T = a, c = 0..63 in turn ------------------------------------
-  const bool rhs = rb == nb;
+  // ---- this workgroup's rows of the panel: x L^T = a, c = 0..63 in turn (the row was requested before the
+  // factorisation: its memory round trip ran underneath) -----------------------------------------------------
   if (rhs && lane > 0) return;                    // the right-hand side is one row
-  float* rowp = A + (size_t)(rhs ? npad : CNB * rb + lane) * lda + c0;
-  float x[CNB];
-#pragma unroll
-  for (int c4 = 0; c4 < CNB / 4; c4++) {
-    const cdv_float4 q = *reinterpret_cast<const cdv_float4*>(rowp + 4 * c4);
-    x[4 * c4] = q[0]; x[4 * c4 + 1] = q[1]; x[4 * c4 + 2] = q[2]; x[4 * c4 + 3] = q[3];
-  }
 #pragma unroll
   for (int c = 0; c < CNB; c++) {
     float sacc = x[c];
