@@ -349,7 +349,6 @@ __global__ __launch_bounds__(64 * MKW) void ba_mid_chunk_kernel(BaWinArgs A) {
       if (tid < slabf - (TRI_N + n6)) Sd[TRI_N + n6 + tid] = 0.f;
       const int T16 = ER / 16, ntile = T16 * (T16 + 1) / 2;
       const float* Fij0 = Fw + 54 + 27 * N;
-      const float* Fij1 = Fij0 + 36 * N;
       for (int pidx = wave; pidx < ntile; pidx += MKW) {
         int ti = (int)((sqrtf(8.0f * (float)pidx + 1.0f) - 1.0f) * 0.5f);   // lower-triangular tile pair (ti >= tj)
         if (((ti + 1) * (ti + 2)) >> 1 <= pidx) ti++;

@@ -53,7 +53,7 @@ static inline GraphLayout graph_layout(int64_t E_max, int64_t k_range) {
   L.koff_u = o;   o = align256(o + sizeof(int32_t) * (size_t)(U_max + 1));
   L.kx = o;       o = align256(o + sizeof(int64_t) * (size_t)U_max);
   L.ku = o;       o = align256(o + sizeof(int32_t) * (size_t)E_max);
-  L.pcsr_tmp = o; o = align256(o + sizeof(int32_t) * (size_t)E_max);
+  L.pcsr_tmp = o; o = align256(o + sizeof(int32_t) * 4 * (size_t)E_max);   // unsorted per-patch lists, {edge, jj, id - kmin, 0} per entry
   L.pcsr = o;     o = align256(o + sizeof(int32_t) * (size_t)E_max);
   L.prec = o;     o = align256(o + sizeof(int32_t) * 4 * (size_t)E_max);   // CSR records {edge, ii, jj, 0} in pcsr order
   L.ell_chunks = (U_max + 15) / 16 < ELL_CHUNKS ? (U_max + 15) / 16 : ELL_CHUNKS;

@@ -145,8 +145,11 @@ __global__ __launch_bounds__(256) void graph_fill_kernel(const int64_t* __restri
     }
     if (t < E) {
       const int d = (int)(t == t_first ? kk_first : kk[t]) - kmin;
+      const int jt = (int)jj[t];
       const int p = atomicAdd(&kcursor[d], 1);
-      pcsr_tmp[kcount[d] + p] = t;
+      // what the segment sort needs of the edge, in one 16-byte entry: it then walks the lists without going back to
+      // kk / jj (three dependent load levels instead of five)
+      *reinterpret_cast<int4*>(pcsr_tmp + 4 * (size_t)(kcount[d] + p)) = make_int4(t, jt, d, 0);
       ku[t] = krank[d];
     }
   }
@@ -173,24 +176,24 @@ __global__ __launch_bounds__(256) void graph_segsort_kernel(const int64_t* __res
     return;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) meta[GM_HAS_II] = ii ? 1 : 0;
-  const int kmin = meta[GM_KMIN], krange = meta[GM_KRANGE];
+  const int krange = meta[GM_KRANGE];
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t <= krange; t += gridDim.x * blockDim.x)
     kcursor[t] = 0;   // the fill cursors of this build: zero again for the next one
   for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < E; p += gridDim.x * blockDim.x) {
-    const int e = pcsr_tmp[p];
-    const int d = (int)kk[e] - kmin;
+    const int4 me = *reinterpret_cast<const int4*>(pcsr_tmp + 4 * (size_t)p);    // {edge, jj, id - kmin, 0} from the fill
+    const int e = me.x, d = me.z;
     const int lo = kcount[d], hi = kcount[d + 1];
     // one 64-bit key per edge: (jj, edge id), both below 2^31
-    const uint64_t ke = ((uint64_t)jj[e] << 32) | (uint32_t)e;
+    const uint64_t ke = ((uint64_t)(uint32_t)me.y << 32) | (uint32_t)e;
     int r = 0;
     uint64_t pk = 0, nk = ~(uint64_t)0;   // best predecessor / successor key so far (sentinels: none)
     for (int s0 = lo; s0 < hi; s0 += 4) {
-      int o[4];
       uint64_t ko[4];
 #pragma unroll
-      for (int u = 0; u < 4; u++) o[u] = pcsr_tmp[min(s0 + u, hi - 1)];
-#pragma unroll
-      for (int u = 0; u < 4; u++) ko[u] = ((uint64_t)jj[o[u]] << 32) | (uint32_t)o[u];
+      for (int u = 0; u < 4; u++) {
+        const int2 o = *reinterpret_cast<const int2*>(pcsr_tmp + 4 * (size_t)min(s0 + u, hi - 1));
+        ko[u] = ((uint64_t)(uint32_t)o.y << 32) | (uint32_t)o.x;
+      }
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const bool in = s0 + u < hi;
