@@ -89,7 +89,17 @@ __global__ __launch_bounds__(256) void graph_fill_kernel(const int64_t* __restri
   // this thread's first edge: requested before the order computation (whose barriers the loads would not cross)
   const int t_first = blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t kk_first = t_first < E ? kk[t_first] : 0;
-  const int64_t jj_first = (do_order && t_first < E) ? jj[t_first] : 0;
+  const int64_t jj_first = t_first < E ? jj[t_first] : 0;
+  // ... and its slot in the patch's list: the cursor's round trip runs under the order computation as well
+  const int err = meta[GM_ERROR];
+  const int krange = meta[GM_KRANGE], kmin = meta[GM_KMIN];
+  int d_first = 0, p_first = 0, kc_first = 0, kr_first = 0;
+  if (!err && t_first < E) {
+    d_first = (int)kk_first - kmin;
+    p_first = atomicAdd(&kcursor[d_first], 1);
+    kc_first = kcount[d_first];
+    kr_first = krank[d_first];
+  }
   if (do_order) {
     __shared__ int s_tot[32][ORD_BINS + 1], s_pre[32][ORD_BINS + 1];
     const int tid = threadIdx.x, bq = tid & 7, part = tid >> 3;   // 256 threads: 8 groups of four bins x 32 parts
@@ -130,8 +140,7 @@ __global__ __launch_bounds__(256) void graph_fill_kernel(const int64_t* __restri
       order[atomicAdd(&s_pos[b], 1)] = e;
     }
   }
-  if (meta[GM_ERROR]) return;
-  const int krange = meta[GM_KRANGE], kmin = meta[GM_KMIN];
+  if (err) return;
   const int n = max(E, krange + 1);
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
     if (t <= krange) {  // dense bins -> unique ranks
@@ -144,13 +153,14 @@ __global__ __launch_bounds__(256) void graph_fill_kernel(const int64_t* __restri
       }
     }
     if (t < E) {
-      const int d = (int)(t == t_first ? kk_first : kk[t]) - kmin;
-      const int jt = (int)jj[t];
-      const int p = atomicAdd(&kcursor[d], 1);
+      const bool first = t == t_first;
+      const int d = first ? d_first : (int)kk[t] - kmin;
+      const int jt = first ? (int)jj_first : (int)jj[t];
+      const int p = first ? p_first : atomicAdd(&kcursor[d], 1);
       // what the segment sort needs of the edge, in one 16-byte entry: it then walks the lists without going back to
       // kk / jj (three dependent load levels instead of five)
-      *reinterpret_cast<int4*>(pcsr_tmp + 4 * (size_t)(kcount[d] + p)) = make_int4(t, jt, d, 0);
-      ku[t] = krank[d];
+      *reinterpret_cast<int4*>(pcsr_tmp + 4 * (size_t)((first ? kc_first : kcount[d]) + p)) = make_int4(t, jt, d, 0);
+      ku[t] = first ? kr_first : krank[d];
     }
   }
 }
