@@ -161,5 +161,122 @@ def main():
     print("golden fixtures written:", out)
 
 
+def _patch_inputs(st):
+    """patches of the synthetic states are a 3x3 coordinate grid with one inverse depth per patch (synth.make_state):
+    the fixtures keep the three x values, the three y values and d per patch; tests/golden_util.py rebuilds the planes"""
+    xy = np.stack([st.patches[:, 0, 0, :], st.patches[:, 1, :, 0]], 1).copy()      # [P, 2, 3]
+    d = st.patches[:, 2, 1, 1].copy()
+    rebuilt = np.empty_like(st.patches)
+    rebuilt[:, 0] = xy[:, 0, None, :]
+    rebuilt[:, 1] = xy[:, 1, :, None]
+    rebuilt[:, 2] = d[:, None, None]
+    assert np.array_equal(rebuilt, st.patches)
+    return xy, d
+
+
+def bench_size():
+    """Round 3: fixtures at benchmark size, produced by the reference's own Python files.
+    (i)   cdvslam/ba.py:86-185 on BASELINE configs[0] (synth `pr1`: 10 frames x 96 patches, fully connected,
+          E = 9,600), ep = 1.0, two successive calls                                   -> ba_py_pr1.npz
+    (ii)  cdvslam/altcorr/correlation.py:51-71 `patchify` (bilinear / upperleft / raw; r = 0, 1, 3; f16 and f32
+          maps) with cuda_corr.patchify_forward backed by the oracle's gather           -> patchify_py.npz
+    (iii) cdvslam/projective_ops.py:53-130 on every 6th edge of the `small` graph with per-frame intrinsics
+                                                                                        -> pops_small_f32.npz"""
+    _install_shims()
+    sys.path.insert(0, REF)
+
+    def patchify_forward(net, coords, radius):
+        out = np.stack([O.patchify_raw(net[b].numpy(), coords[b].numpy(), radius) for b in range(net.shape[0])])
+        return [torch.from_numpy(out)]
+
+    sys.modules["cuda_corr"].patchify_forward = patchify_forward
+    from cdvslam import projective_ops as pops
+    from cdvslam.lietorch import SE3
+    from cdvslam import ba as refba
+    from cdvslam.altcorr import correlation as refcorr
+
+    out = {}
+    # ---- (i) ba.py on configs[0] --------------------------------------------------------------------
+    st = synth.make_state("pr1", features=False)
+    tdt = torch.float32
+    poses = torch.from_numpy(st.poses).to(tdt)[None]
+    patches = torch.from_numpy(st.patches).to(tdt)[None]
+    intr = torch.from_numpy(st.intrinsics).to(tdt)[None]
+    ii, jj, kk = (torch.from_numpy(x) for x in (st.ii, st.jj, st.kk))
+    target = torch.from_numpy(st.target)[None]
+    weight = torch.from_numpy(st.weight)[None]
+    h, w = st.cfg.ht // st.cfg.res, st.cfg.wd // st.cfg.res
+    bounds = [-64, -64, w + 64, h + 64]
+    with torch.no_grad():
+        P2, X2 = refba.BA(SE3(poses.clone()), patches.clone(), intr, target, weight, torch.as_tensor([1e-4]), ii, jj,
+                          kk, bounds, ep=1.0, fixedp=1)
+        P3, X3 = refba.BA(P2, X2, intr, target, weight, torch.as_tensor([1e-4]), ii, jj, kk, bounds, ep=1.0, fixedp=1)
+        _, Xs = refba.BA(SE3(poses.clone()), patches.clone(), intr, target, weight, torch.as_tensor([1e-4]), ii, jj,
+                         kk, bounds, ep=1.0, fixedp=1, structure_only=True)
+    c, d = _patch_inputs(st)
+    P = st.n * st.cfg.M
+    assert int(st.kk.max()) < P
+    for X in (X2, X3, Xs):                       # ba.py writes one inverse depth to all nine pixels (ba.py:176-180)
+        assert torch.equal(X[0, :P, 2], X[0, :P, 2, :1, :1].expand(-1, 3, 3))
+        assert torch.equal(X[0, :, :2], patches[0, :, :2])
+    np.savez_compressed(
+        os.path.join(HERE, "ba_py_pr1.npz"), poses=st.poses, patch_xy=c, patch_d=d, intrinsics=st.intrinsics,
+        target=st.target, weight=st.weight, frames=np.int64(st.n), M=np.int64(st.cfg.M),
+        bounds=np.array(bounds, np.float32), poses1=P2.data[0].numpy(), d1=X2[0, :, 2, 0, 0].numpy(),
+        poses2=P3.data[0].numpy(), d2=X3[0, :, 2, 0, 0].numpy(), d_structure_only=Xs[0, :, 2, 0, 0].numpy())
+    out["ba_py_pr1"] = len(st.ii)
+
+    # ---- (ii) altcorr.patchify, Python layer ---------------------------------------------------------
+    g = torch.Generator().manual_seed(1234)
+    B, C, H, W, M = 2, 8, 24, 32, 24
+    net16 = (torch.randn((B, C, H, W), generator=g) / 4).half()
+    net32 = torch.randn((B, 3, H, W), generator=g)
+    coords = torch.stack([torch.rand((B, M), generator=g) * (W + 6) - 3, torch.rand((B, M), generator=g) * (H + 6) - 3], -1)
+    coords[0, 0] = torch.tensor([0.0, 0.0])                 # integer coordinates, the four map corners, far outside
+    coords[0, 1] = torch.tensor([W - 1.0, H - 1.0])
+    coords[0, 2] = torch.tensor([-0.25, H - 0.5])
+    coords[0, 3] = torch.tensor([W + 20.0, -20.0])
+    res = dict(net16=net16.numpy(), net32=net32.numpy(), coords=coords.numpy())
+    with torch.no_grad():
+        for tag, net in (("f16", net16), ("f32", net32)):
+            for r in (0, 1, 3):
+                for mode in ("bilinear", "upperleft", "raw"):
+                    y = refcorr.patchify(net, coords, r, mode=mode)
+                    res["%s_r%d_%s" % (tag, r, mode)] = y.numpy()
+    np.savez_compressed(os.path.join(HERE, "patchify_py.npz"), **res)
+    out["patchify_py"] = len(res)
+
+    # ---- (iii) projective_ops on the `small` graph, per-frame intrinsics ------------------------------
+    st = synth.make_state("small", features=False)
+    poses = torch.from_numpy(st.poses)[None]
+    patches = torch.from_numpy(st.patches)[None]
+    intr = torch.from_numpy(st.intrinsics)[None]
+    intr = intr * (1 + 0.004 * torch.arange(intr.shape[1], dtype=torch.float32)[None, :, None])
+    sel = np.arange(0, st.E, 6)
+    ii, jj, kk = (torch.from_numpy(x[sel]) for x in (st.ii, st.jj, st.kk))
+    with torch.no_grad():
+        x1j, v, (Ji, Jj, Jz) = pops.transform(SE3(poses), patches, intr, ii, jj, kk, jacobian=True)
+        x1 = pops.transform(SE3(poses), patches, intr, ii, jj, kk)
+        x1v, val = pops.transform(SE3(poses), patches, intr, ii, jj, kk, valid=True)
+        fm, fv = pops.flow_mag(SE3(poses), patches, intr, ii, jj, kk, beta=0.5)
+        m = st.n * st.cfg.M
+        ix = torch.arange(m) // st.cfg.M
+        pc = pops.point_cloud(SE3(poses), patches[:, :m], intr, ix)
+    assert torch.equal(x1, x1v)
+    c, d = _patch_inputs(st)
+    np.savez_compressed(
+        os.path.join(HERE, "pops_small_f32.npz"), poses=st.poses, patch_xy=c, patch_d=d, intrinsics=intr[0].numpy(),
+        ii=ii.numpy(), jj=jj.numpy(), kk=kk.numpy(), coords=x1[0].numpy(), coords_jac_centre=x1j[0].numpy()[:, 1, 1],
+        valid=v[0].numpy(), Ji=Ji[0].numpy(), Jj=Jj[0].numpy(), Jz=Jz[0].numpy(), validpx=val[0].numpy(),
+        flow_mag=fm[0].numpy(), flow_valid=fv[0].numpy(), point_cloud_centre=pc[0].numpy()[:, 1, 1])
+    out["pops_small"] = len(sel)
+    for f in ("ba_py_pr1.npz", "patchify_py.npz", "pops_small_f32.npz"):
+        print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
+    print("benchmark-size fixtures written:", out)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "bench-size":
+        bench_size()
+    else:
+        main()

@@ -813,6 +813,106 @@ def test_ba_py_mirror_vs_reference_golden(golden_dir, tag):
     assert torch.equal(Ps.data, G("poses")[None])
 
 
+def test_ba_py_mirror_vs_reference_run_on_configs0():
+    """BASELINE configs[0] (10 x 96 fully connected, E = 9,600): cdv_slam_amd.ba.BA against what the reference's own
+    cdvslam/ba.py:86-185 produced on the same inputs (tests/golden/ba_py_pr1.npz), two successive calls and the
+    structure-only branch"""
+    from cdv_slam_amd import ba
+    from cdv_slam_amd.lietorch import SE3
+    from tests import golden_util
+    g = golden_util.load_ba_pr1()
+    args = (T(g["intrinsics"])[None], T(g["target"])[None], T(g["weight"])[None], torch.tensor([1e-4], device=DEV),
+            T(g["ii"]), T(g["jj"]), T(g["kk"]), [float(b) for b in g["bounds"]])
+    P1, X1 = ba.BA(SE3(T(g["poses"])[None]), T(g["patches"])[None], *args, ep=1.0, fixedp=1)
+    e1 = (np.abs(P1.data[0].cpu().numpy() - g["poses1"]).max(), np.abs(X1[0, :, 2, 0, 0].cpu().numpy() - g["d1"]).max())
+    P2, X2 = ba.BA(P1, X1, *args, ep=1.0, fixedp=1)
+    e2 = (np.abs(P2.data[0].cpu().numpy() - g["poses2"]).max(), np.abs(X2[0, :, 2, 0, 0].cpu().numpy() - g["d2"]).max())
+    print("ba.py mirror vs reference run (pr1): call 1 poses %.2e depth %.2e, call 2 poses %.2e depth %.2e" % (e1 + e2))
+    # the reference is a float32 Gauss-Newton on a weak-gauge system (one fixed pose): tests/ba_checks.py BA_TOL['pr1']
+    assert e1[0] <= 3e-5 and e1[1] <= 1e-4 and e2[0] <= 6e-5 and e2[1] <= 2e-4
+    assert torch.equal(X2[0, :, :2], T(g["patches"])[:, :2]) and torch.equal(X2[0, :, 2], X2[0, :, 2, :1, :1].expand(-1, 3, 3))
+    _, Xs = ba.BA(SE3(T(g["poses"])[None]), T(g["patches"])[None], *args, ep=1.0, fixedp=1, structure_only=True)
+    assert np.abs(Xs[0, :, 2, 0, 0].cpu().numpy() - g["d_structure_only"]).max() <= 2e-5
+
+
+def test_fastba_hip_vs_reference_ba_py_run_on_configs0():
+    """the HIP fastba (cdv_ba_forward through ops.ba_forward) against the reference's own ba.py run on BASELINE
+    configs[0]: ep = 1.0 is fastba's damping (ba_cuda.cu:589 == ba.py:66-73), and on this state no gate the two differ in
+    fires (checked on the CPU in tests/test_oracle_golden.py), so one fastba iteration == one ba.py call and two
+    iterations == two successive calls, to the float32 weak-gauge bounds BA_TOL['pr1'] -- plus the gauge-free ATE."""
+    from cdv_slam_amd import metrics
+    from tests import golden_util
+    g = golden_util.load_ba_pr1()
+    n, M = int(g["frames"]), int(g["M"])
+    tol = ba_checks.BA_TOL["pr1"]
+    for it, pk, dk in ((1, "poses1", "d1"), (2, "poses2", "d2")):
+        poses, patches = T(g["poses"]).clone(), T(g["patches"]).clone()
+        ops.ba_forward(poses, patches, T(g["intrinsics"]), T(g["target"]), T(g["weight"]), torch.tensor([1e-4], device=DEV),
+                       T(g["ii"]), T(g["jj"]), T(g["kk"]), M, 1, n, it, False)
+        torch.cuda.synchronize()
+        p, d = poses.cpu().numpy(), patches[:, 2, 0, 0].cpu().numpy()
+        got = dict(t=np.abs(p[:, :3] - g[pk][:, :3]).max(), q=np.abs(p[:, 3:] - g[pk][:, 3:]).max(),
+                   d=(np.abs(d - g[dk]) / np.maximum(np.abs(g[dk]), 1e-2)).max(), ate=metrics.ate_rmse(g[pk][:n], p[:n]))
+        print("HIP fastba x%d vs reference ba.py (pr1): " % it + "  ".join("%s %.2e" % kv for kv in got.items()))
+        ba_checks._log("vs_reference_ba_py", "pr1_it%d" % it, got, {k: tol[k] * it for k in got})
+        for k in got:
+            assert got[k] <= tol[k] * it, (it, k, got[k])
+        # in-place contract on the reference's state: the fixed pose and the x / y planes are untouched, nine equal depths
+        assert torch.equal(poses[0], T(g["poses"])[0]) and torch.equal(patches[:, :2], T(g["patches"])[:, :2])
+        assert torch.equal(patches[:n * M, 2], patches[:n * M, 2, :1, :1].expand(-1, 3, 3))
+
+
+def test_patchify_vs_reference_python_layer(golden_dir):
+    """altcorr.patchify (one launch: gather + blend) and ops.patchify_multi against the outputs of the reference's own
+    cdvslam/altcorr/correlation.py:51-71 (tests/golden/patchify_py.npz): three modes, r = 0 / 1 / 3, f16 and f32 maps,
+    batch 2, corners and far-outside coordinates"""
+    from cdv_slam_amd import altcorr
+    g = np.load(os.path.join(golden_dir, "patchify_py.npz"))
+    coords = T(g["coords"])
+    for tag in ("f16", "f32"):
+        net = T(g["net16" if tag == "f16" else "net32"])
+        for r in (0, 1, 3):
+            for mode in ("bilinear", "upperleft", "raw"):
+                want = g["%s_r%d_%s" % (tag, r, mode)]
+                got = altcorr.patchify(net, coords, r, mode=mode).cpu().numpy()
+                assert got.dtype == want.dtype and got.shape == want.shape, (tag, r, mode)
+                if mode == "bilinear":
+                    assert np.abs(got - want).max() <= 1e-6 * max(1.0, np.abs(want).max()), (tag, r, mode)
+                else:
+                    assert np.array_equal(got, want), (tag, r, mode)
+            if r < 3:
+                multi = ops.patchify_multi([dict(net=net, radius=r, mode="bilinear"), dict(net=net, radius=r, mode="upperleft")],
+                                           coords)
+                assert np.abs(multi[0].cpu().numpy() - g["%s_r%d_bilinear" % (tag, r)]).max() <= 1e-6 * 4
+                assert np.array_equal(multi[1].cpu().numpy(), g["%s_r%d_upperleft" % (tag, r)])
+
+
+def test_transform_vs_reference_run_on_small():
+    """cdv_transform against the reference's own projective_ops.py:53-130 on every 6th edge of the `small` graph with
+    per-frame intrinsics (tests/golden/pops_small_f32.npz)"""
+    from cdv_slam_amd import projective_ops as pops
+    from cdv_slam_amd.lietorch import SE3
+    from tests import golden_util
+    g = golden_util.load_pops_small()
+    poses, patches, intr = T(g["poses"])[None], T(g["patches"])[None], T(g["intrinsics"])[None]
+    ii, jj, kk = T(g["ii"]), T(g["jj"]), T(g["kk"])
+    x1 = pops.transform(SE3(poses), patches, intr, ii, jj, kk)
+    assert np.abs(x1[0].cpu().numpy() - g["coords"]).max() < 1e-3
+    x1j, v, (Ji, Jj, Jz) = pops.transform(SE3(poses), patches, intr, ii, jj, kk, jacobian=True)
+    assert np.array_equal(v[0].cpu().numpy(), g["valid"])
+    assert np.abs(x1j[0, :, 1, 1].cpu().numpy() - g["coords_jac_centre"]).max() < 1e-3
+    for a, b in ((Ji, g["Ji"]), (Jj, g["Jj"]), (Jz, g["Jz"])):
+        assert np.allclose(a[0].cpu().numpy(), b, rtol=2e-4, atol=1e-4 * np.abs(b).max())
+    x1v, val = pops.transform(SE3(poses), patches, intr, ii, jj, kk, valid=True)
+    assert np.array_equal(val[0].cpu().numpy(), g["validpx"])
+    fm, fv = pops.flow_mag(SE3(poses), patches, intr, ii, jj, kk, beta=0.5)
+    assert np.allclose(fm[0].cpu().numpy(), g["flow_mag"], atol=2e-3) and np.array_equal(fv[0].cpu().numpy(), g["flow_valid"])
+    m = g["point_cloud_centre"].shape[0]
+    ix = T((np.arange(m) // 16).astype(np.int64))
+    pc = pops.point_cloud(SE3(poses), patches[:, :m], intr, ix)
+    assert np.allclose(pc[0, :, 1, 1].cpu().numpy(), g["point_cloud_centre"], rtol=1e-4, atol=1e-4)
+
+
 def test_fused_flow_mag_point_cloud_patchify_vs_composed():
     """the one-launch forms of pops.flow_mag / pops.point_cloud / altcorr.patchify(mode=...) against the op-by-op
     composition the reference writes (projective_ops.py:115-130, correlation.py:51-71) and the oracle"""

@@ -118,3 +118,79 @@ def test_ate_metric_umeyama():
     noisy = np.concatenate([-(c0 + rng.normal(0, 1e-3, c0.shape)), np.tile([0, 0, 0, 1.0], (n, 1))], 1)
     e = metrics.ate_rmse(ref, noisy)
     assert 1.2e-3 < e < 2.2e-3     # sqrt(3) * 1e-3, minus what the alignment absorbs
+
+
+# ---------------------------------------------------------------------------------------------------
+# round 3: fixtures at benchmark size (tests/golden/make_golden.py bench-size)
+# ---------------------------------------------------------------------------------------------------
+
+def test_ba_py_reference_run_on_configs0_pins_both_oracles():
+    """BASELINE configs[0] (10 frames x 96 patches fully connected, E = 9,600) as the reference's OWN cdvslam/ba.py:86-185
+    computed it, two successive calls at ep = 1.0 (== fastba's damping, ba_cuda.cu:589):
+      * oracle/ba_py.py (the restatement of ba.py) reproduces both calls and the structure-only branch;
+      * the fastba restatement (oracle/fastba_impl.h, ba_cuda.cu:232-611) reproduces them too -- on this state none of the
+        gates the two differ in fires (residual < 128 px, every centre in bounds, inverse depth inside (1e-3, 10)) --
+        at the float32 level of the reference's arithmetic: the float32 instantiation to 1e-5, the float64 one within
+        the weak-gauge bounds of tests/ba_checks.py BA_TOL['pr1'] (the reference itself is float32)."""
+    from tests import golden_util, ba_checks
+    g = golden_util.load_ba_pr1()
+    args = (g["intrinsics"], g["target"], g["weight"], 1e-4, g["ii"], g["jj"], g["kk"], g["bounds"])
+    P1, X1, info = ba_py.BA(g["poses"], g["patches"], *args, ep=1.0, fixedp=1)
+    assert info == 0
+    assert np.abs(P1 - g["poses1"]).max() < 1e-5 and np.abs(X1[:, 2, 0, 0] - g["d1"]).max() < 2e-5
+    P2, X2, info = ba_py.BA(P1, X1, *args, ep=1.0, fixedp=1)
+    assert np.abs(P2 - g["poses2"]).max() < 2e-5 and np.abs(X2[:, 2, 0, 0] - g["d2"]).max() < 5e-5
+    _, Xs, _ = ba_py.BA(g["poses"], g["patches"], *args, ep=1.0, fixedp=1, structure_only=True)
+    assert np.abs(Xs[:, 2, 0, 0] - g["d_structure_only"]).max() < 1e-6
+    # the gates in which fastba and ba.py differ do not fire here
+    for d in (g["d1"], g["d2"]):
+        used = d[np.unique(g["kk"])]
+        assert used.min() > 1.001e-3 and used.max() < 9.99
+    c = O.fastba_reproject(g["poses"], g["patches"], g["intrinsics"][0], g["ii"], g["jj"], g["kk"], dtype=np.float64)[:, :, 1, 1]
+    b = g["bounds"]
+    assert (c[:, 0] > b[0]).all() and (c[:, 1] > b[1]).all() and (c[:, 0] < b[2]).all() and (c[:, 1] < b[3]).all()
+    assert np.linalg.norm(g["target"] - c, axis=-1).max() < 128
+    n = int(g["frames"])
+    tol = ba_checks.BA_TOL["pr1"]
+    for dt, (tt, tq, td) in ((np.float32, (1e-5, 1e-6, 5e-5)), (np.float64, (tol["t"], tol["q"], tol["d"]))):
+        for it, pk, dk in ((1, "poses1", "d1"), (2, "poses2", "d2")):
+            p, x, info = O.fastba(g["poses"], g["patches"], g["intrinsics"][0], g["target"], g["weight"], 1e-4, g["ii"],
+                                  g["jj"], g["kk"], 1, n, it, dt)
+            assert info == 0
+            assert np.abs(p[:, :3] - g[pk][:, :3]).max() <= tt * it, (dt, it)
+            assert np.abs(p[:, 3:] - g[pk][:, 3:]).max() <= tq, (dt, it)
+            assert (np.abs(x[:, 2, 0, 0] - g[dk]) / np.maximum(np.abs(g[dk]), 1e-2)).max() <= td * it, (dt, it)
+
+
+def test_patchify_python_layer_golden(golden_dir):
+    """altcorr.patchify (cdvslam/altcorr/correlation.py:51-71) as the reference's own Python computed it on top of the
+    gather: bilinear / upperleft / raw, r = 0, 1, 3, float16 and float32 maps, corner / outside coordinates."""
+    g = np.load(os.path.join(golden_dir, "patchify_py.npz"))
+    for tag in ("f16", "f32"):
+        net = g["net16" if tag == "f16" else "net32"]
+        for r in (0, 1, 3):
+            for mode in ("bilinear", "upperleft", "raw"):
+                want = g["%s_r%d_%s" % (tag, r, mode)]
+                got = np.stack([O.patchify(net[b], g["coords"][b], r, mode) for b in range(net.shape[0])])
+                assert got.dtype == want.dtype and got.shape == want.shape, (tag, r, mode)
+                if mode == "bilinear":
+                    assert np.allclose(got, want, rtol=0, atol=1e-6), (tag, r, mode)
+                else:
+                    assert np.array_equal(got, want), (tag, r, mode)
+
+
+def test_pops_small_golden():
+    """projective_ops.py:53-130 on every 6th edge of the `small` graph, per-frame intrinsics (ii's for iproj, jj's for
+    proj): coords, validity, Jacobians, flow_mag, point_cloud as the reference's own file computed them."""
+    from tests import golden_util
+    g = golden_util.load_pops_small()
+    args = (g["poses"], g["patches"], g["intrinsics"], g["ii"], g["jj"], g["kk"])
+    coords = O.transform(*args, dtype=np.float32)
+    assert np.abs(coords - g["coords"]).max() < 1e-3
+    c2, v, (Ji, Jj, Jz) = O.transform(*args, jacobian=True, dtype=np.float32)
+    assert np.array_equal(v, g["valid"])
+    assert np.abs(c2[:, 1, 1] - g["coords_jac_centre"]).max() < 1e-3
+    for a, b in ((Ji, g["Ji"]), (Jj, g["Jj"]), (Jz, g["Jz"])):
+        assert np.allclose(a, b, rtol=2e-4, atol=2e-5 * np.abs(b).max())
+    c3, vpx = O.transform(*args, valid=True, dtype=np.float32)
+    assert np.array_equal(vpx, g["validpx"])
