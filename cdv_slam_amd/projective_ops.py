@@ -1,102 +1,83 @@
-"""Host-side mirror of cdvslam/projective_ops.py on the fused HIP reprojection kernel.
+"""`projective_ops` operator surface (names and argument meaning of cdvslam/projective_ops.py) on the fused HIP kernels.
 
-`transform` is ONE kernel launch (cdv_transform) instead of the reference's gather + lietorch Inv /
-Mul / Act4 + elementwise chain (projective_ops.py:53-113); the remaining helpers are thin torch code.
+`transform` (+ validity, Jacobians, translation-only), `flow_mag` and `point_cloud` are ONE launch each
+(cdv_transform / cdv_flow_mag / cdv_point_cloud) where the reference composes gathers, lietorch Inv / Mul / Act4 and
+elementwise ops (projective_ops.py:53-130).  The kernels serve what the update path hands them -- float32 state, batch
+1, SE3 poses -- and anything else raises: there is no composed fallback.  `iproj` / `proj` are the two pinhole maps as
+plain tensor expressions for callers that want them on their own.
 """
 import torch
 
 from . import ops
-from .lietorch import SE3
+from .lietorch import LieGroup
 
 MIN_DEPTH = 0.2
 
 
-def extract_intrinsics(intrinsics):
-    return intrinsics[..., None, None, :].unbind(dim=-1)
-
-
-def coords_grid(ht, wd, **kwargs):
-    y, x = torch.meshgrid(torch.arange(ht).to(**kwargs).float(), torch.arange(wd).to(**kwargs).float(),
-                          indexing="ij")
-    return torch.stack([x, y], dim=-1)
+def _fc(intrinsics):
+    """[b,n,4] -> focal lengths and principal point as [b,n,2,1,1] each"""
+    k = intrinsics[..., None, None]
+    return k[:, :, 0:2], k[:, :, 2:4]
 
 
 def iproj(patches, intrinsics):
-    """inverse projection (projective_ops.py:19-29): patches [b,n,3,P,P], intrinsics [b,n,4] -> [b,n,P,P,4]"""
-    x, y, d = patches.unbind(dim=2)
-    fx, fy, cx, cy = intrinsics[..., None, None].unbind(dim=2)
-    return torch.stack([(x - cx) / fx, (y - cy) / fy, torch.ones_like(d), d], dim=-1)
+    """pixel grid + inverse depth -> homogeneous rays: patches [b,n,3,P,P], intrinsics [b,n,4] -> [b,n,P,P,4]
+    (x - cx) / fx, (y - cy) / fy, 1, d    (projective_ops.py:19-29)"""
+    f, c = _fc(intrinsics)
+    rays = (patches[:, :, 0:2] - c) / f
+    d = patches[:, :, 2:3]
+    return torch.cat([rays, torch.ones_like(d), d], dim=2).movedim(2, -1)
 
 
 def proj(X, intrinsics, depth=False):
-    """projection with d = 1 / Z.clamp(min=0.1) (projective_ops.py:32-50)"""
-    X, Y, Z, W = X.unbind(dim=-1)
-    fx, fy, cx, cy = intrinsics[..., None, None].unbind(dim=2)
-    d = 1.0 / Z.clamp(min=0.1)
-    x = fx * (d * X) + cx
-    y = fy * (d * Y) + cy
-    if depth:
-        return torch.stack([x, y, d], dim=-1)
-    return torch.stack([x, y], dim=-1)
+    """homogeneous points [b,n,P,P,4] -> pixels [b,n,P,P,2] (or 3 with the inverse depth), 1 / max(Z, 0.1) as the
+    reference clamps it (projective_ops.py:32-50)"""
+    f, c = _fc(intrinsics)
+    inv_z = X[..., 2].clamp(min=0.1).reciprocal()
+    uv = f.movedim(2, -1) * (X[..., 0:2] * inv_z[..., None]) + c.movedim(2, -1)
+    return torch.cat([uv, inv_z[..., None]], dim=-1) if depth else uv
 
 
-def _pose_data(poses):
-    return poses.data if isinstance(poses, SE3) else poses
+def _kernel_pose_rows(poses, what):
+    """the [1,n,7] float32 tensor the kernels read, or an error naming what is not served"""
+    data = poses.data if isinstance(poses, LieGroup) else poses
+    if isinstance(poses, LieGroup) and poses.group_id != 3:
+        raise NotImplementedError("%s: SE3 poses only (Sim3 belongs to loop closure, out of scope)" % what)
+    if not torch.is_tensor(data):
+        raise TypeError("%s: poses must be an SE3 or a tensor" % what)
+    if data.dtype != torch.float32 or data.dim() != 3 or data.shape[0] != 1:
+        raise NotImplementedError("%s: the HIP path serves float32 poses of batch 1 (got %s %s); no composed fallback"
+                                  % (what, data.dtype, tuple(data.shape)))
+    return data
 
 
 def transform(poses, patches, intrinsics, ii, jj, kk, depth=False, valid=False, jacobian=False, tonly=False):
-    """projective transform of patch k from frame i to frame j (projective_ops.py:53-113).
+    """patch k of frame i seen from frame j (projective_ops.py:53-113), one launch.
 
-    Returns coords [b,E,P,P,2]; with valid=True also (X1.z > 0.2) [b,E,P,P]; with jacobian=True
-    (coords, (Z > 0.2) [b,E], (Ji [b,E,2,6], Jj [b,E,2,6], Jz [b,E,2,1]))."""
-    data = _pose_data(poses)
-    if not isinstance(poses, SE3) and not torch.is_tensor(poses):
-        raise NotImplementedError("transform: only SE3 poses are on the update path (Sim3 is loop closure)")
-    if depth or data.dtype != torch.float32 or data.shape[0] != 1:
-        return _transform_composed(SE3(data), patches, intrinsics, ii, jj, kk, depth, valid, jacobian, tonly)
-    return ops.transform(data, patches, intrinsics, ii, jj, kk, layout_e2pp=False, valid=valid, jacobian=jacobian,
-                         tonly=tonly)
+    -> coords [1,E,P,P,2]; valid=True: also (Z > 0.2) per pixel [1,E,P,P]; jacobian=True:
+    (coords, (Z > 0.2) at the centre [1,E], (Ji [1,E,2,6], Jj [1,E,2,6], Jz [1,E,2,1]))."""
+    if depth:
+        raise NotImplementedError("transform(depth=True) is not on the update path")
+    return ops.transform(_kernel_pose_rows(poses, "transform"), patches, intrinsics, ii, jj, kk, layout_e2pp=False,
+                         valid=valid, jacobian=jacobian, tonly=tonly)
 
 
 def reproject(poses, patches, intrinsics, ii, jj, kk):
-    """SLAM.reproject (cdvslam/slam.py:325-329): transform(...).permute(0,1,4,2,3).contiguous() -> [1,E,2,P,P],
-    written directly in that layout."""
-    return ops.transform(_pose_data(poses), patches, intrinsics, ii, jj, kk, layout_e2pp=True)
-
-
-def _transform_composed(poses, patches, intrinsics, ii, jj, kk, depth, valid, jacobian, tonly):
-    """General path out of individual Lie ops (float64 poses, batch > 1, depth=True)."""
-    if jacobian:
-        raise NotImplementedError("transform(jacobian=True) is fused for float32 / batch 1 only")
-    X0 = iproj(patches[:, kk], intrinsics[:, ii])
-    Gij = poses[:, jj] * poses[:, ii].inv()
-    if tonly:
-        Gij.data[..., 3:] = torch.as_tensor([0, 0, 0, 1], device=Gij.device, dtype=Gij.dtype)
-    X1 = Gij[:, :, None, None] * X0
-    x1 = proj(X1, intrinsics[:, jj], depth)
-    if valid:
-        return x1, (X1[..., 2] > 0.2).float()
-    return x1
+    """SLAM.reproject (cdvslam/slam.py:325-329): the coords in the [1,E,2,P,P] layout the correlation reads, written
+    directly in that layout"""
+    return ops.transform(_kernel_pose_rows(poses, "reproject"), patches, intrinsics, ii, jj, kk, layout_e2pp=True)
 
 
 def point_cloud(poses, patches, intrinsics, ix):
-    """world points of patches (projective_ops.py:115-117)"""
-    data = _pose_data(poses)
-    if (data.dtype == torch.float32 and data.shape[0] == 1 and patches.dtype == torch.float32
-            and patches.shape[1] == ix.numel()):
-        return ops.point_cloud(data, patches, intrinsics, ix)     # one launch
-    poses = poses if isinstance(poses, SE3) else SE3(poses)
-    return poses[:, ix, None, None].inv() * iproj(patches, intrinsics[:, ix])
+    """world points of patches [1,m,3,P,P] whose frames are ix [m] -> [1,m,P,P,4] (projective_ops.py:115-117)"""
+    if patches.dtype != torch.float32 or patches.shape[1] != ix.numel():
+        raise NotImplementedError("point_cloud: float32 patches, one frame index per patch")
+    return ops.point_cloud(_kernel_pose_rows(poses, "point_cloud"), patches, intrinsics, ix)
 
 
 def flow_mag(poses, patches, intrinsics, ii, jj, kk, beta=0.3):
-    """flow magnitude used by the keyframe test (projective_ops.py:120-130)"""
-    data = _pose_data(poses)
-    if data.dtype == torch.float32 and data.shape[0] == 1 and patches.dtype == torch.float32:
-        return ops.flow_mag(data, patches, intrinsics, ii, jj, kk, beta)   # one launch instead of three + torch ops
-    coords0 = transform(poses, patches, intrinsics, ii, ii, kk)
-    coords1, val = transform(poses, patches, intrinsics, ii, jj, kk, tonly=False, valid=True)
-    coords2 = transform(poses, patches, intrinsics, ii, jj, kk, tonly=True)
-    flow1 = (coords1 - coords0).norm(dim=-1)
-    flow2 = (coords2 - coords0).norm(dim=-1)
-    return beta * flow1 + (1 - beta) * flow2, (val > 0.5)
+    """keyframe-test flow magnitude, beta * |full flow| + (1 - beta) * |translation-only flow|, and the validity mask
+    (projective_ops.py:120-130) -> ([1,E,P,P] f32, [1,E,P,P] bool)"""
+    if patches.dtype != torch.float32:
+        raise NotImplementedError("flow_mag: float32 patches")
+    return ops.flow_mag(_kernel_pose_rows(poses, "flow_mag"), patches, intrinsics, ii, jj, kk, beta)

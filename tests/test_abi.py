@@ -58,7 +58,7 @@ def test_operator_surface_names():
     assert callable(fastba.BA) and callable(fastba.neighbors) and callable(fastba.reproject)
     for n in ("SE3", "SO3", "cat", "stack"):
         assert hasattr(lietorch, n)
-    for n in ("transform", "iproj", "proj", "point_cloud", "flow_mag", "coords_grid"):
+    for n in ("transform", "iproj", "proj", "point_cloud", "flow_mag", "reproject"):
         assert hasattr(projective_ops, n)
     cc, cb, lb = cdv_slam_amd.install_dropin()
     for n in ("forward", "backward", "patchify_forward", "patchify_backward"):

@@ -880,11 +880,11 @@ def test_patchify_vs_reference_python_layer(golden_dir):
                     assert np.abs(got - want).max() <= 1e-6 * max(1.0, np.abs(want).max()), (tag, r, mode)
                 else:
                     assert np.array_equal(got, want), (tag, r, mode)
-            if r < 3:
-                multi = ops.patchify_multi([dict(net=net, radius=r, mode="bilinear"), dict(net=net, radius=r, mode="upperleft")],
-                                           coords)
-                assert np.abs(multi[0].cpu().numpy() - g["%s_r%d_bilinear" % (tag, r)]).max() <= 1e-6 * 4
-                assert np.array_equal(multi[1].cpu().numpy(), g["%s_r%d_upperleft" % (tag, r)])
+            for b in range(net.shape[0]):                       # the one-launch form of a frame's calls (batch 1)
+                multi = ops.patchify_multi([dict(net=net[b], radius=r, mode="bilinear"), dict(net=net[b], radius=r, mode="upperleft")],
+                                           coords[b])
+                assert np.abs(multi[0][0].cpu().numpy() - g["%s_r%d_bilinear" % (tag, r)][b]).max() <= 4e-6
+                assert np.array_equal(multi[1][0].cpu().numpy(), g["%s_r%d_upperleft" % (tag, r)][b])
 
 
 def test_transform_vs_reference_run_on_small():
