@@ -106,6 +106,8 @@ def dry_run(args):
     import numpy as np
     import torch
     from cdv_slam_amd.replicas import ReplicaGroup, aggregate_rate, summarise
+    if os.environ.get("CDV_BENCH_TEST_FAIL_RANK") == os.environ.get("RANK", "0"):
+        raise SystemExit(3)      # tests/test_replicas_gloo.py: a rank that dies before the rendezvous
     grp = ReplicaGroup(backend="gloo", device=torch.device("cpu"))
     if grp.world != args.gpus:
         raise SystemExit("process group has %d ranks, --gpus says %d" % (grp.world, args.gpus))
@@ -130,24 +132,52 @@ def dry_run(args):
     grp.close()
 
 
-def spawn_ranks(n, argv):
+def spawn_ranks(n, argv, timeout_s=900.0):
     """`bench.py --gpus N` run plainly: start the N rank processes (one per GPU, rendezvous on 127.0.0.1) from a parent
-    that never touches a GPU, forward rank 0's JSON line, exit with the worst status."""
+    that never touches a GPU, forward rank 0's JSON line, exit with the worst status.  All children are polled: when one
+    exits non-zero (or the whole run exceeds `timeout_s`) the others are terminated instead of waiting in the rendezvous
+    for torch's own timeout.  Every rank's stdout / stderr is kept on disk (gpurun_out/bench_rank<r>.log)."""
     import socket
     import subprocess
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    procs = []
+    logdir = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(logdir, exist_ok=True)
+    procs, logs = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
+        out = open(os.path.join(logdir, "bench_rank%d.log" % r), "w+")
+        err = open(os.path.join(logdir, "bench_rank%d.err" % r), "w")
+        logs.append((out, err))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=out, stderr=err))
+    t0 = time.perf_counter()
+    failed = None
+    while any(p.poll() is None for p in procs):
+        bad = [r for r, p in enumerate(procs) if p.poll() not in (None, 0)]
+        if bad or time.perf_counter() - t0 > timeout_s:
+            failed = "rank %d exited with %d" % (bad[0], procs[bad[0]].returncode) if bad else "timed out after %.0f s" % timeout_s
+            for p in procs:                    # the exact PIDs started above
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+        time.sleep(0.05)
+    rcs = [p.wait() for p in procs]
+    logs[0][0].seek(0)
+    sys.stdout.write(logs[0][0].read())
     sys.stdout.flush()
+    for out, err in logs:
+        out.close()
+        err.close()
+    if failed:
+        sys.stderr.write("bench.py --gpus %d: %s; per-rank logs in %s/bench_rank*.{log,err}\n" % (n, failed, logdir))
+        return max(1, max(abs(rc) for rc in rcs))
     return max(abs(rc) for rc in rcs)
 
 

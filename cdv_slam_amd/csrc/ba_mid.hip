@@ -595,11 +595,15 @@ __device__ __forceinline__ void mid_solve(const BaWinArgs& A, float* smem) {
         float o[NB];
 #pragma unroll
         for (int j = 0; j < NB; j++) o[j] = (lane == j) ? rs_k[j] : a[j];
+        bool copied = false;
         for (int spins = 0; spins < (1 << 16); spins++) {
-          if (__hip_atomic_load(&s_read, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= readers_due) break;
+          if (__hip_atomic_load(&s_read, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= readers_due) { copied = true; break; }
           __builtin_amdgcn_s_sleep(1);
         }
-        if (has) {
+        // a reader that never checked in: the block is NOT overwritten under it (the factor is then wrong, and said to be:
+        // the hand-off word is raised like for every other lost hand-off of this path)
+        if (!copied && lane == 0) ba_flag(A.info, BI_HANDOFF, 1);
+        if (has && copied) {
           float* rp = &Am[row * LD + c0];
 #pragma unroll
           for (int j = 0; j < NB; j += 4)

@@ -68,6 +68,23 @@ class GraphIndex:
         self.ws_bytes = nbytes
         self._key = None
 
+    @staticmethod
+    def _make_key(jj, kk, ii):
+        """identity + version of every tensor whose CONTENT is baked into the index: jj, kk, and ii when the build was
+        given it (the per-patch edge records carry the source frames the N <= 32 bundle adjustment reads).  Strong
+        references pin the tensors, so identity + version implies content."""
+        return (jj, kk, jj._version, kk._version, ii, None if ii is None else ii._version)
+
+    def _same_key(self, key):
+        """is the index in the workspace the one `key` describes?  A build WITH ii also serves a request without it
+        (neighbors() after the prologue); a build without ii, or with another / modified ii, does not serve a request with."""
+        k = self._key
+        if k is None or k[0] is not key[0] or k[1] is not key[1] or k[2] != key[2] or k[3] != key[3]:
+            return False
+        if key[4] is None:
+            return True
+        return k[4] is key[4] and k[5] == key[5]
+
     def corr_order_ptr(self):
         """device pointer (ctypes.c_void_p) of the correlation's processing order of the index currently in the
         workspace (edges grouped by target frame; cdv_graph_corr_order), for ops.corr_fused(order_ptr=...)"""
@@ -83,9 +100,10 @@ class GraphIndex:
         if jj.dtype != torch.int64 or kk.dtype != torch.int64:
             raise TypeError("index tensors must be int64")
         jj, kk = jj.contiguous(), kk.contiguous()
-        key = (jj, kk, jj._version, kk._version)
-        if (not force and self._key is not None and self._key[0] is jj and self._key[1] is kk
-                and self._key[2] == jj._version and self._key[3] == kk._version):
+        if ii is not None:
+            ii = ii.contiguous()
+        key = self._make_key(jj, kk, ii)
+        if not force and self._same_key(key):
             return self
         E = kk.numel()
         if jj.numel() != E:
@@ -96,7 +114,6 @@ class GraphIndex:
             _need_cuda(ii)
             if ii.dtype != torch.int64 or ii.numel() != E:
                 raise TypeError("ii must be int64 with one entry per edge")
-            ii = ii.contiguous()
         ix = jx = None
         if with_neighbors and E > 0:
             ix = torch.empty(E, dtype=torch.int64, device=self.device)
@@ -161,7 +178,7 @@ def update_prologue(graph, fmap_chw, fmap1_nhwc, fmap2_nhwc, slot, gmap, gmap_pm
                                  _p(intrinsics), _p(ii), _p(jj), _p(kk), E, 1 if layout_e2pp else 0, _p(coords),
                                  _p(graph.ws), graph.ws_bytes, graph.E_cap, graph.k_range, _p(ix), _p(jx), _stream())
     _lib.check(rc, "cdv_update_prologue")
-    graph._key = (jj, kk, jj._version, kk._version)
+    graph._key = graph._make_key(jj, kk, ii)
     graph.E = E
     graph._nbr = (ix, jx)
     return coords
@@ -368,6 +385,12 @@ def corr_fused(gmap, fmap0_nhwc, fmap1_nhwc, coords, kk, jj, kmod=0, jmod=0, sca
     return out
 
 
+def pair_levels_enabled():
+    """CDV_PAIR_LEVELS=0 switches the pairing of the two per-level cuda_corr.forward calls off (every call is then
+    computed on its own, as the reference's extension does); default on.  Read at every call."""
+    return os.environ.get("CDV_PAIR_LEVELS", "1") != "0"
+
+
 class _LevelPairing:
     """The reference calls cuda_corr.forward twice per update: pyramid[0] with coords, then pyramid[1] with coords / 4
     (slam.py:321-322), and stacks the two results (slam.py:323).  Seen from here the second call repeats the per-edge
@@ -375,29 +398,56 @@ class _LevelPairing:
     tensors, on two rings whose sizes differ by a power of two), the call on the first ring computes BOTH levels in one
     launch (cdv_corr_fused_split) into one buffer [E][2][442] and returns its level-0 view; the call that follows on the
     second ring only checks, per edge and on the device, that its coords are the first call's divided by the same power
-    of two, recomputes the edges for which they are not (cdv_corr_level_checked), and returns the level-1 view.  Nothing
-    is assumed: a second call that never comes, or comes with other tensors, costs the speculative level and nothing
-    else.  drops `n_fused` += 1 per pair served this way."""
+    of two, recomputes the edges for which they are not (cdv_corr_level_checked), and returns the level-1 view.
+
+    What is assumed, and what guards it (a documented mode, CDV_PAIR_LEVELS=0 turns it off):
+      * the speculative level-1 result is only handed out to the call that IMMEDIATELY follows, with the very same
+        tensor objects (patch tiles, ii, jj: identity AND version counter -- held alive by `pending`, so an address
+        the allocator recycles cannot impersonate them) on the ring that was learned as the partner, unchanged since
+        (identity + version); any other call in between -- a third caller -- drops the pending result;
+      * the learned partnership is keyed by the identity of ring A (a weak reference that must still resolve to the
+        very object), re-validated (shapes, dtype, contiguity, ratio) before every split launch;
+      * the coords are checked per edge on the device, so a caller whose second call is not coords / ratio gets the
+        recomputed values.
+    A second call that never comes costs the speculative level and nothing else.  `n_fused` counts pairs served."""
 
     def __init__(self):
-        self.learned = {}      # data_ptr of ring A -> (weakref of ring B, ratio)
-        self.last = None       # signature of the previous call
+        self.learned = {}      # id(ring A) -> (weakref ring A, weakref ring B, ratio)
+        self.last = None       # the previous call when it was an ordinary one
         self.pending = None
         self.n_fused = 0
 
     @staticmethod
-    def _sig(fmap1, fmap2, coords, ii, jj):
-        return (fmap1.data_ptr(), fmap1._version, ii.data_ptr(), jj.data_ptr(), ii.numel(), coords.shape[1])
+    def _same(held, now):
+        """every (tensor, version) pair recorded at the first call is the very object, unmodified"""
+        return all(t is u and v == u._version for (t, v), u in zip(held, now))
+
+    @staticmethod
+    def _hold(*ts):
+        return tuple((t, t._version) for t in ts)
+
+    def _partner(self, ringA):
+        ent = self.learned.get(id(ringA))
+        if ent is None:
+            return None, 0
+        ra, rb, ratio = ent[0](), ent[1](), ent[2]
+        if ra is not ringA or rb is None:          # the id was recycled by another tensor, or the partner is gone
+            del self.learned[id(ringA)]
+            return None, 0
+        ok = (rb.is_contiguous() and rb.dtype == torch.float16 and rb.shape[:3] == ringA.shape[:3]
+              and rb.shape[3] * ratio == ringA.shape[3] and rb.shape[4] * ratio == ringA.shape[4])
+        return (rb, ratio) if ok else (None, 0)
 
     def call(self, fmap1, fmap2, coords, ii, jj):
         import weakref
         lib = _lib.load()
-        sig = self._sig(fmap1, fmap2, coords, ii, jj)
         E = coords.shape[1]
         pend, self.pending = self.pending, None
+        last, self.last = self.last, None
+        if not pair_levels_enabled():
+            return None
         # ---- the second call of a pair whose first call computed both levels
-        if (pend is not None and pend["sig"] == sig and pend["ringB"]() is fmap2 and pend["verB"] == fmap2._version
-                and E == ii.numel()):
+        if (pend is not None and E == pend["E"] and self._same(pend["held"], (fmap1, ii, jj, fmap2))):
             shadow = _nhwc.get(fmap2)          # in step already (synchronised by the first call; the version has not moved)
             N2, H2, W2 = fmap2.shape[1], fmap2.shape[3], fmap2.shape[4]
             C = fmap1.shape[2]
@@ -407,13 +457,10 @@ class _LevelPairing:
                                             0, 0, 0, _stream())
             _lib.check(rc, "cdv_corr_level_checked")
             self.n_fused += 1
-            self.last = None
             return pend["buf"][:, 1, :441].view(1, E, 7, 7, 3, 3)
         # ---- a first call whose second is expected: both levels now
-        known = self.learned.get(fmap2.data_ptr())
-        ringB = known[0]() if known else None
-        if ringB is not None and ringB.is_contiguous() and ringB.dtype == torch.float16 and E == ii.numel() and E > 0:
-            ratio = known[1]
+        ringB, ratio = self._partner(fmap2)
+        if ringB is not None and E == ii.numel() == jj.numel() and E > 0:
             sa, sb = _nhwc.get(fmap2), _nhwc.get(ringB)
             C = fmap1.shape[2]
             g = fmap1[0].contiguous()
@@ -422,19 +469,19 @@ class _LevelPairing:
                                           g.numel() // (C * 9), fmap2.shape[1], C, fmap2.shape[3], fmap2.shape[4],
                                           ringB.shape[3], ringB.shape[4], 1.0, float(ratio), 0, 0, 0, _stream())
             _lib.check(rc, "cdv_corr_fused_split")
-            self.pending = {"sig": sig, "ringB": weakref.ref(ringB), "verB": ringB._version, "coords": coords, "ratio": ratio,
-                            "buf": buf}
-            self.last = None
+            self.pending = {"held": self._hold(fmap1, ii, jj, ringB), "E": E, "coords": coords, "ratio": ratio, "buf": buf}
             return buf[:, 0, :441].view(1, E, 7, 7, 3, 3)
-        # ---- an ordinary call: remember it, and learn the pairing from two in a row
-        if self.last is not None and self.last["sig"] == sig and self.last["ring"]() is not None:
-            ra = self.last["ring"]()
-            if ra is not fmap2 and ra.shape[:3] == fmap2.shape[:3]:
+        # ---- an ordinary call: remember it, and learn the pairing from two in a row on the same tiles and indices
+        if last is not None and E == last["E"] and self._same(last["held"], (fmap1, ii, jj)):
+            ra = last["ring"]
+            if ra is not fmap2 and ra.shape[:3] == fmap2.shape[:3] and fmap2.dtype == torch.float16:
                 h, w, H, W = fmap2.shape[3], fmap2.shape[4], ra.shape[3], ra.shape[4]
                 ratio = H // h if h > 0 else 0
                 if ratio >= 2 and (ratio & (ratio - 1)) == 0 and h * ratio == H and w * ratio == W:
-                    self.learned[ra.data_ptr()] = (weakref.ref(fmap2), ratio)
-        self.last = {"sig": sig, "ring": weakref.ref(fmap2)}
+                    if len(self.learned) >= 16:    # rings that died since
+                        self.learned = {k: v for k, v in self.learned.items() if v[0]() is not None and v[1]() is not None}
+                    self.learned[id(ra)] = (weakref.ref(ra), weakref.ref(fmap2), ratio)
+        self.last = {"held": self._hold(fmap1, ii, jj), "E": E, "ring": fmap2}
         return None
 
 

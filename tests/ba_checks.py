@@ -70,7 +70,7 @@ def check_end_state(name, st, poses, patches, p64, x64):
     et = np.abs(poses[:, :3] - p64[:, :3]).max()
     eq = np.abs(poses[:, 3:] - p64[:, 3:]).max()
     d, d64 = patches[:, 2, 0, 0].astype(np.float64), x64[:, 2, 0, 0]
-    ed = np.abs(d - d64).max() / np.maximum(np.abs(d64), 1e-2).max()
+    ed = (np.abs(d - d64) / np.maximum(np.abs(d64), 1e-2)).max()      # relative error per patch (of max(|d|, 1e-2))
     ate = metrics.ate_rmse(p64[:st.n], poses[:st.n])
     c64 = reprojection_cost(p64, x64, st)
     cg = reprojection_cost(poses, patches, st)

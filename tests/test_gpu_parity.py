@@ -337,6 +337,65 @@ def test_dropin_corr_pairs_the_two_level_calls():
         assert torch.equal(b, plain(f2, c1)), it
         assert stacked.shape[-1] == 882
     assert ops._pairing.n_fused == 2          # updates 1 and 2; update 0 taught the pattern
+    # a third caller between the two calls of a pair: the speculative level is dropped, nothing is mis-paired
+    other = base[:, : st.E // 2].contiguous() + 1.5
+    io, jo = ii1[: st.E // 2].contiguous(), jj1[: st.E // 2].contiguous()
+    coords = base + 2.11
+    a = ops.corr_forward(gmap, f1, coords / 1, ii1, jj1, 3)
+    x = ops.corr_forward(gmap, f2, other / 4, io, jo, 3)              # somebody else, other tensors, the partner ring
+    b = ops.corr_forward(gmap, f2, coords / 4, ii1, jj1, 3)
+    assert ops._pairing.n_fused == 2
+    assert torch.equal(a, plain(f1, coords / 1)) and torch.equal(b, plain(f2, coords / 4)) and torch.equal(x, plain(f2, other / 4))
+    # index tensors modified in place between the two calls (same objects, same addresses): not served from the pair
+    jj_mut = jj1.clone()
+    a = ops.corr_forward(gmap, f1, coords / 1, ii1, jj_mut, 3)
+    jj_mut[::3] = (jj_mut[::3] + 1) % st.cfg.mem
+    b = ops.corr_forward(gmap, f2, coords / 4, ii1, jj_mut, 3)
+    assert ops._pairing.n_fused == 2 and torch.equal(b, ops.corr_forward(gmap, f2, coords / 4, ii1, jj_mut.clone(), 3))
+    # the documented switch: CDV_PAIR_LEVELS=0 computes every call on its own
+    os.environ["CDV_PAIR_LEVELS"] = "0"
+    try:
+        n0 = ops._pairing.n_fused
+        for it in range(2):
+            a = ops.corr_forward(gmap, f1, coords / 1, ii1, jj1, 3)
+            b = ops.corr_forward(gmap, f2, coords / 4, ii1, jj1, 3)
+        assert ops._pairing.n_fused == n0 and ops._pairing.pending is None
+    finally:
+        del os.environ["CDV_PAIR_LEVELS"]
+    ops._pairing = ops._LevelPairing()
+
+
+def test_ba_rebuilds_the_index_when_only_ii_changes():
+    """the per-patch edge records carry the source frames (the N <= 32 kernels read them instead of ii): a second BA on
+    the SAME jj / kk tensors with another ii, or with ii modified in place, must not reuse the index built for the first"""
+    st = synth.make_state("small", features=False)
+    dev = torch.device(DEV)
+    jj, kk = T(st.jj), T(st.kk)
+    g = ops.GraphIndex(dev, E_cap=st.E, k_range=st.cfg.buffer_size * st.cfg.M)
+    ii_a = T(st.ii)
+    ii_b = ii_a.clone()
+    sel = torch.arange(0, st.E, 5, device=dev)
+    ii_b[sel] = torch.clamp(ii_b[sel] - 1, min=0)                  # some edges claim another source frame
+
+    def run(ii, graph):
+        poses, patches = T(st.poses).clone(), T(st.patches).clone()
+        ops.ba_forward(poses, patches, T(st.intrinsics), T(st.target), T(st.weight), torch.tensor([st.lmbda], device=dev), ii,
+                       jj, kk, st.cfg.M, st.t0, st.n, 2, False, graph=graph)
+        torch.cuda.synchronize()
+        return poses.cpu().numpy()
+
+    fresh = lambda: ops.GraphIndex(dev, E_cap=st.E, k_range=st.cfg.buffer_size * st.cfg.M)
+    want_a, want_b = run(ii_a, fresh()), run(ii_b, fresh())
+    assert not np.array_equal(want_a, want_b)
+    assert np.array_equal(run(ii_a, g), want_a)
+    assert np.array_equal(run(ii_b, g), want_b)                    # same jj / kk objects, another ii
+    ii_c = ii_a.clone()
+    assert np.array_equal(run(ii_c, g), want_a)
+    ii_c.copy_(ii_b)                                               # modified in place: the version counter moved
+    assert np.array_equal(run(ii_c, g), want_b)
+    # an index built without ii (neighbors) does not serve a BA that brings ii
+    g.build(jj, kk, force=True)
+    assert np.array_equal(run(ii_b, g), want_b)
 
 
 @pytest.mark.parametrize("name", ["small", "default"])
@@ -1120,6 +1179,32 @@ def test_ba_window_is_bitwise_reproducible():
         p2, x2, _ = _run_ba(st, iterations=2)
         assert np.array_equal(p1, p2) and np.array_equal(x1, x2), name
         assert not np.array_equal(p1, st.poses)
+
+
+def test_ba_never_dereferences_unwritten_index_slots():
+    """Regression for the round-2 abort ("the 11:36 abort"): the chunk-slot (ELL) copy of the edge
+    records has 32 slots per patch and the index build writes only the first deg(patch) of them; the chunk kernels load
+    all their first-round slots unconditionally and must replace what lies beyond a patch's degree BEFORE any field is used
+    as an index (settle_rec).  Here the index and BA workspaces are filled with a poison pattern (huge positive ints /
+    NaN-ish floats) before their first use, as a fresh allocation may be: the update must neither fault nor change."""
+    for name in ("default", "init", "stress", "mid19_m5"):
+        st, _ = _make(name)
+        want_p, want_x, _ = _run_ba(st, iterations=2)
+        g = ops.GraphIndex(torch.device(DEV), E_cap=st.E, k_range=st.cfg.buffer_size * st.cfg.M)
+        g.ws.view(torch.int32).fill_(0x7F7F7F7F)
+        dev = torch.device(DEV)
+        ws = ops._ba_workspace(dev, st.E, min(st.E, len(st.patches)), st.n - st.t0)   # the one ba_forward will pick up
+        ws.fill_(0x7F)
+        lib = ops._lib.load()
+        lib.cdv_workspace_forget(ops._p(ws))                   # as after a fresh allocation: the next use initialises it
+        import ctypes
+        ops._lib.check(lib.cdv_ba_bind_status_counters(ops._p(ws), ctypes.c_void_p(ops._ba_counters[dev].data_ptr())), "bind")
+        poses, patches = T(st.poses).clone(), T(st.patches).clone()
+        ops.ba_forward(poses, patches, T(st.intrinsics), T(st.target), T(st.weight), torch.tensor([st.lmbda], device=DEV),
+                       T(st.ii), T(st.jj), T(st.kk), st.cfg.M, st.t0, st.n, 2, False, graph=g)
+        torch.cuda.synchronize()
+        assert ops.ba_status(raise_on_error=False) == (0, 0, 0, 0), name
+        assert np.array_equal(poses.cpu().numpy(), want_p) and np.array_equal(patches.cpu().numpy(), want_x), name
 
 
 @pytest.mark.parametrize("variant", ["small", "mid15", "mid19_m5"])

@@ -101,3 +101,17 @@ def test_bench_starts_its_own_ranks():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"],
                          env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, timeout=120)
     assert bad.returncode != 0
+
+
+def test_bench_parent_stops_the_group_when_a_rank_dies():
+    """a rank that exits before the rendezvous: the parent notices, terminates the other rank (which would otherwise
+    sit in init_process_group until torch's own timeout), exits non-zero and says where the per-rank logs are"""
+    import subprocess
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    t0 = time.perf_counter()
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1",
+                          "--dry-run"], env=dict(env, CDV_BENCH_TEST_FAIL_RANK="1"), capture_output=True, timeout=200)
+    assert out.returncode != 0
+    assert time.perf_counter() - t0 < 120
+    assert b"rank 1 exited with 3" in out.stderr and b"bench_rank" in out.stderr
