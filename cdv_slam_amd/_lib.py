@@ -53,6 +53,10 @@ SIGNATURES = {
                                    _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _sz, _i64, _i64, _vp, _vp, _vp]),
     "cdv_graph_read_meta_host": (_i32, [_vp, _vp, _vp]),
     "cdv_graph_corr_order": (_vp, [_vp]),
+    "cdv_graph_bind_corr_stream": (_i32, [_vp, _vp, _i64, _i64, _i64, _i64, _f32]),
+    "cdv_graph_corr_records": (_vp, [_vp]),
+    "cdv_corr_fused_stream": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _f32, _f32,
+                                     _i32, _vp]),
     "cdv_graph_get_unique": (_i32, [_vp, _vp, _i64, _vp, _i64, _vp]),
     "cdv_neighbors": (_i32, [_vp, _i64, _vp, _vp, _vp]),
     "cdv_ba_workspace_bytes": (_sz, [_i64, _i64, _i32]),

@@ -30,10 +30,23 @@ constexpr int ELL_CHUNKS = 4096;
 // list an XCD works through touches three frames' feature maps instead of sixteen (counting sort riding the index build:
 // per-block counts from the histogram launch, positions and scatter in the fill launch)
 constexpr int ORD_BINS = 32;
+// packed input stream of the fused correlation, one record per edge in PROCESSING order (position p of `order`):
+// words [0, 18) the edge's reprojected coordinates (x[9], y[9]), [18] edge id, [19] patch-ring index, [20] frame-ring
+// index (both 0xFFFFFFFF when an index is outside its ring), [21] / [22] the extremes of floor(x / scale0) / floor(y / scale0)
+// over the nine pixels as (max << 16) | (min & 0xffff), [23] reserved.  96 bytes: a record never straddles more
+// than two 64-byte lines, and the correlation reads it with one vector and one scalar load.
+constexpr int CORR_REC_WORDS = 24;
+
+// what the index build needs to write that stream (bound to a workspace with cdv_graph_bind_corr_stream)
+struct CorrStream {
+  const float* coords;   // [E][2][3][3] f32, written earlier on the same stream (the prologue's reprojection)
+  uint32_t kmod, jmod, kmagic, jmagic, Ng, slots;
+  float inv_scale0;      // 1 / scale of pyramid level 0 (slam.py:321: 1)
+};
 
 struct GraphLayout {
   int64_t E_max, k_range;
-  size_t meta, stage, khist, kcount, kcursor, krank, koff_u, kx, ku, pcsr_tmp, pcsr, prec, pell, nprev, nnext, ocnt, order, total;
+  size_t meta, stage, khist, kcount, kcursor, krank, koff_u, kx, ku, pcsr_tmp, pcsr, prec, pell, nprev, nnext, ocnt, order, crec, total;
   int64_t ell_chunks;
 };
 
@@ -62,6 +75,7 @@ static inline GraphLayout graph_layout(int64_t E_max, int64_t k_range) {
   L.nnext = o;    o = align256(o + sizeof(int32_t) * (size_t)E_max);
   L.ocnt = o;     o = align256(o + sizeof(int32_t) * ORD_BINS * GRAPH_MAX_BLOCKS);   // [block][bin] edges of the block per target bin
   L.order = o;    o = align256(o + sizeof(int32_t) * (size_t)E_max);
+  L.crec = o;     o = align256(o + sizeof(uint32_t) * CORR_REC_WORDS * (size_t)E_max);
   L.total = o;
   return L;
 }
@@ -69,6 +83,7 @@ static inline GraphLayout graph_layout(int64_t E_max, int64_t k_range) {
 struct GraphView {
   int32_t* meta;
   int32_t *stage, *khist, *kcount, *kcursor, *krank, *koff_u, *ku, *pcsr_tmp, *pcsr, *prec, *pell, *nprev, *nnext, *ocnt, *order;
+  uint32_t* crec;
   int64_t* kx;
 };
 
@@ -92,6 +107,7 @@ static inline GraphView graph_view(void* ws, const GraphLayout& L) {
   v.nnext = (int32_t*)(b + L.nnext);
   v.ocnt = (int32_t*)(b + L.ocnt);
   v.order = (int32_t*)(b + L.order);
+  v.crec = (uint32_t*)(b + L.crec);
   return v;
 }
 

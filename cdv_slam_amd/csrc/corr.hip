@@ -22,6 +22,7 @@
 #include <stdlib.h>
 
 #include "cdv_common.h"
+#include "cdv_graph.h"
 #include "cdv_parts.h"
 
 CDV_STAMP_TU(corr)
@@ -490,6 +491,9 @@ struct CorrArgs2 {
   // two-level launches: != 0 keeps the levels apart, [E][2][442] halves (row 884 B: each level a contiguous run of 441 --
   // what two separate one-level results look like to torch.stack) instead of [E][441][2]
   int split;
+  // packed per-edge input stream in PROCESSING order (written by the index build next to `order`): record p =
+  // {18 coords, edge id, patch-ring index, frame-ring index (0xFFFFFFFF: invalid), ...} -- cdv_graph.h CORR_REC_WORDS
+  const uint32_t* rec;
 };
 
 constexpr uint32_t FBIAS = 0x4B000000u;   // bit pattern of 2^23
@@ -498,10 +502,20 @@ __device__ __forceinline__ LevelParams level_params(const CorrLevel& L) {
   return LevelParams{reinterpret_cast<const _Float16*>(L.base_m + (size_t)FBIAS), L.H, L.W, L.inv_scale, L.shift};
 }
 
-// one edge; its first round trip (coordinates: lane l < 18 holds value l; indices) was issued by the caller
-template <int CC, int NLEV, bool SPLIT>
-__device__ __forceinline__ void corr_edge(const CorrArgs2& a, int p, int e, int cval, int64_t k64, int64_t j64, int lane,
-                                          _Float16* __restrict__ raw, _Float16* __restrict__ outT) {
+// one edge; its first round trip (coordinates: lane l < 18 holds value l; ring indices already reduced and checked)
+// was issued by the caller
+// what the caller's first round trip brought: either the 18 coordinates spread over the lanes (cval: lane l < 18 holds
+// value l; the box is then found here), or -- from the packed input stream -- this lane's blend coordinates directly and
+// the wave-uniform extremes of floor(x), floor(y) over the patch (level 0) as scalars
+struct EdgeCoords {
+  int cval;
+  float xb, yb;
+  int ixmin, ixmax, iymin, iymax;
+};
+
+template <int CC, int NLEV, bool SPLIT, bool REC>
+__device__ __forceinline__ void corr_edge(const CorrArgs2& a, int p, int e, const EdgeCoords& ec, uint32_t kq, uint32_t jq,
+                                          bool idx_ok, int lane, _Float16* __restrict__ raw, _Float16* __restrict__ outT) {
   CDV_STAMP(corr, p, 0);
   const int C = CC ? CC : a.C;
 #ifdef CDV_STAMPS
@@ -510,24 +524,6 @@ __device__ __forceinline__ void corr_edge(const CorrArgs2& a, int p, int e, int 
   const int mm = lane < 9 ? lane : 0;       // row 0 of the wave: lanes 0..8 own patch pixel m, 9..15 mirror 0
   const int bm = min(lane / 7, 8), bxo = lane - 7 * (lane / 7);  // blend role of this lane: (m, x offset)
   const int n = lane & 15, g = lane >> 4;
-  // index % modulus (slam.py:319-320) with the host's reciprocal: q = mulhi(x, ceil(2^32 / d)) is x / d or one more
-  // for 0 <= x < 2^31, so one correction step
-  uint32_t kq = (uint32_t)k64, jq = (uint32_t)j64;
-  const bool k_small = (uint32_t)(k64 >> 32) == 0u && kq < 0x80000000u;
-  const bool j_small = (uint32_t)(j64 >> 32) == 0u && jq < 0x80000000u;
-  if (a.kmod > 1u) {
-    const int32_t r = (int32_t)(kq - __umulhi(kq, a.kmagic) * a.kmod);
-    kq = (uint32_t)(r < 0 ? r + (int32_t)a.kmod : r);
-  } else if (a.kmod == 1u) {
-    kq = 0u;
-  }
-  if (a.jmod > 1u) {
-    const int32_t r = (int32_t)(jq - __umulhi(jq, a.jmagic) * a.jmod);
-    jq = (uint32_t)(r < 0 ? r + (int32_t)a.jmod : r);
-  } else if (a.jmod == 1u) {
-    jq = 0u;
-  }
-  const bool idx_ok = k_small && j_small && kq < a.Ng && jq < a.slots;
   if (!idx_ok) { kq = 0u; jq = 0u; }  // reference behaviour is undefined here; stay in bounds, emit zeros
   if (CDV_EXP(16)) jq = 0u;
   const int64_t jslot = (int64_t)jq;
@@ -553,16 +549,28 @@ __device__ __forceinline__ void corr_edge(const CorrArgs2& a, int p, int e, int 
     }
   }
 
-  const float xv = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * mm, cval));
-  const float yv = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * (9 + mm), cval));
-  const float xb = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * bm, cval));
-  const float yb = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * (9 + bm), cval));
   const LevelParams L0 = level_params(a.L0), L1 = level_params(NLEV == 2 ? a.L1 : a.L0);
-  const int ixl = floor_clamped(xv * L0.inv_scale), iyl = floor_clamped(yv * L0.inv_scale);
-  int vxmin, vxmax, vymin, vymax;
-  row16_minmax4(ixl, iyl, vxmin, vxmax, vymin, vymax);
-  const int ixmin = __builtin_amdgcn_readfirstlane(vxmin), ixmax = __builtin_amdgcn_readfirstlane(vxmax);
-  const int iymin = __builtin_amdgcn_readfirstlane(vymin), iymax = __builtin_amdgcn_readfirstlane(vymax);
+  float xv, yv, xb, yb;
+  int ixmin, ixmax, iymin, iymax;
+  if (REC) {
+    // the stream brought this lane's blend coordinates and the box extremes: nothing to exchange between lanes.  (The
+    // per-pixel path below -- rare -- is the only user of (xv, yv): lanes 0..8 of the blend coordinates 7 m + xo.)
+    xb = ec.xb; yb = ec.yb;
+    xv = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * 7 * mm, __float_as_int(xb)));
+    yv = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * 7 * mm, __float_as_int(yb)));
+    ixmin = ec.ixmin; ixmax = ec.ixmax; iymin = ec.iymin; iymax = ec.iymax;
+  } else {
+    const int cval = ec.cval;
+    xv = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * mm, cval));
+    yv = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * (9 + mm), cval));
+    xb = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * bm, cval));
+    yb = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * (9 + bm), cval));
+    const int ixl = floor_clamped(xv * L0.inv_scale), iyl = floor_clamped(yv * L0.inv_scale);
+    int vxmin, vxmax, vymin, vymax;
+    row16_minmax4(ixl, iyl, vxmin, vxmax, vymin, vymax);
+    ixmin = __builtin_amdgcn_readfirstlane(vxmin); ixmax = __builtin_amdgcn_readfirstlane(vxmax);
+    iymin = __builtin_amdgcn_readfirstlane(vymin); iymax = __builtin_amdgcn_readfirstlane(vymax);
+  }
   const Box b0 = make_box(ixmin, ixmax, iymin, iymax, L0);
   const int sh1 = NLEV == 2 ? L1.shift : 0;
   const Box b1 = make_box(ixmin >> sh1, ixmax >> sh1, iymin >> sh1, iymax >> sh1, L1);
@@ -717,7 +725,21 @@ __device__ __forceinline__ void corr_edge(const CorrArgs2& a, int p, int e, int 
   CDV_STAMP(corr, p, 8);
 }
 
-template <int CC, int NLEV, bool SPLIT = false>
+// index % modulus (slam.py:319-320) with the host's reciprocal: q = mulhi(x, ceil(2^32 / d)) is x / d or one more
+// for 0 <= x < 2^31, so one correction step.  Returns false for an index outside its ring (or not a 31-bit value).
+__device__ __forceinline__ bool ring_index(int64_t v64, uint32_t mod, uint32_t magic, uint32_t limit, uint32_t& q) {
+  q = (uint32_t)v64;
+  const bool small = (uint32_t)(v64 >> 32) == 0u && q < 0x80000000u;
+  if (mod > 1u) {
+    const int32_t r = (int32_t)(q - __umulhi(q, magic) * mod);
+    q = (uint32_t)(r < 0 ? r + (int32_t)mod : r);
+  } else if (mod == 1u) {
+    q = 0u;
+  }
+  return small && q < limit;
+}
+
+template <int CC, int NLEV, bool SPLIT = false, bool REC = false>
 __global__ __launch_bounds__(256) void corr_fused2_kernel(const CorrArgs2 a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lane = threadIdx.x & 63;
@@ -729,6 +751,24 @@ __global__ __launch_bounds__(256) void corr_fused2_kernel(const CorrArgs2 a) {
   // 10 % slower -- fewer, longer waves.)
   const int p0 = (((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3)) * 4 + wave;
   if (p0 >= a.E) return;  // no block-wide barriers below: waves are independent
+  if (REC) {
+    // ---- ONE round trip: record p0 of the packed input stream the index build wrote in processing order -- the 18
+    // coordinates as one vector load, edge id and ring indices as scalar loads of the same line (no order[] -> coords /
+    // kk / jj indirection: one dependent memory round trip less per wave, no index arithmetic)
+    const uint32_t* r = a.rec + (size_t)p0 * cdv::CORR_REC_WORDS;
+    const int bm = min(lane / 7, 8);
+    EdgeCoords ec;
+    ec.cval = 0;
+    ec.xb = __int_as_float((int)r[bm]);          // two gathers from the record's one or two cache lines: each lane gets
+    ec.yb = __int_as_float((int)r[9 + bm]);      // the coordinates of ITS patch pixel, no cross-lane exchange
+    const int e = (int)r[18];
+    const uint32_t kq = r[19], jq = r[20];
+    const int bx = (int)r[21], by = (int)r[22];   // extremes of floor(x), floor(y): (max << 16) | (min & 0xffff)
+    ec.ixmin = (int)(short)(bx & 0xffff); ec.ixmax = bx >> 16;
+    ec.iymin = (int)(short)(by & 0xffff); ec.iymax = by >> 16;
+    corr_edge<CC, NLEV, SPLIT, true>(a, p0, e, ec, kq, jq, jq != 0xFFFFFFFFu, lane, raw, outT);
+    return;
+  }
   // ---- round trip 1: the 18 coordinates (one vector load) and the two indices (scalar loads) -----------------------
   const int e = a.order ? __builtin_amdgcn_readfirstlane(a.order[p0]) : p0;   // wave-uniform
   const int cval = __float_as_int(a.coords[(size_t)e * 18 + min(lane, 17)]);
@@ -736,7 +776,12 @@ __global__ __launch_bounds__(256) void corr_fused2_kernel(const CorrArgs2 a) {
     const float r = a.coords_ref[(size_t)e * 18 + min(lane, 17)] * a.ref_mul;
     if (__all(lane >= 18 || __float_as_int(r) == cval)) return;
   }
-  corr_edge<CC, NLEV, SPLIT>(a, p0, e, cval, a.kk[e], a.jj[e], lane, raw, outT);
+  uint32_t kq, jq;
+  const bool k_ok = ring_index(a.kk[e], a.kmod, a.kmagic, a.Ng, kq);
+  const bool j_ok = ring_index(a.jj[e], a.jmod, a.jmagic, a.slots, jq);
+  EdgeCoords ec;
+  ec.cval = cval;
+  corr_edge<CC, NLEV, SPLIT, false>(a, p0, e, ec, kq, jq, k_ok && j_ok, lane, raw, outT);
 }
 
 // ---- generic per-level kernel: planar layouts, any C / P / radius, f16 or f32 ----------------------
@@ -1135,7 +1180,8 @@ static int corr_fused_impl(const void* gmap, const void* fmap0_nhwc, const void*
                            const int64_t* kk, const int64_t* jj, const int32_t* order, void* out, int64_t E,
                            int64_t Ng, int64_t slots, int C, int H0, int W0, int H1, int W1, float scale0,
                            float scale1, int nlev, int64_t kmod, int64_t jmod, int gmap_pixel_major, void* stream,
-                           int out_stride, int out_off, int out_pitch, const float* coords_ref, float ref_mul, int split) {
+                           int out_stride, int out_off, int out_pitch, const float* coords_ref, float ref_mul, int split,
+                           const uint32_t* rec = nullptr) {
   CDV_REQUIRE(nlev == 1 || nlev == 2, CDV_ERR_ARG, "cdv_corr_fused: nlev must be 1 or 2");
   CDV_REQUIRE(C % 8 == 0 && C > 0 && C <= 128, CDV_ERR_UNSUPPORTED, "cdv_corr_fused: C must be a multiple of 8, <= 128");
   CDV_REQUIRE(E >= 0 && E < ((int64_t)1 << 31), CDV_ERR_ARG, "cdv_corr_fused: E out of range");
@@ -1167,9 +1213,13 @@ static int corr_fused_impl(const void* gmap, const void* fmap0_nhwc, const void*
     const CorrArgs2 a{coords, kk, jj, order, (int)E, (uint32_t)kmod, (uint32_t)jmod, kmagic, jmagic, (uint32_t)Ng,
                       (uint32_t)slots, (const char*)gmap, (_Float16*)out, A0,
                       nlev == 2 ? level(fmap1_nhwc, H1, W1, scale1, ex1 - ex0) : A0, C, gmap_pixel_major, exp,
-                      out_stride, out_off, out_pitch, coords_ref, ref_mul, split};
+                      out_stride, out_off, out_pitch, coords_ref, ref_mul, split, rec};
     const int blocks = 8 * (int)cdv_div_up(E, 32);   // a multiple of 8: the kernel deals contiguous eighths to the XCDs
-    if (nlev == 2 && split) {   // levels kept apart (cdv_corr_fused_split): a variant of its own, so that the main kernel
+    if (rec) {   // packed input stream in processing order (cdv_corr_fused_stream)
+      CDV_REQUIRE(nlev == 2 && !split && coords_ref == nullptr, CDV_ERR_UNSUPPORTED, "cdv_corr_fused_stream: two fused levels only");
+      if (C == 24) hipLaunchKernelGGL((corr_fused2_kernel<24, 2, false, true>), dim3(blocks), dim3(256), smem, s, a);
+      else hipLaunchKernelGGL((corr_fused2_kernel<0, 2, false, true>), dim3(blocks), dim3(256), smem, s, a);
+    } else if (nlev == 2 && split) {   // levels kept apart (cdv_corr_fused_split): a variant of its own, so that the main kernel
                               // keeps its 72 VGPRs (74 with the choice at run time: 6 instead of 7 waves per SIMD, +7 %)
       if (C == 24) hipLaunchKernelGGL((corr_fused2_kernel<24, 2, true>), dim3(blocks), dim3(256), smem, s, a);
       else hipLaunchKernelGGL((corr_fused2_kernel<0, 2, true>), dim3(blocks), dim3(256), smem, s, a);
@@ -1200,6 +1250,16 @@ extern "C" int cdv_corr_fused(const void* gmap, const void* fmap0_nhwc, const vo
                               float scale1, int nlev, int64_t kmod, int64_t jmod, int gmap_pixel_major, void* stream) {
   return corr_fused_impl(gmap, fmap0_nhwc, fmap1_nhwc, coords, kk, jj, order, out, E, Ng, slots, C, H0, W0, H1, W1, scale0,
                          scale1, nlev, kmod, jmod, gmap_pixel_major, stream, 1, 0, 441, nullptr, 1.0f, 0);
+}
+
+extern "C" int cdv_corr_fused_stream(const void* gmap, const void* fmap0_nhwc, const void* fmap1_nhwc, const void* records,
+                                     void* out, int64_t E, int64_t Ng, int64_t slots, int C, int H0, int W0, int H1, int W1,
+                                     float scale0, float scale1, int gmap_pixel_major, void* stream) {
+  CDV_REQUIRE(records != nullptr, CDV_ERR_ARG, "cdv_corr_fused_stream: NULL record stream");
+  CDV_REQUIRE(C <= 32, CDV_ERR_UNSUPPORTED, "cdv_corr_fused_stream: C must be <= 32");
+  return corr_fused_impl(gmap, fmap0_nhwc, fmap1_nhwc, nullptr, nullptr, nullptr, nullptr, out, E, Ng, slots, C, H0, W0, H1,
+                         W1, scale0, scale1, 2, 0, 0, gmap_pixel_major, stream, 1, 0, 441, nullptr, 1.0f, 0,
+                         (const uint32_t*)records);
 }
 
 extern "C" int cdv_corr_fused_split(const void* gmap, const void* fmap0_nhwc, const void* fmap1_nhwc, const float* coords,

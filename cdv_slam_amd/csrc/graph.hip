@@ -38,6 +38,7 @@ struct RegEntry {
   GraphLayout L;
   bool initialised;
   bool has_ii;
+  CorrStream cs;      // coords == nullptr: no packed correlation stream is written
 };
 std::mutex g_reg_mutex;
 std::unordered_map<const void*, RegEntry> g_registry;
@@ -70,6 +71,19 @@ __global__ __launch_bounds__(1024) void graph_scan_kernel(int32_t* meta, const i
   cdv::graph_scan_body(meta, stage, nstage, khist, kcount, krank, E, k_cap, (int)blockDim.x, (int)threadIdx.x);
 }
 
+// index % modulus with the host's reciprocal (as the correlation kernel reduces kk / jj itself when it reads them)
+__device__ __forceinline__ bool corr_ring_index(int64_t v64, uint32_t mod, uint32_t magic, uint32_t limit, uint32_t& q) {
+  q = (uint32_t)v64;
+  const bool small = (uint32_t)(v64 >> 32) == 0u && q < 0x80000000u;
+  if (mod > 1u) {
+    const int32_t r = (int32_t)(q - __umulhi(q, magic) * mod);
+    q = (uint32_t)(r < 0 ? r + (int32_t)mod : r);
+  } else if (mod == 1u) {
+    q = 0u;
+  }
+  return small && q < limit;
+}
+
 __global__ __launch_bounds__(256) void graph_fill_kernel(const int64_t* __restrict__ kk, int32_t E,
                                                          const int32_t* __restrict__ meta,
                                                          const int32_t* __restrict__ kcount, int32_t* kcursor,
@@ -78,7 +92,8 @@ __global__ __launch_bounds__(256) void graph_fill_kernel(const int64_t* __restri
                                                          int32_t* __restrict__ ku, int32_t* __restrict__ pcsr_tmp,
                                                          const int64_t* __restrict__ jj,
                                                          const int32_t* __restrict__ ocnt, int nblk_hist,
-                                                         int32_t* __restrict__ order) {
+                                                         int32_t* __restrict__ order, const CorrStream cs,
+                                                         uint32_t* __restrict__ crec) {
   // ---- the correlation's processing order (independent of the patch index and of its error state): a counting sort
   // of the edges by target bin.  The histogram launch left every workgroup's count per bin; this workgroup handles the
   // same edges, so its first position in bin b is (edges of the bins before b) + (edges of bin b in the workgroups
@@ -136,8 +151,42 @@ __global__ __launch_bounds__(256) void graph_fill_kernel(const int64_t* __restri
     }
     __syncthreads();
     for (int e = t_first; e < E; e += gridDim.x * blockDim.x) {
-      const int b = (int)(e == t_first ? jj_first : jj[e]) & (ORD_BINS - 1);
-      order[atomicAdd(&s_pos[b], 1)] = e;
+      const int64_t j64 = e == t_first ? jj_first : jj[e];
+      const int b = (int)j64 & (ORD_BINS - 1);
+      const int pos = atomicAdd(&s_pos[b], 1);
+      order[pos] = e;
+      if (cs.coords) {
+        // the correlation's packed input record of this edge, at its processing position: coordinates + reduced ring
+        // indices (slam.py:319-320), so that the correlation wave needs ONE memory round trip before its window loads
+        const int64_t k64 = e == t_first ? kk_first : kk[e];
+        uint32_t kq, jq;
+        const bool ok = corr_ring_index(k64, cs.kmod, cs.kmagic, cs.Ng, kq) & corr_ring_index(j64, cs.jmod, cs.jmagic, cs.slots, jq);
+        const float2* c2 = reinterpret_cast<const float2*>(cs.coords + (size_t)e * 18);   // 72 e: 8-byte aligned
+        uint32_t* r = crec + (size_t)pos * CORR_REC_WORDS;
+        float2 c[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) c[i] = c2[i];
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const auto bits = [](float f) { return (uint32_t)__float_as_int(f); };
+        u32x4* r4 = reinterpret_cast<u32x4*>(r);
+        r4[0] = u32x4{bits(c[0].x), bits(c[0].y), bits(c[1].x), bits(c[1].y)};
+        r4[1] = u32x4{bits(c[2].x), bits(c[2].y), bits(c[3].x), bits(c[3].y)};
+        r4[2] = u32x4{bits(c[4].x), bits(c[4].y), bits(c[5].x), bits(c[5].y)};
+        r4[3] = u32x4{bits(c[6].x), bits(c[6].y), bits(c[7].x), bits(c[7].y)};
+        r4[4] = u32x4{bits(c[8].x), bits(c[8].y), (uint32_t)e, ok ? kq : 0xFFFFFFFFu};
+        // extremes of floor(coordinate / scale of level 0) over the nine pixels, clamped to 16 bits (a box that far out
+        // is off the map either way): the correlation's window boxes without a cross-lane reduction
+        const auto fl = [&](float v) { return (int)fminf(fmaxf(floorf(v * cs.inv_scale0), -30000.f), 30000.f); };
+        int xlo = 30000, xhi = -30000, ylo = 30000, yhi = -30000;      // x = values 0..8, y = values 9..17
+#pragma unroll
+        for (int i = 0; i < 18; i++) {
+          const int v = fl((i & 1) ? c[i >> 1].y : c[i >> 1].x);       // per value, like the kernel's own reduction (NaN -> far out)
+          if (i < 9) { xlo = min(xlo, v); xhi = max(xhi, v); } else { ylo = min(ylo, v); yhi = max(yhi, v); }
+        }
+        const uint32_t bxw = ((uint32_t)xhi << 16) | ((uint32_t)xlo & 0xffffu);
+        const uint32_t byw = ((uint32_t)yhi << 16) | ((uint32_t)ylo & 0xffffu);
+        r4[5] = u32x4{ok ? jq : 0xFFFFFFFFu, bxw, byw, 0u};
+      }
     }
   }
   if (err) return;
@@ -314,7 +363,8 @@ int cdv_graph_prepare(const int64_t* jj, const int64_t* kk, int64_t E, void* ws,
     auto it = g_registry.find(ws);
     need_init = it == g_registry.end() || !it->second.initialised || it->second.L.E_max != E_max ||
                 it->second.L.k_range != k_range;
-    g_registry[ws] = RegEntry{L, true, false};
+    const CorrStream keep = it != g_registry.end() ? it->second.cs : CorrStream{nullptr, 0, 0, 0, 0, 0, 0, 1.0f};
+    g_registry[ws] = RegEntry{L, true, false, keep};
   }
   const GraphView v = graph_view(ws, L);
   if (need_init)
@@ -329,10 +379,14 @@ int cdv_graph_finish(const int64_t* ii, const int64_t* jj, const int64_t* kk, in
                      int64_t k_range, int hist_blocks, int64_t* ix, int64_t* jx, void* stream) {
   const GraphLayout L = graph_layout(E_max, k_range);
   const GraphView v = graph_view(ws, L);
+  CorrStream cs{nullptr, 0, 0, 0, 0, 0, 0, 1.0f};
   {
     std::lock_guard<std::mutex> lk(g_reg_mutex);
     auto it = g_registry.find(ws);
-    if (it != g_registry.end()) it->second.has_ii = ii != nullptr && E > 0;
+    if (it != g_registry.end()) {
+      it->second.has_ii = ii != nullptr && E > 0;
+      cs = it->second.cs;
+    }
   }
   hipStream_t s = (hipStream_t)stream;
   const int32_t En = (int32_t)E;
@@ -343,7 +397,7 @@ int cdv_graph_finish(const int64_t* ii, const int64_t* jj, const int64_t* kk, in
                        v.krank, En, k_range);
   if (E > 0) {
     hipLaunchKernelGGL(graph_fill_kernel, dim3(fb), dim3(tb), 0, s, kk, En, v.meta, v.kcount, v.kcursor, v.krank,
-                       v.koff_u, v.kx, v.ku, v.pcsr_tmp, jj, v.ocnt, hist_blocks, v.order);
+                       v.koff_u, v.kx, v.ku, v.pcsr_tmp, jj, v.ocnt, hist_blocks, v.order, cs, v.crec);
     hipLaunchKernelGGL(graph_segsort_kernel, dim3(fb), dim3(tb), 0, s, ii, jj, kk, En, v.meta, v.kcount, v.pcsr_tmp,
                        v.pcsr, v.prec, v.pell, (int)L.ell_chunks, v.krank, v.nprev, v.nnext, v.kcursor, ix, jx);
   }
@@ -371,6 +425,29 @@ extern "C" const int32_t* cdv_graph_corr_order(const void* ws) {
   GraphLayout L;
   if (!cdv_graph_lookup(ws, &L)) return nullptr;
   return graph_view((void*)ws, L).order;
+}
+
+extern "C" int cdv_graph_bind_corr_stream(void* ws, const float* coords, int64_t kmod, int64_t jmod, int64_t Ng,
+                                          int64_t slots, float scale0) {
+  CDV_REQUIRE(scale0 > 0.f, CDV_ERR_ARG, "cdv_graph_bind_corr_stream: scale of level 0 must be positive");
+  CDV_REQUIRE(ws != nullptr, CDV_ERR_ARG, "cdv_graph_bind_corr_stream: workspace is NULL");
+  CDV_REQUIRE(kmod >= 0 && jmod >= 0 && kmod < ((int64_t)1 << 31) && jmod < ((int64_t)1 << 31) && Ng >= 0 &&
+                  Ng < ((int64_t)1 << 31) && slots >= 0 && slots < ((int64_t)1 << 31),
+              CDV_ERR_ARG, "cdv_graph_bind_corr_stream: moduli / ring sizes out of range");
+  CorrStream cs{coords, (uint32_t)kmod, (uint32_t)jmod, 0u, 0u, (uint32_t)Ng, (uint32_t)slots, 1.0f / scale0};
+  cs.kmagic = kmod > 1 ? (uint32_t)((((uint64_t)1 << 32) + (uint64_t)kmod - 1) / (uint64_t)kmod) : 0u;
+  cs.jmagic = jmod > 1 ? (uint32_t)((((uint64_t)1 << 32) + (uint64_t)jmod - 1) / (uint64_t)jmod) : 0u;
+  std::lock_guard<std::mutex> lk(g_reg_mutex);
+  auto it = g_registry.find(ws);
+  if (it == g_registry.end()) g_registry[ws] = RegEntry{GraphLayout{}, false, false, cs};
+  else it->second.cs = cs;
+  return CDV_OK;
+}
+
+extern "C" const uint32_t* cdv_graph_corr_records(const void* ws) {
+  GraphLayout L;
+  if (!cdv_graph_lookup(ws, &L)) return nullptr;
+  return graph_view((void*)ws, L).crec;
 }
 
 extern "C" int cdv_graph_read_meta_host(const void* ws, int64_t* meta_host, void* stream) {

@@ -91,6 +91,22 @@ class GraphIndex:
         p = self.lib.cdv_graph_corr_order(_p(self.ws))
         return ctypes.c_void_p(p) if p else None
 
+    def bind_corr_stream(self, coords, kmod, jmod, Ng, slots, scale0=1.0):
+        """cdv_graph_bind_corr_stream: the following builds on this workspace also write the correlation's packed input
+        stream (coordinates + reduced ring indices in processing order) from `coords` [1,E,2,3,3] f32 -- a buffer that is
+        written earlier on the stream (update_prologue(coords_out=...)).  coords None unbinds."""
+        if coords is not None:
+            _need_cuda(coords)
+            if coords.dtype != torch.float32 or not coords.is_contiguous():
+                raise TypeError("bind_corr_stream: coords must be a contiguous float32 buffer")
+        _lib.check(self.lib.cdv_graph_bind_corr_stream(_p(self.ws), _p(coords), int(kmod), int(jmod), int(Ng), int(slots), float(scale0)),
+                   "cdv_graph_bind_corr_stream")
+        self._stream_coords = coords          # pinned: the builds read it
+
+    def corr_records_ptr(self):
+        p = self.lib.cdv_graph_corr_records(_p(self.ws))
+        return ctypes.c_void_p(p) if p else None
+
     def build(self, jj, kk, force=False, with_neighbors=False, ii=None):
         """Enqueue the index build for (jj, kk).  Re-used when called again with the same, unmodified
         tensor objects (neighbors() and BA() of one update share one build).  with_neighbors: the build also
@@ -157,7 +173,7 @@ class GraphIndex:
 
 
 def update_prologue(graph, fmap_chw, fmap1_nhwc, fmap2_nhwc, slot, gmap, gmap_pm, gmap_first, gmap_count, poses, patches,
-                    intrinsics, ii, jj, kk, layout_e2pp=True):
+                    intrinsics, ii, jj, kk, layout_e2pp=True, coords_out=None):
     """cdv_update_prologue: ring / tile ingest of the new frame, reprojection of all edges and the start of the
     patch-graph index in ONE launch (then the rest of the index build, with neighbors).  Returns coords; the
     neighbors are picked up with graph.neighbors()."""
@@ -169,7 +185,11 @@ def update_prologue(graph, fmap_chw, fmap1_nhwc, fmap2_nhwc, slot, gmap, gmap_pm
         raise TypeError("update_prologue: float32 state, 3x3 patches")
     dev = poses.device
     graph._reserve(E)
-    coords = torch.empty((1, E, 2, P, P) if layout_e2pp else (1, E, P, P, 2), dtype=torch.float32, device=dev)
+    shape = (1, E, 2, P, P) if layout_e2pp else (1, E, P, P, 2)
+    if coords_out is not None:      # a caller-owned buffer (the one bound with GraphIndex.bind_corr_stream)
+        coords = coords_out.view(-1)[: E * 2 * P * P].view(shape)
+    else:
+        coords = torch.empty(shape, dtype=torch.float32, device=dev)
     ix = torch.empty(E, dtype=torch.int64, device=dev)
     jx = torch.empty(E, dtype=torch.int64, device=dev)
     Ng = gmap.numel() // (C * 9) if gmap is not None else 0
@@ -389,6 +409,24 @@ def pair_levels_enabled():
     """CDV_PAIR_LEVELS=0 switches the pairing of the two per-level cuda_corr.forward calls off (every call is then
     computed on its own, as the reference's extension does); default on.  Read at every call."""
     return os.environ.get("CDV_PAIR_LEVELS", "1") != "0"
+
+
+def corr_fused_stream(gmap_pm, fmap0_nhwc, fmap1_nhwc, records_ptr, E, scales=(1.0, 4.0), out=None):
+    """cdv_corr_fused_stream: SLAM.corr (slam.py:316-323) in one launch from the packed input stream the index build
+    wrote (GraphIndex.bind_corr_stream / corr_records_ptr).  gmap_pm [Ng,9,C] pixel-major tiles -> [1,E,882] f16."""
+    lib = _lib.load()
+    _need_cuda(gmap_pm, fmap0_nhwc, fmap1_nhwc)
+    C = gmap_pm.shape[-1]
+    Ng = gmap_pm.numel() // (C * 9)
+    slots = fmap0_nhwc.shape[-4]
+    H0, W0 = fmap0_nhwc.shape[-3] - 2 * FMAP_PADY, fmap0_nhwc.shape[-2] - 2 * FMAP_PADX
+    H1, W1 = fmap1_nhwc.shape[-3] - 2 * FMAP_PADY, fmap1_nhwc.shape[-2] - 2 * FMAP_PADX
+    if out is None:
+        out = torch.empty((1, E, 882), dtype=torch.float16, device=gmap_pm.device)
+    rc = lib.cdv_corr_fused_stream(_p(gmap_pm), _p(fmap0_nhwc), _p(fmap1_nhwc), records_ptr, _p(out), E, Ng, slots, C, H0, W0,
+                                   H1, W1, float(scales[0]), float(scales[1]), 1, _stream())
+    _lib.check(rc, "cdv_corr_fused_stream")
+    return out
 
 
 class _LevelPairing:

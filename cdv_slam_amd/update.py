@@ -57,6 +57,14 @@ class UpdatePath:
             # together with its feature maps (what patchify + the ring writes do once per frame, net_cdv.py:355-374)
             self.gmap_pm = ops.gmap_to_pixel_major(self.gmap)
             self.new_tiles = ((st.n - 1) % st.cfg.pmem) * st.cfg.M
+            # the correlation reads its inputs as one packed stream in processing order, written by the index build from
+            # the coordinates the prologue leaves in this buffer (cdv_graph_bind_corr_stream); CDV_CORR_STREAM=0: the
+            # separate order[] / coords / kk / jj reads
+            import os
+            self.corr_stream = os.environ.get("CDV_CORR_STREAM", "1") != "0" and st.cfg.C <= 32
+            self.coords_buf = torch.empty((1, self.E, 2, 3, 3), dtype=torch.float32, device=device)
+            if self.corr_stream:
+                self.graph.bind_corr_stream(self.coords_buf, self.kmod, self.jmod, self.gmap_pm.shape[0], mem)
 
     def reset(self):
         self.poses.copy_(self._poses0)
@@ -88,9 +96,11 @@ class UpdatePath:
             # side in ONE launch, then the rest of the index build with 3. neighbors (net_cdv.py:102 -> ba.cpp:59-97)
             coords = ops.update_prologue(self.graph, self.new_frame, self.fmap1, self.fmap2, self.new_slot, self.gmap,
                                          self.gmap_pm, self.new_tiles, self.M, self.poses, self.patches, self.intrinsics,
-                                         self.ii, self.jj, self.kk)
+                                         self.ii, self.jj, self.kk, coords_out=self.coords_buf)
             out["ix"], out["jx"] = self.graph.neighbors()
+            self._stream_ready = self.corr_stream
         else:
+            self._stream_ready = False
             # patch-graph index (shared by neighbors and BA) + 3. neighbors: launches that only need (jj, kk)
             if self.overlap:
                 self._aux.wait_stream(main)      # the previous BA still reads the index this build overwrites
@@ -125,6 +135,9 @@ class UpdatePath:
         """just the fused correlation launch (dominant kernel) on the current stream"""
         # processing order by target frame, a by-product of this update's index build (prologue): each XCD's share of
         # the edges then works on ~3 frames' maps
+        if getattr(self, "_stream_ready", False) and coords.data_ptr() == self.coords_buf.data_ptr():
+            return ops.corr_fused_stream(self.gmap_pm, self.fmap1, self.fmap2, self.graph.corr_records_ptr(), self.E,
+                                         out=self.corr_out)
         return ops.corr_fused(self.gmap_pm, self.fmap1, self.fmap2, coords, self.kk, self.jj, kmod=self.kmod,
                               jmod=self.jmod, out=self.corr_out, pixel_major=True,
                               order_ptr=self.graph.corr_order_ptr() if (self.sorted_corr and not self.overlap) else None)

@@ -245,6 +245,23 @@ int cdv_graph_read_meta_host(const void* ws, int64_t* meta_host, void* stream);
  * next build; NULL if the workspace holds no index. */
 const int32_t* cdv_graph_corr_order(const void* graph_ws);
 
+/* The correlation's inputs as ONE packed stream in that processing order, written by the index build as well: record p
+ * (24 x 4 bytes) = the 18 reprojected coordinates of edge order[p], its edge id, and its ring indices kk % kmod, jj % jmod
+ * (slam.py:319-320; 0xFFFFFFFF when outside [0, Ng) / [0, slots)).  A correlation wave then needs one memory round trip
+ * (its record) before it can request its windows, instead of order[] -> coords / kk / jj.  Replaces nothing in the
+ * reference (which reads coords, ii, jj per thread, correlation_kernel.cu:93-113); same values, other placement.
+ *   cdv_graph_bind_corr_stream  tells a workspace where the coordinates of the NEXT builds live (coords [E][2][3][3] f32,
+ *                               written earlier on the same stream -- cdv_update_prologue does) and the ring sizes;
+ *                               coords == NULL unbinds.  Kept across builds, dropped by cdv_workspace_forget.
+ *   cdv_graph_corr_records      device pointer of the stream (valid like cdv_graph_corr_order), NULL without an index
+ *   cdv_corr_fused_stream       cdv_corr_fused (two levels, C <= 32) reading that stream */
+int cdv_graph_bind_corr_stream(void* graph_ws, const float* coords, int64_t kmod, int64_t jmod, int64_t Ng, int64_t slots,
+                               float scale0);
+const uint32_t* cdv_graph_corr_records(const void* graph_ws);
+int cdv_corr_fused_stream(const void* gmap, const void* fmap0_nhwc, const void* fmap1_nhwc, const void* records, void* out,
+                          int64_t E, int64_t Ng, int64_t slots, int C, int H0, int W0, int H1, int W1, float scale0,
+                          float scale1, int gmap_pixel_major, void* stream);
+
 /* copy out torch::_unique results (kx needs U from cdv_graph_read_meta_host to size it) */
 int cdv_graph_get_unique(const void* ws, int64_t* kx, int64_t kx_capacity, int64_t* ku, int64_t E, void* stream);
 

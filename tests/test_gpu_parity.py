@@ -316,10 +316,10 @@ def test_dropin_corr_pairs_the_two_level_calls():
     base = torch.as_tensor(np.stack([rng.uniform(4, w - 4, (st.E, 3, 3)), rng.uniform(4, h - 4, (st.E, 3, 3))], 1)[None]
                            .astype(np.float32), device=dev)
 
-    def plain(ring, c):      # an unpaired call: a fresh pairing state sees one call only
+    def plain(ring, c, ii=None, jj=None):      # an unpaired call: a fresh pairing state sees one call only
         saved, ops._pairing = ops._pairing, ops._LevelPairing()
         try:
-            return ops.corr_forward(gmap, ring, c, ii1, jj1, 3).clone()
+            return ops.corr_forward(gmap, ring, c, ii1 if ii is None else ii, jj1 if jj is None else jj, 3).clone()
         finally:
             ops._pairing = saved
 
@@ -345,7 +345,7 @@ def test_dropin_corr_pairs_the_two_level_calls():
     x = ops.corr_forward(gmap, f2, other / 4, io, jo, 3)              # somebody else, other tensors, the partner ring
     b = ops.corr_forward(gmap, f2, coords / 4, ii1, jj1, 3)
     assert ops._pairing.n_fused == 2
-    assert torch.equal(a, plain(f1, coords / 1)) and torch.equal(b, plain(f2, coords / 4)) and torch.equal(x, plain(f2, other / 4))
+    assert torch.equal(a, plain(f1, coords / 1)) and torch.equal(b, plain(f2, coords / 4)) and torch.equal(x, plain(f2, other / 4, io, jo))
     # index tensors modified in place between the two calls (same objects, same addresses): not served from the pair
     jj_mut = jj1.clone()
     a = ops.corr_forward(gmap, f1, coords / 1, ii1, jj_mut, 3)
@@ -386,16 +386,19 @@ def test_ba_rebuilds_the_index_when_only_ii_changes():
 
     fresh = lambda: ops.GraphIndex(dev, E_cap=st.E, k_range=st.cfg.buffer_size * st.cfg.M)
     want_a, want_b = run(ii_a, fresh()), run(ii_b, fresh())
-    assert not np.array_equal(want_a, want_b)
+    # (a patch with two source frames sums part of its E column with LDS atomics: ii_b's result is reproducible to
+    # rounding, not bit for bit -- hence a tolerance far below the difference between the two)
+    same = lambda x, y: np.abs(x - y).max() < 1e-6
+    assert np.abs(want_a - want_b).max() > 1e-4
     assert np.array_equal(run(ii_a, g), want_a)
-    assert np.array_equal(run(ii_b, g), want_b)                    # same jj / kk objects, another ii
+    assert same(run(ii_b, g), want_b)                              # same jj / kk objects, another ii
     ii_c = ii_a.clone()
     assert np.array_equal(run(ii_c, g), want_a)
     ii_c.copy_(ii_b)                                               # modified in place: the version counter moved
-    assert np.array_equal(run(ii_c, g), want_b)
+    assert same(run(ii_c, g), want_b)
     # an index built without ii (neighbors) does not serve a BA that brings ii
     g.build(jj, kk, force=True)
-    assert np.array_equal(run(ii_b, g), want_b)
+    assert same(run(ii_b, g), want_b)
 
 
 @pytest.mark.parametrize("name", ["small", "default"])
