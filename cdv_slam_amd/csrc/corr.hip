@@ -218,18 +218,21 @@ __device__ __forceinline__ void blend_level(const _Float16* __restrict__ raw, co
 
 // wide reprojection footprint (strong zoom / rotation): every patch pixel gets its own 8x8 window; two
 // window rows share one MFMA (pixels 0-7 | 8-15), only column m of D is kept.  Rare: compact, not tuned.
-template <int KS>
+// (xv, yv): the coordinates of patch pixel m are in lane LM * m
+template <int KS, int LM = 1>
 __device__ __forceinline__ void slow_level(const LevelParams& LP, int64_t jslot, float xv, float yv,
                                            const cdv_half8 (&pat)[KS], _Float16* __restrict__ raw, int lane, int C) {
   const int n = lane & 15, g = lane >> 4;
   const int Wp = LP.W + 2 * PADX, Hp = LP.H + 2 * PADY;
   const _Float16* fbase = LP.fmap + (size_t)jslot * Hp * Wp * C;
+#pragma unroll 1   // rare path: kept rolled, so that it adds no registers to the kernel (occupancy of the common path)
   for (int m = 0; m < 9; m++) {
-    const float xm = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv), m));
-    const float ym = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(yv), m));
+    const float xm = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv), LM * m));
+    const float ym = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(yv), LM * m));
     const int x0 = floor_clamped(xm * LP.inv_scale) - 3, y0 = floor_clamped(ym * LP.inv_scale) - 3;
     const int x0c = min(max(x0, -PADX), LP.W), y0c = min(max(y0, -PADY), LP.H);
     const bool outside = (x0c != x0) || (y0c != y0);
+#pragma unroll 1
     for (int t2 = 0; t2 < 4; t2++) {
       const int py = y0c + PADY + 2 * t2 + (n >> 3), px = x0c + PADX + (n & 7);
       cdv_float4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -256,20 +259,6 @@ __device__ __forceinline__ void zero_raw(_Float16* __restrict__ raw, int lane) {
   const cdv_u32x4z z = {0u, 0u, 0u, 0u};
   for (int i = lane; i < RAW_HALFS / 8; i += 64) reinterpret_cast<cdv_u32x4z*>(raw)[i] = z;
 }
-
-// groups q = 0 .. NQ_MAX - 1 of a round, in order, stopping at the first one past the window (nested tests: nothing
-// is tested after the last group).  A window has at least 8 x 8 pixels, so the first four groups of the first
-// round always exist.
-#define CDV_QCHAIN(OP, NQ, Q0)                                                                     \
-      if ((Q0) == 0) {                                                                             \
-        OP(0, Q0) OP(1, Q0) OP(2, Q0) OP(3, Q0)                                                    \
-        if ((NQ) > 4) { OP(4, Q0) if ((NQ) > 5) { OP(5, Q0) if ((NQ) > 6) { OP(6, Q0)              \
-          if ((NQ) > 7) { OP(7, Q0) if (NQ_MAX > 8 && (NQ) > 8) { OP(8, Q0) } } } } }              \
-      } else {                                                                                     \
-        OP(0, Q0) if ((NQ) > (Q0) + 1) { OP(1, Q0) if ((NQ) > (Q0) + 2) { OP(2, Q0) if ((NQ) > (Q0) + 3) { OP(3, Q0) \
-          if ((NQ) > (Q0) + 4) { OP(4, Q0) if ((NQ) > (Q0) + 5) { OP(5, Q0) if ((NQ) > (Q0) + 6) { OP(6, Q0) \
-          if ((NQ) > (Q0) + 7) { OP(7, Q0) if (NQ_MAX > 8 && (NQ) > (Q0) + 8) { OP(8, Q0) } } } } } } } } \
-      }
 
 // ---- wide feature vectors (DPVO, C = 128; KS = C / 32 k-steps): one 16-pixel tile per window row ---------------
 template <int KS>
@@ -554,10 +543,9 @@ __device__ __forceinline__ void corr_edge(const CorrArgs2& a, int p, int e, cons
   int ixmin, ixmax, iymin, iymax;
   if (REC) {
     // the stream brought this lane's blend coordinates and the box extremes: nothing to exchange between lanes.  (The
-    // per-pixel path below -- rare -- is the only user of (xv, yv): lanes 0..8 of the blend coordinates 7 m + xo.)
+    // per-pixel path below -- rare -- is the only user of (xv, yv) and picks pixel m's pair from lane 7 m.)
     xb = ec.xb; yb = ec.yb;
-    xv = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * 7 * mm, __float_as_int(xb)));
-    yv = __int_as_float(__builtin_amdgcn_ds_bpermute(4 * 7 * mm, __float_as_int(yb)));
+    xv = xb; yv = yb;      // patch pixel m sits in lane 7 m (slow_level<1, 7>)
     ixmin = ec.ixmin; ixmax = ec.ixmax; iymin = ec.iymin; iymax = ec.iymax;
   } else {
     const int cval = ec.cval;
@@ -607,48 +595,81 @@ __device__ __forceinline__ void corr_edge(const CorrArgs2& a, int p, int e, cons
   typedef float cdv_f32x2 __attribute__((ext_vector_type(2)));
   const float nhalf = (float)n + 0.5f;
   const float lanebase = (8 * g < C) ? (float)((unsigned)n * CB + (unsigned)(8 * g) * 2u) + 8388608.0f : 33554432.0f;
-#define CDV2_LOAD_LEVEL(BX, RB, PITCH, NQ, Q0)                                                     \
-  {                                                                                                \
+  // Groups per level: a FIXED number is requested and multiplied without any test -- 8 at level 0 (windows up to 128
+  // pixels: 10 x 10 ... 11 x 11, what a patch at roughly its own scale gives), 6 at level 1 (up to 96: 8 x 8 ... 9 x 10).
+  // Groups past the window lie past its last row, where the descriptor's range check returns zeros without touching
+  // memory, and their products land in raw-volume rows nobody reads.  With the count known at compile time the waits
+  // between the loads and the matrix instructions are progressive (vmcnt(n) instead of vmcnt(0): the first MFMA starts
+  // when the first group has arrived), and the 2 x 2 tested chains of the earlier version (a compare and a branch per
+  // group, four times per edge) are gone.  Larger windows (strong zoom) finish in a rolled tail loop, one group at a
+  // time through one register set.
+  constexpr int NQF0 = 8, NQF1 = 6;
+#define CDV2_LOAD_SETUP(BX, RB, PITCH)                                                             \
     const unsigned Wb_ = (unsigned)(BX).Wb, pitch_ = (PITCH);                                      \
     const auto rsrc_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(RB), (short)0,          \
                                                          (int)((unsigned)(BX).Hb * pitch_ + FBIAS), 0x00020000); \
     const float invW_ = __builtin_amdgcn_rcpf((float)Wb_);                                         \
     const float wrapf_ = (float)(pitch_ - Wb_ * CB);                                               \
-    cdv_f32x2 tb_ = {(nhalf + (float)(16 * (Q0))) * invW_, lanebase + (float)(16u * (unsigned)(Q0) * CB)}; \
-    const cdv_f32x2 dtb_ = {16.0f * invW_, (float)(16u * CB)};                                     \
-    CDV_QCHAIN(CDV2_LD1, NQ, Q0)                                                                   \
-  }
-#define CDV2_LD1(q, Q0)                                                                            \
+    const cdv_f32x2 dtb_ = {16.0f * invW_, (float)(16u * CB)};
+#define CDV2_LD1(q)                                                                                \
     {                                                                                              \
       const float vf_ = __builtin_fmaf(__builtin_floorf(tb_[0]), wrapf_, tb_[1]);                  \
       const cdv_i32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(rsrc_, __float_as_int(vf_), 0, 0); \
-      w[(q) < NQ_MAX ? (q) : 0][0] = __builtin_bit_cast(cdv_half8, v_);                            \
+      w[q][0] = __builtin_bit_cast(cdv_half8, v_);                                                 \
       tb_ += dtb_;                                                                                 \
     }
-#define CDV2_MF1(q, Q0)                                                                            \
+  // NQF - 1 groups unconditionally, the NQF-th if the window has it (level 0: 7 groups for 93 % of the edges of the
+  // synthetic stream, 8 for 4 %; level 1: 4 or 5 for 72 %, 6 for 28 %)
+#define CDV2_LOAD_FIXED(BX, RB, PITCH, NQF, NQ)                                                    \
+  {                                                                                                \
+    CDV2_LOAD_SETUP(BX, RB, PITCH)                                                                 \
+    cdv_f32x2 tb_ = {nhalf * invW_, lanebase};                                                     \
+    CDV2_LD1(0) CDV2_LD1(1) CDV2_LD1(2) CDV2_LD1(3) CDV2_LD1(4)                                    \
+    if (NQF > 6) { CDV2_LD1(5) CDV2_LD1(6) }                                                       \
+    if ((NQ) >= (NQF)) { CDV2_LD1(NQF - 1) }                                                       \
+  }
+#define CDV2_MF1(WQ, q)                                                                            \
     {                                                                                              \
       cdv_float4 acc = {0.f, 0.f, 0.f, 0.f};                                                       \
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(w[(q) < NQ_MAX ? (q) : 0][0], pat[0], acc, 0, 0, 0); \
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(WQ, pat[0], acc, 0, 0, 0);                      \
       cdv_half4 h = {(_Float16)acc[0], (_Float16)acc[1], (_Float16)acc[2], (_Float16)acc[3]};      \
-      *reinterpret_cast<cdv_half4*>(raw_lane + ((Q0) + q) * 16) = h;                               \
+      *reinterpret_cast<cdv_half4*>(raw_lane + (q) * 16) = h;                                      \
     }
-#define CDV2_MFMA_LEVEL(NQ, Q0) CDV_QCHAIN(CDV2_MF1, NQ, Q0)
-  if (do0 && !CDV_EXP(1)) CDV2_LOAD_LEVEL(b0, r0, pitch0, nq0, 0)
+  // (scheduling barriers between pairs of groups: left alone, the scheduler runs all matrix instructions first and keeps
+  // eight accumulators alive)
+#define CDV2_MF2(qa, qb) CDV2_MF1(w[qa][0], qa) CDV2_MF1(w[qb][0], qb) __builtin_amdgcn_sched_barrier(0);
+#define CDV2_MFMA_FIXED(NQF, NQ)                                                                   \
+  {                                                                                                \
+    CDV2_MF2(0, 1) CDV2_MF2(2, 3)                                                                  \
+    if (NQF > 6) { CDV2_MF2(4, 5) CDV2_MF1(w[6][0], 6) } else { CDV2_MF1(w[4][0], 4) }             \
+    if ((NQ) >= (NQF)) { CDV2_MF1(w[NQF - 1][0], NQF - 1) }                                        \
+  }
+  // groups NQF .. NQ - 1 of a large window, rolled (rare)
+#define CDV2_TAIL(BX, RB, PITCH, NQF, NQ)                                                          \
+  if ((NQ) > (NQF)) {                                                                              \
+    CDV2_LOAD_SETUP(BX, RB, PITCH)                                                                 \
+    cdv_f32x2 tb_ = {(nhalf + (float)(16 * (NQF))) * invW_, lanebase + (float)(16u * (unsigned)(NQF) * CB)}; \
+    _Pragma("unroll 1") for (int q_ = (NQF); q_ < (NQ); q_++) {                                    \
+      const float vf_ = __builtin_fmaf(__builtin_floorf(tb_[0]), wrapf_, tb_[1]);                  \
+      const cdv_i32x4 v_ = __builtin_amdgcn_raw_buffer_load_b128(rsrc_, __float_as_int(vf_), 0, 0); \
+      tb_ += dtb_;                                                                                 \
+      CDV2_MF1(__builtin_bit_cast(cdv_half8, v_), q_)                                              \
+    }                                                                                              \
+  }
+  if (do0 && !CDV_EXP(1)) CDV2_LOAD_FIXED(b0, r0, pitch0, NQF0, nq0)
   const BlendGeo g0 = blend_geo(xb, yb, bm, bxo, L0, b0, !b0.fast);
   const BlendGeo g1 = blend_geo(xb, yb, bm, bxo, L1, b1, !b1.fast);
   CDV_STAMP(corr, p, 2);
   if (do0 && !CDV_EXP(256)) {
-    CDV2_MFMA_LEVEL(nq0, 0)
-    if (nq0 > NQ_MAX) {   // window of more than 16 NQ_MAX pixels: a second round through the same registers
-      CDV2_LOAD_LEVEL(b0, r0, pitch0, nq0, NQ_MAX)
-      CDV2_MFMA_LEVEL(nq0, NQ_MAX)
-    }
+    CDV2_MFMA_FIXED(NQF0, nq0)
+    CDV2_TAIL(b0, r0, pitch0, NQF0, nq0)
   } else if (!b0.fast && idx_ok) {
-    slow_level<1>(L0, jslot, xv, yv, pat, raw, lane, C);
+    slow_level<1, REC ? 7 : 1>(L0, jslot, xv, yv, pat, raw, lane, C);
   } else {
     zero_raw(raw, lane);
   }
-  if (do1 && !CDV_EXP(1)) CDV2_LOAD_LEVEL(b1, r1, pitch1, nq1, 0)
+  __builtin_amdgcn_sched_barrier(0);   // the level-1 request reuses the window registers: not before level 0 has left them
+  if (do1 && !CDV_EXP(1)) CDV2_LOAD_FIXED(b1, r1, pitch1, NQF1, nq1)
   wave_lds_sync();
   CDV_STAMP(corr, p, 3);
   if (!CDV_EXP(128)) blend_level(raw, g0, res0);
@@ -656,13 +677,10 @@ __device__ __forceinline__ void corr_edge(const CorrArgs2& a, int p, int e, cons
   if (NLEV == 2) {
     wave_lds_sync();
     if (do1 && !CDV_EXP(256)) {
-      CDV2_MFMA_LEVEL(nq1, 0)
-      if (nq1 > NQ_MAX) {
-        CDV2_LOAD_LEVEL(b1, r1, pitch1, nq1, NQ_MAX)
-        CDV2_MFMA_LEVEL(nq1, NQ_MAX)
-      }
+      CDV2_MFMA_FIXED(NQF1, nq1)
+      CDV2_TAIL(b1, r1, pitch1, NQF1, nq1)
     } else if (!b1.fast && idx_ok) {
-      slow_level<1>(L1, jslot, xv, yv, pat, raw, lane, C);
+      slow_level<1, REC ? 7 : 1>(L1, jslot, xv, yv, pat, raw, lane, C);
     } else {
       zero_raw(raw, lane);
     }
@@ -671,10 +689,13 @@ __device__ __forceinline__ void corr_edge(const CorrArgs2& a, int p, int e, cons
     if (!CDV_EXP(128)) blend_level(raw, g1, res1);
     CDV_STAMP(corr, p, 6);
   }
-#undef CDV2_LOAD_LEVEL
+#undef CDV2_LOAD_FIXED
+#undef CDV2_LOAD_SETUP
 #undef CDV2_LD1
 #undef CDV2_MF1
-#undef CDV2_MFMA_LEVEL
+#undef CDV2_MF2
+#undef CDV2_MFMA_FIXED
+#undef CDV2_TAIL
 
   // ---- stage the edge's output row [x][y][m][lev] in LDS, then 16-byte-per-lane stores ------------------------------
   wave_lds_sync();   // the row overwrites the raw volume: keep the stores behind the last blend's reads
