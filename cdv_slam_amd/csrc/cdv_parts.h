@@ -369,4 +369,55 @@ __device__ __forceinline__ void graph_hist_body(const HistArgs& a, int bid, int 
   graph_scan_body(a.meta, a.stage, nblocks, a.khist, a.kcount, a.krank, a.E, (int64_t)a.R, nthreads_per_block, tid);
 }
 
+
+
+// ---- patch TABLE, launch 1 of the two-launch index build (graph.hip: cdv_graph_build_table) -----------------------------
+// One pass over the edges, no scan and no second pass behind it: slot = patch id, the t-th arriving edge of a patch takes
+// record t of its slot (chunk-slot layout of `pell`, cdv_graph.h), later arrivals go to the overflow list.  Order inside
+// a slot is arrival order here; the sort launch puts it into (jj, edge id) order.  Rides cdv_update_prologue_table next to
+// the ring ingest.
+struct TFillArgs {
+  const int64_t *ii, *jj, *kk;   // ii may be NULL (records then carry -1: the bundle adjustment reads ii itself)
+  int32_t E, R;                  // R = k_range: ids must lie in [0, R)
+  int32_t* meta;
+  int32_t* tcur;
+  int32_t *ttab, *tovf, *tprec;
+  int32_t* ocnt;                 // [blocks][ORD_BINS]
+  int32_t gen;                   // generation of this build (> 0)
+};
+
+__device__ __forceinline__ void graph_tfill_body(const TFillArgs& a, int bid, int nblocks, int nthreads_per_block, int tid) {
+  __shared__ int s_obin[ORD_BINS];
+  if (tid < ORD_BINS) s_obin[tid] = 0;
+  if (bid == 0 && tid == 0) {     // words the sort launch accumulates into; nobody reads them between the two launches
+    a.meta[GM_LO] = 0x7fffffff; a.meta[GM_HI] = -1; a.meta[GM_NLIVE] = 0; a.meta[GM_PRECN] = 1;
+    a.meta[GM_MODE] = 1; a.meta[GM_GEN] = a.gen; a.meta[GM_E] = a.E; a.meta[GM_HAS_II] = a.ii ? 1 : 0;
+  }
+  __syncthreads();
+  typedef int cdv_i4 __attribute__((ext_vector_type(4)));
+  for (int e = bid * nthreads_per_block + tid; e < a.E; e += nblocks * nthreads_per_block) {
+    const int64_t k64 = a.kk[e];
+    const int j = (int)a.jj[e];
+    const int i = a.ii ? (int)a.ii[e] : -1;
+    atomicAdd(&s_obin[j & (ORD_BINS - 1)], 1);
+    const cdv_i4 rec = {e, i, j, (int)k64};
+    if (e == 0) *reinterpret_cast<cdv_i4*>(a.tprec) = rec;        // overflow-CSR record 0: the "always valid" record
+    if (k64 < 0 || k64 >= (int64_t)a.R) {
+      a.meta[GM_TERR] = a.gen;                                    // every writer stores the same value
+      continue;
+    }
+    const int k = (int)k64;
+    const int t = atomicAdd(&a.tcur[k], 1);
+    if (t >= TAB_MAX_DEG) a.meta[GM_TERR] = a.gen;               // more edges than the sort launch serves: known before it starts
+    if (t < ELL_SLOTS) {
+      *reinterpret_cast<cdv_i4*>(a.ttab + 4 * ((size_t)((k >> 4) * ELL_SLOTS + t) * 16 + (k & 15))) = rec;
+    } else {
+      const int p = atomicAdd(&a.meta[GM_OVFN + (a.gen & 1)], 1);
+      *reinterpret_cast<cdv_i4*>(a.tovf + 4 * (size_t)p) = rec;
+    }
+  }
+  __syncthreads();
+  if (tid < ORD_BINS) a.ocnt[bid * ORD_BINS + tid] = s_obin[tid];   // read by the sort launch (the correlation's order)
+}
+
 }  // namespace cdv

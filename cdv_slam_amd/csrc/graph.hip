@@ -39,18 +39,21 @@ struct RegEntry {
   bool initialised;
   bool has_ii;
   CorrStream cs;      // coords == nullptr: no packed correlation stream is written
+  int32_t gen;        // table builds on this workspace so far
+  bool table;         // the index in the workspace is a patch table
 };
 std::mutex g_reg_mutex;
 std::unordered_map<const void*, RegEntry> g_registry;
 
 
-__global__ __launch_bounds__(256) void graph_init_kernel(int32_t* meta, int32_t* khist, int32_t* kcursor,
+__global__ __launch_bounds__(256) void graph_init_kernel(int32_t* meta, int32_t* khist, int32_t* kcursor, int32_t* tcur,
                                                          int64_t k_cap) {
   const int64_t n = k_cap + 1 > GM_WORDS ? k_cap + 1 : GM_WORDS;   // the meta words too when the id range is tiny
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
     if (t <= k_cap) {
       khist[t] = 0;
       kcursor[t] = 0;
+      tcur[t] = 0;
     }
     if (t < GM_WORDS) {
       meta[t] = 0;   // incl. the arrival counter of the histogram launch (GM_STAGE)
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(256) void graph_segsort_kernel(const int64_t* __res
       for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) { ix[e] = -1; jx[e] = -1; }
     return;
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) meta[GM_HAS_II] = ii ? 1 : 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { meta[GM_HAS_II] = ii ? 1 : 0; meta[GM_MODE] = 0; }
   const int krange = meta[GM_KRANGE];
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t <= krange; t += gridDim.x * blockDim.x)
     kcursor[t] = 0;   // the fill cursors of this build: zero again for the next one
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(256) void graph_neighbors_kernel(int32_t E, const i
                                                               const int32_t* __restrict__ nprev,
                                                               const int32_t* __restrict__ nnext,
                                                               int64_t* __restrict__ ix, int64_t* __restrict__ jx) {
-  const bool bad = meta[GM_ERROR] != 0;   // no index: "none" everywhere instead of uninitialised memory
+  const bool bad = graph_error(meta) != 0;   // no index: "none" everywhere instead of uninitialised memory
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) {
     if (bad) { ix[e] = -1; jx[e] = -1; continue; }
     ix[e] = (int64_t)nprev[e];   // previous edge in time (-1: none)
@@ -304,6 +307,305 @@ __global__ __launch_bounds__(256) void graph_copy_unique_kernel(const int32_t* _
     if (kx && t < U && t < kx_cap) kx[t] = kx_src[t];
     if (ku && t < E) ku[t] = (int64_t)ku_src[t];
   }
+}
+
+// ---- patch TABLE, launch 2: sort every slot into (jj, edge id) order (== std::stable_sort by jj over an ascending index
+// list, ba.cpp:84-86), neighbors, live range; and, by further workgroups of the same launch, everything that is per EDGE
+// and wants the processing order: the correlation's order and packed input stream, with the edge's reprojection
+// (projective_ops.py:53-113) computed right there when the caller asks for it (cdv_update_prologue_table) ------------
+struct TSortArgs {
+  int32_t* meta;
+  int32_t R, E, gen;
+  int32_t *tcur, *tdeg, *tplo, *ttab, *tovf, *tprec;
+  int32_t *nprev, *nnext;
+  int64_t *ix, *jx;
+  int n_patch_wg;                 // workgroups [0, n_patch_wg) take 64 slots each, the rest are edge workgroups
+  const int32_t* ocnt;
+  int nblk_edges;
+  int32_t* order;
+  const int64_t *ii, *jj, *kk;
+  CorrStream cs;                  // ring sizes of the packed stream; cs.coords: where finished coordinates are read from
+  uint32_t* crec;                 // NULL: no packed stream
+  const float *poses, *patches, *intr;   // poses != NULL: reproject here and write coords_out [E][2][3][3]
+  float* coords_out;
+};
+
+constexpr int TS_OVF_MAX = TAB_MAX_DEG;   // edges of one patch the sort launch handles (beyond: range-error state)
+
+typedef int cdv_i4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ size_t tab_index(int slot, int t) {   // int32 index of record t of a slot (chunk-slot layout)
+  return 4 * ((size_t)((slot >> 4) * ELL_SLOTS + t) * 16 + (slot & 15));
+}
+
+__device__ __forceinline__ uint64_t rec_key(const cdv_i4& r) { return ((uint64_t)(uint32_t)r.z << 32) | (uint32_t)r.x; }
+
+// reprojection of one edge: the arithmetic of transform_body<3> (cdv_parts.h), coordinates only
+__device__ __forceinline__ void reproject_edge(const TSortArgs& A, int64_t ix, int64_t jx, int64_t kx, float (&cx)[9],
+                                               float (&cy)[9]) {
+  const float* __restrict__ poses = A.poses;
+  const float* __restrict__ intr = A.intr;
+  float Pi[7], Pj[7], Pinv[7], G[7];
+#pragma unroll
+  for (int a = 0; a < 7; a++) { Pi[a] = poses[7 * ix + a]; Pj[a] = poses[7 * jx + a]; }
+  lt_se3_inv(Pi, Pinv);
+  lt_se3_mul(Pj, Pinv, G);
+  float t[3], q[4];
+  lt_se3_load(G, t, q);
+  const cdv_float4 Ki = *reinterpret_cast<const cdv_float4*>(intr + 4 * ix);
+  const cdv_float4 Kj = *reinterpret_cast<const cdv_float4*>(intr + 4 * jx);
+  // the patch: 27 consecutive floats, 4-byte aligned -- seven wide loads instead of 27 scalar ones
+  typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+  const float* pk = A.patches + kx * 27;
+  float pv[28];
+#pragma unroll
+  for (int v = 0; v < 6; v++) {
+    const f4u x4 = *reinterpret_cast<const f4u*>(pk + 4 * v);
+    pv[4 * v] = x4[0]; pv[4 * v + 1] = x4[1]; pv[4 * v + 2] = x4[2]; pv[4 * v + 3] = x4[3];
+  }
+  pv[24] = pk[24]; pv[25] = pk[25]; pv[26] = pk[26];
+#pragma unroll
+  for (int a = 0; a < 9; a++) {
+    float X0[4], X1[4];
+    X0[0] = (pv[a] - Ki[2]) / Ki[0];
+    X0[1] = (pv[9 + a] - Ki[3]) / Ki[1];
+    X0[2] = 1.f;
+    X0[3] = pv[18 + a];
+    lt_act4_loaded(t, q, X0, X1);
+    const float d = 1.0f / fmaxf(X1[2], 0.1f);
+    cx[a] = Kj[0] * (d * X1[0]) + Kj[2];
+    cy[a] = Kj[1] * (d * X1[1]) + Kj[3];
+  }
+}
+
+__global__ __launch_bounds__(256) void graph_tsort_kernel(const TSortArgs A) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool terr = A.meta[GM_TERR] == A.gen;      // written by the fill launch
+  if ((int)blockIdx.x >= A.n_patch_wg) {
+    // =================================== edge workgroups ===================================
+    const int bid = (int)blockIdx.x - A.n_patch_wg;
+    const int nblk = A.nblk_edges;
+    __shared__ int s_pos[ORD_BINS];
+    __shared__ int s_tot[32][ORD_BINS + 1], s_pre[32][ORD_BINS + 1];
+    __shared__ __attribute__((aligned(16))) float s_xy[256 * 18];
+    // this workgroup's first position per target bin: (edges of the bins before) + (edges of this bin in the workgroups
+    // before it), summed from the per-workgroup counts the fill launch left
+    {
+      const int bq = tid & 7, part = tid >> 3;
+      int tot[4] = {0, 0, 0, 0}, pre[4] = {0, 0, 0, 0};
+      const cdv_i4* tab = reinterpret_cast<const cdv_i4*>(A.ocnt);
+      for (int b0 = part; b0 < nblk; b0 += 32 * 4) {
+        cdv_i4 c[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int b = b0 + 32 * u;
+          c[u] = (b < nblk) ? tab[b * (ORD_BINS / 4) + bq] : cdv_i4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const bool before = b0 + 32 * u < bid;
+#pragma unroll
+          for (int q = 0; q < 4; q++) { tot[q] += c[u][q]; pre[q] += before ? c[u][q] : 0; }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) { s_tot[part][4 * bq + q] = tot[q]; s_pre[part][4 * bq + q] = pre[q]; }
+      __syncthreads();
+      if (tid < ORD_BINS) {
+        int t = 0, p = 0;
+#pragma unroll
+        for (int q = 0; q < 32; q++) { t += s_tot[q][tid]; p += s_pre[q][tid]; }
+        int incl = t;
+#pragma unroll
+        for (int o = 1; o < ORD_BINS; o <<= 1) {
+          const int up = __shfl_up(incl, o);
+          if (tid >= o) incl += up;
+        }
+        s_pos[tid] = incl - t + p;
+      }
+      __syncthreads();
+    }
+    for (int e0 = bid * 256; e0 < A.E; e0 += nblk * 256) {      // workgroup-uniform trip count
+      const int e = e0 + tid;
+      const bool in = e < A.E;
+      float cx[9], cy[9];
+      int64_t k64 = 0, j64 = 0;
+      if (in) {
+        k64 = A.kk[e]; j64 = A.jj[e];
+        if (A.poses) {
+          reproject_edge(A, A.ii[e], j64, k64, cx, cy);
+#pragma unroll
+          for (int a = 0; a < 9; a++) { s_xy[tid * 18 + a] = cx[a]; s_xy[tid * 18 + 9 + a] = cy[a]; }
+        } else if (A.cs.coords && A.crec) {
+          const float2* c2 = reinterpret_cast<const float2*>(A.cs.coords + (size_t)e * 18);
+#pragma unroll
+          for (int a = 0; a < 9; a++) {
+            const float2 v = c2[a];
+            if (2 * a < 9) cx[2 * a] = v.x; else cy[2 * a - 9] = v.x;
+            if (2 * a + 1 < 9) cx[2 * a + 1] = v.y; else cy[2 * a + 1 - 9] = v.y;
+          }
+        }
+        if (terr && A.ix) { A.ix[e] = -1; A.jx[e] = -1; }         // no index: "none", not uninitialised memory
+      }
+      if (A.poses) {
+        // the tile's coordinates leave as one contiguous block: 256 edges x 72 bytes, 16 bytes per lane
+        __syncthreads();
+        const int n_e = min(256, A.E - e0);
+        cdv_float4* dst = reinterpret_cast<cdv_float4*>(A.coords_out + (size_t)e0 * 18);   // 72 e0 bytes: e0 % 256 == 0, 16-byte aligned
+        const cdv_float4* src = reinterpret_cast<const cdv_float4*>(s_xy);
+        const int n4 = (n_e * 18) >> 2;                          // n_e * 18 is a multiple of 2; a last half vector below
+        for (int v = tid; v < n4; v += 256) dst[v] = src[v];
+        if (tid == 0 && ((n_e * 18) & 3)) {
+          A.coords_out[(size_t)e0 * 18 + 4 * n4] = s_xy[4 * n4];
+          A.coords_out[(size_t)e0 * 18 + 4 * n4 + 1] = s_xy[4 * n4 + 1];
+        }
+      }
+      if (in) {
+        const int b = (int)j64 & (ORD_BINS - 1);
+        const int pos = atomicAdd(&s_pos[b], 1);
+        A.order[pos] = e;
+        if (A.crec) {
+          uint32_t kq, jq;
+          const bool ok = corr_ring_index(k64, A.cs.kmod, A.cs.kmagic, A.cs.Ng, kq) &
+                          corr_ring_index(j64, A.cs.jmod, A.cs.jmagic, A.cs.slots, jq);
+          const auto bits = [](float f) { return (uint32_t)__float_as_int(f); };
+          const auto fl = [&](float v) { return (int)fminf(fmaxf(floorf(v * A.cs.inv_scale0), -30000.f), 30000.f); };
+          int xlo = 30000, xhi = -30000, ylo = 30000, yhi = -30000;
+#pragma unroll
+          for (int a = 0; a < 9; a++) {
+            const int vx = fl(cx[a]), vy = fl(cy[a]);
+            xlo = min(xlo, vx); xhi = max(xhi, vx); ylo = min(ylo, vy); yhi = max(yhi, vy);
+          }
+          typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+          u32x4* r4 = reinterpret_cast<u32x4*>(A.crec + (size_t)pos * CORR_REC_WORDS);
+          r4[0] = u32x4{bits(cx[0]), bits(cx[1]), bits(cx[2]), bits(cx[3])};
+          r4[1] = u32x4{bits(cx[4]), bits(cx[5]), bits(cx[6]), bits(cx[7])};
+          r4[2] = u32x4{bits(cx[8]), bits(cy[0]), bits(cy[1]), bits(cy[2])};
+          r4[3] = u32x4{bits(cy[3]), bits(cy[4]), bits(cy[5]), bits(cy[6])};
+          r4[4] = u32x4{bits(cy[7]), bits(cy[8]), (uint32_t)e, ok ? kq : 0xFFFFFFFFu};
+          r4[5] = u32x4{ok ? jq : 0xFFFFFFFFu, ((uint32_t)xhi << 16) | ((uint32_t)xlo & 0xffffu),
+                        ((uint32_t)yhi << 16) | ((uint32_t)ylo & 0xffffu), 0u};
+        }
+      }
+      if (A.poses) __syncthreads();                              // the tile is reused by the next trip
+    }
+    return;
+  }
+  // =================================== patch workgroups: 64 slots each ===================================
+  const int s0 = 64 * (int)blockIdx.x;
+  __shared__ int s_c[64], s_list[64], s_nlive;
+  __shared__ uint64_t s_key[8][32];
+  __shared__ int s_e[8][32];
+  __shared__ cdv_i4 s_orec[TS_OVF_MAX];
+  __shared__ uint64_t s_okey[TS_OVF_MAX];
+  __shared__ int s_osort[TS_OVF_MAX], s_ocnt;
+  if (blockIdx.x == 0 && tid == 0) A.meta[GM_OVFN + ((A.gen & 1) ^ 1)] = 0;   // the next build's overflow counter
+  if (tid < 64) {
+    const int c = (s0 + tid < A.R) ? A.tcur[s0 + tid] : 0;
+    s_c[tid] = c;
+    const unsigned long long bal = __ballot(c > 0);
+    if (c > 0) s_list[__popcll(bal & ((1ull << lane) - 1ull))] = tid;
+    if (tid == 0) s_nlive = __popcll(bal);
+    if (s0 + tid < A.R) {
+      A.tdeg[s0 + tid] = min(c, TS_OVF_MAX);
+      A.tplo[s0 + tid] = 0;
+      if (c > 0) A.tcur[s0 + tid] = 0;                            // zero again for the next build
+    }
+    if (bal != 0ull && tid == 0) {                                // the live range and count: only workgroups with patches
+      const int first = __ffsll((long long)bal) - 1, last = 63 - __clzll((long long)bal);
+      atomicMin(&A.meta[GM_LO], s0 + first);
+      atomicMax(&A.meta[GM_HI], s0 + last);
+      atomicAdd(&A.meta[GM_NLIVE], __popcll(bal));
+    }
+  }
+  __syncthreads();
+  const int nlive = s_nlive;
+  if (nlive == 0) return;
+  const int h = tid >> 5, hl = tid & 31;
+  for (int li = h; li < nlive; li += 8) {
+    const int sl = s_list[li];
+    const int slot = s0 + sl, deg = s_c[sl];
+    if (deg > ELL_SLOTS) continue;                                // overflowing patches: below
+    cdv_i4 rec = {0, 0, 0, 0};
+    if (hl < deg) rec = *reinterpret_cast<const cdv_i4*>(A.ttab + tab_index(slot, hl));
+    const uint64_t key = hl < deg ? rec_key(rec) : ~0ull;
+    s_key[h][hl] = key;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    int rank = 0;
+    for (int u = 0; u < deg; u++) rank += (s_key[h][u] < key) ? 1 : 0;
+    if (hl < deg) s_e[h][rank] = rec.x;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (hl < deg) {
+      *reinterpret_cast<cdv_i4*>(A.ttab + tab_index(slot, rank)) = rec;   // every lane holds its record: in place
+      const int pe = rank > 0 ? s_e[h][rank - 1] : -1, ne = rank + 1 < deg ? s_e[h][rank + 1] : -1;
+      A.nprev[rec.x] = pe;
+      A.nnext[rec.x] = ne;
+      if (A.ix && !terr) { A.ix[rec.x] = (int64_t)pe; A.jx[rec.x] = (int64_t)ne; }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();                              // s_key / s_e are reused by the next slot of this half-wave
+  }
+  // ---- patches with more than ELL_SLOTS edges (loop-closure graphs): wave 0, one after the other.  The first ELL_SLOTS
+  // records are in the table, the rest in the overflow list; all of them are sorted into an overflow CSR segment
+  // (tprec[tplo + t], t = 0 .. deg - 1) whose first ELL_SLOTS records also go back into the table ----
+  __syncthreads();
+  if (wave != 0) return;
+  const int n_ovf = A.meta[GM_OVFN + (A.gen & 1)];
+  for (int li = 0; li < nlive; li++) {
+    const int sl = s_list[li];
+    const int slot = s0 + sl, deg = s_c[sl];
+    if (deg <= ELL_SLOTS) continue;
+    if (deg > TS_OVF_MAX) {                                       // not served: the index goes into its error state
+      if (lane == 0) A.meta[GM_TERR] = A.gen;
+      continue;
+    }
+    if (lane < ELL_SLOTS) s_orec[lane] = *reinterpret_cast<const cdv_i4*>(A.ttab + tab_index(slot, lane));
+    if (lane == 0) s_ocnt = ELL_SLOTS;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    for (int u = lane; u < n_ovf; u += 64) {
+      const cdv_i4 r = *reinterpret_cast<const cdv_i4*>(A.tovf + 4 * (size_t)u);
+      if (r.w == slot) {
+        const int idx = atomicAdd(&s_ocnt, 1);
+        if (idx < TS_OVF_MAX) s_orec[idx] = r;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    const int total = min(s_ocnt, TS_OVF_MAX);                   // == deg
+    for (int x = lane; x < total; x += 64) s_okey[x] = rec_key(s_orec[x]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    for (int x = lane; x < total; x += 64) {
+      const uint64_t key = s_okey[x];
+      int rank = 0;
+      for (int y = 0; y < total; y++) rank += (s_okey[y] < key) ? 1 : 0;
+      s_osort[rank] = x;
+    }
+    int plo = 0;
+    if (lane == 0) plo = atomicAdd(&A.meta[GM_PRECN], total);
+    plo = __shfl(plo, 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    for (int x = lane; x < total; x += 64) {
+      const cdv_i4 rec = s_orec[s_osort[x]];
+      *reinterpret_cast<cdv_i4*>(A.tprec + 4 * (size_t)(plo + x)) = rec;
+      if (x < ELL_SLOTS) *reinterpret_cast<cdv_i4*>(A.ttab + tab_index(slot, x)) = rec;
+      const int pe = x > 0 ? s_orec[s_osort[x - 1]].x : -1, ne = x + 1 < total ? s_orec[s_osort[x + 1]].x : -1;
+      A.nprev[rec.x] = pe;
+      A.nnext[rec.x] = ne;
+      if (A.ix && !terr) { A.ix[rec.x] = (int64_t)pe; A.jx[rec.x] = (int64_t)ne; }
+    }
+    if (lane == 0) A.tplo[slot] = plo;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+__global__ __launch_bounds__(256) void graph_tfill_kernel(cdv::TFillArgs a) {
+  cdv::graph_tfill_body(a, (int)blockIdx.x, (int)gridDim.x, (int)blockDim.x, (int)threadIdx.x);
 }
 
 inline int grid_for(int64_t n, int threads, int cap) {
@@ -364,12 +666,13 @@ int cdv_graph_prepare(const int64_t* jj, const int64_t* kk, int64_t E, void* ws,
     need_init = it == g_registry.end() || !it->second.initialised || it->second.L.E_max != E_max ||
                 it->second.L.k_range != k_range;
     const CorrStream keep = it != g_registry.end() ? it->second.cs : CorrStream{nullptr, 0, 0, 0, 0, 0, 0, 1.0f};
-    g_registry[ws] = RegEntry{L, true, false, keep};
+    const int32_t gen = it != g_registry.end() ? it->second.gen : 0;
+    g_registry[ws] = RegEntry{L, true, false, keep, gen, false};
   }
   const GraphView v = graph_view(ws, L);
   if (need_init)
     hipLaunchKernelGGL(graph_init_kernel, dim3(grid_for(k_range + 1 + GM_WORDS, 256, 2048)), dim3(256), 0,
-                       (hipStream_t)stream, v.meta, v.khist, v.kcursor, k_range);
+                       (hipStream_t)stream, v.meta, v.khist, v.kcursor, v.tcur, k_range);
   *hist = cdv::HistArgs{jj, kk, (int32_t)E, v.stage, v.khist, (int32_t)k_range, v.meta, v.kcount, v.krank, v.ocnt};
   *hist_blocks = E > 0 ? grid_for(E, 256, GRAPH_MAX_BLOCKS) : 0;
   return CDV_OK;
@@ -402,6 +705,95 @@ int cdv_graph_finish(const int64_t* ii, const int64_t* jj, const int64_t* kk, in
                        v.pcsr, v.prec, v.pell, (int)L.ell_chunks, v.krank, v.nprev, v.nnext, v.kcursor, ix, jx);
   }
   CDV_LAUNCH_CHECK();
+  return CDV_OK;
+}
+
+bool cdv_graph_is_table(const void* ws) {
+  std::lock_guard<std::mutex> lk(g_reg_mutex);
+  auto it = g_registry.find(ws);
+  return it != g_registry.end() && it->second.table;
+}
+
+// The table build in two halves (like cdv_graph_prepare / cdv_graph_finish), so that cdv_update_prologue_table can run the
+// fill pass inside its own first launch: prepare = checks, registry, one-time initialisation, arguments of the fill pass;
+// finish = the sort launch (patch workgroups + edge workgroups).
+int cdv_graph_table_prepare(const int64_t* ii, const int64_t* jj, const int64_t* kk, int64_t E, void* ws, size_t ws_bytes,
+                            int64_t E_max, int64_t k_range, int64_t* ix, int64_t* jx, void* stream, cdv::TFillArgs* fill,
+                            int* fill_blocks) {
+  CDV_REQUIRE((ix == nullptr) == (jx == nullptr), CDV_ERR_ARG, "cdv_graph_build_table: give both ix and jx or neither");
+  CDV_REQUIRE(ws != nullptr, CDV_ERR_ARG, "cdv_graph_build_table: workspace is NULL");
+  CDV_REQUIRE(E >= 0 && E < (int64_t)1 << 31, CDV_ERR_ARG, "cdv_graph_build_table: E out of range");
+  CDV_REQUIRE(k_range >= 1 && k_range < ((int64_t)1 << 31) - 64 && E_max >= 1 && E <= E_max, CDV_ERR_ARG,
+              "cdv_graph_build_table: need 1 <= E <= E_max, 1 <= k_range < 2^31");
+  const GraphLayout L = graph_layout(E_max, k_range);
+  CDV_REQUIRE(L.total <= ws_bytes, CDV_ERR_WORKSPACE, "cdv_graph_build_table: workspace too small for (E_max, k_range)");
+  bool need_init;
+  int32_t gen;
+  {
+    std::lock_guard<std::mutex> lk(g_reg_mutex);
+    auto it = g_registry.find(ws);
+    need_init = it == g_registry.end() || !it->second.initialised || it->second.L.E_max != E_max ||
+                it->second.L.k_range != k_range;
+    const CorrStream keep = it != g_registry.end() ? it->second.cs : CorrStream{nullptr, 0, 0, 0, 0, 0, 0, 1.0f};
+    gen = (it != g_registry.end() && !need_init) ? it->second.gen : 0;
+    gen = gen >= 0x7ffffff0 ? 1 : gen + 1;
+    g_registry[ws] = RegEntry{L, true, ii != nullptr && E > 0, keep, gen, true};
+  }
+  const GraphView v = graph_view(ws, L);
+  if (need_init)
+    hipLaunchKernelGGL(graph_init_kernel, dim3(grid_for(k_range + 1 + GM_WORDS, 256, 2048)), dim3(256), 0,
+                       (hipStream_t)stream, v.meta, v.khist, v.kcursor, v.tcur, k_range);
+  *fill = cdv::TFillArgs{ii, jj, kk, (int32_t)E, (int32_t)k_range, v.meta, v.tcur, v.ttab, v.tovf, v.tprec, v.ocnt, gen};
+  *fill_blocks = grid_for(E, 256, GRAPH_MAX_BLOCKS);   // >= 1: the first workgroup also resets the words of this build
+  return CDV_OK;
+}
+
+int cdv_graph_table_finish(const cdv::TFillArgs& fill, int fill_blocks, void* ws, int64_t E_max, int64_t k_range, int64_t* ix,
+                           int64_t* jx, const float* poses, const float* patches, const float* intr, float* coords_out,
+                           bool with_stream, void* stream) {
+  const GraphLayout L = graph_layout(E_max, k_range);
+  const GraphView v = graph_view(ws, L);
+  CorrStream cs{nullptr, 0, 0, 0, 0, 0, 0, 1.0f};
+  {
+    std::lock_guard<std::mutex> lk(g_reg_mutex);
+    auto it = g_registry.find(ws);
+    if (it != g_registry.end()) cs = it->second.cs;
+  }
+  const bool stream_ok = with_stream && (poses != nullptr || cs.coords != nullptr);
+  TSortArgs A;
+  A.meta = v.meta; A.R = (int32_t)k_range; A.E = fill.E; A.gen = fill.gen;
+  A.tcur = v.tcur; A.tdeg = v.tdeg; A.tplo = v.tplo; A.ttab = v.ttab; A.tovf = v.tovf; A.tprec = v.tprec;
+  A.nprev = v.nprev; A.nnext = v.nnext; A.ix = ix; A.jx = jx;
+  A.n_patch_wg = (int)((k_range + 63) / 64);
+  A.ocnt = v.ocnt; A.nblk_edges = fill_blocks; A.order = v.order;
+  A.ii = fill.ii; A.jj = fill.jj; A.kk = fill.kk;
+  A.cs = cs; A.crec = stream_ok ? v.crec : nullptr;
+  A.poses = poses; A.patches = patches; A.intr = intr; A.coords_out = coords_out;
+  const int n_edge_wg = fill.E > 0 ? fill_blocks : 0;
+  hipLaunchKernelGGL(graph_tsort_kernel, dim3(A.n_patch_wg + n_edge_wg), dim3(256), 0, (hipStream_t)stream, A);
+  CDV_LAUNCH_CHECK();
+  return CDV_OK;
+}
+
+extern "C" int cdv_graph_build_table(const int64_t* ii, const int64_t* jj, const int64_t* kk, int64_t E, void* ws,
+                                     size_t ws_bytes, int64_t E_max, int64_t k_range, int64_t* ix, int64_t* jx,
+                                     void* stream) {
+  cdv::TFillArgs f;
+  int fb = 0;
+  const int rc = cdv_graph_table_prepare(ii, jj, kk, E, ws, ws_bytes, E_max, k_range, ix, jx, stream, &f, &fb);
+  if (rc != CDV_OK) return rc;
+  hipLaunchKernelGGL(graph_tfill_kernel, dim3(fb), dim3(256), 0, (hipStream_t)stream, f);
+  return cdv_graph_table_finish(f, fb, ws, E_max, k_range, ix, jx, nullptr, nullptr, nullptr, nullptr, true, stream);
+}
+
+// byte offsets (into the workspace) of the table's arrays, for tools and tests that want to look at it:
+// out[0..5] = degree per slot (int32 [k_range]), overflow-CSR offset per slot (int32 [k_range]), records (int32 x 4, chunk-
+// slot layout), overflow-CSR records (int32 x 4), the correlation's order (int32 [E]), its packed stream (24 x uint32 per edge)
+extern "C" int cdv_graph_table_offsets(int64_t E_max, int64_t k_range, int64_t* out) {
+  CDV_REQUIRE(out != nullptr && E_max >= 1 && k_range >= 1, CDV_ERR_ARG, "cdv_graph_table_offsets: bad argument");
+  const GraphLayout L = graph_layout(E_max, k_range);
+  out[0] = (int64_t)L.tdeg; out[1] = (int64_t)L.tplo; out[2] = (int64_t)L.ttab; out[3] = (int64_t)L.tprec;
+  out[4] = (int64_t)L.order; out[5] = (int64_t)L.crec;
   return CDV_OK;
 }
 
@@ -439,7 +831,7 @@ extern "C" int cdv_graph_bind_corr_stream(void* ws, const float* coords, int64_t
   cs.jmagic = jmod > 1 ? (uint32_t)((((uint64_t)1 << 32) + (uint64_t)jmod - 1) / (uint64_t)jmod) : 0u;
   std::lock_guard<std::mutex> lk(g_reg_mutex);
   auto it = g_registry.find(ws);
-  if (it == g_registry.end()) g_registry[ws] = RegEntry{GraphLayout{}, false, false, cs};
+  if (it == g_registry.end()) g_registry[ws] = RegEntry{GraphLayout{}, false, false, cs, 0, false};
   else it->second.cs = cs;
   return CDV_OK;
 }
@@ -456,6 +848,12 @@ extern "C" int cdv_graph_read_meta_host(const void* ws, int64_t* meta_host, void
   int32_t m[GM_WORDS];
   CDV_HIP_CHECK(hipMemcpyAsync(m, (const char*)ws + L.meta, sizeof(m), hipMemcpyDeviceToHost, (hipStream_t)stream));
   CDV_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+  if (m[GM_MODE]) {   // patch table: live patches, their id range; no frame range is kept
+    const int err = m[GM_TERR] == m[GM_GEN];
+    meta_host[0] = err ? 0 : m[GM_NLIVE]; meta_host[1] = 1; meta_host[2] = m[GM_LO]; meta_host[3] = m[GM_HI];
+    meta_host[4] = 0; meta_host[5] = 0; meta_host[6] = err; meta_host[7] = m[GM_E];
+    return CDV_OK;
+  }
   meta_host[0] = m[GM_U]; meta_host[1] = 0; meta_host[2] = m[GM_KMIN]; meta_host[3] = m[GM_KMAX];
   meta_host[4] = m[GM_JMIN]; meta_host[5] = m[GM_JMAX]; meta_host[6] = m[GM_ERROR]; meta_host[7] = m[GM_E];
   return CDV_OK;
@@ -465,6 +863,8 @@ extern "C" int cdv_graph_get_unique(const void* ws, int64_t* kx, int64_t kx_capa
                                     void* stream) {
   GraphLayout L;
   CDV_REQUIRE(cdv_graph_lookup(ws, &L), CDV_ERR_ARG, "cdv_graph_get_unique: workspace has no built graph");
+  CDV_REQUIRE(!cdv_graph_is_table(ws), CDV_ERR_UNSUPPORTED,
+              "cdv_graph_get_unique: the workspace holds a patch table (no ranks); build the ranked index (cdv_graph_build*)");
   if (E == 0) return CDV_OK;
   const GraphView v = graph_view((void*)ws, L);
   const int64_t n = E > kx_capacity ? E : kx_capacity;

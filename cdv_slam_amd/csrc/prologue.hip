@@ -30,7 +30,49 @@ __global__ __launch_bounds__(256) void update_prologue_kernel(cdv::IngestArgs in
   cdv::transform_body<3>(tf, (int64_t)b * 256 + threadIdx.x);
 }
 
+// the same opening with the table index: ring / tile ingest next to the table's fill pass (nothing else has to wait for
+// a scan any more); the reprojection moves into the index's second launch, where the processing order is known and the
+// correlation's packed input stream can be written from the registers that hold the coordinates
+__global__ __launch_bounds__(256) void update_prologue_table_kernel(cdv::IngestArgs ing, int n_ing, cdv::TFillArgs fill,
+                                                                    int n_fill) {
+  int b = (int)blockIdx.x;
+  if (b < n_fill) {
+    cdv::graph_tfill_body(fill, b, n_fill, 256, (int)threadIdx.x);
+    return;
+  }
+  cdv::ingest_body(ing, b - n_fill, 256, (int)threadIdx.x);
+}
+
 }  // namespace
+
+extern "C" int cdv_update_prologue_table(
+    const void* fmap_chw, void* fmap1_nhwc, void* fmap2_nhwc, int slot, int C, int H, int W, const void* gmap_planar,
+    void* gmap_pm, int64_t Ng, int64_t gmap_first, int64_t gmap_count, const float* poses, const float* patches,
+    const float* intrinsics, const int64_t* ii, const int64_t* jj, const int64_t* kk, int64_t E, float* coords,
+    void* graph_ws, size_t graph_ws_bytes, int64_t E_max, int64_t k_range, int64_t* ix, int64_t* jx, void* stream) {
+  CDV_REQUIRE(C % 8 == 0 && C > 0, CDV_ERR_ARG, "cdv_update_prologue_table: C must be a multiple of 8");
+  CDV_REQUIRE(H % 4 == 0 && W % 4 == 0, CDV_ERR_ARG, "cdv_update_prologue_table: H and W must be multiples of 4");
+  CDV_REQUIRE(slot >= 0, CDV_ERR_ARG, "cdv_update_prologue_table: slot");
+  CDV_REQUIRE(fmap_chw && fmap1_nhwc && fmap2_nhwc && coords && poses && patches && intrinsics && ii, CDV_ERR_ARG,
+              "cdv_update_prologue_table: NULL buffer");
+  CDV_REQUIRE(((uintptr_t)coords & 15) == 0, CDV_ERR_ARG, "cdv_update_prologue_table: coords must be 16-byte aligned");
+  const bool do_g = gmap_planar != nullptr && gmap_pm != nullptr && gmap_count > 0;
+  CDV_REQUIRE(!do_g || (gmap_first >= 0 && gmap_first + gmap_count <= Ng), CDV_ERR_ARG, "cdv_update_prologue_table: tile range");
+  cdv::TFillArgs fill;
+  int n_fill = 0;
+  const int rc = cdv_graph_table_prepare(ii, jj, kk, E, graph_ws, graph_ws_bytes, E_max, k_range, ix, jx, stream, &fill, &n_fill);
+  if (rc != CDV_OK) return rc;
+  const int fblocks = cdv_div_up((int64_t)(H / 4) * (W / 4) * (C / 8) * 16, 256);
+  const int gblocks = do_g ? cdv_div_up(gmap_count * 9 * (C / 8), 256) : 0;
+  const cdv::IngestArgs ing{(const _Float16*)fmap_chw, (_Float16*)fmap1_nhwc, (_Float16*)fmap2_nhwc, nullptr, nullptr,
+                            slot, C, H, W, (const _Float16*)gmap_planar, (_Float16*)gmap_pm, gmap_first, gmap_count,
+                            fblocks, gblocks};
+  const int n_ing = fblocks + gblocks;
+  hipLaunchKernelGGL(update_prologue_table_kernel, dim3(n_fill + n_ing), dim3(256), 0, (hipStream_t)stream, ing, n_ing, fill,
+                     n_fill);
+  CDV_LAUNCH_CHECK();
+  return cdv_graph_table_finish(fill, n_fill, graph_ws, E_max, k_range, ix, jx, poses, patches, intrinsics, coords, true, stream);
+}
 
 extern "C" int cdv_update_prologue(
     // cdv_frame_ingest

@@ -56,6 +56,7 @@ class GraphIndex:
         self.ws = None
         self._key = None
         self.E = 0
+        self.is_table = False
         self._reserve(E_cap)
 
     def _reserve(self, E):
@@ -119,11 +120,12 @@ class GraphIndex:
         if ii is not None:
             ii = ii.contiguous()
         key = self._make_key(jj, kk, ii)
-        if not force and self._same_key(key):
+        if not force and not self.is_table and self._same_key(key):
             return self
         E = kk.numel()
         if jj.numel() != E:
             raise ValueError("jj and kk must have the same length")
+        self.is_table = False
         self._reserve(E)
         self._nbr = None
         if ii is not None:
@@ -144,8 +146,54 @@ class GraphIndex:
             self.meta()
         return self
 
+    def build_table(self, jj, kk, ii=None, force=False, with_neighbors=False):
+        """cdv_graph_build_table: the same index as a patch table (slot = patch id; two launches, no scan).  Serves
+        neighbors(), the window / mid bundle adjustment (N <= 32) and the correlation's order + packed stream; not
+        unique() (no ranks) and not the global bundle adjustment -- build() is there for those.  Same caching rule as
+        build(): identity + version of the tensors."""
+        _need_cuda(jj, kk)
+        if jj.dtype != torch.int64 or kk.dtype != torch.int64:
+            raise TypeError("index tensors must be int64")
+        jj, kk = jj.contiguous(), kk.contiguous()
+        if ii is not None:
+            ii = ii.contiguous()
+        key = self._make_key(jj, kk, ii) + ("table",)
+        if not force and self.is_table and self._same_key(key):
+            return self
+        E = kk.numel()
+        if jj.numel() != E or (ii is not None and (ii.dtype != torch.int64 or ii.numel() != E)):
+            raise ValueError("ii / jj / kk must be int64 tensors of one length")
+        self._reserve(E)
+        self._nbr = None
+        ix = jx = None
+        if with_neighbors and E > 0:
+            ix = torch.empty(E, dtype=torch.int64, device=self.device)
+            jx = torch.empty(E, dtype=torch.int64, device=self.device)
+            self._nbr = (ix, jx)
+        rc = self.lib.cdv_graph_build_table(_p(ii), _p(jj), _p(kk), E, _p(self.ws), self.ws_bytes, self.E_cap, self.k_range,
+                                            _p(ix), _p(jx), _stream())
+        _lib.check(rc, "cdv_graph_build_table")
+        self._key = key
+        self.E = E
+        self.is_table = True
+        if _sync_check():
+            self.meta()
+        return self
+
+    def table_arrays(self):
+        """(deg [k_range] int32, plo [k_range] int32, records [chunks*32*16, 4] int32, overflow records [E_cap + 1, 4] int32,
+        order [E_cap] int32, stream [E_cap, 24] int32): views into the workspace (tests, tools)"""
+        off = (ctypes.c_int64 * 6)()
+        _lib.check(self.lib.cdv_graph_table_offsets(self.E_cap, self.k_range, off), "cdv_graph_table_offsets")
+        w32 = self.ws.view(torch.int32)
+        o = [int(v) // 4 for v in off]
+        R, chunks = self.k_range, (self.k_range + 15) // 16
+        return (w32[o[0]:o[0] + R], w32[o[1]:o[1] + R], w32[o[2]:o[2] + chunks * 32 * 16 * 4].view(-1, 4),
+                w32[o[3]:o[3] + (self.E_cap + 1) * 4].view(-1, 4), w32[o[4]:o[4] + self.E_cap],
+                w32[o[5]:o[5] + self.E_cap * 24].view(-1, 24))
+
     def meta(self):
-        """(U, 0, kmin, kmax, jmin, jmax, error, E) -- synchronises the stream."""
+        """(U, is_table, kmin, kmax, jmin, jmax, error, E) -- synchronises the stream."""
         m = (ctypes.c_int64 * 8)()
         _lib.check(self.lib.cdv_graph_read_meta_host(_p(self.ws), m, _stream()), "cdv_graph_read_meta_host")
         m = list(m)
@@ -164,6 +212,9 @@ class GraphIndex:
 
     def unique(self):
         """(kx, ku) == torch._unique(kk, sorted=True, return_inverse=True); one host sync for U."""
+        if self.is_table:      # a table has no ranks: rebuild as the ranked index from the tensors it was built from
+            k = self._key
+            self.build(k[0], k[1], force=True, ii=k[4])
         U = self.meta()[0] if self.E else 0
         kx = torch.empty(U, dtype=torch.int64, device=self.device)
         ku = torch.empty(self.E, dtype=torch.int64, device=self.device)
@@ -200,6 +251,40 @@ def update_prologue(graph, fmap_chw, fmap1_nhwc, fmap2_nhwc, slot, gmap, gmap_pm
     _lib.check(rc, "cdv_update_prologue")
     graph._key = graph._make_key(jj, kk, ii)
     graph.E = E
+    graph.is_table = False
+    graph._nbr = (ix, jx)
+    return coords
+
+
+def update_prologue_table(graph, fmap_chw, fmap1_nhwc, fmap2_nhwc, slot, gmap, gmap_pm, gmap_first, gmap_count, poses, patches,
+                          intrinsics, ii, jj, kk, coords_out=None):
+    """cdv_update_prologue_table: everything in front of the correlation in TWO launches -- ring / tile ingest + the
+    table's fill pass, then slot sort + neighbors + reprojection + the correlation's order and packed stream.  Returns
+    coords [1,E,2,3,3]; neighbors with graph.neighbors(); the stream with graph.corr_records_ptr() (ring sizes must have
+    been bound with graph.bind_corr_stream)."""
+    lib = _lib.load()
+    _need_cuda(fmap_chw, fmap1_nhwc, fmap2_nhwc, poses, patches, intrinsics, ii, jj, kk)
+    C, H, W = fmap_chw.shape[-3:]
+    E, P = kk.numel(), patches.shape[-1]
+    if P != 3 or poses.dtype != torch.float32:
+        raise TypeError("update_prologue_table: float32 state, 3x3 patches")
+    dev = poses.device
+    graph._reserve(E)
+    if coords_out is not None:
+        coords = coords_out.view(-1)[: E * 18].view(1, E, 2, P, P)
+    else:
+        coords = torch.empty((1, E, 2, P, P), dtype=torch.float32, device=dev)
+    ix = torch.empty(E, dtype=torch.int64, device=dev)
+    jx = torch.empty(E, dtype=torch.int64, device=dev)
+    Ng = gmap.numel() // (C * 9) if gmap is not None else 0
+    rc = lib.cdv_update_prologue_table(_p(fmap_chw.contiguous()), _p(fmap1_nhwc), _p(fmap2_nhwc), int(slot), C, H, W, _p(gmap),
+                                       _p(gmap_pm), Ng, int(gmap_first), int(gmap_count), _p(poses), _p(patches),
+                                       _p(intrinsics), _p(ii), _p(jj), _p(kk), E, _p(coords), _p(graph.ws), graph.ws_bytes,
+                                       graph.E_cap, graph.k_range, _p(ix), _p(jx), _stream())
+    _lib.check(rc, "cdv_update_prologue_table")
+    graph._key = graph._make_key(jj, kk, ii) + ("table",)
+    graph.E = E
+    graph.is_table = True
     graph._nbr = (ix, jx)
     return coords
 

@@ -238,6 +238,24 @@ int cdv_graph_build_edges(const int64_t* ii, const int64_t* jj, const int64_t* k
 
 int cdv_graph_read_meta_host(const void* ws, int64_t* meta_host, void* stream);
 
+/* The same index as a patch TABLE, in two launches instead of four and with no scan between them: a patch is its own slot
+ * (slot = patch id, which must lie in [0, k_range) -- the reference's ids do: they index patches_ [N * M], patchgraph.py:29),
+ * so nothing has to be counted before records can be placed.  Launch 1 puts every edge's record {edge, ii, jj, kk} into its
+ * patch's slot in arrival order; launch 2 sorts each slot into (jj, edge id) order -- the order std::stable_sort by jj gives
+ * on an ascending index list, ba.cpp:84-86 -- and writes fastba.neighbors from it (ix / jx as in cdv_graph_build_neighbors,
+ * bit-exact), the live id range, the correlation's processing order and, when a coordinate source is bound
+ * (cdv_graph_bind_corr_stream), its packed input stream.  What it does NOT produce is torch::_unique's (kx, ku): no ranks
+ * exist (cdv_graph_get_unique refuses; cdv_graph_build* is still there for that and for more than 32 free poses).
+ * cdv_ba_forward accepts either index for N <= 32: over the live id range [lo, hi] it treats id - lo as the "unique rank",
+ * which IS the rank whenever every id in the range has an edge (always, in a graph slam.py builds); ids without an edge
+ * inside the range contribute nothing and are not retracted.  A patch with more than 32 edges keeps its first 32 records
+ * in the table and all of them in an overflow list (up to 128 per patch; beyond that, and for an id outside [0, k_range),
+ * the index goes into its error state: neighbors all -1, bundle adjustment skipped with CDV_ERR_GRAPH_RANGE).
+ *   cdv_graph_table_offsets: byte offsets of the table's arrays inside the workspace (tools, tests). */
+int cdv_graph_build_table(const int64_t* ii, const int64_t* jj, const int64_t* kk, int64_t E, void* ws, size_t ws_bytes,
+                          int64_t E_max, int64_t k_range, int64_t* ix, int64_t* jx, void* stream);
+int cdv_graph_table_offsets(int64_t E_max, int64_t k_range, int64_t* out6);
+
 /* A processing order for cdv_corr_fused that the index build produces on the side: the edge ids [E] (int32) grouped by target
  * frame (jj mod 32), so that the share of the list one XCD works through touches ~3 frames' feature maps instead of ~16
  * (the reference launches one thread block per edge in list order, correlation_kernel.cu:82-136; results do not depend on
@@ -371,6 +389,18 @@ int cdv_point_cloud(const float* poses, const float* patches, const float* intri
 /* ------------------------------------------------------------------------------------------------
  * Start of an update in one launch
  * ---------------------------------------------------------------------------------------------- */
+
+/* cdv_update_prologue with the table index (cdv_graph_build_table): launch 1 = ring / tile ingest next to the table's fill
+ * pass, launch 2 = slot sort + neighbors next to the per-edge work -- the reprojection (coords [1,E,2,3,3], the layout
+ * SLAM.reproject returns, slam.py:325-329), the correlation's processing order and its packed input stream (ring sizes as
+ * bound with cdv_graph_bind_corr_stream; its coords argument is not used here: the coordinates go from registers into
+ * both places).  Two launches for everything in front of the correlation (the ranked variant: four).  coords 16-byte
+ * aligned; P = 3. */
+int cdv_update_prologue_table(const void* fmap_chw, void* fmap1_nhwc, void* fmap2_nhwc, int slot, int C, int H, int W,
+                              const void* gmap_planar, void* gmap_pm, int64_t Ng, int64_t gmap_first, int64_t gmap_count,
+                              const float* poses, const float* patches, const float* intrinsics, const int64_t* ii,
+                              const int64_t* jj, const int64_t* kk, int64_t E, float* coords, void* graph_ws,
+                              size_t graph_ws_bytes, int64_t E_max, int64_t k_range, int64_t* ix, int64_t* jx, void* stream);
 
 /*
  * cdv_frame_ingest + cdv_transform (P = 3, coordinates only) + the first launch of

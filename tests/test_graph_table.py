@@ -1,0 +1,206 @@
+"""The patch-graph index as a TABLE (cdv_graph_build_table / cdv_update_prologue_table: two launches, no scan) against its
+checkers: numpy (per-patch lists in (jj, edge id) order == std::stable_sort by jj, ba.cpp:84-86), the CPU oracle
+(fastba.neighbors, ba.cpp:59-97) and the ranked index build (cdv_graph_build*) -- all integer work, bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from cdv_slam_amd import ops, synth
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def T(a):
+    return torch.as_tensor(np.ascontiguousarray(a), device=DEV)
+
+
+def table_lists(g, E):
+    """{patch id: [(edge, ii, jj), ...] in table order} from the workspace (first 32 records from the table, longer lists
+    from the overflow segment)"""
+    deg, plo, recs, ovf, order, stream = (a.cpu().numpy() for a in g.table_arrays())
+    out = {}
+    for k in np.nonzero(deg)[0]:
+        d = int(deg[k])
+        if d <= 32:
+            rows = [recs[((k >> 4) * 32 + t) * 16 + (k & 15)] for t in range(d)]
+        else:
+            rows = [ovf[plo[k] + t] for t in range(d)]
+            first = [recs[((k >> 4) * 32 + t) * 16 + (k & 15)] for t in range(32)]
+            assert np.array_equal(np.array(first), np.array(rows[:32]))           # the table holds the first 32 of them
+        rows = np.array(rows)
+        assert (rows[:, 3] == k).all()
+        out[int(k)] = rows[:, :3]
+    return out, order[:E], stream[:E]
+
+
+def check_table(ii, jj, kk, k_range, bind=None):
+    g = ops.GraphIndex(torch.device(DEV), E_cap=len(kk), k_range=k_range)
+    if bind is not None:
+        g.bind_corr_stream(*bind)
+    g.build_table(T(jj), T(kk), ii=None if ii is None else T(ii), with_neighbors=True)
+    ix, jx = g.neighbors()
+    ix_o, jx_o = O.neighbors(kk, jj)
+    assert np.array_equal(ix.cpu().numpy(), ix_o) and np.array_equal(jx.cpu().numpy(), jx_o)
+    lists, order, stream = table_lists(g, len(kk))
+    # numpy: the edges of every patch ordered by (jj, edge id)
+    perm = np.lexsort((np.arange(len(kk)), jj, kk))
+    ks, first = np.unique(kk[perm], return_index=True)
+    assert sorted(lists) == [int(k) for k in ks]
+    bounds = list(first) + [len(kk)]
+    for n, k in enumerate(ks):
+        es = perm[bounds[n]:bounds[n + 1]]
+        got = lists[int(k)]
+        assert np.array_equal(got[:, 0], es) and np.array_equal(got[:, 2], jj[es])
+        assert np.array_equal(got[:, 1], ii[es] if ii is not None else np.full(len(es), -1))
+    m = g.meta()
+    assert m[0] == len(ks) and m[1] == 1 and m[2] == ks.min() and m[3] == ks.max() and m[6] == 0 and m[7] == len(kk)
+    # the correlation's processing order: a permutation of the edges, grouped by target frame mod 32
+    assert np.array_equal(np.sort(order), np.arange(len(kk)))
+    bins = jj[order] & 31
+    assert (np.diff(bins) >= 0).all()
+    # a second build on the same workspace (cursors zero again, generation moved on) gives the same index
+    g.build_table(T(jj), T(kk), ii=None if ii is None else T(ii), with_neighbors=True, force=True)
+    ix2, jx2 = g.neighbors()
+    assert torch.equal(ix, ix2) and torch.equal(jx, jx2)
+    lists2, _, _ = table_lists(g, len(kk))
+    assert all(np.array_equal(lists[k], lists2[k]) for k in lists)
+    # ... and agrees with the ranked build's neighbors on the same workspace, which then serves unique() again
+    kx, ku = g.unique()
+    kx_o, ku_o = O.unique(kk)
+    assert np.array_equal(kx.cpu().numpy(), kx_o) and np.array_equal(ku.cpu().numpy(), ku_o) and not g.is_table
+    return g, order, stream
+
+
+@pytest.mark.parametrize("name", ["tiny", "small", "pr1", "default", "stress"])
+def test_table_index_bit_exact(name):
+    cfg = synth.CONFIGS[name]
+    ii, jj, kk = synth.replay_edges(cfg)
+    check_table(ii, jj, kk, cfg.buffer_size * cfg.M)
+    check_table(None, jj, kk, cfg.buffer_size * cfg.M)
+
+
+def test_table_index_irregular_and_overflowing_patches():
+    """random multigraphs: duplicate (k, j) edges, gaps in the id range (ids without an edge between live ones), patches
+    with more than 32 edges (overflow segment) next to ordinary ones, a single edge, one patch owning every edge"""
+    rng = np.random.default_rng(11)
+    E = 20000
+    kk = rng.choice(np.arange(100, 9000, 3), size=E).astype(np.int64)
+    jj = rng.integers(5, 300, size=E).astype(np.int64)
+    ii = rng.integers(0, 300, size=E).astype(np.int64)
+    check_table(ii, jj, kk, 9000)
+    kk = np.concatenate([rng.integers(40, 60, 1500), rng.integers(1000, 3000, 6000)]).astype(np.int64)   # ~75 edges per patch in [40, 60)
+    jj = rng.integers(0, 64, len(kk)).astype(np.int64)
+    ii = rng.integers(0, 64, len(kk)).astype(np.int64)
+    sh = rng.permutation(len(kk))
+    check_table(ii[sh], jj[sh], kk[sh], 4096)
+    check_table(None, np.array([3], np.int64), np.array([7], np.int64), 64)
+    check_table(None, rng.integers(0, 20, 120).astype(np.int64), np.full(120, 42, np.int64), 64)
+    # one workspace re-used for graphs with different id ranges (shrinking and growing)
+    g = ops.GraphIndex(torch.device(DEV), E_cap=4096, k_range=5000)
+    for lo, hi, E in ((100, 4000, 3000), (2000, 2100, 500), (0, 4999, 4096), (4500, 4600, 50)):
+        kk = rng.integers(lo, hi, E).astype(np.int64)
+        jj = rng.integers(0, 40, E).astype(np.int64)
+        g.build_table(T(jj), T(kk), with_neighbors=True)
+        ix, jx = g.neighbors()
+        ix_o, jx_o = O.neighbors(kk, jj)
+        assert np.array_equal(ix.cpu().numpy(), ix_o) and np.array_equal(jx.cpu().numpy(), jx_o)
+        m = g.meta()
+        assert m[0] == len(np.unique(kk)) and m[2] == kk.min() and m[3] == kk.max()
+
+
+def test_table_index_error_states():
+    """an id outside [0, k_range), or a patch with more edges than the sort launch serves (128): the index reports its
+    error state, neighbors say "none", and the next well-formed build on the workspace is fine again"""
+    rng = np.random.default_rng(5)
+    g = ops.GraphIndex(torch.device(DEV), E_cap=4096, k_range=1000)
+    good_k, good_j = rng.integers(0, 1000, 2000).astype(np.int64), rng.integers(0, 30, 2000).astype(np.int64)
+    for bad_k in (np.where(np.arange(2000) == 77, 1000, good_k), np.where(np.arange(2000) == 5, -1, good_k),
+                  np.where(np.arange(2000) < 200, 321, good_k)):
+        import os
+        os.environ["CDV_CHECK"] = "0"
+        g.build_table(T(good_j), T(bad_k.astype(np.int64)), with_neighbors=True, force=True)
+        ix, jx = g.neighbors()
+        assert bool((ix == -1).all()), int((ix != -1).sum())
+        assert bool((jx == -1).all()), int((jx != -1).sum())
+        with pytest.raises(ops._lib.CdvError):
+            g.meta()
+        g.build_table(T(good_j), T(good_k), with_neighbors=True, force=True)
+        ix, jx = g.neighbors()
+        ix_o, jx_o = O.neighbors(good_k, good_j)
+        assert np.array_equal(ix.cpu().numpy(), ix_o) and np.array_equal(jx.cpu().numpy(), jx_o) and g.meta()[6] == 0
+
+
+def test_table_stream_from_bound_coordinates():
+    """cdv_graph_build_table with a bound coordinate buffer writes the correlation's packed input stream: record p belongs
+    to edge order[p] and carries its 18 coordinates, the reduced ring indices (slam.py:319-320) and the floor extremes"""
+    st = synth.make_state("small", features=False)
+    rng = np.random.default_rng(2)
+    coords = (rng.uniform(-5, 70, (1, st.E, 2, 3, 3))).astype(np.float32)
+    coords[0, 7] = 1e9
+    coords[0, 8] = -1e9
+    ct = T(coords)
+    kmod, jmod, Ng, slots = st.cfg.M * st.cfg.pmem, st.cfg.mem, (st.cfg.M * st.cfg.pmem * 3) // 4, st.cfg.mem
+    g, order, stream = check_table(st.ii, st.jj, st.kk, st.cfg.buffer_size * st.cfg.M, bind=(ct, kmod, jmod, Ng, slots))
+    # check_table ended with a ranked build (unique()): build the table once more for the stream it leaves
+    g.build_table(T(st.jj), T(st.kk), ii=T(st.ii), force=True)
+    _, order, stream = table_lists(g, st.E)
+    e = stream[:, 18]
+    assert np.array_equal(e, order)
+    assert np.array_equal(stream[:, :18].view(np.float32), coords[0].reshape(st.E, 18)[e])
+    kq, jq = st.kk[e] % kmod, st.jj[e] % jmod
+    ok = kq < Ng
+    assert np.array_equal(stream[:, 19].astype(np.int64)[ok], kq[ok]) and np.array_equal(stream[:, 20].astype(np.int64)[ok], jq[ok])
+    assert (stream[:, 19][~ok] == -1).all() and (stream[:, 20][~ok] == -1).all() and (~ok).any()
+    fl = lambda v: np.clip(np.floor(v), -30000, 30000).astype(np.int64)
+    x, y = fl(coords[0, e, 0].reshape(st.E, 9)), fl(coords[0, e, 1].reshape(st.E, 9))
+    bx, by = stream[:, 21].astype(np.int64), stream[:, 22].astype(np.int64)
+    s16 = lambda v: ((v & 0xffff) ^ 0x8000) - 0x8000
+    assert np.array_equal(s16(bx), x.min(1)) and np.array_equal(bx >> 16, x.max(1))
+    assert np.array_equal(s16(by), y.min(1)) and np.array_equal(by >> 16, y.max(1))
+
+
+@pytest.mark.parametrize("name", ["small", "default"])
+def test_prologue_table_equals_separate_launches(name):
+    """cdv_update_prologue_table (2 launches) == ring ingest + cdv_transform + table build issued one by one: rings and
+    pixel-major tiles bit for bit, coordinates bit for bit, neighbors, and the stream carries those coordinates"""
+    st = synth.make_state(name)
+    dev = torch.device(DEV)
+    mem, C, h, w = st.fmap1.shape
+    M = st.cfg.M
+
+    def rings():
+        f1, f2 = ops.alloc_fmap_ring(mem, C, h, w, dev), ops.alloc_fmap_ring(mem, C, h // 4, w // 4, dev)
+        for s in range(mem - 1):
+            ops.fmap_ingest(T(st.fmap1[s]), f1, f2, s)
+        return f1, f2
+
+    gmap = T(st.gmap)
+    new_frame, slot, tiles = T(st.fmap1[mem - 1]), mem - 1, ((st.n - 1) % st.cfg.pmem) * M
+    poses, patches, intr = T(st.poses), T(st.patches), T(st.intrinsics)
+    ii, jj, kk = T(st.ii), T(st.jj), T(st.kk)
+    # one by one
+    a1, a2 = rings()
+    pm_a = ops.gmap_to_pixel_major(gmap)
+    pm_a[tiles:tiles + M] = 0
+    ops.fmap_ingest(new_frame, a1, a2, slot, gmap=gmap, gmap_pm=pm_a, gmap_first=tiles, gmap_count=M)
+    coords_a = ops.transform(poses[None], patches[None], intr[None], ii, jj, kk, layout_e2pp=True)
+    # fused
+    b1, b2 = rings()
+    pm_b = ops.gmap_to_pixel_major(gmap)
+    pm_b[tiles:tiles + M] = 0
+    g = ops.GraphIndex(dev, E_cap=st.E, k_range=st.cfg.buffer_size * M)
+    g.bind_corr_stream(None, M * st.cfg.pmem, st.cfg.mem, gmap.shape[0], mem)
+    coords_b = ops.update_prologue_table(g, new_frame, b1, b2, slot, gmap, pm_b, tiles, M, poses, patches, intr, ii, jj, kk)
+    assert torch.equal(a1, b1) and torch.equal(a2, b2) and torch.equal(pm_a, pm_b)
+    # (the two kernels run the same formulas; the compiler contracts their multiply-adds differently: last-bit differences)
+    assert float((coords_a - coords_b).abs().max()) < 1e-4
+    want = O.transform(st.poses, st.patches, st.intrinsics, st.ii, st.jj, st.kk, dtype=np.float64).transpose(0, 3, 1, 2)
+    assert np.abs(coords_b[0].cpu().numpy() - want).max() < 1e-3
+    ix, jx = g.neighbors()
+    ix_o, jx_o = O.neighbors(st.kk, st.jj)
+    assert np.array_equal(ix.cpu().numpy(), ix_o) and np.array_equal(jx.cpu().numpy(), jx_o)
+    _, order, stream = table_lists(g, st.E)
+    assert np.array_equal(np.sort(order), np.arange(st.E)) and np.array_equal(stream[:, 18], order)
+    assert np.array_equal(stream[:, :18].view(np.float32), coords_b[0].cpu().numpy().reshape(st.E, 18)[order])
