@@ -15,11 +15,18 @@ Layout (only what the path needs):
 __all__ = ["ops", "altcorr", "fastba", "lietorch", "projective_ops", "ba", "synth", "install_dropin"]
 
 
-def install_dropin():
+def install_dropin(table_capacity=None):
     """Register cuda_corr, cuda_ba and lietorch_backends in sys.modules (reference import names:
-    cdvslam/altcorr/correlation.py:2, cdvslam/fastba/ba.py:2, cdvslam/lietorch/group_ops.py:1)."""
+    cdvslam/altcorr/correlation.py:2, cdvslam/fastba/ba.py:2, cdvslam/lietorch/group_ops.py:1).
+    table_capacity (optional): the number of patch ids that can be live at once, (REMOVAL_WINDOW + 2) * PATCHES_PER_FRAME of
+    the configuration the SLAM object runs (2,304 for default_cdvo.yaml): cuda_ba.neighbors / forward then use the
+    two-launch table form of the patch-graph index (ops.configure_table); without it the ranked index, which assumes
+    nothing about the ids."""
     import sys
+    from . import ops
     from .dropin import cuda_ba, cuda_corr, lietorch_backends
+    if table_capacity is not None:
+        ops.configure_table(table_capacity)
     sys.modules.setdefault("cuda_corr", cuda_corr)
     sys.modules.setdefault("cuda_ba", cuda_ba)
     sys.modules.setdefault("lietorch_backends", lietorch_backends)

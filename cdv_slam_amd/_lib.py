@@ -49,10 +49,10 @@ SIGNATURES = {
     "cdv_graph_build": (_i32, [_vp, _vp, _i64, _vp, _sz, _i64, _i64, _vp]),
     "cdv_graph_build_neighbors": (_i32, [_vp, _vp, _i64, _vp, _sz, _i64, _i64, _vp, _vp, _vp]),
     "cdv_graph_build_edges": (_i32, [_vp, _vp, _vp, _i64, _vp, _sz, _i64, _i64, _vp, _vp, _vp]),
-    "cdv_graph_build_table": (_i32, [_vp, _vp, _vp, _i64, _vp, _sz, _i64, _i64, _vp, _vp, _vp]),
+    "cdv_graph_build_table": (_i32, [_vp, _vp, _vp, _i64, _vp, _sz, _i64, _i64, _i64, _vp, _vp, _vp]),
     "cdv_graph_table_offsets": (_i32, [_i64, _i64, _vp]),
     "cdv_update_prologue_table": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i64, _i64, _i64,
-                                         _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _sz, _i64, _i64, _vp, _vp, _vp]),
+                                         _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _sz, _i64, _i64, _i64, _vp, _vp, _vp]),
     "cdv_update_prologue": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i64, _i64, _i64,
                                    _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _sz, _i64, _i64, _vp, _vp, _vp]),
     "cdv_graph_read_meta_host": (_i32, [_vp, _vp, _vp]),

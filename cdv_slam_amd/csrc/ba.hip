@@ -952,6 +952,10 @@ extern "C" int cdv_ba_forward(float* poses, float* patches, const float* intrins
   }
   // the slab paths: two launches per iteration, no float atomics (ba_win.hip up to 10 free poses, ba_mid.hip up to 32)
   const bool window = N >= 1 && N <= MID_N;
+  const bool table = cdv_graph_is_table(graph_ws);
+  CDV_REQUIRE(!table || window, CDV_ERR_UNSUPPORTED,
+              "cdv_ba_forward: graph_ws holds a patch table (cdv_graph_build_table), which serves 1 .. 32 free poses; build "
+              "the ranked index (cdv_graph_build_edges) for the global bundle adjustment");
   if (fresh) {
     if (!window) CDV_HIP_CHECK(hipMemsetAsync(b + L.sy, 0, L.zero_bytes, s));   // the window path keeps no accumulators
     CDV_HIP_CHECK(hipMemsetAsync(info, 0, sizeof(int32_t) * 16 + sizeof(uint64_t) * MID_GRAN, s));
@@ -961,8 +965,16 @@ extern "C" int cdv_ba_forward(float* poses, float* patches, const float* intrins
     BaWinArgs wa;
     wa.poses = poses; wa.patches = patches; wa.intr = intrinsics; wa.target = target; wa.weight = weight; wa.lmbda = lmbda;
     wa.ii = ii; wa.P = P; wa.t0 = t0; wa.N = N;
-    wa.gmeta = gv.meta; wa.prec = gv.prec; wa.koff_u = gv.koff_u; wa.kx = gv.kx;
-    wa.pell = gv.pell; wa.ell_chunks = (int)GL.ell_chunks;
+    wa.gmeta = gv.meta; wa.koff_u = gv.koff_u; wa.kx = gv.kx;
+    wa.tdeg = gv.tdeg; wa.tplo = gv.tplo; wa.tkid = gv.tkid; wa.tab_cap = 0;
+    if (table) {   // patch table: rows are slots, the overflow CSR stands where the CSR records do
+      wa.prec = gv.tprec; wa.pell = gv.ttab; wa.ell_chunks = 0x7fffffff;
+      wa.tab_cap = (int)cdv_graph_table_capacity(graph_ws);
+      CDV_REQUIRE(wa.tab_cap >= 1 && wa.tab_cap <= U_max, CDV_ERR_ARG,
+                  "cdv_ba_forward: U_max must be at least the capacity of the patch table in graph_ws");
+    } else {
+      wa.prec = gv.prec; wa.pell = gv.pell; wa.ell_chunks = (int)GL.ell_chunks;
+    }
     wa.has_ii = cdv_graph_has_ii(graph_ws) ? 1 : 0;
     wa.slabs = (float*)(b + L.slabs); wa.ared = (float*)(b + L.ared);
     wa.arrive = (int32_t*)(b + L.hand);

@@ -85,8 +85,9 @@ __global__ __launch_bounds__(64 * MKW) void ba_mid_chunk_kernel(BaWinArgs A) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: loops over a wave's share are uniform
   const int32_t* __restrict__ gmeta = A.gmeta;
-  const int gerr = gmeta[GM_ERROR];
-  const int U = gmeta[GM_U];
+  const PatchSpan sp = patch_span(A);
+  const int gerr = graph_error_of(gmeta, sp.table != 0);
+  const int U = sp.U;
   if (blockIdx.x == 0) {
     if (tid == 0) {
       ba_begin_status(A.info, A.counters, A.first, gerr, U > A.U_max);
@@ -125,14 +126,12 @@ __global__ __launch_bounds__(64 * MKW) void ba_mid_chunk_kernel(BaWinArgs A) {
       // chunk-slot copy, the patch's CSR offsets and id; everything unconditional on clamped indices
       const int step = 4 * MKW;
       int tb = 4 * wave;
-      const bool use_ell = chunk < A.ell_chunks;
-      const int4* cell = use_ell ? reinterpret_cast<const int4*>(A.pell) + (size_t)chunk * ELL_SLOTS * 16
-                                 : reinterpret_cast<const int4*>(A.prec);
-      int4 raw = cell[(use_ell && tb + sub < ELL_SLOTS) ? (tb + sub) * 16 + p : 0];
-      int4 raw0 = cell[use_ell ? p : 0];
+      const bool use_ell = sp.table || chunk < A.ell_chunks;
       const int rs = live ? r : 0;
-      const int plo_raw = A.koff_u[rs], phi_raw = A.koff_u[rs + 1];
-      const int64_t kx_raw = A.kx[rs];
+      const int4* cell = use_ell ? reinterpret_cast<const int4*>(A.pell) : reinterpret_cast<const int4*>(A.prec);
+      int4 raw = cell[(use_ell && tb + sub < ELL_SLOTS) ? cell_index(rs, tb + sub) : 0];
+      int4 raw0 = cell[use_ell ? cell_index(rs, 0) : 0];
+      const PatchRow row = patch_row(A, sp, rs);
       const float fx = A.intr[0], fy = A.intr[1], cx = A.intr[2], cy = A.intr[3];
       const float lm = A.lmbda[0];
       const EdgeRec safe = {A.prec[0], A.prec[1], A.prec[2]};   // stands in for slots that do not exist
@@ -144,9 +143,9 @@ __global__ __launch_bounds__(64 * MKW) void ba_mid_chunk_kernel(BaWinArgs A) {
         for (int i = tid; i < ER * EDL; i += 64 * MKW) Ed[i] = 0.f;
         if (tid == 0) smask[par ^ 1] = 0u;      // the word of the NEXT pass
       }
-      const int plo = live ? plo_raw : 0;
-      const int deg = live ? phi_raw - plo_raw : 0;
-      const int64_t kxr = live ? kx_raw : 0;
+      const int plo = live ? row.plo : 0;
+      const int deg = live ? row.deg : 0;
+      const int64_t kxr = live ? row.id : 0;
       if (!use_ell || tb + sub >= ELL_SLOTS) {   // beyond the chunk-slot copy: the CSR records, one round trip later
         const int4* csr = reinterpret_cast<const int4*>(A.prec);
         raw = csr[(tb + sub < deg) ? plo + tb + sub : 0];
@@ -726,8 +725,9 @@ __device__ __forceinline__ void mid_solve(const BaWinArgs& A, float* smem) {
 // only: the sum is the same whatever the launch geometry.
 __global__ __launch_bounds__(256) void ba_mid_reduce_kernel(BaWinArgs A) {
   const int32_t* __restrict__ gmeta = A.gmeta;
-  const int U = gmeta[GM_U];
-  if (gmeta[GM_ERROR] || U > A.U_max) return;
+  const PatchSpan sp = patch_span(A);
+  const int U = sp.U;
+  if (graph_error_of(gmeta, sp.table != 0) || U > A.U_max) return;
   __shared__ cdv_float4 partial[16];
   const int n6 = 6 * A.N;
   const int TRI_N = (n6 * (n6 + 1)) >> 1;
@@ -812,8 +812,9 @@ template <int SNP>
 __global__ __launch_bounds__(FT) void ba_mid_finish_kernel(BaWinArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int32_t* __restrict__ gmeta = A.gmeta;
-  const int U = gmeta[GM_U];
-  if (gmeta[GM_ERROR] || U > A.U_max) return;
+  const PatchSpan sp = patch_span(A);
+  const int U = sp.U;
+  if (graph_error_of(gmeta, sp.table != 0) || U > A.U_max) return;
   const int RT = (int)gridDim.x - 1;   // retract workgroups, FT patches each per pass
   const int tid = threadIdx.x;
   if (blockIdx.x == 0) {
@@ -837,8 +838,10 @@ __global__ __launch_bounds__(FT) void ba_mid_finish_kernel(BaWinArgs A) {
   float uv = 0.f, qv = 0.f, d0 = 0.f;
   float* pk = nullptr;
   if (livep) {
+    const PatchRow row = patch_row(A, sp, r);
+    livep = row.deg > 0;             // a table id without an edge: not part of the graph, not retracted
     uv = A.ug[r]; qv = A.qg[r];
-    pk = A.patches + A.kx[r] * 3 * PP + 2 * PP;
+    pk = A.patches + row.id * 3 * PP + 2 * PP;
     d0 = pk[0];                      // the depth is read from pixel [0][0]   (ba_cuda.cu:218 semantics)
   }
   CDV_STAMP(bam, sslot, 2);
@@ -901,8 +904,10 @@ __global__ __launch_bounds__(FT) void ba_mid_finish_kernel(BaWinArgs A) {
 #pragma unroll
     for (int i = 0; i < SNP; i++) ev[i] = (livep && i < n6) ? A.Edg[(size_t)i * A.U_stride + r] : 0.f;
     if (livep) {
+      const PatchRow row = patch_row(A, sp, r);
+      livep = row.deg > 0;
       uv = A.ug[r]; qv = A.qg[r];
-      pk = A.patches + A.kx[r] * 3 * PP + 2 * PP;
+      pk = A.patches + row.id * 3 * PP + 2 * PP;
       d0 = pk[0];
     }
   }

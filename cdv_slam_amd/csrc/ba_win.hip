@@ -72,8 +72,9 @@ __global__ __launch_bounds__(64 * CKW) void ba_chunk_kernel(BaWinArgs A) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int32_t* __restrict__ gmeta = A.gmeta;
-  const int gerr = gmeta[GM_ERROR];
-  const int U = gmeta[GM_U];
+  const PatchSpan sp = patch_span(A);
+  const int gerr = graph_error_of(gmeta, sp.table != 0);
+  const int U = sp.U;
   if (blockIdx.x == 0) {
     if (tid == 0) {
       ba_begin_status(A.info, A.counters, A.first, gerr, U > A.U_max);
@@ -110,15 +111,13 @@ __global__ __launch_bounds__(64 * CKW) void ba_chunk_kernel(BaWinArgs A) {
     // offset), the patch's CSR offsets and id
     const int step = 4 * CKW;
     int tb = 4 * wave;
-    const bool use_ell = chunk < A.ell_chunks;               // workgroup-uniform; false only beyond 65,536 patches
+    const bool use_ell = sp.table || chunk < A.ell_chunks;   // workgroup-uniform; false only beyond 65,536 unique patches
     // (no branch around these loads: a chunk without a chunk-slot copy reads CSR record 0 here and the real ones below)
-    const int4* cell = use_ell ? reinterpret_cast<const int4*>(A.pell) + (size_t)chunk * ELL_SLOTS * 16
-                               : reinterpret_cast<const int4*>(A.prec);
-    int4 raw = cell[use_ell ? (tb + sub) * 16 + p : 0];
-    int4 raw0 = cell[use_ell ? p : 0];
     const int rs = live ? r : 0;
-    const int plo_raw = A.koff_u[rs], phi_raw = A.koff_u[rs + 1];
-    const int64_t kx_raw = A.kx[rs];
+    const int4* cell = use_ell ? reinterpret_cast<const int4*>(A.pell) : reinterpret_cast<const int4*>(A.prec);
+    int4 raw = cell[use_ell ? cell_index(rs, tb + sub) : 0];
+    int4 raw0 = cell[use_ell ? cell_index(rs, 0) : 0];
+    const PatchRow row = patch_row(A, sp, rs);
     // the wave-uniform inputs travel with level 1 as well (read here, not before the loop: nothing waits for them
     // before the loads above are out): intrinsics of row 0 (ba_cuda.cu:253-259), lambda, CSR record 0
     const float fx = A.intr[0], fy = A.intr[1], cx = A.intr[2], cy = A.intr[3];
@@ -131,9 +130,9 @@ __global__ __launch_bounds__(64 * CKW) void ba_chunk_kernel(BaWinArgs A) {
       for (int i = tid; i < CKW * SLAB / 4; i += 64 * CKW) s4[i] = z4;
       for (int i = tid; i < 64 * EDL; i += 64 * CKW) Ed[i] = 0.f;
     }
-    const int plo = live ? plo_raw : 0;
-    const int deg = live ? phi_raw - plo_raw : 0;
-    const int64_t kxr = live ? kx_raw : 0;
+    const int plo = live ? row.plo : 0;
+    const int deg = live ? row.deg : 0;
+    const int64_t kxr = live ? row.id : 0;
     if (!use_ell) {   // beyond the chunk-slot copy: the CSR records, one round trip later
       const int4* csr = reinterpret_cast<const int4*>(A.prec);
       raw = csr[(tb + sub < deg) ? plo + tb + sub : 0];
@@ -496,8 +495,9 @@ __device__ __forceinline__ void solve_wave(const BaWinArgs& A, int RW) {
 
 __global__ __launch_bounds__(256) void ba_finish_kernel(BaWinArgs A) {
   const int32_t* __restrict__ gmeta = A.gmeta;
-  const int U = gmeta[GM_U];
-  if (gmeta[GM_ERROR] || U > A.U_max) return;
+  const PatchSpan sp = patch_span(A);
+  const int U = sp.U;
+  if (graph_error_of(gmeta, sp.table != 0) || U > A.U_max) return;
   const int RW = (int)gridDim.x - 1;
   const int tid = threadIdx.x;
   if (blockIdx.x == 0) {
@@ -578,8 +578,10 @@ __global__ __launch_bounds__(256) void ba_finish_kernel(BaWinArgs A) {
   float uv = 0.f, qv = 0.f, d0 = 0.f;
   float* pk = nullptr;
   if (livep) {
+    const PatchRow row = patch_row(A, sp, r);
+    livep = row.deg > 0;             // a table id without an edge: not part of the graph, not retracted
     uv = A.ug[r]; qv = A.qg[r];
-    pk = A.patches + A.kx[r] * 3 * PP + 2 * PP;
+    pk = A.patches + row.id * 3 * PP + 2 * PP;
     d0 = pk[0];                      // the depth is read from pixel [0][0]   (ba_cuda.cu:218 semantics)
   }
   CDV_IF_STAMPS(asm volatile("v_nop" :: "v"(ev[0] + ev[59] + d0));)
@@ -641,8 +643,10 @@ __global__ __launch_bounds__(256) void ba_finish_kernel(BaWinArgs A) {
 #pragma unroll
     for (int i = 0; i < SN; i++) ev[i] = (livep && i < 6 * N) ? A.Edg[(size_t)i * A.U_stride + r] : 0.f;
     if (livep) {
+      const PatchRow row = patch_row(A, sp, r);
+      livep = row.deg > 0;
       uv = A.ug[r]; qv = A.qg[r];
-      pk = A.patches + A.kx[r] * 3 * PP + 2 * PP;
+      pk = A.patches + row.id * 3 * PP + 2 * PP;
       d0 = pk[0];
     }
   }

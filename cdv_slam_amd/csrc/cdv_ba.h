@@ -93,6 +93,10 @@ struct BaWinArgs {
   const int32_t *prec, *koff_u;
   const int32_t* pell;               // chunk-slot copy of the records (cdv_graph.h: ELL_SLOTS, ELL_CHUNKS)
   int ell_chunks;
+  // patch TABLE instead of the ranked index (cdv_ba_pairs.h patch_span): pell = the table, prec = its overflow CSR, and
+  // per slot its degree, overflow offset and patch id
+  const int32_t *tdeg, *tplo, *tkid;
+  int tab_cap;                       // > 0: the index is a patch table of this many slots (cdv_ba_pairs.h patch_span)
   const int64_t* kx;
   float *slabs, *ared;
   int32_t* arrive;                   // hand-off words (HAND_WORDS): token and arrival flags of the reduce workgroups

@@ -112,6 +112,44 @@ __device__ __forceinline__ float transpose_reduce16(const float* v, int c16) {
   return (b3 ? u2[1] : u2[0]) + row_ror<8>(b3 ? u2[0] : u2[1]);
 }
 
+// The "ranks" the slab kernels work through, for either form of the index (cdv_graph.h):
+//   ranked CSR index  U unique patches (read from the index); rank r: id kx[r], CSR segment koff_u[r] .. koff_u[r + 1],
+//                     chunk-slot row r
+//   patch table       U = the table's capacity (a kernel argument: nothing of the span is read from memory, so the first
+//                     load level does not wait for another one); rank r IS slot r = id mod capacity: id tkid[r], degree
+//                     tdeg[r] (0: no patch in this slot -- it contributes nothing and is not retracted; a chunk without
+//                     any patch leaves a zero slab), overflow segment tplo[r], table row r
+// Slot order is not id order where the ids wrap around the capacity; every sum still has one owner and a fixed order.
+struct PatchSpan {
+  int U, table;
+};
+__device__ __forceinline__ PatchSpan patch_span(const BaWinArgs& A) {
+  PatchSpan s;
+  s.table = A.tab_cap > 0;
+  s.U = s.table ? A.tab_cap : A.gmeta[GM_U];
+  return s;
+}
+// int4 index of record t of row u in the chunk-slot layout (row = unique rank, or slot of a table)
+__device__ __forceinline__ size_t cell_index(int u, int t) { return (size_t)((u >> 4) * ELL_SLOTS + t) * 16 + (u & 15); }
+
+// CSR offset / degree / id of rank rs (< U), all loads unconditional (select-computed addresses: see the load levels)
+struct PatchRow {
+  int plo, deg;
+  int64_t id;
+};
+__device__ __forceinline__ PatchRow patch_row(const BaWinArgs& A, const PatchSpan& sp, int rs) {
+  const int32_t* pa = sp.table ? A.tplo + rs : A.koff_u + rs;
+  const int32_t* pb = sp.table ? A.tdeg + rs : A.koff_u + rs + 1;
+  const int va = *pa, vb = *pb;
+  const int64_t kx = A.kx[sp.table ? 0 : rs];
+  const int kid = A.tkid[sp.table ? rs : 0];
+  PatchRow r;
+  r.plo = va;
+  r.deg = sp.table ? vb : vb - va;
+  r.id = sp.table ? (int64_t)(kid < 0 ? 0 : kid) : kx;
+  return r;
+}
+
 struct EdgeRec {
   int e, ix, jx;
 };

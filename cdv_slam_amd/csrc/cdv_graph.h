@@ -17,13 +17,12 @@ enum {
   GM_KRANGE = 8,   // kmax - kmin + 1 of the LAST successful build (0 if none): the range to re-zero
   GM_HAS_II = 9,   // != 0: the CSR records carry the source frame of every edge (the build was given ii)
   GM_STAGE = 16,   // arrival counter of the histogram launch (its last workgroup does the scan); zero between builds
-  // ---- table build (cdv_graph_build_table / cdv_update_prologue_table; no scan, no ranks: a patch is its own slot) ----
-  GM_MODE = 20,    // 1: the index in the workspace is a patch TABLE (slot = patch id), 0: the ranked CSR index above
+  // ---- table build (cdv_graph_build_table / cdv_update_prologue_table; no scan, no ranks: a patch's slot is id mod R) ----
+  GM_MODE = 20,    // 1: the index in the workspace is a patch TABLE, 0: the ranked CSR index above
   GM_GEN = 21,     // generation (build counter) of the table build in the workspace
-  GM_TERR = 22,    // == GM_GEN: a patch id of this build was outside [0, k_range) (no reset needed: compared, not tested)
-  GM_LO = 23,      // smallest / largest patch id with an edge (reset by the fill launch, atomic min / max by the sort launch)
-  GM_HI = 24,
-  GM_NLIVE = 25,   // number of patches with an edge
+  GM_TERR = 22,    // == GM_GEN: this build is in its error state (negative id, two live ids in one slot, a patch with more
+                   // than TAB_MAX_DEG edges) -- no reset needed: compared, not tested
+  GM_TCAP = 23,    // capacity R (slots) of the table build in the workspace
   GM_PRECN = 26,   // records handed out of the overflow CSR (patches with more than ELL_SLOTS edges)
   GM_OVFN = 28,    // [2], by build parity: edges that did not fit their patch's ELL_SLOTS table slots
   GM_WORDS = 64
@@ -36,6 +35,7 @@ constexpr int GRAPH_MAX_BLOCKS = 1024;   // workgroups of the per-edge kernels (
 constexpr int ELL_SLOTS = 32;
 constexpr int ELL_CHUNKS = 4096;
 constexpr int TAB_MAX_DEG = 128;   // table build: edges of one patch the sort launch handles (beyond: error state)
+constexpr int64_t TAB_CAP_MAX = 1 << 16;   // largest table capacity (slots) a workspace is laid out for
 // processing order of the fused correlation: edges grouped by target frame (jj mod ORD_BINS), so that the eighth of the
 // list an XCD works through touches three frames' feature maps instead of sixteen (counting sort riding the index build:
 // per-block counts from the histogram launch, positions and scatter in the fill launch)
@@ -57,7 +57,7 @@ struct CorrStream {
 struct GraphLayout {
   int64_t E_max, k_range;
   size_t meta, stage, khist, kcount, kcursor, krank, koff_u, kx, ku, pcsr_tmp, pcsr, prec, pell, nprev, nnext, ocnt, order, crec,
-      tcur, tdeg, tplo, ttab, tovf, tprec, total;
+      tcur, town, tdeg, tplo, tkid, tlive, ttab, tovf, tprec, total;
   int64_t tab_chunks;
   int64_t ell_chunks;
 };
@@ -88,12 +88,18 @@ static inline GraphLayout graph_layout(int64_t E_max, int64_t k_range) {
   L.ocnt = o;     o = align256(o + sizeof(int32_t) * ORD_BINS * GRAPH_MAX_BLOCKS);   // [block][bin] edges of the block per target bin
   L.order = o;    o = align256(o + sizeof(int32_t) * (size_t)E_max);
   L.crec = o;     o = align256(o + sizeof(uint32_t) * CORR_REC_WORDS * (size_t)E_max);
-  // patch table: slot = patch id in [0, k_range).  Records in the chunk-slot layout of `pell` with the patch id in place
-  // of the unique rank; tcur = fill cursors (zero between builds), tdeg / tplo = degree and overflow-CSR offset per slot
-  L.tab_chunks = (k_range + 15) / 16;
-  L.tcur = o;     o = align256(o + sizeof(int32_t) * (size_t)(k_range + 1));
-  L.tdeg = o;     o = align256(o + sizeof(int32_t) * (size_t)(k_range + 1));
-  L.tplo = o;     o = align256(o + sizeof(int32_t) * (size_t)(k_range + 1));
+  // patch table: slot = patch id mod R, R <= the table capacity the workspace was sized for = min(k_range, TAB_CAP_MAX).
+  // Records in the chunk-slot layout of `pell` with the slot in place of the unique rank; tcur = fill cursors (zero
+  // between builds), tdeg / tplo / tkid = degree, overflow-CSR offset and patch id per slot, tlive = live slots per
+  // workgroup of the sort launch
+  const int64_t tcap = k_range < TAB_CAP_MAX ? k_range : TAB_CAP_MAX;
+  L.tab_chunks = (tcap + 15) / 16;
+  L.tcur = o;     o = align256(o + sizeof(int32_t) * (size_t)(tcap + 16));
+  L.town = o;     o = align256(o + sizeof(uint64_t) * (size_t)(tcap + 16));
+  L.tdeg = o;     o = align256(o + sizeof(int32_t) * (size_t)(tcap + 16));
+  L.tplo = o;     o = align256(o + sizeof(int32_t) * (size_t)(tcap + 16));
+  L.tkid = o;     o = align256(o + sizeof(int32_t) * (size_t)(tcap + 16));
+  L.tlive = o;    o = align256(o + sizeof(int32_t) * (size_t)(tcap / 8 + 2));
   L.ttab = o;     o = align256(o + sizeof(int32_t) * 4 * 16 * (size_t)ELL_SLOTS * (size_t)L.tab_chunks);
   L.tovf = o;     o = align256(o + sizeof(int32_t) * 4 * (size_t)E_max);
   L.tprec = o;    o = align256(o + sizeof(int32_t) * 4 * ((size_t)E_max + 1));   // [0]: a record that is always valid
@@ -105,7 +111,8 @@ struct GraphView {
   int32_t* meta;
   int32_t *stage, *khist, *kcount, *kcursor, *krank, *koff_u, *ku, *pcsr_tmp, *pcsr, *prec, *pell, *nprev, *nnext, *ocnt, *order;
   uint32_t* crec;
-  int32_t *tcur, *tdeg, *tplo, *ttab, *tovf, *tprec;
+  int32_t *tcur, *tdeg, *tplo, *tkid, *tlive, *ttab, *tovf, *tprec;
+  unsigned long long* town;
   int64_t* kx;
 };
 
@@ -133,6 +140,9 @@ static inline GraphView graph_view(void* ws, const GraphLayout& L) {
   v.tcur = (int32_t*)(b + L.tcur);
   v.tdeg = (int32_t*)(b + L.tdeg);
   v.tplo = (int32_t*)(b + L.tplo);
+  v.town = (unsigned long long*)(b + L.town);
+  v.tkid = (int32_t*)(b + L.tkid);
+  v.tlive = (int32_t*)(b + L.tlive);
   v.ttab = (int32_t*)(b + L.ttab);
   v.tovf = (int32_t*)(b + L.tovf);
   v.tprec = (int32_t*)(b + L.tprec);
@@ -151,20 +161,28 @@ bool cdv_graph_has_ii(const void* ws);
 
 // is the index in the workspace a patch table (cdv_graph_build_table)?
 bool cdv_graph_is_table(const void* ws);
+// ... and its capacity in slots (0: not a table)
+int64_t cdv_graph_table_capacity(const void* ws);
 
-// is the index a usable one: the error state of the ranked build, or of the table build (an id outside [0, k_range), a
-// patch with more edges than the sort launch serves)
+// is the index a usable one: the error state of the ranked build, or of the table build (a negative id, two ids in one
+// slot, a patch with more edges than the sort launch serves)
 namespace cdv {
 __device__ __forceinline__ int graph_error(const int32_t* __restrict__ meta) {
   return meta[GM_MODE] ? (meta[GM_TERR] == meta[GM_GEN]) : meta[GM_ERROR];
+}
+// the same for a caller that knows which form the index has (a kernel argument): every word is read unconditionally, so
+// the answer costs ONE memory round trip, not two dependent ones, at the head of a latency-bound kernel
+__device__ __forceinline__ int graph_error_of(const int32_t* __restrict__ meta, bool table) {
+  const int e = meta[GM_ERROR], t = meta[GM_TERR], g = meta[GM_GEN];
+  return table ? (t == g) : e;
 }
 }  // namespace cdv
 
 // the table build in two halves (graph.hip), for cdv_update_prologue_table
 namespace cdv { struct TFillArgs; }
 int cdv_graph_table_prepare(const int64_t* ii, const int64_t* jj, const int64_t* kk, int64_t E, void* ws, size_t ws_bytes,
-                            int64_t E_max, int64_t k_range, int64_t* ix, int64_t* jx, void* stream, cdv::TFillArgs* fill,
-                            int* fill_blocks);
+                            int64_t E_max, int64_t k_range, int64_t tab_cap, int64_t* ix, int64_t* jx, void* stream,
+                            cdv::TFillArgs* fill, int* fill_blocks);
 int cdv_graph_table_finish(const cdv::TFillArgs& fill, int fill_blocks, void* ws, int64_t E_max, int64_t k_range, int64_t* ix,
                            int64_t* jx, const float* poses, const float* patches, const float* intr, float* coords_out,
                            bool with_stream, void* stream);

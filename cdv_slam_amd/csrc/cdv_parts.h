@@ -100,6 +100,35 @@ struct TfArgs {
   float *coords, *validpx, *valid, *Ji, *Jj, *Jz;
 };
 
+// one patch pixel through iproj -> Act4 -> proj (projective_ops.py:19-50): shared by every kernel that reprojects, so
+// that they agree bit for bit (the same expression tree gets the same multiply-add contractions)
+__device__ __forceinline__ void tf_pixel(const float* t, const float* q, float px, float py, float pd, float fxi, float fyi,
+                                         float cxi, float cyi, float fxj, float fyj, float cxj, float cyj, float& x, float& y,
+                                         float (&X1)[4]) {
+  CDV_NOCONTRACT
+  float X0[4];
+  X0[0] = (px - cxi) / fxi;              // iproj, projective_ops.py:19-29
+  X0[1] = (py - cyi) / fyi;
+  X0[2] = 1.f;
+  X0[3] = pd;
+  lt_act4_loaded(t, q, X0, X1);
+  const float d = 1.0f / fmaxf(X1[2], 0.1f); // proj, projective_ops.py:43
+  x = fxj * (d * X1[0]) + cxj;
+  y = fyj * (d * X1[1]) + cyj;
+}
+
+// relative transform of an edge as Act4 uses it: poses[jj] * poses[ii].inv(), re-normalised on load (so3.h:30-37)
+__device__ __forceinline__ void tf_relative(const float* __restrict__ poses, int64_t ix, int64_t jx, bool tonly, float* G,
+                                            float* t, float* q) {
+  float Pi[7], Pj[7], Pinv[7];
+#pragma unroll
+  for (int a = 0; a < 7; a++) { Pi[a] = poses[7 * ix + a]; Pj[a] = poses[7 * jx + a]; }
+  lt_se3_inv(Pi, Pinv);          // poses[:, ii].inv()          projective_ops.py:60
+  lt_se3_mul(Pj, Pinv, G);       // poses[:, jj] * ...
+  if (tonly) { G[3] = 0.f; G[4] = 0.f; G[5] = 0.f; G[6] = 1.f; }
+  lt_se3_load(G, t, q);          // Act4 reloads (re-normalises) Gij  so3.h:30-37
+}
+
 template <int P>
 __device__ __forceinline__ void transform_body(const TfArgs& A, int64_t n) {
   if (n >= A.E) return;
@@ -109,14 +138,8 @@ __device__ __forceinline__ void transform_body(const TfArgs& A, int64_t n) {
   const int64_t ix = A.ii[n], jx = A.jj[n], kx = A.kk[n];
   constexpr int PP = P * P;
 
-  float Pi[7], Pj[7], Pinv[7], G[7];
-#pragma unroll
-  for (int a = 0; a < 7; a++) { Pi[a] = poses[7 * ix + a]; Pj[a] = poses[7 * jx + a]; }
-  lt_se3_inv(Pi, Pinv);          // poses[:, ii].inv()          projective_ops.py:60
-  lt_se3_mul(Pj, Pinv, G);       // poses[:, jj] * ...
-  if (A.flags & CDV_TF_TONLY) { G[3] = 0.f; G[4] = 0.f; G[5] = 0.f; G[6] = 1.f; }
-  float t[3], q[4];
-  lt_se3_load(G, t, q);          // Act4 reloads (re-normalises) Gij  so3.h:30-37
+  float G[7], t[3], q[4];
+  tf_relative(poses, ix, jx, (A.flags & CDV_TF_TONLY) != 0, G, t, q);
 
   const float fxi = intr[4 * ix + 0], fyi = intr[4 * ix + 1], cxi = intr[4 * ix + 2], cyi = intr[4 * ix + 3];
   const float fxj = intr[4 * jx + 0], fyj = intr[4 * jx + 1], cxj = intr[4 * jx + 2], cyj = intr[4 * jx + 3];
@@ -126,15 +149,8 @@ __device__ __forceinline__ void transform_body(const TfArgs& A, int64_t n) {
   float Xc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int a = 0; a < PP; a++) {
-    float X0[4], X1[4];
-    X0[0] = (pk[a] - cxi) / fxi;              // iproj, projective_ops.py:19-29
-    X0[1] = (pk[PP + a] - cyi) / fyi;
-    X0[2] = 1.f;
-    X0[3] = pk[2 * PP + a];
-    lt_act4_loaded(t, q, X0, X1);
-    const float d = 1.0f / fmaxf(X1[2], 0.1f); // proj, projective_ops.py:43
-    const float x = fxj * (d * X1[0]) + cxj;
-    const float y = fyj * (d * X1[1]) + cyj;
+    float X1[4], x, y;
+    tf_pixel(t, q, pk[a], pk[PP + a], pk[2 * PP + a], fxi, fyi, cxi, cyi, fxj, fyj, cxj, cyj, x, y, X1);
     if (e2pp) {
       coords[(n * 2 + 0) * PP + a] = x;
       coords[(n * 2 + 1) * PP + a] = y;
@@ -372,15 +388,17 @@ __device__ __forceinline__ void graph_hist_body(const HistArgs& a, int bid, int 
 
 
 // ---- patch TABLE, launch 1 of the two-launch index build (graph.hip: cdv_graph_build_table) -----------------------------
-// One pass over the edges, no scan and no second pass behind it: slot = patch id, the t-th arriving edge of a patch takes
-// record t of its slot (chunk-slot layout of `pell`, cdv_graph.h), later arrivals go to the overflow list.  Order inside
-// a slot is arrival order here; the sort launch puts it into (jj, edge id) order.  Rides cdv_update_prologue_table next to
-// the ring ingest.
+// One pass over the edges, no scan and no second pass behind it: slot = patch id mod R (R = the table's capacity: at least
+// the number of ids between the oldest and the newest patch with an edge, so that no two of them share a slot -- checked by
+// the sort launch), the t-th arriving edge of a patch takes record t of its slot (chunk-slot layout of `pell`,
+// cdv_graph.h), later arrivals go to the overflow list.  Order inside a slot is arrival order here; the sort launch puts
+// it into (jj, edge id) order.  Rides cdv_update_prologue_table next to the ring ingest.
 struct TFillArgs {
   const int64_t *ii, *jj, *kk;   // ii may be NULL (records then carry -1: the bundle adjustment reads ii itself)
-  int32_t E, R;                  // R = k_range: ids must lie in [0, R)
+  int32_t E, R;                  // R = capacity (slots) of this build
   int32_t* meta;
   int32_t* tcur;
+  unsigned long long* town;      // per slot (generation << 32 | id) of the patch that owns it
   int32_t *ttab, *tovf, *tprec;
   int32_t* ocnt;                 // [blocks][ORD_BINS]
   int32_t gen;                   // generation of this build (> 0)
@@ -390,27 +408,56 @@ __device__ __forceinline__ void graph_tfill_body(const TFillArgs& a, int bid, in
   __shared__ int s_obin[ORD_BINS];
   if (tid < ORD_BINS) s_obin[tid] = 0;
   if (bid == 0 && tid == 0) {     // words the sort launch accumulates into; nobody reads them between the two launches
-    a.meta[GM_LO] = 0x7fffffff; a.meta[GM_HI] = -1; a.meta[GM_NLIVE] = 0; a.meta[GM_PRECN] = 1;
-    a.meta[GM_MODE] = 1; a.meta[GM_GEN] = a.gen; a.meta[GM_E] = a.E; a.meta[GM_HAS_II] = a.ii ? 1 : 0;
+    a.meta[GM_PRECN] = 1;
+    a.meta[GM_MODE] = 1; a.meta[GM_GEN] = a.gen; a.meta[GM_E] = a.E; a.meta[GM_HAS_II] = a.ii ? 1 : 0; a.meta[GM_TCAP] = a.R;
   }
   __syncthreads();
   typedef int cdv_i4 __attribute__((ext_vector_type(4)));
-  for (int e = bid * nthreads_per_block + tid; e < a.E; e += nblocks * nthreads_per_block) {
-    const int64_t k64 = a.kk[e];
-    const int j = (int)a.jj[e];
-    const int i = a.ii ? (int)a.ii[e] : -1;
-    atomicAdd(&s_obin[j & (ORD_BINS - 1)], 1);
+  const int R = a.R;
+  const float rinv = 1.0f / (float)R;
+  const int lane = tid & 63;
+  for (int e0 = bid * nthreads_per_block; e0 < a.E; e0 += nblocks * nthreads_per_block) {   // workgroup-uniform trips
+    const int e = e0 + tid;
+    const bool in = e < a.E;
+    const int64_t k64 = in ? a.kk[e] : -1;
+    const int j = in ? (int)a.jj[e] : 0;
+    const int i = (in && a.ii) ? (int)a.ii[e] : -1;
+    if (in) atomicAdd(&s_obin[j & (ORD_BINS - 1)], 1);
     const cdv_i4 rec = {e, i, j, (int)k64};
     if (e == 0) *reinterpret_cast<cdv_i4*>(a.tprec) = rec;        // overflow-CSR record 0: the "always valid" record
-    if (k64 < 0 || k64 >= (int64_t)a.R) {
-      a.meta[GM_TERR] = a.gen;                                    // every writer stores the same value
-      continue;
+    const bool ok = in && k64 >= 0 && k64 < ((int64_t)1 << 31);
+    if (in && !ok) a.meta[GM_TERR] = a.gen;                       // every writer stores the same value
+    // id mod R without an integer division: float quotient estimate, then one correction step each way
+    const int k = ok ? (int)k64 : -1 - lane;                      // invalid lanes: ids no neighbour shares
+    int q = (int)((float)k * rinv);
+    int slot = k - q * R;
+    slot = (slot < 0) ? slot + R : slot;
+    slot = (slot >= R) ? slot - R : slot;
+    // Neighbouring lanes that hold edges of ONE patch (the 13 backward edges of a new patch sit next to each other in the
+    // list, slam.py:536-541) take their table positions with ONE atomic of the run's first lane instead of one each on
+    // the same address: a run = consecutive lanes with equal id.
+    const int kprev = __shfl_up(k, 1);
+    const bool head = lane == 0 || k != kprev;
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long upto = heads & ((2ull << lane) - 1ull);          // heads at or below this lane (lane 63: all)
+    const int start = 63 - __clzll((long long)(lane == 63 ? heads : upto));
+    const unsigned long long above = lane == 63 ? 0ull : (heads >> (lane + 1)) << (lane + 1);
+    const int nexth = above ? __ffsll((long long)above) - 1 : 64;
+    int base = 0;
+    if (ok && head) {
+      // one patch per slot: the slot's owner word takes (generation, id) by an atomic max -- whoever finds another id of
+      // THIS generation there has met a second patch in the slot (stale generations are simply replaced: no reset pass)
+      const unsigned long long mine = ((unsigned long long)(uint32_t)a.gen << 32) | (uint32_t)k;
+      const unsigned long long was = atomicMax(&a.town[slot], mine);
+      if ((uint32_t)(was >> 32) == (uint32_t)a.gen && (uint32_t)was != (uint32_t)k) a.meta[GM_TERR] = a.gen;
+      base = atomicAdd(&a.tcur[slot], nexth - start);
     }
-    const int k = (int)k64;
-    const int t = atomicAdd(&a.tcur[k], 1);
+    base = __shfl(base, start);
+    if (!ok) continue;
+    const int t = base + (lane - start);
     if (t >= TAB_MAX_DEG) a.meta[GM_TERR] = a.gen;               // more edges than the sort launch serves: known before it starts
     if (t < ELL_SLOTS) {
-      *reinterpret_cast<cdv_i4*>(a.ttab + 4 * ((size_t)((k >> 4) * ELL_SLOTS + t) * 16 + (k & 15))) = rec;
+      *reinterpret_cast<cdv_i4*>(a.ttab + 4 * ((size_t)((slot >> 4) * ELL_SLOTS + t) * 16 + (slot & 15))) = rec;
     } else {
       const int p = atomicAdd(&a.meta[GM_OVFN + (a.gen & 1)], 1);
       *reinterpret_cast<cdv_i4*>(a.tovf + 4 * (size_t)p) = rec;

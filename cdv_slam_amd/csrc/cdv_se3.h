@@ -28,8 +28,15 @@ template <typename T> __device__ __forceinline__ T t_atan(T x);
 template <> __device__ __forceinline__ float t_atan<float>(float x) { return atanf(x); }
 template <> __device__ __forceinline__ double t_atan<double>(double x) { return atan(x); }
 
+#ifdef CDV_EXP_CONTRACT
+#define CDV_NOCONTRACT
+#else
+#define CDV_NOCONTRACT _Pragma("clang fp contract(off)")
+#endif
+
 template <typename T>
 __device__ __forceinline__ void cross3(const T* a, const T* b, T* o) {
+  CDV_NOCONTRACT
   T x = a[1] * b[2] - a[2] * b[1];
   T y = a[2] * b[0] - a[0] * b[2];
   T z = a[0] * b[1] - a[1] * b[0];
@@ -37,15 +44,20 @@ __device__ __forceinline__ void cross3(const T* a, const T* b, T* o) {
 }
 
 // ---- lietorch family ---------------------------------------------------------------------------
+// (the quaternion / rotation primitives run WITHOUT multiply-add contraction: `#pragma clang fp contract(off)` in their
+// bodies.  Contraction is decided per call site after inlining, so two kernels running the same formula could differ in
+// the last bit -- the reprojection of cdv_transform and of the table prologue must not, cdv_parts.h tf_pixel.)
 
 template <typename T>
 __device__ __forceinline__ void lt_quat_load(const T* d, T* q) {  // so3.h:30-37
+  CDV_NOCONTRACT
   T n = t_sqrt<T>(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]);
   q[0] = d[0] / n; q[1] = d[1] / n; q[2] = d[2] / n; q[3] = d[3] / n;
 }
 
 template <typename T>
 __device__ __forceinline__ void lt_quat_mul(const T* a, const T* b, T* o) {
+  CDV_NOCONTRACT
   T w = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
   T x = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
   T y = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
@@ -55,6 +67,7 @@ __device__ __forceinline__ void lt_quat_mul(const T* a, const T* b, T* o) {
 
 template <typename T>
 __device__ __forceinline__ void lt_rot(const T* q, const T* p, T* o) {  // so3.h:54-59
+  CDV_NOCONTRACT
   T uv[3], c[3];
   cross3(q, p, uv);
   uv[0] += uv[0]; uv[1] += uv[1]; uv[2] += uv[2];
@@ -78,12 +91,14 @@ __device__ __forceinline__ void lt_quat_to_R(const T* q, T* R) {
 
 template <typename T>
 __device__ __forceinline__ void lt_se3_load(const T* d, T* t, T* q) {  // se3.h:36
+  CDV_NOCONTRACT
   t[0] = d[0]; t[1] = d[1]; t[2] = d[2];
   lt_quat_load(d + 3, q);
 }
 
 template <typename T>
 __device__ __forceinline__ void lt_se3_inv(const T* X, T* Y) {  // se3.h:38-40
+  CDV_NOCONTRACT
   T t[3], q[4], qc[4], qi[4], r[3];
   lt_se3_load(X, t, q);
   qc[0] = -q[0]; qc[1] = -q[1]; qc[2] = -q[2]; qc[3] = q[3];
@@ -95,6 +110,7 @@ __device__ __forceinline__ void lt_se3_inv(const T* X, T* Y) {  // se3.h:38-40
 
 template <typename T>
 __device__ __forceinline__ void lt_se3_mul(const T* X, const T* Y, T* Z) {  // se3.h:47-49
+  CDV_NOCONTRACT
   T t1[3], q1[4], t2[3], q2[4], qr[4], q[4], r[3];
   lt_se3_load(X, t1, q1);
   lt_se3_load(Y, t2, q2);
@@ -108,6 +124,7 @@ __device__ __forceinline__ void lt_se3_mul(const T* X, const T* Y, T* Z) {  // s
 // act4 with an already loaded (normalised) element (se3.h:55-58)
 template <typename T>
 __device__ __forceinline__ void lt_act4_loaded(const T* t, const T* q, const T* p, T* o) {
+  CDV_NOCONTRACT
   T r[3];
   lt_rot(q, p, r);
   T w = p[3];

@@ -25,6 +25,7 @@
 //                predecessor / successor in time (fastba.neighbors); clears the fill cursors
 #include <mutex>
 #include <unordered_map>
+#include <vector>
 
 #include "cdv_common.h"
 #include "cdv_graph.h"
@@ -41,19 +42,21 @@ struct RegEntry {
   CorrStream cs;      // coords == nullptr: no packed correlation stream is written
   int32_t gen;        // table builds on this workspace so far
   bool table;         // the index in the workspace is a patch table
+  int32_t tab_cap;    // ... of this capacity (slots)
 };
 std::mutex g_reg_mutex;
 std::unordered_map<const void*, RegEntry> g_registry;
 
 
 __global__ __launch_bounds__(256) void graph_init_kernel(int32_t* meta, int32_t* khist, int32_t* kcursor, int32_t* tcur,
-                                                         int64_t k_cap) {
+                                                         unsigned long long* town, int64_t k_cap) {
   const int64_t n = k_cap + 1 > GM_WORDS ? k_cap + 1 : GM_WORDS;   // the meta words too when the id range is tiny
+  const int64_t tcap = (k_cap < TAB_CAP_MAX ? k_cap : TAB_CAP_MAX) + 16;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
     if (t <= k_cap) {
       khist[t] = 0;
       kcursor[t] = 0;
-      tcur[t] = 0;
+      if (t < tcap) { tcur[t] = 0; town[t] = 0ull; }
     }
     if (t < GM_WORDS) {
       meta[t] = 0;   // incl. the arrival counter of the histogram launch (GM_STAGE)
@@ -316,10 +319,10 @@ __global__ __launch_bounds__(256) void graph_copy_unique_kernel(const int32_t* _
 struct TSortArgs {
   int32_t* meta;
   int32_t R, E, gen;
-  int32_t *tcur, *tdeg, *tplo, *ttab, *tovf, *tprec;
+  int32_t *tcur, *tdeg, *tplo, *tkid, *tlive, *ttab, *tovf, *tprec;
   int32_t *nprev, *nnext;
   int64_t *ix, *jx;
-  int n_patch_wg;                 // workgroups [0, n_patch_wg) take 64 slots each, the rest are edge workgroups
+  int n_patch_wg;                 // workgroups [0, n_patch_wg) take 8 slots each, the rest are edge workgroups
   const int32_t* ocnt;
   int nblk_edges;
   int32_t* order;
@@ -345,13 +348,8 @@ __device__ __forceinline__ void reproject_edge(const TSortArgs& A, int64_t ix, i
                                                float (&cy)[9]) {
   const float* __restrict__ poses = A.poses;
   const float* __restrict__ intr = A.intr;
-  float Pi[7], Pj[7], Pinv[7], G[7];
-#pragma unroll
-  for (int a = 0; a < 7; a++) { Pi[a] = poses[7 * ix + a]; Pj[a] = poses[7 * jx + a]; }
-  lt_se3_inv(Pi, Pinv);
-  lt_se3_mul(Pj, Pinv, G);
-  float t[3], q[4];
-  lt_se3_load(G, t, q);
+  float G[7], t[3], q[4];
+  tf_relative(poses, ix, jx, false, G, t, q);
   const cdv_float4 Ki = *reinterpret_cast<const cdv_float4*>(intr + 4 * ix);
   const cdv_float4 Kj = *reinterpret_cast<const cdv_float4*>(intr + 4 * jx);
   // the patch: 27 consecutive floats, 4-byte aligned -- seven wide loads instead of 27 scalar ones
@@ -366,15 +364,8 @@ __device__ __forceinline__ void reproject_edge(const TSortArgs& A, int64_t ix, i
   pv[24] = pk[24]; pv[25] = pk[25]; pv[26] = pk[26];
 #pragma unroll
   for (int a = 0; a < 9; a++) {
-    float X0[4], X1[4];
-    X0[0] = (pv[a] - Ki[2]) / Ki[0];
-    X0[1] = (pv[9 + a] - Ki[3]) / Ki[1];
-    X0[2] = 1.f;
-    X0[3] = pv[18 + a];
-    lt_act4_loaded(t, q, X0, X1);
-    const float d = 1.0f / fmaxf(X1[2], 0.1f);
-    cx[a] = Kj[0] * (d * X1[0]) + Kj[2];
-    cy[a] = Kj[1] * (d * X1[1]) + Kj[3];
+    float X1[4];
+    tf_pixel(t, q, pv[a], pv[9 + a], pv[18 + a], Ki[0], Ki[1], Ki[2], Ki[3], Kj[0], Kj[1], Kj[2], Kj[3], cx[a], cy[a], X1);
   }
 }
 
@@ -394,15 +385,15 @@ __global__ __launch_bounds__(256) void graph_tsort_kernel(const TSortArgs A) {
       const int bq = tid & 7, part = tid >> 3;
       int tot[4] = {0, 0, 0, 0}, pre[4] = {0, 0, 0, 0};
       const cdv_i4* tab = reinterpret_cast<const cdv_i4*>(A.ocnt);
-      for (int b0 = part; b0 < nblk; b0 += 32 * 4) {
-        cdv_i4 c[4];
+      for (int b0 = part; b0 < nblk; b0 += 32 * 8) {   // eight 16-byte loads in flight: 256 rows per memory round trip
+        cdv_i4 c[8];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < 8; u++) {
           const int b = b0 + 32 * u;
           c[u] = (b < nblk) ? tab[b * (ORD_BINS / 4) + bq] : cdv_i4{0, 0, 0, 0};
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < 8; u++) {
           const bool before = b0 + 32 * u < bid;
 #pragma unroll
           for (int q = 0; q < 4; q++) { tot[q] += c[u][q]; pre[q] += before ? c[u][q] : 0; }
@@ -491,43 +482,38 @@ __global__ __launch_bounds__(256) void graph_tsort_kernel(const TSortArgs A) {
     }
     return;
   }
-  // =================================== patch workgroups: 64 slots each ===================================
-  const int s0 = 64 * (int)blockIdx.x;
-  __shared__ int s_c[64], s_list[64], s_nlive;
+  // =================================== patch workgroups: 8 slots each, a half-wave per slot ===================================
+  // everything a slot needs is requested at once, before its degree is known: cursor and all ELL_SLOTS records (a slot's
+  // unused records hold old data: masked by the degree when it arrives)
+  const int h = tid >> 5, hl = tid & 31;
+  const int slot = 8 * (int)blockIdx.x + h;
+  const bool in_tab = slot < A.R;
+  const int cs = in_tab ? slot : 0;
+  const int deg_raw = A.tcur[cs];
+  cdv_i4 rec = *reinterpret_cast<const cdv_i4*>(A.ttab + tab_index(cs, hl));
   __shared__ uint64_t s_key[8][32];
   __shared__ int s_e[8][32];
+  __shared__ int s_flag[8];
   __shared__ cdv_i4 s_orec[TS_OVF_MAX];
   __shared__ uint64_t s_okey[TS_OVF_MAX];
   __shared__ int s_osort[TS_OVF_MAX], s_ocnt;
   if (blockIdx.x == 0 && tid == 0) A.meta[GM_OVFN + ((A.gen & 1) ^ 1)] = 0;   // the next build's overflow counter
-  if (tid < 64) {
-    const int c = (s0 + tid < A.R) ? A.tcur[s0 + tid] : 0;
-    s_c[tid] = c;
-    const unsigned long long bal = __ballot(c > 0);
-    if (c > 0) s_list[__popcll(bal & ((1ull << lane) - 1ull))] = tid;
-    if (tid == 0) s_nlive = __popcll(bal);
-    if (s0 + tid < A.R) {
-      A.tdeg[s0 + tid] = min(c, TS_OVF_MAX);
-      A.tplo[s0 + tid] = 0;
-      if (c > 0) A.tcur[s0 + tid] = 0;                            // zero again for the next build
-    }
-    if (bal != 0ull && tid == 0) {                                // the live range and count: only workgroups with patches
-      const int first = __ffsll((long long)bal) - 1, last = 63 - __clzll((long long)bal);
-      atomicMin(&A.meta[GM_LO], s0 + first);
-      atomicMax(&A.meta[GM_HI], s0 + last);
-      atomicAdd(&A.meta[GM_NLIVE], __popcll(bal));
-    }
+  const int deg = in_tab ? deg_raw : 0;
+  const int d32 = min(deg, ELL_SLOTS);
+  // two patch ids in one slot (the table's capacity is smaller than the live id range): error state
+  const int k0 = __shfl(rec.w, lane & 32);                      // record 0 of this half-wave's slot
+  const bool clash = hl < d32 && rec.w != k0;
+  if (__ballot(clash) != 0ull && lane == 0) A.meta[GM_TERR] = A.gen;
+  if (in_tab && hl == 0) {
+    A.tdeg[slot] = min(deg, TS_OVF_MAX);
+    A.tplo[slot] = 0;
+    A.tkid[slot] = deg > 0 ? k0 : -1;
+    if (deg > 0) A.tcur[slot] = 0;                              // zero again for the next build
+    s_flag[h] = deg > 0 ? 1 : 0;
+  } else if (hl == 0) {
+    s_flag[h] = 0;
   }
-  __syncthreads();
-  const int nlive = s_nlive;
-  if (nlive == 0) return;
-  const int h = tid >> 5, hl = tid & 31;
-  for (int li = h; li < nlive; li += 8) {
-    const int sl = s_list[li];
-    const int slot = s0 + sl, deg = s_c[sl];
-    if (deg > ELL_SLOTS) continue;                                // overflowing patches: below
-    cdv_i4 rec = {0, 0, 0, 0};
-    if (hl < deg) rec = *reinterpret_cast<const cdv_i4*>(A.ttab + tab_index(slot, hl));
+  if (deg > 0 && deg <= ELL_SLOTS) {
     const uint64_t key = hl < deg ? rec_key(rec) : ~0ull;
     s_key[h][hl] = key;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -544,30 +530,47 @@ __global__ __launch_bounds__(256) void graph_tsort_kernel(const TSortArgs A) {
       A.nnext[rec.x] = ne;
       if (A.ix && !terr) { A.ix[rec.x] = (int64_t)pe; A.jx[rec.x] = (int64_t)ne; }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();                              // s_key / s_e are reused by the next slot of this half-wave
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int n = 0;
+#pragma unroll
+    for (int u = 0; u < 8; u++) n += s_flag[u];
+    A.tlive[blockIdx.x] = n;                                     // live patches of this workgroup (summed by whoever asks)
   }
   // ---- patches with more than ELL_SLOTS edges (loop-closure graphs): wave 0, one after the other.  The first ELL_SLOTS
   // records are in the table, the rest in the overflow list; all of them are sorted into an overflow CSR segment
   // (tprec[tplo + t], t = 0 .. deg - 1) whose first ELL_SLOTS records also go back into the table ----
+  __shared__ int s_deg8[8];
+  if (hl == 0) s_deg8[h] = deg;
   __syncthreads();
   if (wave != 0) return;
+  bool any_ovf = false;
+#pragma unroll
+  for (int u = 0; u < 8; u++) any_ovf |= s_deg8[u] > ELL_SLOTS;
+  if (!any_ovf) return;
   const int n_ovf = A.meta[GM_OVFN + (A.gen & 1)];
-  for (int li = 0; li < nlive; li++) {
-    const int sl = s_list[li];
-    const int slot = s0 + sl, deg = s_c[sl];
-    if (deg <= ELL_SLOTS) continue;
-    if (deg > TS_OVF_MAX) {                                       // not served: the index goes into its error state
+  for (int hs = 0; hs < 8; hs++) {
+    const int sdeg = s_deg8[hs], oslot = 8 * (int)blockIdx.x + hs;
+    if (sdeg <= ELL_SLOTS) continue;
+    if (sdeg > TS_OVF_MAX) {                                      // not served (flagged by the fill launch already)
       if (lane == 0) A.meta[GM_TERR] = A.gen;
       continue;
     }
-    if (lane < ELL_SLOTS) s_orec[lane] = *reinterpret_cast<const cdv_i4*>(A.ttab + tab_index(slot, lane));
+    if (lane < ELL_SLOTS) s_orec[lane] = *reinterpret_cast<const cdv_i4*>(A.ttab + tab_index(oslot, lane));
     if (lane == 0) s_ocnt = ELL_SLOTS;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+    const int okid = s_orec[0].w;
+    const float rinv = 1.0f / (float)A.R;
     for (int u = lane; u < n_ovf; u += 64) {
       const cdv_i4 r = *reinterpret_cast<const cdv_i4*>(A.tovf + 4 * (size_t)u);
-      if (r.w == slot) {
+      int q = (int)((float)r.w * rinv);
+      int rs = r.w - q * A.R;
+      rs = (rs < 0) ? rs + A.R : rs;
+      rs = (rs >= A.R) ? rs - A.R : rs;
+      if (rs == oslot) {
+        if (r.w != okid) A.meta[GM_TERR] = A.gen;                 // another id in this slot
         const int idx = atomicAdd(&s_ocnt, 1);
         if (idx < TS_OVF_MAX) s_orec[idx] = r;
       }
@@ -590,15 +593,15 @@ __global__ __launch_bounds__(256) void graph_tsort_kernel(const TSortArgs A) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     for (int x = lane; x < total; x += 64) {
-      const cdv_i4 rec = s_orec[s_osort[x]];
-      *reinterpret_cast<cdv_i4*>(A.tprec + 4 * (size_t)(plo + x)) = rec;
-      if (x < ELL_SLOTS) *reinterpret_cast<cdv_i4*>(A.ttab + tab_index(slot, x)) = rec;
+      const cdv_i4 r = s_orec[s_osort[x]];
+      *reinterpret_cast<cdv_i4*>(A.tprec + 4 * (size_t)(plo + x)) = r;
+      if (x < ELL_SLOTS) *reinterpret_cast<cdv_i4*>(A.ttab + tab_index(oslot, x)) = r;
       const int pe = x > 0 ? s_orec[s_osort[x - 1]].x : -1, ne = x + 1 < total ? s_orec[s_osort[x + 1]].x : -1;
-      A.nprev[rec.x] = pe;
-      A.nnext[rec.x] = ne;
-      if (A.ix && !terr) { A.ix[rec.x] = (int64_t)pe; A.jx[rec.x] = (int64_t)ne; }
+      A.nprev[r.x] = pe;
+      A.nnext[r.x] = ne;
+      if (A.ix && !terr) { A.ix[r.x] = (int64_t)pe; A.jx[r.x] = (int64_t)ne; }
     }
-    if (lane == 0) A.tplo[slot] = plo;
+    if (lane == 0) A.tplo[oslot] = plo;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
   }
@@ -667,12 +670,12 @@ int cdv_graph_prepare(const int64_t* jj, const int64_t* kk, int64_t E, void* ws,
                 it->second.L.k_range != k_range;
     const CorrStream keep = it != g_registry.end() ? it->second.cs : CorrStream{nullptr, 0, 0, 0, 0, 0, 0, 1.0f};
     const int32_t gen = it != g_registry.end() ? it->second.gen : 0;
-    g_registry[ws] = RegEntry{L, true, false, keep, gen, false};
+    g_registry[ws] = RegEntry{L, true, false, keep, gen, false, 0};
   }
   const GraphView v = graph_view(ws, L);
   if (need_init)
     hipLaunchKernelGGL(graph_init_kernel, dim3(grid_for(k_range + 1 + GM_WORDS, 256, 2048)), dim3(256), 0,
-                       (hipStream_t)stream, v.meta, v.khist, v.kcursor, v.tcur, k_range);
+                       (hipStream_t)stream, v.meta, v.khist, v.kcursor, v.tcur, v.town, k_range);
   *hist = cdv::HistArgs{jj, kk, (int32_t)E, v.stage, v.khist, (int32_t)k_range, v.meta, v.kcount, v.krank, v.ocnt};
   *hist_blocks = E > 0 ? grid_for(E, 256, GRAPH_MAX_BLOCKS) : 0;
   return CDV_OK;
@@ -714,17 +717,25 @@ bool cdv_graph_is_table(const void* ws) {
   return it != g_registry.end() && it->second.table;
 }
 
+int64_t cdv_graph_table_capacity(const void* ws) {
+  std::lock_guard<std::mutex> lk(g_reg_mutex);
+  auto it = g_registry.find(ws);
+  return (it != g_registry.end() && it->second.table) ? it->second.tab_cap : 0;
+}
+
 // The table build in two halves (like cdv_graph_prepare / cdv_graph_finish), so that cdv_update_prologue_table can run the
 // fill pass inside its own first launch: prepare = checks, registry, one-time initialisation, arguments of the fill pass;
 // finish = the sort launch (patch workgroups + edge workgroups).
 int cdv_graph_table_prepare(const int64_t* ii, const int64_t* jj, const int64_t* kk, int64_t E, void* ws, size_t ws_bytes,
-                            int64_t E_max, int64_t k_range, int64_t* ix, int64_t* jx, void* stream, cdv::TFillArgs* fill,
-                            int* fill_blocks) {
+                            int64_t E_max, int64_t k_range, int64_t tab_cap, int64_t* ix, int64_t* jx, void* stream,
+                            cdv::TFillArgs* fill, int* fill_blocks) {
   CDV_REQUIRE((ix == nullptr) == (jx == nullptr), CDV_ERR_ARG, "cdv_graph_build_table: give both ix and jx or neither");
   CDV_REQUIRE(ws != nullptr, CDV_ERR_ARG, "cdv_graph_build_table: workspace is NULL");
   CDV_REQUIRE(E >= 0 && E < (int64_t)1 << 31, CDV_ERR_ARG, "cdv_graph_build_table: E out of range");
   CDV_REQUIRE(k_range >= 1 && k_range < ((int64_t)1 << 31) - 64 && E_max >= 1 && E <= E_max, CDV_ERR_ARG,
               "cdv_graph_build_table: need 1 <= E <= E_max, 1 <= k_range < 2^31");
+  CDV_REQUIRE(tab_cap >= 1 && tab_cap <= k_range && tab_cap <= TAB_CAP_MAX, CDV_ERR_ARG,
+              "cdv_graph_build_table: table capacity must lie in [1, min(k_range, 65536)]");
   const GraphLayout L = graph_layout(E_max, k_range);
   CDV_REQUIRE(L.total <= ws_bytes, CDV_ERR_WORKSPACE, "cdv_graph_build_table: workspace too small for (E_max, k_range)");
   bool need_init;
@@ -736,14 +747,15 @@ int cdv_graph_table_prepare(const int64_t* ii, const int64_t* jj, const int64_t*
                 it->second.L.k_range != k_range;
     const CorrStream keep = it != g_registry.end() ? it->second.cs : CorrStream{nullptr, 0, 0, 0, 0, 0, 0, 1.0f};
     gen = (it != g_registry.end() && !need_init) ? it->second.gen : 0;
-    gen = gen >= 0x7ffffff0 ? 1 : gen + 1;
-    g_registry[ws] = RegEntry{L, true, ii != nullptr && E > 0, keep, gen, true};
+    if (gen >= 0x7ffffff0) { gen = 0; need_init = true; }   // the owner words compare generations: start over from a clean table
+    gen += 1;
+    g_registry[ws] = RegEntry{L, true, ii != nullptr && E > 0, keep, gen, true, (int32_t)tab_cap};
   }
   const GraphView v = graph_view(ws, L);
   if (need_init)
     hipLaunchKernelGGL(graph_init_kernel, dim3(grid_for(k_range + 1 + GM_WORDS, 256, 2048)), dim3(256), 0,
-                       (hipStream_t)stream, v.meta, v.khist, v.kcursor, v.tcur, k_range);
-  *fill = cdv::TFillArgs{ii, jj, kk, (int32_t)E, (int32_t)k_range, v.meta, v.tcur, v.ttab, v.tovf, v.tprec, v.ocnt, gen};
+                       (hipStream_t)stream, v.meta, v.khist, v.kcursor, v.tcur, v.town, k_range);
+  *fill = cdv::TFillArgs{ii, jj, kk, (int32_t)E, (int32_t)tab_cap, v.meta, v.tcur, v.town, v.ttab, v.tovf, v.tprec, v.ocnt, gen};
   *fill_blocks = grid_for(E, 256, GRAPH_MAX_BLOCKS);   // >= 1: the first workgroup also resets the words of this build
   return CDV_OK;
 }
@@ -761,10 +773,11 @@ int cdv_graph_table_finish(const cdv::TFillArgs& fill, int fill_blocks, void* ws
   }
   const bool stream_ok = with_stream && (poses != nullptr || cs.coords != nullptr);
   TSortArgs A;
-  A.meta = v.meta; A.R = (int32_t)k_range; A.E = fill.E; A.gen = fill.gen;
-  A.tcur = v.tcur; A.tdeg = v.tdeg; A.tplo = v.tplo; A.ttab = v.ttab; A.tovf = v.tovf; A.tprec = v.tprec;
+  A.meta = v.meta; A.R = fill.R; A.E = fill.E; A.gen = fill.gen;
+  A.tcur = v.tcur; A.tdeg = v.tdeg; A.tplo = v.tplo; A.tkid = v.tkid; A.tlive = v.tlive; A.ttab = v.ttab; A.tovf = v.tovf;
+  A.tprec = v.tprec;
   A.nprev = v.nprev; A.nnext = v.nnext; A.ix = ix; A.jx = jx;
-  A.n_patch_wg = (int)((k_range + 63) / 64);
+  A.n_patch_wg = (fill.R + 7) / 8;
   A.ocnt = v.ocnt; A.nblk_edges = fill_blocks; A.order = v.order;
   A.ii = fill.ii; A.jj = fill.jj; A.kk = fill.kk;
   A.cs = cs; A.crec = stream_ok ? v.crec : nullptr;
@@ -776,24 +789,25 @@ int cdv_graph_table_finish(const cdv::TFillArgs& fill, int fill_blocks, void* ws
 }
 
 extern "C" int cdv_graph_build_table(const int64_t* ii, const int64_t* jj, const int64_t* kk, int64_t E, void* ws,
-                                     size_t ws_bytes, int64_t E_max, int64_t k_range, int64_t* ix, int64_t* jx,
-                                     void* stream) {
+                                     size_t ws_bytes, int64_t E_max, int64_t k_range, int64_t table_capacity, int64_t* ix,
+                                     int64_t* jx, void* stream) {
   cdv::TFillArgs f;
   int fb = 0;
-  const int rc = cdv_graph_table_prepare(ii, jj, kk, E, ws, ws_bytes, E_max, k_range, ix, jx, stream, &f, &fb);
+  const int rc = cdv_graph_table_prepare(ii, jj, kk, E, ws, ws_bytes, E_max, k_range, table_capacity, ix, jx, stream, &f, &fb);
   if (rc != CDV_OK) return rc;
   hipLaunchKernelGGL(graph_tfill_kernel, dim3(fb), dim3(256), 0, (hipStream_t)stream, f);
   return cdv_graph_table_finish(f, fb, ws, E_max, k_range, ix, jx, nullptr, nullptr, nullptr, nullptr, true, stream);
 }
 
 // byte offsets (into the workspace) of the table's arrays, for tools and tests that want to look at it:
-// out[0..5] = degree per slot (int32 [k_range]), overflow-CSR offset per slot (int32 [k_range]), records (int32 x 4, chunk-
-// slot layout), overflow-CSR records (int32 x 4), the correlation's order (int32 [E]), its packed stream (24 x uint32 per edge)
+// out[0..6] = degree per slot (int32 [capacity]), overflow-CSR offset per slot (int32 [capacity]), records (int32 x 4, chunk-
+// slot layout), overflow-CSR records (int32 x 4), the correlation's order (int32 [E]), its packed stream (24 x uint32 per edge),
+// patch id per slot (int32 [capacity], -1: none)
 extern "C" int cdv_graph_table_offsets(int64_t E_max, int64_t k_range, int64_t* out) {
   CDV_REQUIRE(out != nullptr && E_max >= 1 && k_range >= 1, CDV_ERR_ARG, "cdv_graph_table_offsets: bad argument");
   const GraphLayout L = graph_layout(E_max, k_range);
   out[0] = (int64_t)L.tdeg; out[1] = (int64_t)L.tplo; out[2] = (int64_t)L.ttab; out[3] = (int64_t)L.tprec;
-  out[4] = (int64_t)L.order; out[5] = (int64_t)L.crec;
+  out[4] = (int64_t)L.order; out[5] = (int64_t)L.crec; out[6] = (int64_t)L.tkid;
   return CDV_OK;
 }
 
@@ -831,7 +845,7 @@ extern "C" int cdv_graph_bind_corr_stream(void* ws, const float* coords, int64_t
   cs.jmagic = jmod > 1 ? (uint32_t)((((uint64_t)1 << 32) + (uint64_t)jmod - 1) / (uint64_t)jmod) : 0u;
   std::lock_guard<std::mutex> lk(g_reg_mutex);
   auto it = g_registry.find(ws);
-  if (it == g_registry.end()) g_registry[ws] = RegEntry{GraphLayout{}, false, false, cs, 0, false};
+  if (it == g_registry.end()) g_registry[ws] = RegEntry{GraphLayout{}, false, false, cs, 0, false, 0};
   else it->second.cs = cs;
   return CDV_OK;
 }
@@ -848,9 +862,19 @@ extern "C" int cdv_graph_read_meta_host(const void* ws, int64_t* meta_host, void
   int32_t m[GM_WORDS];
   CDV_HIP_CHECK(hipMemcpyAsync(m, (const char*)ws + L.meta, sizeof(m), hipMemcpyDeviceToHost, (hipStream_t)stream));
   CDV_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
-  if (m[GM_MODE]) {   // patch table: live patches, their id range; no frame range is kept
+  if (m[GM_MODE]) {   // patch table: live patches and their id range from the per-slot ids; no frame range is kept
     const int err = m[GM_TERR] == m[GM_GEN];
-    meta_host[0] = err ? 0 : m[GM_NLIVE]; meta_host[1] = 1; meta_host[2] = m[GM_LO]; meta_host[3] = m[GM_HI];
+    const int cap = m[GM_TCAP];
+    std::vector<int32_t> kid((size_t)(cap > 0 ? cap : 0));
+    if (cap > 0) {
+      CDV_HIP_CHECK(hipMemcpyAsync(kid.data(), (const char*)ws + L.tkid, sizeof(int32_t) * (size_t)cap, hipMemcpyDeviceToHost,
+                                   (hipStream_t)stream));
+      CDV_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    }
+    int64_t U = 0, lo = 0x7fffffff, hi = -1;
+    for (int32_t k : kid)
+      if (k >= 0) { U++; lo = k < lo ? k : lo; hi = k > hi ? k : hi; }
+    meta_host[0] = err ? 0 : U; meta_host[1] = 1; meta_host[2] = lo; meta_host[3] = hi;
     meta_host[4] = 0; meta_host[5] = 0; meta_host[6] = err; meta_host[7] = m[GM_E];
     return CDV_OK;
   }

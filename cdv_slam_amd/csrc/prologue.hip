@@ -49,7 +49,8 @@ extern "C" int cdv_update_prologue_table(
     const void* fmap_chw, void* fmap1_nhwc, void* fmap2_nhwc, int slot, int C, int H, int W, const void* gmap_planar,
     void* gmap_pm, int64_t Ng, int64_t gmap_first, int64_t gmap_count, const float* poses, const float* patches,
     const float* intrinsics, const int64_t* ii, const int64_t* jj, const int64_t* kk, int64_t E, float* coords,
-    void* graph_ws, size_t graph_ws_bytes, int64_t E_max, int64_t k_range, int64_t* ix, int64_t* jx, void* stream) {
+    void* graph_ws, size_t graph_ws_bytes, int64_t E_max, int64_t k_range, int64_t table_capacity, int64_t* ix, int64_t* jx,
+    void* stream) {
   CDV_REQUIRE(C % 8 == 0 && C > 0, CDV_ERR_ARG, "cdv_update_prologue_table: C must be a multiple of 8");
   CDV_REQUIRE(H % 4 == 0 && W % 4 == 0, CDV_ERR_ARG, "cdv_update_prologue_table: H and W must be multiples of 4");
   CDV_REQUIRE(slot >= 0, CDV_ERR_ARG, "cdv_update_prologue_table: slot");
@@ -60,7 +61,8 @@ extern "C" int cdv_update_prologue_table(
   CDV_REQUIRE(!do_g || (gmap_first >= 0 && gmap_first + gmap_count <= Ng), CDV_ERR_ARG, "cdv_update_prologue_table: tile range");
   cdv::TFillArgs fill;
   int n_fill = 0;
-  const int rc = cdv_graph_table_prepare(ii, jj, kk, E, graph_ws, graph_ws_bytes, E_max, k_range, ix, jx, stream, &fill, &n_fill);
+  const int rc = cdv_graph_table_prepare(ii, jj, kk, E, graph_ws, graph_ws_bytes, E_max, k_range, table_capacity, ix, jx, stream,
+                                         &fill, &n_fill);
   if (rc != CDV_OK) return rc;
   const int fblocks = cdv_div_up((int64_t)(H / 4) * (W / 4) * (C / 8) * 16, 256);
   const int gblocks = do_g ? cdv_div_up(gmap_count * 9 * (C / 8), 256) : 0;

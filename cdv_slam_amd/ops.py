@@ -49,10 +49,14 @@ def version():
 class GraphIndex:
     """Device workspace holding unique(kk) and the patch CSR (edges of every patch in (jj, id) order)."""
 
-    def __init__(self, device, E_cap=1 << 16, k_range=DEFAULT_K_RANGE):
+    def __init__(self, device, E_cap=1 << 16, k_range=DEFAULT_K_RANGE, table_capacity=None):
+        """k_range: capacity of the ranked build's id range; table_capacity: slots of the table build (slot = id mod
+        capacity) -- at least the ids between the oldest and newest patch with an edge, (REMOVAL_WINDOW + 2) x
+        PATCHES_PER_FRAME for a SLAM object; None / 0: this workspace only ever holds the ranked index"""
         self.lib = _lib.load()
         self.device = device
         self.E_cap, self.k_range = 0, k_range
+        self.table_capacity = min(k_range, 1 << 16, int(table_capacity)) if table_capacity else 0   # 0: ranked index only
         self.ws = None
         self._key = None
         self.E = 0
@@ -146,12 +150,25 @@ class GraphIndex:
             self.meta()
         return self
 
+    def index_for_ba(self, jj, kk, ii, N):
+        """make sure the workspace holds an index of (ii, jj, kk) the bundle adjustment with N free poses can use: either
+        form for N <= 32 (whatever is there and current is kept; otherwise the preferred one is built, CDV_INDEX), the ranked
+        one for the global bundle adjustment"""
+        if N > 32 or N < 1:      # global bundle adjustment, and the structure-only call (no free pose): ranked index
+            return self.build(jj, kk, ii=ii)
+        key = self._make_key(jj, kk, ii)
+        if self._key is not None and self._same_key(key):
+            return self
+        return self.build_table(jj, kk, ii=ii) if (prefer_table() and self.table_capacity) else self.build(jj, kk, ii=ii)
+
     def build_table(self, jj, kk, ii=None, force=False, with_neighbors=False):
         """cdv_graph_build_table: the same index as a patch table (slot = patch id; two launches, no scan).  Serves
         neighbors(), the window / mid bundle adjustment (N <= 32) and the correlation's order + packed stream; not
         unique() (no ranks) and not the global bundle adjustment -- build() is there for those.  Same caching rule as
         build(): identity + version of the tensors."""
         _need_cuda(jj, kk)
+        if not self.table_capacity:
+            raise RuntimeError("GraphIndex.build_table: this workspace was created without a table capacity")
         if jj.dtype != torch.int64 or kk.dtype != torch.int64:
             raise TypeError("index tensors must be int64")
         jj, kk = jj.contiguous(), kk.contiguous()
@@ -171,7 +188,7 @@ class GraphIndex:
             jx = torch.empty(E, dtype=torch.int64, device=self.device)
             self._nbr = (ix, jx)
         rc = self.lib.cdv_graph_build_table(_p(ii), _p(jj), _p(kk), E, _p(self.ws), self.ws_bytes, self.E_cap, self.k_range,
-                                            _p(ix), _p(jx), _stream())
+                                            self.table_capacity, _p(ix), _p(jx), _stream())
         _lib.check(rc, "cdv_graph_build_table")
         self._key = key
         self.E = E
@@ -181,16 +198,17 @@ class GraphIndex:
         return self
 
     def table_arrays(self):
-        """(deg [k_range] int32, plo [k_range] int32, records [chunks*32*16, 4] int32, overflow records [E_cap + 1, 4] int32,
-        order [E_cap] int32, stream [E_cap, 24] int32): views into the workspace (tests, tools)"""
-        off = (ctypes.c_int64 * 6)()
+        """(deg [capacity] int32, plo [capacity] int32, records [chunks*32*16, 4] int32, overflow records [E_cap + 1, 4]
+        int32, order [E_cap] int32, stream [E_cap, 24] int32, patch id per slot [capacity] int32): views into the
+        workspace (tests, tools)"""
+        off = (ctypes.c_int64 * 7)()
         _lib.check(self.lib.cdv_graph_table_offsets(self.E_cap, self.k_range, off), "cdv_graph_table_offsets")
         w32 = self.ws.view(torch.int32)
         o = [int(v) // 4 for v in off]
-        R, chunks = self.k_range, (self.k_range + 15) // 16
+        R, chunks = self.table_capacity, (self.table_capacity + 15) // 16
         return (w32[o[0]:o[0] + R], w32[o[1]:o[1] + R], w32[o[2]:o[2] + chunks * 32 * 16 * 4].view(-1, 4),
                 w32[o[3]:o[3] + (self.E_cap + 1) * 4].view(-1, 4), w32[o[4]:o[4] + self.E_cap],
-                w32[o[5]:o[5] + self.E_cap * 24].view(-1, 24))
+                w32[o[5]:o[5] + self.E_cap * 24].view(-1, 24), w32[o[6]:o[6] + R])
 
     def meta(self):
         """(U, is_table, kmin, kmax, jmin, jmax, error, E) -- synchronises the stream."""
@@ -280,7 +298,7 @@ def update_prologue_table(graph, fmap_chw, fmap1_nhwc, fmap2_nhwc, slot, gmap, g
     rc = lib.cdv_update_prologue_table(_p(fmap_chw.contiguous()), _p(fmap1_nhwc), _p(fmap2_nhwc), int(slot), C, H, W, _p(gmap),
                                        _p(gmap_pm), Ng, int(gmap_first), int(gmap_count), _p(poses), _p(patches),
                                        _p(intrinsics), _p(ii), _p(jj), _p(kk), E, _p(coords), _p(graph.ws), graph.ws_bytes,
-                                       graph.E_cap, graph.k_range, _p(ix), _p(jx), _stream())
+                                       graph.E_cap, graph.k_range, graph.table_capacity, _p(ix), _p(jx), _stream())
     _lib.check(rc, "cdv_update_prologue_table")
     graph._key = graph._make_key(jj, kk, ii) + ("table",)
     graph.E = E
@@ -292,13 +310,56 @@ def update_prologue_table(graph, fmap_chw, fmap1_nhwc, fmap2_nhwc, slot, gmap, g
 _graphs = {}
 
 
-def graph_for(jj, kk, ii=None, **kw):
-    """Per-device shared GraphIndex, (re)built for (jj, kk)."""
-    dev = kk.device
+def prefer_table():
+    """CDV_INDEX=ranked keeps the four-launch ranked index (unique ranks + CSR) as the form of the patch-graph index even
+    where a table capacity is known; default: the two-launch patch table wherever one is.  Read at every call."""
+    return os.environ.get("CDV_INDEX", "table") != "ranked"
+
+
+_table_capacity = None
+
+
+def configure_table(capacity):
+    """Tell the per-device index workspaces that neighbors() / BA() create (the drop-in modules use them) how many patch
+    ids can be live at once -- (REMOVAL_WINDOW + 2) x PATCHES_PER_FRAME of the SLAM object (cdvslam/slam.py:453-458; 2,304
+    for default_cdvo.yaml) -- so that they use the two-launch table index (slot = id mod capacity).  None: ranked index
+    (no assumption about the ids).  install_dropin(table_capacity=...) calls this; CDV_TABLE_CAPACITY sets the default."""
+    global _table_capacity
+    _table_capacity = int(capacity) if capacity else None
+    _graphs.clear()
+
+
+def table_capacity():
+    if _table_capacity is not None:
+        return _table_capacity
+    env = os.environ.get("CDV_TABLE_CAPACITY")
+    return int(env) if env else 0
+
+
+def set_patch_capacity(n_patches):
+    """capacity (number of patch ids: BUFFER_SIZE x PATCHES_PER_FRAME of the SLAM object, cdvslam/patchgraph.py:25-29) of
+    the ranked index of the per-device workspaces created from now on by neighbors() / BA()"""
+    global DEFAULT_K_RANGE
+    DEFAULT_K_RANGE = int(n_patches)
+    _graphs.clear()
+
+
+def _device_graph(dev, **kw):
     g = _graphs.get(dev)
     if g is None:
-        g = _graphs[dev] = GraphIndex(dev, **kw)
-    return g.build(jj, kk, ii=ii)
+        g = _graphs[dev] = GraphIndex(dev, **({"k_range": DEFAULT_K_RANGE, "table_capacity": table_capacity()} | kw))
+    return g
+
+
+def graph_for(jj, kk, ii=None, **kw):
+    """Per-device shared GraphIndex, (re)built for (jj, kk) in the preferred form."""
+    g = _device_graph(kk.device, **kw)
+    key = g._make_key(jj.contiguous(), kk.contiguous(), None if ii is None else ii.contiguous())
+    if g._key is not None and g._same_key(key):
+        return g
+    if prefer_table() and g.table_capacity:
+        return g.build_table(jj, kk, ii=ii, with_neighbors=True)
+    return g.build(jj, kk, ii=ii, with_neighbors=True)
 
 
 def neighbors(kk, jj):
@@ -828,10 +889,13 @@ def ba_forward(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, PP
         lmbda = torch.tensor([float(lmbda)], dtype=torch.float32, device=dev)
     lmbda = lmbda.reshape(-1).float().contiguous().to(dev)
     ii, jj, kk = ii.contiguous(), jj.contiguous(), kk.contiguous()
-    g = graph.build(jj, kk, ii=ii) if graph is not None else graph_for(jj, kk, ii=ii)
+    g = graph if graph is not None else _device_graph(dev)
+    g.index_for_ba(jj, kk, ii, N)
     _ba_report_events(dev)
     if U_max is None:
         U_max = min(E, patches.numel() // (3 * P * P))
+    if g.is_table:
+        U_max = max(U_max, g.table_capacity)      # the slab kernels work through every slot of the table
     ws = _ba_workspace(dev, E, U_max, N)
     dbg = None
     if debug:
@@ -851,6 +915,12 @@ def ba_forward(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, PP
                                   ("C", Us, (Us,)), ("u", Us, (Us,)), ("E", n6 * Us, (n6, Us))):
             out[name] = dbg[o:o + size].view(shape)
             o += size
+        if g.is_table:
+            # per-patch rows are indexed by slot (id mod capacity) here; hand them out by unique rank as the ranked index does
+            pos = torch.unique(kk) % g.table_capacity
+            for name in ("dZ", "C", "u"):
+                v = torch.zeros_like(out[name]); v[:pos.numel()] = out[name][pos]; out[name] = v
+            v = torch.zeros_like(out["E"]); v[:, :pos.numel()] = out["E"][:, pos]; out["E"] = v
         return out
     return []
 

@@ -36,9 +36,12 @@ class UpdatePath:
         self.M = st.cfg.M
         self.E = st.E
         self._poses0, self._patches0 = self.poses.clone(), self.patches.clone()
-        self.graph = ops.GraphIndex(device, E_cap=self.E, k_range=st.cfg.buffer_size * st.cfg.M)
         self.U_max = min(self.E, (st.cfg.removal_window + 2) * st.cfg.M) if not st.cfg.fully_connected \
             else st.cfg.frames * st.cfg.M
+        # the table form of the index: one slot per patch id of the removal window (ids wrap around it), which is also the
+        # number of per-patch rows the bundle adjustment's workspace is sized for
+        self.graph = ops.GraphIndex(device, E_cap=self.E, k_range=st.cfg.buffer_size * st.cfg.M,
+                                    table_capacity=min(self.U_max, st.cfg.buffer_size * st.cfg.M))
         self.has_features = st.fmap1 is not None
         if self.has_features:
             self.gmap = t(st.gmap).contiguous()
@@ -91,7 +94,17 @@ class UpdatePath:
         """One update.  Everything is enqueued on the current stream; no host synchronisation."""
         out = {}
         main = torch.cuda.current_stream()
-        if self.has_features and ingest and rebuild_graph and not self.overlap and self.fused_prologue:
+        if (self.has_features and ingest and rebuild_graph and not self.overlap and self.fused_prologue and self.corr_stream
+                and ops.prefer_table() and self.n - self.t0 <= 32):
+            # everything in front of the correlation in TWO launches: ring / tile ingest + the table's fill pass, then slot
+            # sort + 3. neighbors (net_cdv.py:102 -> ba.cpp:59-97) + 1. reproject (slam.py:325-329) + the correlation's order
+            # and packed input stream
+            coords = ops.update_prologue_table(self.graph, self.new_frame, self.fmap1, self.fmap2, self.new_slot, self.gmap,
+                                               self.gmap_pm, self.new_tiles, self.M, self.poses, self.patches,
+                                               self.intrinsics, self.ii, self.jj, self.kk, coords_out=self.coords_buf)
+            out["ix"], out["jx"] = self.graph.neighbors()
+            self._stream_ready = True
+        elif self.has_features and ingest and rebuild_graph and not self.overlap and self.fused_prologue:
             # ring / tile ingest, 1. reproject (slam.py:325-329) and the first launch of the patch-graph index side by
             # side in ONE launch, then the rest of the index build with 3. neighbors (net_cdv.py:102 -> ba.cpp:59-97)
             coords = ops.update_prologue(self.graph, self.new_frame, self.fmap1, self.fmap2, self.new_slot, self.gmap,
@@ -176,6 +189,11 @@ class UpdatePath:
             res["prologue_fused"] = timed(lambda: (ops.update_prologue(
                 self.graph, self.new_frame, self.fmap1, self.fmap2, self.new_slot, self.gmap, self.gmap_pm, self.new_tiles,
                 self.M, self.poses, self.patches, self.intrinsics, self.ii, self.jj, self.kk), self.graph.neighbors()))
+            if getattr(self, "corr_stream", False):
+                res["prologue_table"] = timed(lambda: (ops.update_prologue_table(
+                    self.graph, self.new_frame, self.fmap1, self.fmap2, self.new_slot, self.gmap, self.gmap_pm, self.new_tiles,
+                    self.M, self.poses, self.patches, self.intrinsics, self.ii, self.jj, self.kk, coords_out=self.coords_buf),
+                    self.graph.neighbors()))
         res["step"] = timed(lambda: self.step())
         return res
 
@@ -192,7 +210,9 @@ class DropinPath:
         import cdv_slam_amd
         from . import projective_ops as pops
         from .lietorch import SE3
-        cdv_slam_amd.install_dropin()
+        # the configuration this SLAM object runs is known here: live patch ids span at most the removal window
+        cdv_slam_amd.install_dropin(table_capacity=None if st.cfg.fully_connected
+                                    else min(st.E, (st.cfg.removal_window + 2) * st.cfg.M))
         self.cuda_corr, self.cuda_ba = importlib.import_module("cuda_corr"), importlib.import_module("cuda_ba")
         self.pops, self.SE3 = pops, SE3
         t = lambda a: torch.as_tensor(a, device=device)

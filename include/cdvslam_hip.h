@@ -238,23 +238,25 @@ int cdv_graph_build_edges(const int64_t* ii, const int64_t* jj, const int64_t* k
 
 int cdv_graph_read_meta_host(const void* ws, int64_t* meta_host, void* stream);
 
-/* The same index as a patch TABLE, in two launches instead of four and with no scan between them: a patch is its own slot
- * (slot = patch id, which must lie in [0, k_range) -- the reference's ids do: they index patches_ [N * M], patchgraph.py:29),
- * so nothing has to be counted before records can be placed.  Launch 1 puts every edge's record {edge, ii, jj, kk} into its
- * patch's slot in arrival order; launch 2 sorts each slot into (jj, edge id) order -- the order std::stable_sort by jj gives
- * on an ascending index list, ba.cpp:84-86 -- and writes fastba.neighbors from it (ix / jx as in cdv_graph_build_neighbors,
- * bit-exact), the live id range, the correlation's processing order and, when a coordinate source is bound
- * (cdv_graph_bind_corr_stream), its packed input stream.  What it does NOT produce is torch::_unique's (kx, ku): no ranks
- * exist (cdv_graph_get_unique refuses; cdv_graph_build* is still there for that and for more than 32 free poses).
- * cdv_ba_forward accepts either index for N <= 32: over the live id range [lo, hi] it treats id - lo as the "unique rank",
- * which IS the rank whenever every id in the range has an edge (always, in a graph slam.py builds); ids without an edge
- * inside the range contribute nothing and are not retracted.  A patch with more than 32 edges keeps its first 32 records
- * in the table and all of them in an overflow list (up to 128 per patch; beyond that, and for an id outside [0, k_range),
- * the index goes into its error state: neighbors all -1, bundle adjustment skipped with CDV_ERR_GRAPH_RANGE).
+/* The same index as a patch TABLE, in two launches instead of four and with no scan between them: a patch's slot is
+ * id mod table_capacity, so nothing has to be counted before records can be placed.  table_capacity (<= min(k_range,
+ * 65536)) must be at least the number of ids between the oldest and the newest patch that has an edge -- for a SLAM
+ * object (REMOVAL_WINDOW + 2) * PATCHES_PER_FRAME (slam.py:453-458 drops edges of older patches; ids are renumbered when
+ * a frame is dropped, :425-427) -- so that no two live ids share a slot; two ids in one slot put the index into its error
+ * state, as do a negative id and a patch with more than 128 edges (neighbors all -1, cdv_ba_forward skipped with
+ * CDV_ERR_GRAPH_RANGE).
+ * Launch 1 puts every edge's record {edge, ii, jj, kk} into its patch's slot in arrival order; launch 2 sorts each slot
+ * into (jj, edge id) order -- the order std::stable_sort by jj gives on an ascending index list, ba.cpp:84-86 -- and writes
+ * fastba.neighbors from it (ix / jx as in cdv_graph_build_neighbors, bit-exact), the correlation's processing order and,
+ * when a coordinate source is bound (cdv_graph_bind_corr_stream), its packed input stream.  A patch with more than 32
+ * edges keeps its first 32 records in the table and all of them in an overflow segment.
+ * What it does NOT produce is torch::_unique's (kx, ku): no ranks exist (cdv_graph_get_unique refuses; cdv_graph_build* is
+ * still there for that and for more than 32 free poses).  cdv_ba_forward accepts either index for 1 <= N <= 32 (U_max >=
+ * table_capacity): it works through the slots, a slot without a patch contributes nothing and is not retracted.
  *   cdv_graph_table_offsets: byte offsets of the table's arrays inside the workspace (tools, tests). */
 int cdv_graph_build_table(const int64_t* ii, const int64_t* jj, const int64_t* kk, int64_t E, void* ws, size_t ws_bytes,
-                          int64_t E_max, int64_t k_range, int64_t* ix, int64_t* jx, void* stream);
-int cdv_graph_table_offsets(int64_t E_max, int64_t k_range, int64_t* out6);
+                          int64_t E_max, int64_t k_range, int64_t table_capacity, int64_t* ix, int64_t* jx, void* stream);
+int cdv_graph_table_offsets(int64_t E_max, int64_t k_range, int64_t* out7);
 
 /* A processing order for cdv_corr_fused that the index build produces on the side: the edge ids [E] (int32) grouped by target
  * frame (jj mod 32), so that the share of the list one XCD works through touches ~3 frames' feature maps instead of ~16
@@ -400,7 +402,8 @@ int cdv_update_prologue_table(const void* fmap_chw, void* fmap1_nhwc, void* fmap
                               const void* gmap_planar, void* gmap_pm, int64_t Ng, int64_t gmap_first, int64_t gmap_count,
                               const float* poses, const float* patches, const float* intrinsics, const int64_t* ii,
                               const int64_t* jj, const int64_t* kk, int64_t E, float* coords, void* graph_ws,
-                              size_t graph_ws_bytes, int64_t E_max, int64_t k_range, int64_t* ix, int64_t* jx, void* stream);
+                              size_t graph_ws_bytes, int64_t E_max, int64_t k_range, int64_t table_capacity, int64_t* ix,
+                              int64_t* jx, void* stream);
 
 /*
  * cdv_frame_ingest + cdv_transform (P = 3, coordinates only) + the first launch of

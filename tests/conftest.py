@@ -17,3 +17,13 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _reset_table_configuration():
+    """install_dropin(table_capacity=...) / ops.configure_table set process-wide state (like the reference's own module
+    registration): every test starts from the default (ranked index for the implicit per-device workspaces)"""
+    yield
+    ops = sys.modules.get("cdv_slam_amd.ops")
+    if ops is not None and getattr(ops, "_table_capacity", None) is not None:
+        ops.configure_table(None)

@@ -19,24 +19,28 @@ def T(a):
 def table_lists(g, E):
     """{patch id: [(edge, ii, jj), ...] in table order} from the workspace (first 32 records from the table, longer lists
     from the overflow segment)"""
-    deg, plo, recs, ovf, order, stream = (a.cpu().numpy() for a in g.table_arrays())
+    deg, plo, recs, ovf, order, stream, kid = (a.cpu().numpy() for a in g.table_arrays())
     out = {}
-    for k in np.nonzero(deg)[0]:
-        d = int(deg[k])
+    assert ((deg > 0) == (kid >= 0)).all()
+    for s in np.nonzero(deg)[0]:
+        d = int(deg[s])
         if d <= 32:
-            rows = [recs[((k >> 4) * 32 + t) * 16 + (k & 15)] for t in range(d)]
+            rows = [recs[((s >> 4) * 32 + t) * 16 + (s & 15)] for t in range(d)]
         else:
-            rows = [ovf[plo[k] + t] for t in range(d)]
-            first = [recs[((k >> 4) * 32 + t) * 16 + (k & 15)] for t in range(32)]
+            rows = [ovf[plo[s] + t] for t in range(d)]
+            first = [recs[((s >> 4) * 32 + t) * 16 + (s & 15)] for t in range(32)]
             assert np.array_equal(np.array(first), np.array(rows[:32]))           # the table holds the first 32 of them
         rows = np.array(rows)
-        assert (rows[:, 3] == k).all()
-        out[int(k)] = rows[:, :3]
+        k = int(kid[s])
+        assert (rows[:, 3] == k).all() and k % g.table_capacity == s             # one patch per slot, slot = id mod capacity
+        out[k] = rows[:, :3]
     return out, order[:E], stream[:E]
 
 
-def check_table(ii, jj, kk, k_range, bind=None):
-    g = ops.GraphIndex(torch.device(DEV), E_cap=len(kk), k_range=k_range)
+def check_table(ii, jj, kk, k_range, bind=None, cap=None):
+    if cap is None:
+        cap = min(k_range, (int(kk.max()) - int(kk.min()) + 16) // 16 * 16)      # just the live id range: ids wrap around it
+    g = ops.GraphIndex(torch.device(DEV), E_cap=len(kk), k_range=k_range, table_capacity=cap)
     if bind is not None:
         g.bind_corr_stream(*bind)
     g.build_table(T(jj), T(kk), ii=None if ii is None else T(ii), with_neighbors=True)
@@ -78,7 +82,7 @@ def test_table_index_bit_exact(name):
     cfg = synth.CONFIGS[name]
     ii, jj, kk = synth.replay_edges(cfg)
     check_table(ii, jj, kk, cfg.buffer_size * cfg.M)
-    check_table(None, jj, kk, cfg.buffer_size * cfg.M)
+    check_table(None, jj, kk, cfg.buffer_size * cfg.M, cap=min(cfg.buffer_size * cfg.M, 1 << 16))   # a roomy table: no wrap
 
 
 def test_table_index_irregular_and_overflowing_patches():
@@ -97,9 +101,9 @@ def test_table_index_irregular_and_overflowing_patches():
     check_table(ii[sh], jj[sh], kk[sh], 4096)
     check_table(None, np.array([3], np.int64), np.array([7], np.int64), 64)
     check_table(None, rng.integers(0, 20, 120).astype(np.int64), np.full(120, 42, np.int64), 64)
-    # one workspace re-used for graphs with different id ranges (shrinking and growing)
-    g = ops.GraphIndex(torch.device(DEV), E_cap=4096, k_range=5000)
-    for lo, hi, E in ((100, 4000, 3000), (2000, 2100, 500), (0, 4999, 4096), (4500, 4600, 50)):
+    # one workspace re-used for graphs with different id ranges (shrinking and growing, far beyond the capacity: ids wrap)
+    g = ops.GraphIndex(torch.device(DEV), E_cap=4096, k_range=5000, table_capacity=4000)
+    for lo, hi, E in ((100, 4000, 3000), (2000, 2100, 500), (70000, 73999, 4096), (4500, 4600, 50), (1_000_000_000, 1_000_003_000, 3000)):
         kk = rng.integers(lo, hi, E).astype(np.int64)
         jj = rng.integers(0, 40, E).astype(np.int64)
         g.build_table(T(jj), T(kk), with_neighbors=True)
@@ -111,14 +115,16 @@ def test_table_index_irregular_and_overflowing_patches():
 
 
 def test_table_index_error_states():
-    """an id outside [0, k_range), or a patch with more edges than the sort launch serves (128): the index reports its
-    error state, neighbors say "none", and the next well-formed build on the workspace is fine again"""
+    """two live ids in one slot (the capacity is smaller than the live id range), a negative id, or a patch with more edges
+    than the sort launch serves (128): the index reports its error state, neighbors say "none", and the next well-formed
+    build on the workspace is fine again"""
+    import os
     rng = np.random.default_rng(5)
-    g = ops.GraphIndex(torch.device(DEV), E_cap=4096, k_range=1000)
-    good_k, good_j = rng.integers(0, 1000, 2000).astype(np.int64), rng.integers(0, 30, 2000).astype(np.int64)
-    for bad_k in (np.where(np.arange(2000) == 77, 1000, good_k), np.where(np.arange(2000) == 5, -1, good_k),
-                  np.where(np.arange(2000) < 200, 321, good_k)):
-        import os
+    g = ops.GraphIndex(torch.device(DEV), E_cap=4096, k_range=4096, table_capacity=1000)
+    good_k, good_j = rng.integers(5000, 6000, 2000).astype(np.int64), rng.integers(0, 30, 2000).astype(np.int64)
+    e = np.arange(2000)
+    for bad_k in (np.where(e == 77, good_k[78] + 1000, good_k), np.where(e == 5, -1, good_k), np.where(e < 200, 5321, good_k),
+                  np.where(e == 3, good_k[3] + (1 << 40), good_k)):
         os.environ["CDV_CHECK"] = "0"
         g.build_table(T(good_j), T(bad_k.astype(np.int64)), with_neighbors=True, force=True)
         ix, jx = g.neighbors()
@@ -190,7 +196,7 @@ def test_prologue_table_equals_separate_launches(name):
     b1, b2 = rings()
     pm_b = ops.gmap_to_pixel_major(gmap)
     pm_b[tiles:tiles + M] = 0
-    g = ops.GraphIndex(dev, E_cap=st.E, k_range=st.cfg.buffer_size * M)
+    g = ops.GraphIndex(dev, E_cap=st.E, k_range=st.cfg.buffer_size * M, table_capacity=(st.cfg.removal_window + 2) * M)
     g.bind_corr_stream(None, M * st.cfg.pmem, st.cfg.mem, gmap.shape[0], mem)
     coords_b = ops.update_prologue_table(g, new_frame, b1, b2, slot, gmap, pm_b, tiles, M, poses, patches, intr, ii, jj, kk)
     assert torch.equal(a1, b1) and torch.equal(a2, b2) and torch.equal(pm_a, pm_b)
@@ -204,3 +210,127 @@ def test_prologue_table_equals_separate_launches(name):
     _, order, stream = table_lists(g, st.E)
     assert np.array_equal(np.sort(order), np.arange(st.E)) and np.array_equal(stream[:, 18], order)
     assert np.array_equal(stream[:, :18].view(np.float32), coords_b[0].cpu().numpy().reshape(st.E, 18)[order])
+
+
+# ---------------------------------------------------------------------------------------------------
+# bundle adjustment on the table index
+# ---------------------------------------------------------------------------------------------------
+
+def _ba(st, form, iterations=2, debug=False, cap=None):
+    dev = torch.device(DEV)
+    if cap is None:
+        cap = (int(st.kk.max()) - int(st.kk.min()) + 16) // 16 * 16            # just the live id range
+    g = ops.GraphIndex(dev, E_cap=st.E, k_range=st.cfg.buffer_size * st.cfg.M, table_capacity=cap)
+    ii, jj, kk = T(st.ii), T(st.jj), T(st.kk)
+    (g.build_table if form == "table" else g.build)(jj, kk, ii=ii)
+    poses, patches = T(st.poses).clone(), T(st.patches).clone()
+    res = ops.ba_forward(poses, patches, T(st.intrinsics), T(st.target), T(st.weight), torch.tensor([st.lmbda], device=dev), ii, jj,
+                         kk, st.cfg.M, st.t0, st.n, iterations, False, graph=g, debug=debug)
+    torch.cuda.synchronize()
+    assert g.is_table == (form == "table")          # the index that was there has been used, not replaced
+    assert ops.ba_status(raise_on_error=False) == (0, 0, 0, 0)
+    return poses.cpu().numpy(), patches.cpu().numpy(), res
+
+
+@pytest.mark.parametrize("name", ["small", "init", "pr1", "default", "stress", "mid15", "mid19_m5", "mid11", "mid32"])
+def test_ba_on_the_table_against_the_ranked_index_and_the_oracle(name):
+    """the same bundle adjustment over the table's slots (N <= 10 and 10 < N <= 32 paths): the stated bounds against the
+    float64 oracle (tests/ba_checks.py), the ranked index's result to rounding (other chunk boundaries and slab order,
+    same sums), identical bits from run to run and for a roomier table whose slots do not wrap"""
+    from tests import ba_checks
+    from tests.test_gpu_parity import _make
+    st, tol = _make(name)
+    pt, xt, _ = _ba(st, "table")
+    pr, xr, _ = _ba(st, "ranked")
+    assert np.abs(pt - pr).max() < 2e-6 and np.abs(xt - xr).max() < 2e-5
+    assert not np.array_equal(pt, st.poses)
+    p64, x64, info = O.fastba(st.poses, st.patches, st.intrinsics[0], st.target, st.weight, st.lmbda, st.ii, st.jj, st.kk, st.t0,
+                              st.n, 2, np.float64)
+    ba_checks.check_end_state(tol, st, pt, xt, p64, x64)
+    pt2, xt2, _ = _ba(st, "table")
+    assert np.array_equal(pt, pt2) and np.array_equal(xt, xt2)
+    pw, xw, _ = _ba(st, "table", cap=min(st.cfg.buffer_size * st.cfg.M, 1 << 16))
+    assert np.abs(pw - pr).max() < 2e-6 and np.abs(xw - xr).max() < 2e-5
+    # iteration-0 intermediates through the table (per-patch rows handed out by unique rank)
+    _, _, dbg = _ba(st, "table", iterations=1, debug=True)
+    _, _, info, o = O.fastba(st.poses, st.patches, st.intrinsics[0], st.target, st.weight, st.lmbda, st.ii, st.jj, st.kk, st.t0,
+                             st.n, 1, np.float64, debug=True)
+    U = len(o["kx"])
+    for key, got, want in (("S", dbg["S"], o["S"]), ("y", dbg["y"], o["y"]), ("C", dbg["C"][:U], o["C"]),
+                           ("u", dbg["u"][:U], o["u"]), ("E", dbg["E"][:, :U], o["E"])):
+        assert np.abs(got.cpu().numpy() - want).max() <= 1e-4 * np.abs(want).max(), key
+
+
+@pytest.mark.parametrize("variant", ["small", "mid15"])
+def test_ba_on_a_table_with_ids_that_have_no_edge(variant):
+    """patches inside the live id range WITHOUT any edge (never produced by slam.py: ids are renumbered when a frame is
+    dropped): they take a row of the table's span, contribute nothing, and are not retracted -- also when their inverse
+    depth lies outside the clamps of patch_retr (ba_cuda.cu:219-221); against the float64 oracle like every other graph"""
+    from tests import ba_checks
+    from tests.test_gpu_parity import _make
+    st, tol = _make(variant)
+    rng = np.random.default_rng(3)
+    ids = np.unique(st.kk)
+    dead = rng.choice(ids[5:-5], size=len(ids) // 7, replace=False)
+    keep = ~np.isin(st.kk, dead)
+    st.ii, st.jj, st.kk = st.ii[keep].copy(), st.jj[keep].copy(), st.kk[keep].copy()
+    st.target, st.weight = st.target[keep].copy(), st.weight[keep].copy()
+    st.patches = st.patches.copy()
+    st.patches[dead[::2], 2] = 50.0                  # > 20: patch_retr would set it to 1
+    st.patches[dead[1::2], 2] = 1e-6                 # < 1e-4: patch_retr would raise it
+    poses, patches, dbg = _ba(st, "table", iterations=1, debug=True)
+    _, _, info, o = O.fastba(st.poses, st.patches, st.intrinsics[0], st.target, st.weight, st.lmbda, st.ii, st.jj, st.kk,
+                             st.t0, st.n, 1, np.float64, debug=True)
+    U = len(o["kx"])
+    for key, got, want in (("S", dbg["S"], o["S"]), ("y", dbg["y"], o["y"]), ("C", dbg["C"][:U], o["C"]),
+                           ("u", dbg["u"][:U], o["u"]), ("E", dbg["E"][:, :U], o["E"])):
+        assert np.abs(got.cpu().numpy() - want).max() <= 1e-4 * np.abs(want).max(), key
+    poses, patches, _ = _ba(st, "table")
+    assert np.array_equal(patches[dead], st.patches[dead])
+    p64, x64, _ = O.fastba(st.poses, st.patches, st.intrinsics[0], st.target, st.weight, st.lmbda, st.ii, st.jj, st.kk, st.t0,
+                           st.n, 2, np.float64)
+    ba_checks.check_end_state(tol, st, poses, patches, p64, x64)
+    pr, xr, _ = _ba(st, "ranked")
+    assert np.abs(pr - poses).max() < 2e-6          # other chunking than the ranked index: same numbers to rounding
+
+
+def test_ba_with_overflowing_patches_on_the_table():
+    """patches with more than 32 edges (first 32 records in the table, all of them in the overflow segment): duplicated
+    edges push some patches of the `small` graph to ~60 edges"""
+    from tests import ba_checks
+    st = synth.make_state("small", features=False)
+    rng = np.random.default_rng(9)
+    heavy = np.unique(st.kk)[10:40]
+    extra = np.flatnonzero(np.isin(st.kk, heavy))
+    sel = np.concatenate([np.arange(st.E), extra, extra[rng.random(len(extra)) < 0.5]])
+    rng.shuffle(sel)
+    st.ii, st.jj, st.kk = st.ii[sel].copy(), st.jj[sel].copy(), st.kk[sel].copy()
+    st.target, st.weight = st.target[sel].copy(), st.weight[sel].copy()
+    assert np.bincount(st.kk).max() > 40
+    poses, patches, _ = _ba(st, "table")
+    p64, x64, _ = O.fastba(st.poses, st.patches, st.intrinsics[0], st.target, st.weight, st.lmbda, st.ii, st.jj, st.kk, st.t0,
+                           st.n, 2, np.float64)
+    ba_checks.check_end_state("small", st, poses, patches, p64, x64)
+    pr, xr, _ = _ba(st, "ranked")
+    assert np.abs(pr - poses).max() < 2e-6 and np.abs(xr - patches).max() < 2e-5
+
+
+def test_global_ba_needs_the_ranked_index_and_gets_it():
+    """N > 32 (the global bundle adjustment) works on unique ranks: the C ABI refuses a table there, ops.ba_forward builds
+    the ranked index"""
+    st = synth.make_state("global", features=False)
+    dev = torch.device(DEV)
+    g = ops.GraphIndex(dev, E_cap=st.E, k_range=st.cfg.buffer_size * st.cfg.M, table_capacity=st.cfg.buffer_size * st.cfg.M)
+    ii, jj, kk = T(st.ii), T(st.jj), T(st.kk)
+    g.build_table(jj, kk, ii=ii)
+    poses, patches = T(st.poses).clone(), T(st.patches).clone()
+    lib = ops._lib.load()
+    ws = ops._ba_workspace(dev, st.E, len(st.patches), st.n - st.t0)
+    rc = lib.cdv_ba_forward(ops._p(poses), ops._p(patches), ops._p(T(st.intrinsics)), ops._p(T(st.target)), ops._p(T(st.weight)),
+                            ops._p(torch.tensor([st.lmbda], device=dev)), ops._p(ii), ops._p(jj), ops._p(kk), st.E, 3, st.t0, st.n, 2,
+                            ops._p(g.ws), ops._p(ws), ws.numel(), len(st.patches), None, ops._stream())
+    assert rc != 0 and b"patch table" in lib.cdv_last_error()
+    ops.ba_forward(poses, patches, T(st.intrinsics), T(st.target), T(st.weight), torch.tensor([st.lmbda], device=dev), ii, jj, kk,
+                   st.cfg.M, st.t0, st.n, 2, True, graph=g)
+    torch.cuda.synchronize()
+    assert not g.is_table and not torch.equal(poses, T(st.poses))
