@@ -67,7 +67,7 @@ __device__ __forceinline__ int nth_bit(uint32_t m, int k) {
   return m ? __ffs((int)m) - 1 : -1;
 }
 
-template <bool HAS_II, int MKW>
+template <bool HAS_II, int MKW, bool TABLE>
 __global__ __launch_bounds__(64 * MKW) void ba_mid_chunk_kernel(BaWinArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int N = A.N, t0 = A.t0, P = A.P;
@@ -85,8 +85,8 @@ __global__ __launch_bounds__(64 * MKW) void ba_mid_chunk_kernel(BaWinArgs A) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: loops over a wave's share are uniform
   const int32_t* __restrict__ gmeta = A.gmeta;
-  const PatchSpan sp = patch_span(A);
-  const int gerr = graph_error_of(gmeta, sp.table != 0);
+  const PatchSpan sp = patch_span<TABLE>(A);
+  const int gerr = graph_error_of(gmeta, TABLE);
   const int U = sp.U;
   if (blockIdx.x == 0) {
     if (tid == 0) {
@@ -126,12 +126,12 @@ __global__ __launch_bounds__(64 * MKW) void ba_mid_chunk_kernel(BaWinArgs A) {
       // chunk-slot copy, the patch's CSR offsets and id; everything unconditional on clamped indices
       const int step = 4 * MKW;
       int tb = 4 * wave;
-      const bool use_ell = sp.table || chunk < A.ell_chunks;
+      const bool use_ell = TABLE || chunk < A.ell_chunks;
       const int rs = live ? r : 0;
       const int4* cell = use_ell ? reinterpret_cast<const int4*>(A.pell) : reinterpret_cast<const int4*>(A.prec);
       int4 raw = cell[(use_ell && tb + sub < ELL_SLOTS) ? cell_index(rs, tb + sub) : 0];
       int4 raw0 = cell[use_ell ? cell_index(rs, 0) : 0];
-      const PatchRow row = patch_row(A, sp, rs);
+      const PatchRow row = patch_row<TABLE>(A, rs);
       const float fx = A.intr[0], fy = A.intr[1], cx = A.intr[2], cy = A.intr[3];
       const float lm = A.lmbda[0];
       const EdgeRec safe = {A.prec[0], A.prec[1], A.prec[2]};   // stands in for slots that do not exist
@@ -723,11 +723,12 @@ __device__ __forceinline__ void mid_solve(const BaWinArgs& A, float* smem) {
 // LDS in every workgroup.  Thread = (16-byte column, slab subset): 16 subsets in the lanes of a DPP row, W in {1, 2, 4}
 // further ones in separate rows whose partials meet in LDS.  W and every summation order depend on the number of slabs
 // only: the sum is the same whatever the launch geometry.
+template <bool TABLE>
 __global__ __launch_bounds__(256) void ba_mid_reduce_kernel(BaWinArgs A) {
   const int32_t* __restrict__ gmeta = A.gmeta;
-  const PatchSpan sp = patch_span(A);
+  const PatchSpan sp = patch_span<TABLE>(A);
   const int U = sp.U;
-  if (graph_error_of(gmeta, sp.table != 0) || U > A.U_max) return;
+  if (graph_error_of(gmeta, TABLE) || U > A.U_max) return;
   __shared__ cdv_float4 partial[16];
   const int n6 = 6 * A.N;
   const int TRI_N = (n6 * (n6 + 1)) >> 1;
@@ -808,13 +809,13 @@ __global__ __launch_bounds__(256) void ba_mid_reduce_kernel(BaWinArgs A) {
 }
 
 // SNP: the E column a retract thread keeps in registers (>= 6 N)
-template <int SNP>
+template <int SNP, bool TABLE>
 __global__ __launch_bounds__(FT) void ba_mid_finish_kernel(BaWinArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int32_t* __restrict__ gmeta = A.gmeta;
-  const PatchSpan sp = patch_span(A);
+  const PatchSpan sp = patch_span<TABLE>(A);
   const int U = sp.U;
-  if (graph_error_of(gmeta, sp.table != 0) || U > A.U_max) return;
+  if (graph_error_of(gmeta, TABLE) || U > A.U_max) return;
   const int RT = (int)gridDim.x - 1;   // retract workgroups, FT patches each per pass
   const int tid = threadIdx.x;
   if (blockIdx.x == 0) {
@@ -838,7 +839,7 @@ __global__ __launch_bounds__(FT) void ba_mid_finish_kernel(BaWinArgs A) {
   float uv = 0.f, qv = 0.f, d0 = 0.f;
   float* pk = nullptr;
   if (livep) {
-    const PatchRow row = patch_row(A, sp, r);
+    const PatchRow row = patch_row<TABLE>(A, r);
     livep = row.deg > 0;             // a table id without an edge: not part of the graph, not retracted
     uv = A.ug[r]; qv = A.qg[r];
     pk = A.patches + row.id * 3 * PP + 2 * PP;
@@ -904,7 +905,7 @@ __global__ __launch_bounds__(FT) void ba_mid_finish_kernel(BaWinArgs A) {
 #pragma unroll
     for (int i = 0; i < SNP; i++) ev[i] = (livep && i < n6) ? A.Edg[(size_t)i * A.U_stride + r] : 0.f;
     if (livep) {
-      const PatchRow row = patch_row(A, sp, r);
+      const PatchRow row = patch_row<TABLE>(A, r);
       livep = row.deg > 0;
       uv = A.ug[r]; qv = A.qg[r];
       pk = A.patches + row.id * 3 * PP + 2 * PP;
@@ -913,16 +914,28 @@ __global__ __launch_bounds__(FT) void ba_mid_finish_kernel(BaWinArgs A) {
   }
 }
 
-template <bool HAS_II, int MKW>
+template <bool HAS_II, int MKW, bool TABLE>
 hipError_t chunk_attr() {
-  return hipFuncSetAttribute((const void*)ba_mid_chunk_kernel<HAS_II, MKW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+  return hipFuncSetAttribute((const void*)ba_mid_chunk_kernel<HAS_II, MKW, TABLE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                              160 * 1024 - 256);
 }
 
-template <int MKW>
+template <int MKW, bool TABLE>
 void launch_chunk(const BaWinArgs& a, int grid, size_t lds, hipStream_t s) {
-  if (a.has_ii) hipLaunchKernelGGL((ba_mid_chunk_kernel<true, MKW>), dim3(grid), dim3(64 * MKW), lds, s, a);
-  else hipLaunchKernelGGL((ba_mid_chunk_kernel<false, MKW>), dim3(grid), dim3(64 * MKW), lds, s, a);
+  if (a.has_ii) hipLaunchKernelGGL((ba_mid_chunk_kernel<true, MKW, TABLE>), dim3(grid), dim3(64 * MKW), lds, s, a);
+  else hipLaunchKernelGGL((ba_mid_chunk_kernel<false, MKW, TABLE>), dim3(grid), dim3(64 * MKW), lds, s, a);
+}
+
+template <int SNP, bool TABLE>
+hipError_t finish_attr() {
+  return hipFuncSetAttribute((const void*)ba_mid_finish_kernel<SNP, TABLE>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024);
+}
+
+template <bool TABLE>
+void launch_finish(const BaWinArgs& a, int n, int RW, size_t lds_f, hipStream_t s) {
+  if (n <= 96) hipLaunchKernelGGL((ba_mid_finish_kernel<96, TABLE>), dim3(1 + RW), dim3(FT), lds_f, s, a);
+  else if (n <= 144) hipLaunchKernelGGL((ba_mid_finish_kernel<144, TABLE>), dim3(1 + RW), dim3(FT), lds_f, s, a);
+  else hipLaunchKernelGGL((ba_mid_finish_kernel<192, TABLE>), dim3(1 + RW), dim3(FT), lds_f, s, a);
 }
 
 }  // namespace
@@ -930,11 +943,16 @@ void launch_chunk(const BaWinArgs& a, int grid, size_t lds, hipStream_t s) {
 int cdv::cdv_ba_mid_iteration(const BaWinArgs& a, hipStream_t s) {
   static hipError_t attr_err = [] {
     hipError_t e = hipSuccess, x;
-    if ((x = chunk_attr<true, 8>()) != hipSuccess) e = x;
-    if ((x = chunk_attr<false, 8>()) != hipSuccess) e = x;
-    if ((x = hipFuncSetAttribute((const void*)ba_mid_finish_kernel<96>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024)) != hipSuccess) e = x;
-    if ((x = hipFuncSetAttribute((const void*)ba_mid_finish_kernel<144>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024)) != hipSuccess) e = x;
-    if ((x = hipFuncSetAttribute((const void*)ba_mid_finish_kernel<192>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024)) != hipSuccess) e = x;
+    if ((x = chunk_attr<true, 8, false>()) != hipSuccess) e = x;
+    if ((x = chunk_attr<false, 8, false>()) != hipSuccess) e = x;
+    if ((x = chunk_attr<true, 8, true>()) != hipSuccess) e = x;
+    if ((x = chunk_attr<false, 8, true>()) != hipSuccess) e = x;
+    if ((x = finish_attr<96, false>()) != hipSuccess) e = x;
+    if ((x = finish_attr<144, false>()) != hipSuccess) e = x;
+    if ((x = finish_attr<192, false>()) != hipSuccess) e = x;
+    if ((x = finish_attr<96, true>()) != hipSuccess) e = x;
+    if ((x = finish_attr<144, true>()) != hipSuccess) e = x;
+    if ((x = finish_attr<192, true>()) != hipSuccess) e = x;
     return e;
   }();
   CDV_HIP_CHECK(attr_err);
@@ -946,20 +964,22 @@ int cdv::cdv_ba_mid_iteration(const BaWinArgs& a, hipStream_t s) {
   const size_t lds = chunk_lds_bytes(N, mkw);
   CDV_REQUIRE(lds <= 160 * 1024 - 256, CDV_ERR_UNSUPPORTED, "cdv_ba_forward: chunk footprint exceeds LDS");
   const int n_ck = a.n_ck_cap < WIN_MAX_GRID ? a.n_ck_cap : WIN_MAX_GRID;
-  launch_chunk<mkw>(a, n_ck, lds, s);
+  const bool table = a.tab_cap > 0;
+  if (table) launch_chunk<mkw, true>(a, n_ck, lds, s);
+  else launch_chunk<mkw, false>(a, n_ck, lds, s);
   const int n = 6 * N;
   {
     const int S4 = mid_slab(N) / 4;
     const int grid = cdv_div_up(S4, 4);    // one trip at W = 4; fewer columns per workgroup only shorten the loop
-    hipLaunchKernelGGL(ba_mid_reduce_kernel, dim3(grid < 1024 ? grid : 1024), dim3(256), 0, s, a);
+    if (table) hipLaunchKernelGGL(ba_mid_reduce_kernel<true>, dim3(grid < 1024 ? grid : 1024), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(ba_mid_reduce_kernel<false>, dim3(grid < 1024 ? grid : 1024), dim3(256), 0, s, a);
   }
   // solver + retract workgroups (FT patches each per pass; they all poll the solver)
   int RW = cdv_div_up(a.U_max, FT);
   RW = RW < 1 ? 1 : (RW > MID_MAX_RW ? MID_MAX_RW : RW);
   const size_t lds_f = sizeof(float) * ((size_t)(n + 1) * solve_ld(n) + 8);
-  if (n <= 96) hipLaunchKernelGGL(ba_mid_finish_kernel<96>, dim3(1 + RW), dim3(FT), lds_f, s, a);
-  else if (n <= 144) hipLaunchKernelGGL(ba_mid_finish_kernel<144>, dim3(1 + RW), dim3(FT), lds_f, s, a);
-  else hipLaunchKernelGGL(ba_mid_finish_kernel<192>, dim3(1 + RW), dim3(FT), lds_f, s, a);
+  if (table) launch_finish<true>(a, n, RW, lds_f, s);
+  else launch_finish<false>(a, n, RW, lds_f, s);
   CDV_LAUNCH_CHECK();
   return CDV_OK;
 }

@@ -61,7 +61,7 @@ __device__ __forceinline__ void pair_emit(float total, int code, int ci, int cj,
   if (ok) lds_add(&Sw[idx], v);
 }
 
-template <bool HAS_II>
+template <bool HAS_II, bool TABLE>
 __global__ __launch_bounds__(64 * CKW) void ba_chunk_kernel(BaWinArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Sc = smem;                           // [CKW][SLAB] per-wave packed copies of [S | y] (B and v parts)
@@ -72,8 +72,8 @@ __global__ __launch_bounds__(64 * CKW) void ba_chunk_kernel(BaWinArgs A) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int32_t* __restrict__ gmeta = A.gmeta;
-  const PatchSpan sp = patch_span(A);
-  const int gerr = graph_error_of(gmeta, sp.table != 0);
+  const PatchSpan sp = patch_span<TABLE>(A);
+  const int gerr = graph_error_of(gmeta, TABLE);
   const int U = sp.U;
   if (blockIdx.x == 0) {
     if (tid == 0) {
@@ -111,13 +111,13 @@ __global__ __launch_bounds__(64 * CKW) void ba_chunk_kernel(BaWinArgs A) {
     // offset), the patch's CSR offsets and id
     const int step = 4 * CKW;
     int tb = 4 * wave;
-    const bool use_ell = sp.table || chunk < A.ell_chunks;   // workgroup-uniform; false only beyond 65,536 unique patches
+    const bool use_ell = TABLE || chunk < A.ell_chunks;   // workgroup-uniform; false only beyond 65,536 unique patches
     // (no branch around these loads: a chunk without a chunk-slot copy reads CSR record 0 here and the real ones below)
     const int rs = live ? r : 0;
     const int4* cell = use_ell ? reinterpret_cast<const int4*>(A.pell) : reinterpret_cast<const int4*>(A.prec);
     int4 raw = cell[use_ell ? cell_index(rs, tb + sub) : 0];
     int4 raw0 = cell[use_ell ? cell_index(rs, 0) : 0];
-    const PatchRow row = patch_row(A, sp, rs);
+    const PatchRow row = patch_row<TABLE>(A, rs);
     // the wave-uniform inputs travel with level 1 as well (read here, not before the loop: nothing waits for them
     // before the loads above are out): intrinsics of row 0 (ba_cuda.cu:253-259), lambda, CSR record 0
     const float fx = A.intr[0], fy = A.intr[1], cx = A.intr[2], cy = A.intr[3];
@@ -493,11 +493,12 @@ __device__ __forceinline__ void solve_wave(const BaWinArgs& A, int RW) {
   CDV_STAMP_RT(baw, sslot, 15);
 }
 
+template <bool TABLE>
 __global__ __launch_bounds__(256) void ba_finish_kernel(BaWinArgs A) {
   const int32_t* __restrict__ gmeta = A.gmeta;
-  const PatchSpan sp = patch_span(A);
+  const PatchSpan sp = patch_span<TABLE>(A);
   const int U = sp.U;
-  if (graph_error_of(gmeta, sp.table != 0) || U > A.U_max) return;
+  if (graph_error_of(gmeta, TABLE) || U > A.U_max) return;
   const int RW = (int)gridDim.x - 1;
   const int tid = threadIdx.x;
   if (blockIdx.x == 0) {
@@ -578,7 +579,7 @@ __global__ __launch_bounds__(256) void ba_finish_kernel(BaWinArgs A) {
   float uv = 0.f, qv = 0.f, d0 = 0.f;
   float* pk = nullptr;
   if (livep) {
-    const PatchRow row = patch_row(A, sp, r);
+    const PatchRow row = patch_row<TABLE>(A, r);
     livep = row.deg > 0;             // a table id without an edge: not part of the graph, not retracted
     uv = A.ug[r]; qv = A.qg[r];
     pk = A.patches + row.id * 3 * PP + 2 * PP;
@@ -643,7 +644,7 @@ __global__ __launch_bounds__(256) void ba_finish_kernel(BaWinArgs A) {
 #pragma unroll
     for (int i = 0; i < SN; i++) ev[i] = (livep && i < 6 * N) ? A.Edg[(size_t)i * A.U_stride + r] : 0.f;
     if (livep) {
-      const PatchRow row = patch_row(A, sp, r);
+      const PatchRow row = patch_row<TABLE>(A, r);
       livep = row.deg > 0;
       uv = A.ug[r]; qv = A.qg[r];
       pk = A.patches + row.id * 3 * PP + 2 * PP;
@@ -656,25 +657,30 @@ __global__ __launch_bounds__(256) void ba_finish_kernel(BaWinArgs A) {
 
 int cdv::cdv_ba_window_iteration(const BaWinArgs& a, hipStream_t s) {
   static hipError_t attr_err = [] {
-    hipError_t e1 = hipFuncSetAttribute((const void*)ba_chunk_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)(sizeof(float) * LDS_CHUNK_FLOATS));
-    hipError_t e2 = hipFuncSetAttribute((const void*)ba_chunk_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)(sizeof(float) * LDS_CHUNK_FLOATS));
-    return e1 != hipSuccess ? e1 : e2;
+    hipError_t e = hipSuccess, x;
+    const int lds = (int)(sizeof(float) * LDS_CHUNK_FLOATS);
+    if ((x = hipFuncSetAttribute((const void*)ba_chunk_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess) e = x;
+    if ((x = hipFuncSetAttribute((const void*)ba_chunk_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess) e = x;
+    if ((x = hipFuncSetAttribute((const void*)ba_chunk_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess) e = x;
+    if ((x = hipFuncSetAttribute((const void*)ba_chunk_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess) e = x;
+    return e;
   }();
   CDV_HIP_CHECK(attr_err);
   const int n_ck = a.n_ck_cap < WIN_MAX_GRID ? a.n_ck_cap : WIN_MAX_GRID;
-  if (a.has_ii)
-    hipLaunchKernelGGL(ba_chunk_kernel<true>, dim3(n_ck), dim3(64 * CKW), sizeof(float) * LDS_CHUNK_FLOATS, s, a);
-  else
-    hipLaunchKernelGGL(ba_chunk_kernel<false>, dim3(n_ck), dim3(64 * CKW), sizeof(float) * LDS_CHUNK_FLOATS, s, a);
+  const bool table = a.tab_cap > 0;
+  const size_t lds = sizeof(float) * LDS_CHUNK_FLOATS;
+  if (a.has_ii && table) hipLaunchKernelGGL((ba_chunk_kernel<true, true>), dim3(n_ck), dim3(64 * CKW), lds, s, a);
+  else if (a.has_ii) hipLaunchKernelGGL((ba_chunk_kernel<true, false>), dim3(n_ck), dim3(64 * CKW), lds, s, a);
+  else if (table) hipLaunchKernelGGL((ba_chunk_kernel<false, true>), dim3(n_ck), dim3(64 * CKW), lds, s, a);
+  else hipLaunchKernelGGL((ba_chunk_kernel<false, false>), dim3(n_ck), dim3(64 * CKW), lds, s, a);
   // reduce workgroups: one per four 16-byte columns of a slab (119), at least one per 256 patches of capacity for the
   // retraction the first of them go on to, at most WIN_MAX_RW (their arrival flags)
   int RW = cdv_div_up(WIN_SLAB / 4, 4);
   const int rw_p = cdv_div_up(a.U_max, 256);
   RW = RW < rw_p ? rw_p : RW;
   RW = RW > WIN_MAX_RW ? WIN_MAX_RW : RW;
-  hipLaunchKernelGGL(ba_finish_kernel, dim3(1 + RW), dim3(256), 0, s, a);
+  if (table) hipLaunchKernelGGL(ba_finish_kernel<true>, dim3(1 + RW), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(ba_finish_kernel<false>, dim3(1 + RW), dim3(256), 0, s, a);
   CDV_LAUNCH_CHECK();
   return CDV_OK;
 }
