@@ -196,6 +196,7 @@ def main():
                     "correlation (measured: no gain, the dispatcher does not interleave the small kernels)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-dropin", action="store_true", help="skip timing the reference-shaped drop-in call sequence")
+    ap.add_argument("--no-extra", action="store_true", help="skip the stress-configuration and stream sub-records")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: the launch / rendezvous / gather plumbing only, on "
                     "gloo with a trivial step (tests/test_replicas_gloo.py); the line says dry_run and is not a measurement")
     args = ap.parse_args()
@@ -294,6 +295,51 @@ def main():
                   "what": "reference-shaped call sequence through install_dropin() names on reference state layouts"}
         del dp
 
+    # ---- the other configurations the metric's neighbourhood asks about, as sub-records measured after the timed region
+    # (rank 0 of a single-GPU run only): BASELINE.json configs[4] (`stress`: 196 patches per frame, window 22) as updates/s
+    # of the same UpdatePath, and SURVEY.md 8(d)(iii): end-to-end frames/s of a synthetic stream -- state write, edge
+    # append, update, keyframe bookkeeping with a dropped frame every third frame, stub networks, Python glue included
+    extra = {}
+    if world == 1 and not args.no_extra and st.fmap1 is not None and args.config == "default":
+        try:
+            st2 = synth.make_state("stress", buffer_size=64, seed=grp.sequence_seed())
+            up2 = UpdatePath(st2, dev)
+            for _ in range(30):
+                up2.step()
+            torch.cuda.synchronize()
+            n2 = max(20, min(args.steps, 200))
+            t2 = time.perf_counter()
+            for _ in range(n2):
+                up2.step()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter() - t2
+            extra["stress"] = {"value": n2 / t2, "unit": "frames/s", "ms_per_step": 1e3 * t2 / n2, "steps": n2,
+                               "what": "BASELINE.json configs[4]: the same update path, M=%d patches/frame, window %d, E=%d edges, "
+                                       "%d free poses" % (st2.cfg.M, st2.cfg.opt_window, st2.E, st2.n - st2.t0)}
+            del up2, st2
+        except Exception as ex:      # a sub-record must not take the headline down with it
+            extra["stress"] = {"error": repr(ex)}
+        try:
+            from cdv_slam_amd.stream import StreamRunner
+            run = StreamRunner(dev)
+            for _ in range(45):       # reach the steady state (E = 47,712 at the default window)
+                run.frame(drop=False)
+            torch.cuda.synchronize()
+            nf = max(30, min(args.steps, 300))
+            ts = time.perf_counter()
+            for f in range(nf):
+                n_kf, E_s = run.frame(drop=(f % 3 == 2))
+            torch.cuda.synchronize()
+            ts = time.perf_counter() - ts
+            extra["stream_fps"] = {"value": nf / ts, "unit": "frames/s", "ms_per_frame": 1e3 * ts / nf, "frames": nf,
+                                   "edges": int(E_s), "keyframes": int(n_kf),
+                                   "what": "SURVEY 8(d)(iii): synthetic 512x384 stream end to end (state write, edge append, update, "
+                                           "keyframe bookkeeping incl. one read-back per removal; every third frame dropped as a "
+                                           "keyframe; stub feature / update networks; Python glue included)"}
+            del run
+        except Exception as ex:
+            extra["stream_fps"] = {"error": repr(ex)}
+
     # ---- gather per-rank metrics: [pose checksum, fps] (trajectory-metric gather of SURVEY.md 8(e)) ---
     per_rank = grp.gather_metrics([float(up.poses.double().abs().sum().item()), args.steps / elapsed])
     if len(per_rank) != args.gpus:
@@ -346,11 +392,16 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "corr_fused2_kernel<24, 2>", "avg_launch_ms": corr_ms, "algorithmic_bytes": corr_bytes,
+                "traffic_source": (None if traffic is None else "NOT measured in this run: FETCH_SIZE (x2, gfx950) + WRITE_SIZE per "
+                                   "launch from separate rocprofv3 --pmc passes of the same workload, profiles/corr_traffic.json (%s)"
+                                   % pmc.get("round", "r2")),
+                "kernel": "corr_fused2_kernel<24, 2, stream>", "avg_launch_ms": corr_ms, "algorithmic_bytes": corr_bytes,
             },
             "roofline_valu": roofline_valu,
             "stages_us": stages,
             "dropin_fps": dropin,
+            "stress": extra.get("stress"),
+            "stream_fps": extra.get("stream_fps"),
             "per_rank": per_rank,
             "per_rank_summary": summarise(per_rank),
         }

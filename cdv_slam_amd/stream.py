@@ -50,7 +50,15 @@ class StreamRunner:
         self.gmap_pm = torch.zeros((pmem * M, 9, C), dtype=torch.float16, device=device)
         ecap = M * (removal_window + 6) * 2 * patch_lifetime + (M * 1000 if loop_closure else 0)
         self.edges = EdgeStore(device, capacity=ecap, net_dim=0, inactive_capacity=ecap + buffer_size * M * 2 * patch_lifetime)
-        self.graph = ops.GraphIndex(device, E_cap=ecap, k_range=(removal_window + 8) * M + M * pmem)
+        # without loop closure the live patch ids span the removal window (+ the frames of this update's bookkeeping): the
+        # index is the two-launch patch table and the correlation reads the packed stream it writes; with loop closure
+        # (patches of any age keep edges) the ranked index
+        self.table = not loop_closure
+        self.graph = ops.GraphIndex(device, E_cap=ecap, k_range=(removal_window + 8) * M + M * pmem,
+                                    table_capacity=(removal_window + 8) * M if self.table else None)
+        if self.table:
+            self.coords_buf = torch.empty((1, ecap, 2, 3, 3), dtype=torch.float32, device=device)
+            self.graph.bind_corr_stream(None, M * pmem, mem, pmem * M, mem)
         self.graph_full = None     # index over inactive + active edges (global BA), built on demand
         self.lmbda = torch.tensor([1e-4], **f32)
         self.n = 0
@@ -84,10 +92,17 @@ class StreamRunner:
 
     def _update(self, fmap, tile0):
         M, n, e = self.M, self.n, self.edges
-        coords = ops.update_prologue(self.graph, fmap, self.fmap1, self.fmap2, (n - 1) % self.mem, self.gmap, self.gmap_pm,
-                                     tile0, M, self.poses, self.patches, self.intrinsics, e.ii, e.jj, e.kk)
-        corr = ops.corr_fused(self.gmap_pm, self.fmap1, self.fmap2, coords, e.kk, e.jj, kmod=M * self.pmem, jmod=self.mem,
-                              pixel_major=True, order_ptr=self.graph.corr_order_ptr())   # edges grouped by target frame
+        ii, jj, kk = e.ii, e.jj, e.kk      # ONE set of view objects for the whole update: the index is keyed on them
+        if self.table:
+            coords = ops.update_prologue_table(self.graph, fmap, self.fmap1, self.fmap2, (n - 1) % self.mem, self.gmap,
+                                               self.gmap_pm, tile0, M, self.poses, self.patches, self.intrinsics, ii, jj, kk,
+                                               coords_out=self.coords_buf)
+            corr = ops.corr_fused_stream(self.gmap_pm, self.fmap1, self.fmap2, self.graph.corr_records_ptr(), e.E)
+        else:
+            coords = ops.update_prologue(self.graph, fmap, self.fmap1, self.fmap2, (n - 1) % self.mem, self.gmap, self.gmap_pm,
+                                         tile0, M, self.poses, self.patches, self.intrinsics, ii, jj, kk)
+            corr = ops.corr_fused(self.gmap_pm, self.fmap1, self.fmap2, coords, kk, jj, kmod=M * self.pmem, jmod=self.mem,
+                                  pixel_major=True, order_ptr=self.graph.corr_order_ptr())   # edges grouped by target frame
         # stub of the update operator (net_cdv.py:66-107): a small correction that depends on the correlation
         delta = 0.01 * torch.tanh(corr[0, :, :2].float())
         e.target[0].copy_(coords[0, :, :, 1, 1] + delta)
@@ -96,7 +111,7 @@ class StreamRunner:
             self._global_ba()      # long-range edges exist: slam.py:507-510
         else:
             t0 = max(1, n - self.ow)
-            ops.ba_forward(self.poses, self.patches, self.intrinsics, e.target, e.weight, self.lmbda, e.ii, e.jj, e.kk, M, t0,
+            ops.ba_forward(self.poses, self.patches, self.intrinsics, e.target, e.weight, self.lmbda, ii, jj, kk, M, t0,
                            n, 2, False, U_max=min(e.E, (self.rw + 8) * M + (1000 * M if self.lc else 0)), graph=self.graph)
         self.n_updates += 1
 
