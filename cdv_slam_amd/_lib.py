@@ -28,6 +28,10 @@ SIGNATURES = {
                                     _f32, _f32, _i64, _i64, _i32, _vp]),
     "cdv_corr_level_checked": (_i32, [_vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _i32, _i64, _i64, _i64, _i32, _i32, _i32, _f32,
                                       _i64, _i64, _i32, _vp]),
+    "cdv_corr_level_checked_interleaved": (_i32, [_vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _i32, _i64, _i64, _i64, _i32, _i32, _i32,
+                                                  _f32, _i64, _i64, _i32, _vp]),
+    "cdv_graph_workspace_init": (_i32, [_vp, _sz, _i64, _i64, _vp]),
+    "cdv_ba_workspace_init": (_i32, [_vp, _vp]),
     "cdv_gmap_to_pixel_major": (_i32, [_vp, _vp, _i64, _i32, _i64, _i64, _vp]),
     "cdv_frame_ingest": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _i64, _i64, _i64, _vp]),
     "cdv_patchify_fwd": (_i32, [_vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _i32, _vp]),

@@ -898,6 +898,17 @@ extern "C" void cdv_workspace_forget(const void* ws) {
   cdv_graph_forget(ws);
 }
 
+// Explicit initialisation (instead of "the first time the library sees this address"): whoever allocates a workspace says so.
+// The bundle-adjustment workspace needs nothing but to be unknown to the library: the first cdv_ba_forward then zeroes what
+// it keeps zero; the status counters stay bound across a re-initialisation.
+extern "C" int cdv_ba_workspace_init(void* ba_ws, void* stream) {
+  (void)stream;
+  CDV_REQUIRE(ba_ws != nullptr, CDV_ERR_ARG, "cdv_ba_workspace_init: workspace is NULL");
+  std::lock_guard<std::mutex> lk(g_ws_mutex);
+  g_ws_state.erase(ba_ws);
+  return CDV_OK;
+}
+
 extern "C" size_t cdv_ba_workspace_bytes(int64_t E_max, int64_t U_max, int N_max) {
   (void)E_max;
   if (U_max < 1) U_max = 1;

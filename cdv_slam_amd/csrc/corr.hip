@@ -1303,6 +1303,19 @@ extern "C" int cdv_corr_level_checked(const void* gmap, const void* fmap_nhwc, c
                          kmod, jmod, gmap_pixel_major, stream, 1, 442 * level, 884, coords_ref, ref_mul, 0);
 }
 
+// cdv_corr_level_checked into the INTERLEAVED two-level result of cdv_corr_fused ([E][441][2] halves: what SLAM.corr's
+// torch.stack(..., -1) produces): level `level` of element t of edge e lives at out[e * 882 + 2 t + level]
+extern "C" int cdv_corr_level_checked_interleaved(const void* gmap, const void* fmap_nhwc, const float* coords,
+                                                  const float* coords_ref, float ref_mul, const int64_t* kk, const int64_t* jj,
+                                                  void* out, int level, int64_t E, int64_t Ng, int64_t slots, int C, int H, int W,
+                                                  float scale, int64_t kmod, int64_t jmod, int gmap_pixel_major, void* stream) {
+  CDV_REQUIRE(level == 0 || level == 1, CDV_ERR_ARG, "cdv_corr_level_checked_interleaved: level must be 0 or 1");
+  CDV_REQUIRE(coords_ref != nullptr && out != nullptr, CDV_ERR_ARG, "cdv_corr_level_checked_interleaved: NULL argument");
+  CDV_REQUIRE(C <= 32, CDV_ERR_UNSUPPORTED, "cdv_corr_level_checked_interleaved: C must be <= 32");
+  return corr_fused_impl(gmap, fmap_nhwc, nullptr, coords, kk, jj, nullptr, out, E, Ng, slots, C, H, W, 0, 0, scale, 1.0f, 1,
+                         kmod, jmod, gmap_pixel_major, stream, 2, level, 882, coords_ref, ref_mul, 0);
+}
+
 extern "C" int cdv_patchify_fwd(const void* net, const float* coords, void* patches, int B, int64_t M, int C, int H,
                                 int W, int radius, int dtype, void* stream) {
   CDV_REQUIRE(dtype == CDV_F16 || dtype == CDV_F32, CDV_ERR_UNSUPPORTED, "cdv_patchify_fwd: dtype must be f16 or f32");

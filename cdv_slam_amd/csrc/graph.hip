@@ -638,6 +638,24 @@ void cdv_graph_forget(const void* ws) {
   g_registry.erase(ws);
 }
 
+// Explicit initialisation of an index workspace: zeroes what the builds keep zero between calls (histogram, cursors,
+// table owner words, meta words) NOW, on `stream`, and records the layout -- so that nothing depends on whether the library
+// has seen this address before (an allocator may hand out the address of a freed workspace: whoever allocates calls this).
+// A bound correlation stream is dropped.
+extern "C" int cdv_graph_workspace_init(void* ws, size_t ws_bytes, int64_t E_max, int64_t k_range, void* stream) {
+  CDV_REQUIRE(ws != nullptr, CDV_ERR_ARG, "cdv_graph_workspace_init: workspace is NULL");
+  CDV_REQUIRE(k_range >= 1 && k_range < ((int64_t)1 << 31) - 64 && E_max >= 1, CDV_ERR_ARG, "cdv_graph_workspace_init: bad sizes");
+  const GraphLayout L = graph_layout(E_max, k_range);
+  CDV_REQUIRE(L.total <= ws_bytes, CDV_ERR_WORKSPACE, "cdv_graph_workspace_init: workspace too small for (E_max, k_range)");
+  const GraphView v = graph_view(ws, L);
+  hipLaunchKernelGGL(graph_init_kernel, dim3(grid_for(k_range + 1 + GM_WORDS, 256, 2048)), dim3(256), 0, (hipStream_t)stream,
+                     v.meta, v.khist, v.kcursor, v.tcur, v.town, k_range);
+  CDV_LAUNCH_CHECK();
+  std::lock_guard<std::mutex> lk(g_reg_mutex);
+  g_registry[ws] = RegEntry{L, true, false, CorrStream{nullptr, 0, 0, 0, 0, 0, 0, 1.0f}, 0, false, 0};
+  return CDV_OK;
+}
+
 extern "C" size_t cdv_graph_workspace_bytes(int64_t E_max, int64_t k_range) {
   if (E_max < 1) E_max = 1;
   if (k_range < 1) k_range = 1;

@@ -14,6 +14,47 @@ __global__ __launch_bounds__(256) void transform_kernel(cdv::TfArgs A) {
   cdv::transform_body<P>(A, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
 }
 
+// The common call -- 3 x 3 patches, coordinates only (SLAM.reproject, slam.py:325-329) -- with the memory side done wave-wide:
+// the 27 floats of a patch arrive as seven wide loads instead of 27 scalar ones, and the 64 edges of a workgroup leave as
+// ONE contiguous block of 64 x 72 bytes (staged in LDS, 16 bytes per lane) instead of 18 stores per lane 72 bytes apart.
+// Same arithmetic as transform_body (tf_relative / tf_pixel): bit-identical coordinates.
+__global__ __launch_bounds__(64) void transform_coords3_kernel(cdv::TfArgs A) {
+  __shared__ __attribute__((aligned(16))) float s_xy[64 * 18];
+  const int tid = threadIdx.x;
+  const int64_t e0 = (int64_t)blockIdx.x * 64, n = e0 + tid;
+  const bool e2pp = (A.flags & CDV_TF_LAYOUT_E2PP) != 0;
+  if (n < A.E) {
+    const int64_t ix = A.ii[n], jx = A.jj[n], kx = A.kk[n];
+    float G[7], t[3], q[4];
+    cdv::tf_relative(A.poses, ix, jx, (A.flags & CDV_TF_TONLY) != 0, G, t, q);
+    const cdv_float4 Ki = *reinterpret_cast<const cdv_float4*>(A.intr + 4 * ix);
+    const cdv_float4 Kj = *reinterpret_cast<const cdv_float4*>(A.intr + 4 * jx);
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    const float* pk = A.patches + kx * 27;
+    float pv[28];
+#pragma unroll
+    for (int v = 0; v < 6; v++) {
+      const f4u x4 = *reinterpret_cast<const f4u*>(pk + 4 * v);
+      pv[4 * v] = x4[0]; pv[4 * v + 1] = x4[1]; pv[4 * v + 2] = x4[2]; pv[4 * v + 3] = x4[3];
+    }
+    pv[24] = pk[24]; pv[25] = pk[25]; pv[26] = pk[26];
+#pragma unroll
+    for (int a = 0; a < 9; a++) {
+      float X1[4], x, y;
+      cdv::tf_pixel(t, q, pv[a], pv[9 + a], pv[18 + a], Ki[0], Ki[1], Ki[2], Ki[3], Kj[0], Kj[1], Kj[2], Kj[3], x, y, X1);
+      if (e2pp) { s_xy[tid * 18 + a] = x; s_xy[tid * 18 + 9 + a] = y; }
+      else { s_xy[tid * 18 + 2 * a] = x; s_xy[tid * 18 + 2 * a + 1] = y; }
+    }
+  }
+  __syncthreads();
+  const int n_e = (int)((A.E - e0) < 64 ? (A.E - e0) : 64);
+  float* dst = A.coords + e0 * 18;                              // 64 x 72 bytes per workgroup: 16-byte aligned
+  const int n4 = (n_e * 18) >> 2;
+  for (int v = tid; v < n4; v += 64)
+    reinterpret_cast<cdv_float4*>(dst)[v] = reinterpret_cast<const cdv_float4*>(s_xy)[v];
+  if (tid == 0 && ((n_e * 18) & 3)) { dst[4 * n4] = s_xy[4 * n4]; dst[4 * n4 + 1] = s_xy[4 * n4 + 1]; }
+}
+
 // cuda_ba.reproject: the projection fastba's residuals use -- stored (not re-normalised) poses, the intrinsics of row 0,
 // no depth clamp (ba_cuda.cu:408-458 semantics) -- for every pixel of the patch; one lane per edge
 template <int P>
@@ -240,7 +281,9 @@ extern "C" int cdv_transform(const float* poses, const float* patches, const flo
   const int threads = 64;  // E ~ 5e4: small blocks spread the edges over all 256 CUs
   const int blocks = cdv_div_up(E, threads);
   const cdv::TfArgs A{poses, patches, intrinsics, ii, jj, kk, E, flags, coords, validpx, valid, Ji, Jj, Jz};
-  if (P == 3)
+  if (P == 3 && !validpx && !Ji && ((uintptr_t)coords & 15) == 0)
+    hipLaunchKernelGGL(transform_coords3_kernel, dim3(blocks), dim3(64), 0, s, A);
+  else if (P == 3)
     hipLaunchKernelGGL(transform_kernel<3>, dim3(blocks), dim3(threads), 0, s, A);
   else
     hipLaunchKernelGGL(transform_kernel<1>, dim3(blocks), dim3(threads), 0, s, A);

@@ -69,8 +69,12 @@ class GraphIndex:
         self.E_cap = max(E, int(self.E_cap * 1.5), 1024)
         nbytes = self.lib.cdv_graph_workspace_bytes(self.E_cap, self.k_range)
         self.ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-        self.lib.cdv_workspace_forget(_p(self.ws))   # a fresh allocation may reuse the address of a dead workspace
         self.ws_bytes = nbytes
+        # whoever allocates initialises: nothing depends on what the library remembers about this address
+        _lib.check(self.lib.cdv_graph_workspace_init(_p(self.ws), nbytes, self.E_cap, self.k_range, _stream()),
+                   "cdv_graph_workspace_init")
+        if getattr(self, "_stream_cfg", None) is not None:     # the correlation stream binding lives with the workspace
+            self.bind_corr_stream(*self._stream_cfg)
         self._key = None
 
     @staticmethod
@@ -82,12 +86,14 @@ class GraphIndex:
 
     def _same_key(self, key):
         """is the index in the workspace the one `key` describes?  A build WITH ii also serves a request without it
-        (neighbors() after the prologue); a build without ii, or with another / modified ii, does not serve a request with."""
+        (neighbors() after the prologue), and a build WITHOUT ii serves a request with any ii (cuda_ba.neighbors builds it,
+        cuda_ba.forward then reads ii per edge: one more dependent load instead of a second build); a build with another or
+        a modified ii does not serve a request with ii."""
         k = self._key
         if k is None or k[0] is not key[0] or k[1] is not key[1] or k[2] != key[2] or k[3] != key[3]:
             return False
-        if key[4] is None:
-            return True
+        if key[4] is None or k[4] is None:
+            return True      # nothing of ii is baked into an index built without it: the bundle adjustment reads ii itself then
         return k[4] is key[4] and k[5] == key[5]
 
     def corr_order_ptr(self):
@@ -107,6 +113,7 @@ class GraphIndex:
         _lib.check(self.lib.cdv_graph_bind_corr_stream(_p(self.ws), _p(coords), int(kmod), int(jmod), int(Ng), int(slots), float(scale0)),
                    "cdv_graph_bind_corr_stream")
         self._stream_coords = coords          # pinned: the builds read it
+        self._stream_cfg = (coords, kmod, jmod, Ng, slots, scale0)
 
     def corr_records_ptr(self):
         p = self.lib.cdv_graph_corr_records(_p(self.ws))
@@ -226,6 +233,7 @@ class GraphIndex:
         ix = torch.empty(self.E, dtype=torch.int64, device=self.device)
         jx = torch.empty(self.E, dtype=torch.int64, device=self.device)
         _lib.check(self.lib.cdv_neighbors(_p(self.ws), self.E, _p(ix), _p(jx), _stream()), "cdv_neighbors")
+        self._nbr = (ix, jx)       # the index has not changed when somebody asks again
         return ix, jx
 
     def unique(self):
@@ -485,6 +493,25 @@ class NhwcCache:
 _nhwc = NhwcCache()
 
 
+class TileCache:
+    """pixel-major shadow [Ng, 9, C] of patch tiles somebody else keeps in the reference layout [1, Ng, C, 3, 3] (slam.py's
+    gmap_): re-converted when the tensor's version counter has moved (1.5 MB in, 1.5 MB out at the default sizes)."""
+
+    def __init__(self):
+        self.src, self.version, self.shadow = None, None, None
+
+    def get(self, gmap):
+        if self.src is not gmap or self.version != gmap._version or self.shadow is None:
+            g = gmap[0] if gmap.dim() == 5 else gmap
+            self.shadow = gmap_to_pixel_major(g.contiguous(), out=self.shadow if (self.shadow is not None and self.src is gmap)
+                                              else None)
+            self.src, self.version = gmap, gmap._version
+        return self.shadow
+
+
+_tiles = TileCache()
+
+
 def fmap_ingest(fmap_chw, fmap1_nhwc, fmap2_nhwc, slot, fmap1_nchw=None, fmap2_nchw=None, gmap=None, gmap_pm=None,
                 gmap_first=0, gmap_count=0):
     """One new frame [C,H,W] f16 -> ring slot `slot` of the channels-last level-0 ring and its 4x4
@@ -575,31 +602,65 @@ def corr_fused_stream(gmap_pm, fmap0_nhwc, fmap1_nhwc, records_ptr, E, scales=(1
     return out
 
 
+class PairedLevel(torch.Tensor):
+    """One pyramid level of a paired two-level correlation: a strided view (stride 2 along the level axis) of the
+    interleaved buffer [1, E, 7, 7, 3, 3, 2] that cdv_corr_fused fills -- the very layout `torch.stack([corr1, corr2], -1)`
+    produces (slam.py:323).  When exactly that stack is asked of the two views of ONE buffer, the buffer itself is the
+    answer (same values, same shape, same strides, no 2 x 84 MB copy); every other operation sees an ordinary tensor."""
+
+    @staticmethod
+    def wrap(view, base, level):
+        t = view.as_subclass(PairedLevel)
+        t._pair_base, t._pair_level = base, level
+        return t
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func is torch.stack and pair_levels_enabled():
+            seq = args[0] if args else kwargs.get("tensors")
+            dim = args[1] if len(args) > 1 else kwargs.get("dim", 0)
+            if (isinstance(seq, (list, tuple)) and len(seq) == 2 and "out" not in kwargs
+                    and all(isinstance(t, PairedLevel) and getattr(t, "_pair_base", None) is not None for t in seq)
+                    and seq[0]._pair_base is seq[1]._pair_base and (seq[0]._pair_level, seq[1]._pair_level) == (0, 1)
+                    and dim in (-1, seq[0]._pair_base.dim() - 1)
+                    and seq[0].shape == seq[0]._pair_base.shape[:-1] and seq[1].shape == seq[1]._pair_base.shape[:-1]):
+                _pairing.n_stacked += 1
+                return seq[0]._pair_base
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*args, **kwargs)
+
+
 class _LevelPairing:
     """The reference calls cuda_corr.forward twice per update: pyramid[0] with coords, then pyramid[1] with coords / 4
     (slam.py:321-322), and stacks the two results (slam.py:323).  Seen from here the second call repeats the per-edge
-    work of the first.  Once that pattern has been observed (two consecutive calls on the same patch tiles and index
-    tensors, on two rings whose sizes differ by a power of two), the call on the first ring computes BOTH levels in one
-    launch (cdv_corr_fused_split) into one buffer [E][2][442] and returns its level-0 view; the call that follows on the
-    second ring only checks, per edge and on the device, that its coords are the first call's divided by the same power
-    of two, recomputes the edges for which they are not (cdv_corr_level_checked), and returns the level-1 view.
+    work of the first, and the stack copies what one launch could have written in place.  Once the pattern has been
+    observed (two consecutive calls on the same patch tiles and index tensors, on two rings whose sizes differ by a power
+    of two), the call on the first ring computes BOTH levels in one launch (cdv_corr_fused) into one interleaved buffer
+    [1, E, 7, 7, 3, 3, 2] and returns its level-0 view; the call that follows on the second ring only checks, per edge and
+    on the device, that its coords are the first call's divided by the same power of two, recomputes the edges for which
+    they are not (cdv_corr_level_checked_interleaved), and returns the level-1 view.  The views are PairedLevel tensors:
+    torch.stack of the two along a new last axis returns the buffer they share.
 
-    What is assumed, and what guards it (a documented mode, CDV_PAIR_LEVELS=0 turns it off):
+    What is assumed, and what guards it (a documented mode, CDV_PAIR_LEVELS=0 turns all of it off):
       * the speculative level-1 result is only handed out to the call that IMMEDIATELY follows, with the very same
         tensor objects (patch tiles, ii, jj: identity AND version counter -- held alive by `pending`, so an address
         the allocator recycles cannot impersonate them) on the ring that was learned as the partner, unchanged since
         (identity + version); any other call in between -- a third caller -- drops the pending result;
       * the learned partnership is keyed by the identity of ring A (a weak reference that must still resolve to the
-        very object), re-validated (shapes, dtype, contiguity, ratio) before every split launch;
+        very object), re-validated (shapes, dtype, contiguity, ratio) before every paired launch;
       * the coords are checked per edge on the device, so a caller whose second call is not coords / ratio gets the
-        recomputed values.
-    A second call that never comes costs the speculative level and nothing else.  `n_fused` counts pairs served."""
+        recomputed values;
+      * the stack shortcut needs the two views of one buffer, levels (0, 1), new last axis -- anything else is a real stack.
+    A second call that never comes costs the speculative level and nothing else.  `n_fused` counts pairs served,
+    `n_stacked` the stacks answered with the shared buffer."""
 
     def __init__(self):
         self.learned = {}      # id(ring A) -> (weakref ring A, weakref ring B, ratio)
         self.last = None       # the previous call when it was an ordinary one
         self.pending = None
         self.n_fused = 0
+        self.n_stacked = 0
 
     @staticmethod
     def _same(held, now):
@@ -636,25 +697,20 @@ class _LevelPairing:
             N2, H2, W2 = fmap2.shape[1], fmap2.shape[3], fmap2.shape[4]
             C = fmap1.shape[2]
             g = fmap1[0].contiguous()
-            rc = lib.cdv_corr_level_checked(_p(g), _p(shadow[0]), _p(coords), _p(pend["coords"]), 1.0 / pend["ratio"],
-                                            _p(ii), _p(jj), _p(pend["buf"]), 1, E, g.numel() // (C * 9), N2, C, H2, W2, 1.0,
-                                            0, 0, 0, _stream())
-            _lib.check(rc, "cdv_corr_level_checked")
+            rc = lib.cdv_corr_level_checked_interleaved(_p(g), _p(shadow[0]), _p(coords), _p(pend["coords"]), 1.0 / pend["ratio"],
+                                                        _p(ii), _p(jj), _p(pend["buf"]), 1, E, g.numel() // (C * 9), N2, C, H2, W2,
+                                                        1.0, 0, 0, 0, _stream())
+            _lib.check(rc, "cdv_corr_level_checked_interleaved")
             self.n_fused += 1
-            return pend["buf"][:, 1, :441].view(1, E, 7, 7, 3, 3)
-        # ---- a first call whose second is expected: both levels now
+            return PairedLevel.wrap(pend["buf"][..., 1], pend["buf"], 1)
+        # ---- a first call whose second is expected: both levels now, interleaved as the stack will want them
         ringB, ratio = self._partner(fmap2)
         if ringB is not None and E == ii.numel() == jj.numel() and E > 0:
             sa, sb = _nhwc.get(fmap2), _nhwc.get(ringB)
-            C = fmap1.shape[2]
-            g = fmap1[0].contiguous()
-            buf = torch.empty((E, 2, 442), dtype=torch.float16, device=g.device)     # levels kept apart: rows of 884 B
-            rc = lib.cdv_corr_fused_split(_p(g), _p(sa[0]), _p(sb[0]), _p(coords), _p(ii), _p(jj), None, _p(buf), E,
-                                          g.numel() // (C * 9), fmap2.shape[1], C, fmap2.shape[3], fmap2.shape[4],
-                                          ringB.shape[3], ringB.shape[4], 1.0, float(ratio), 0, 0, 0, _stream())
-            _lib.check(rc, "cdv_corr_fused_split")
+            buf = torch.empty((1, E, 7, 7, 3, 3, 2), dtype=torch.float16, device=fmap1.device)
+            corr_fused(_tiles.get(fmap1), sa[0], sb[0], coords, ii, jj, scales=(1.0, float(ratio)), out=buf, pixel_major=True)
             self.pending = {"held": self._hold(fmap1, ii, jj, ringB), "E": E, "coords": coords, "ratio": ratio, "buf": buf}
-            return buf[:, 0, :441].view(1, E, 7, 7, 3, 3)
+            return PairedLevel.wrap(buf[..., 0], buf, 0)
         # ---- an ordinary call: remember it, and learn the pairing from two in a row on the same tiles and indices
         if last is not None and E == last["E"] and self._same(last["held"], (fmap1, ii, jj)):
             ra = last["ring"]
@@ -821,7 +877,7 @@ def _ba_workspace(dev, E, U_max, N):
     ws = _ba_ws.get(dev)
     if ws is None or ws.numel() < need:
         ws = _ba_ws[dev] = torch.empty(int(need * 1.25) + 4096, dtype=torch.uint8, device=dev)
-        lib.cdv_workspace_forget(_p(ws))             # a fresh allocation may reuse the address of a dead workspace
+        _lib.check(lib.cdv_ba_workspace_init(_p(ws), _stream()), "cdv_ba_workspace_init")   # whoever allocates initialises
         cnt = _ba_counters.get(dev)
         if cnt is None:
             cnt = _ba_counters[dev] = torch.zeros(4, dtype=torch.int32).pin_memory()

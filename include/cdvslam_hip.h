@@ -55,6 +55,13 @@ const char* cdv_version(void);
  * consistent between calls.  Call this for an address that was freed and may have been written by someone else before
  * it is used as a workspace again (allocators hand addresses back); the next call re-initialises it. */
 void cdv_workspace_forget(const void* ws);
+/* The explicit form: whoever allocates a workspace initialises it, and nothing depends on what the library remembers about
+ * an address.  cdv_graph_workspace_init zeroes on `stream` what the index builds keep zero between calls and records the
+ * layout (a bound correlation stream is dropped); cdv_ba_workspace_init makes the next cdv_ba_forward on the workspace
+ * initialise it (status counters stay bound).  cdv_workspace_forget(ws) stays as the old spelling of "treat as new at
+ * the next use". */
+int cdv_graph_workspace_init(void* graph_ws, size_t ws_bytes, int64_t E_max, int64_t k_range, void* stream);
+int cdv_ba_workspace_init(void* ba_ws, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * altcorr  (replaces cuda_corr.forward / patchify_forward)
@@ -172,6 +179,13 @@ int cdv_corr_level_checked(const void* gmap, const void* fmap_nhwc, const float*
                            float ref_mul, const int64_t* kk, const int64_t* jj, void* out2, int level, int64_t E,
                            int64_t Ng, int64_t slots, int C, int H, int W, float scale, int64_t kmod, int64_t jmod,
                            int gmap_pixel_major, void* stream);
+/* cdv_corr_level_checked writing into the interleaved two-level result of cdv_corr_fused ([E][441][2] halves, exactly what
+ * SLAM.corr's torch.stack([corr1, corr2], -1) holds, slam.py:323): element t of edge e, level `level`, at
+ * out[e * 882 + 2 t + level].  Lets a drop-in hand out both per-level results as views of ONE buffer. */
+int cdv_corr_level_checked_interleaved(const void* gmap, const void* fmap_nhwc, const float* coords, const float* coords_ref,
+                                       float ref_mul, const int64_t* kk, const int64_t* jj, void* out, int level, int64_t E,
+                                       int64_t Ng, int64_t slots, int C, int H, int W, float scale, int64_t kmod, int64_t jmod,
+                                       int gmap_pixel_major, void* stream);
 
 /* cuda_corr.patchify_forward(net, coords, radius) -- correlation.cpp:49-52, kernel :16-47.
  *   net [B][C][H][W] (f16 or f32), coords [B][M][2] f32 -> patches [B][M][C][D][D], zero when OOB */

@@ -335,8 +335,13 @@ def test_dropin_corr_pairs_the_two_level_calls():
         stacked = torch.stack([a, b], -1).view(1, st.E, -1)
         assert torch.equal(a, plain(f1, c0)), it
         assert torch.equal(b, plain(f2, c1)), it
-        assert stacked.shape[-1] == 882
-    assert ops._pairing.n_fused == 2          # updates 1 and 2; update 0 taught the pattern
+        assert stacked.shape[-1] == 882 and type(stacked) is torch.Tensor
+        assert torch.equal(stacked, torch.stack([plain(f1, c0), plain(f2, c1)], -1).view(1, st.E, -1)), it
+        if it > 0:      # the two views of one buffer: the stack IS that buffer (no copy), any other stack is a real one
+            assert stacked.data_ptr() == a.data_ptr() and isinstance(a, ops.PairedLevel)
+            assert torch.stack([b, a], -1).data_ptr() != a.data_ptr() and torch.stack([a, b], 0).shape[0] == 2
+            assert torch.equal(torch.stack([a, b], 0)[1], b) and type(a + 0) is torch.Tensor
+    assert ops._pairing.n_fused == 2 and ops._pairing.n_stacked == 2      # updates 1 and 2; update 0 taught the pattern
     # a third caller between the two calls of a pair: the speculative level is dropped, nothing is mis-paired
     other = base[:, : st.E // 2].contiguous() + 1.5
     io, jo = ii1[: st.E // 2].contiguous(), jj1[: st.E // 2].contiguous()
@@ -396,7 +401,7 @@ def test_ba_rebuilds_the_index_when_only_ii_changes():
     assert np.array_equal(run(ii_c, g), want_a)
     ii_c.copy_(ii_b)                                               # modified in place: the version counter moved
     assert same(run(ii_c, g), want_b)
-    # an index built without ii (neighbors) does not serve a BA that brings ii
+    # an index built without ii (neighbors) serves a BA that brings ii: nothing of ii is baked in, the kernels read it per edge
     g.build(jj, kk, force=True)
     assert same(run(ii_b, g), want_b)
 
