@@ -880,9 +880,9 @@ extern "C" int cdv_graph_read_meta_host(const void* ws, int64_t* meta_host, void
   int32_t m[GM_WORDS];
   CDV_HIP_CHECK(hipMemcpyAsync(m, (const char*)ws + L.meta, sizeof(m), hipMemcpyDeviceToHost, (hipStream_t)stream));
   CDV_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
-  if (m[GM_MODE]) {   // patch table: live patches and their id range from the per-slot ids; no frame range is kept
+  if (cdv_graph_is_table(ws)) {   // patch table: live patches and their id range from the per-slot ids; no frame range is kept
     const int err = m[GM_TERR] == m[GM_GEN];
-    const int cap = m[GM_TCAP];
+    const int cap = (int)cdv_graph_table_capacity(ws);
     std::vector<int32_t> kid((size_t)(cap > 0 ? cap : 0));
     if (cap > 0) {
       CDV_HIP_CHECK(hipMemcpyAsync(kid.data(), (const char*)ws + L.tkid, sizeof(int32_t) * (size_t)cap, hipMemcpyDeviceToHost,

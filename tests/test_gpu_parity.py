@@ -635,6 +635,14 @@ def test_patchify_vs_oracle():
 # fastba
 # ---------------------------------------------------------------------------------------------------
 
+def _run_ba_on(st, graph, iterations=2):
+    poses, patches = T(st.poses).clone(), T(st.patches).clone()
+    ops.ba_forward(poses, patches, T(st.intrinsics), T(st.target), T(st.weight), torch.tensor([st.lmbda], device=DEV), T(st.ii),
+                   T(st.jj), T(st.kk), st.cfg.M, st.t0, st.n, iterations, False, graph=graph)
+    torch.cuda.synchronize()
+    return poses.cpu().numpy(), patches.cpu().numpy(), None
+
+
 def _run_ba(st, iterations=2, debug=False, t0=None, t1=None):
     poses, patches = T(st.poses).clone(), T(st.patches).clone()
     t0 = st.t0 if t0 is None else t0
@@ -1195,16 +1203,19 @@ def test_ba_never_dereferences_unwritten_index_slots():
     all their first-round slots unconditionally and must replace what lies beyond a patch's degree BEFORE any field is used
     as an index (settle_rec).  Here the index and BA workspaces are filled with a poison pattern (huge positive ints /
     NaN-ish floats) before their first use, as a fresh allocation may be: the update must neither fault nor change."""
-    for name in ("default", "init", "stress", "mid19_m5"):
+    for name, cap in (("default", None), ("init", None), ("stress", None), ("mid19_m5", None), ("default", 2304), ("stress", 4704)):
         st, _ = _make(name)
-        want_p, want_x, _ = _run_ba(st, iterations=2)
-        g = ops.GraphIndex(torch.device(DEV), E_cap=st.E, k_range=st.cfg.buffer_size * st.cfg.M)
+        g0 = ops.GraphIndex(torch.device(DEV), E_cap=st.E, k_range=st.cfg.buffer_size * st.cfg.M, table_capacity=cap)
+        want_p, want_x, _ = _run_ba_on(st, g0)
+        g = ops.GraphIndex(torch.device(DEV), E_cap=st.E, k_range=st.cfg.buffer_size * st.cfg.M, table_capacity=cap)
         g.ws.view(torch.int32).fill_(0x7F7F7F7F)
-        dev = torch.device(DEV)
-        ws = ops._ba_workspace(dev, st.E, min(st.E, len(st.patches)), st.n - st.t0)   # the one ba_forward will pick up
-        ws.fill_(0x7F)
         lib = ops._lib.load()
-        lib.cdv_workspace_forget(ops._p(ws))                   # as after a fresh allocation: the next use initialises it
+        # whoever (re)allocates a workspace initialises it: the contract of cdv_graph_workspace_init
+        ops._lib.check(lib.cdv_graph_workspace_init(ops._p(g.ws), g.ws_bytes, g.E_cap, g.k_range, ops._stream()), "init")
+        dev = torch.device(DEV)
+        ws = ops._ba_workspace(dev, st.E, max(min(st.E, len(st.patches)), cap or 0), st.n - st.t0)   # the one ba_forward picks up
+        ws.fill_(0x7F)
+        ops._lib.check(lib.cdv_ba_workspace_init(ops._p(ws), ops._stream()), "init")   # as after a fresh allocation
         import ctypes
         ops._lib.check(lib.cdv_ba_bind_status_counters(ops._p(ws), ctypes.c_void_p(ops._ba_counters[dev].data_ptr())), "bind")
         poses, patches = T(st.poses).clone(), T(st.patches).clone()
