@@ -22,6 +22,8 @@
 //                           panels of 24 columns factored inside single waves (one matrix row per lane, pivots and
 //                           L[m][k] by v_readlane), trailing update as 16 x 16 tiles on the matrix cores (K = 24), back
 //                           substitution inside one wave.
+#include <stdlib.h>
+
 #include "cdv_ba_pairs.h"
 
 using namespace cdv;
@@ -40,8 +42,15 @@ constexpr int FT = 512;                    // threads of a finish workgroup
 //   [54 + 27 N, 54 + 99 N)    F_ij[s][j] 36 (B_ij, rows of the source frame, columns of the target frame)
 __host__ __device__ inline int fp_floats(int N) { return (54 + 99 * N + 3) / 4 * 4; }
 __host__ __device__ inline int ed_rows(int N) { return (6 * N + 1 + 15) / 16 * 16; }
+// stride between the waves' footprint copies: the copies of waves 1 .. W - 1 also stage the chunk's slab, so with few waves
+// the stride grows beyond the footprint itself
+__host__ __device__ inline int fp_stride(int N, int waves) {
+  const int slab = ((6 * N * (6 * N + 1)) / 2 + 6 * N + 7) / 8 * 8;
+  const int need = ((slab + waves - 2) / (waves - 1) + 3) / 4 * 4;
+  return fp_floats(N) > need ? fp_floats(N) : need;
+}
 inline size_t chunk_lds_bytes(int N, int waves) {
-  return sizeof(float) * ((size_t)waves * fp_floats(N) + (size_t)ed_rows(N) * EDL + (size_t)waves * 8 * CK + 2 * CK + 8);
+  return sizeof(float) * ((size_t)waves * fp_stride(N, waves) + (size_t)ed_rows(N) * EDL + (size_t)waves * 8 * CK + 2 * CK + 8);
 }
 
 // where value `code` of a frame pair goes inside a footprint: base + ms * (source slot) + mj * (target frame); need: bit 0
@@ -72,7 +81,7 @@ __global__ __launch_bounds__(64 * MKW) void ba_mid_chunk_kernel(BaWinArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int N = A.N, t0 = A.t0, P = A.P;
   const int n6 = 6 * N;
-  const int FP = fp_floats(N), ER = ed_rows(N);
+  const int FP = fp_stride(N, MKW), ER = ed_rows(N);
   const int TRI_N = (n6 * (n6 + 1)) >> 1;
   const int slabf = (TRI_N + n6 + 7) / 8 * 8;
   float* Fw = smem;                            // [MKW][FP] per-wave footprints
@@ -178,7 +187,7 @@ __global__ __launch_bounds__(64 * MKW) void ba_mid_chunk_kernel(BaWinArgs A) {
         }
         if (maxdeg > step) {   // wave-uniform, rare: the records of this lane's later rounds
           for (int t = tb + so + step; t < deg; t += step) {
-            const int4 rk = reinterpret_cast<const int4*>(A.prec)[plo + t];
+            const int4 rk = (use_ell && t < ELL_SLOTS) ? cell[cell_index(rs, t)] : reinterpret_cast<const int4*>(A.prec)[plo + t];
             const int a = (HAS_II ? rk.y : (int)A.ii[rk.x]) - t0;
             if (a >= 0 && a < N) mbits |= 1u << a;
           }
@@ -198,7 +207,12 @@ __global__ __launch_bounds__(64 * MKW) void ba_mid_chunk_kernel(BaWinArgs A) {
         const bool more = tb + step < maxdeg;      // wave-uniform
         const EdgeRec cur = rec;
         int4 raw_nxt = {0, 0, 0, 0};
-        if (more) raw_nxt = reinterpret_cast<const int4*>(A.prec)[(tb + step + so < deg) ? plo + tb + step + so : 0];
+        if (more) {   // slots below ELL_SLOTS from the chunk-slot rows (a table keeps only longer lists in its CSR too)
+          const int sn = tb + step + so;
+          const bool from_cell = use_ell && sn < ELL_SLOTS;
+          const int4* src = from_cell ? cell : reinterpret_cast<const int4*>(A.prec);
+          raw_nxt = src[from_cell ? cell_index(rs, sn) : ((sn < deg) ? plo + sn : 0)];
+        }
         EdgeFactor J;
         fastba_factor(in.pi, in.pj, px, py, pd, in.tx, in.ty, in.wx, in.wy, fx, fy, cx, cy, J);
         if (more) {
@@ -380,22 +394,23 @@ __global__ __launch_bounds__(64 * MKW) void ba_mid_chunk_kernel(BaWinArgs A) {
       // (the diagonal blocks and v from F_jj; block (i_s, j) from F_ij[s][j], self pairs and the transposed pair of the
       // two source frames having been folded away above): plain read-modify-write, one owner each.  A tile-side lookup
       // of the same values cost 150 vector instructions per tile. ----
-      if (tid < 27 * 18) {
+      constexpr int G27 = (64 * MKW) / 27, G36 = (64 * MKW) / 36;   // thread groups of 27 / 36 the workgroup holds
+      if (tid < 27 * G27) {
         const int jl = tid / 27, t = tid - 27 * jl;
         int a = 0, b = 0;
         if (t < 21) {
           while (((a + 1) * (a + 2)) / 2 <= t) a++;
           b = t - (a * (a + 1)) / 2;
         }
-        for (int j = jl; j < N; j += 18) {
+        for (int j = jl; j < N; j += G27) {
           const int idx = (t < 21) ? tri_index(6 * j + a, 6 * j + b) : TRI_N + 6 * j + (t - 21);
           Sd[idx] += Fw[54 + 27 * j + t];
         }
       }
-      if (tid < 36 * 14) {
+      if (tid < 36 * G36) {
         const int bl = tid / 36, ab = tid - 36 * bl;
         const int a = ab / 6, b = ab - 6 * a;
-        for (int blk = bl; blk < 2 * N; blk += 14) {
+        for (int blk = bl; blk < 2 * N; blk += G36) {
           const int sl = blk >= N ? 1 : 0, j = blk - N * sl;
           const int is = sl ? isrc1 : isrc0;
           // skipped: no such source frame; the self pair (folded onto the diagonal block); slot 1's view of slot 0
@@ -951,6 +966,10 @@ int cdv::cdv_ba_mid_iteration(const BaWinArgs& a, hipStream_t s) {
     if ((x = chunk_attr<false, 8, false>()) != hipSuccess) e = x;
     if ((x = chunk_attr<true, 8, true>()) != hipSuccess) e = x;
     if ((x = chunk_attr<false, 8, true>()) != hipSuccess) e = x;
+    if ((x = chunk_attr<true, 4, false>()) != hipSuccess) e = x;
+    if ((x = chunk_attr<false, 4, false>()) != hipSuccess) e = x;
+    if ((x = chunk_attr<true, 4, true>()) != hipSuccess) e = x;
+    if ((x = chunk_attr<false, 4, true>()) != hipSuccess) e = x;
     if ((x = finish_attr<96, false>()) != hipSuccess) e = x;
     if ((x = finish_attr<144, false>()) != hipSuccess) e = x;
     if ((x = finish_attr<192, false>()) != hipSuccess) e = x;
@@ -961,16 +980,23 @@ int cdv::cdv_ba_mid_iteration(const BaWinArgs& a, hipStream_t s) {
   }();
   CDV_HIP_CHECK(attr_err);
   const int N = a.N;
-  // 8 waves per chunk workgroup: 32 target slots per round.  (The kernel needs ~230 VGPRs, so a CU holds 8 of its waves
-  // whatever the LDS split: one workgroup of 8, not two of fewer.)
-  constexpr int mkw = 8;
-  CDV_REQUIRE((mkw - 1) * fp_floats(N) >= mid_slab(N), CDV_ERR_UNSUPPORTED, "cdv_ba_forward: slab staging exceeds the footprint copies");
-  const size_t lds = chunk_lds_bytes(N, mkw);
-  CDV_REQUIRE(lds <= 160 * 1024 - 256, CDV_ERR_UNSUPPORTED, "cdv_ba_forward: chunk footprint exceeds LDS");
+  // 8 waves per chunk workgroup: 32 target slots per round.  (The kernel needs ~250 VGPRs, so a CU holds 8 of its waves
+  // whatever the split.  Workgroups of 4 waves, two per CU -- so that the stress configuration's 294 chunks are resident at
+  // once instead of taking a second round of 38 workgroups -- were measured: 49.1 against 41.7 us; the kernel is written
+  // for either, CDV_MID_WAVES=4 selects them.)
   const int n_ck = a.n_ck_cap < WIN_MAX_GRID ? a.n_ck_cap : WIN_MAX_GRID;
   const bool table = a.tab_cap > 0;
-  if (table) launch_chunk<mkw, true>(a, n_ck, lds, s);
-  else launch_chunk<mkw, false>(a, n_ck, lds, s);
+  static const int mkw_env = getenv("CDV_MID_WAVES") ? atoi(getenv("CDV_MID_WAVES")) : 8;
+  const int mkw = mkw_env == 4 ? 4 : 8;
+  const size_t lds = chunk_lds_bytes(N, mkw);
+  CDV_REQUIRE(lds <= 160 * 1024 - 256, CDV_ERR_UNSUPPORTED, "cdv_ba_forward: chunk footprint exceeds LDS");
+  if (mkw == 8) {
+    if (table) launch_chunk<8, true>(a, n_ck, lds, s);
+    else launch_chunk<8, false>(a, n_ck, lds, s);
+  } else {
+    if (table) launch_chunk<4, true>(a, n_ck, lds, s);
+    else launch_chunk<4, false>(a, n_ck, lds, s);
+  }
   const int n = 6 * N;
   {
     const int S4 = mid_slab(N) / 4;
