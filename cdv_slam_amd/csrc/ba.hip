@@ -17,6 +17,8 @@
 //        back substitution; 4. ba_retract_kernel: dZ = Q (u - E^T dX), depth and pose update (ba_cuda.cu:178-229, 592).
 //     (Float atomics: results agree with the oracle to the stated tolerances, not bit for bit between runs.)
 //   N = 0           assemble + ba_schur_kernel (q only) + retract: depths alone.
+#include <stdlib.h>
+
 #include <mutex>
 #include <unordered_map>
 
@@ -45,6 +47,7 @@ struct WsState {
   int64_t U_max;
   int N;
   size_t bytes;
+  int32_t token;      // last hand-off tag handed to a launch on this workspace (window path)
 };
 std::mutex g_ws_mutex;
 std::unordered_map<const void*, WsState> g_ws_state;
@@ -952,12 +955,15 @@ extern "C" int cdv_ba_forward(float* poses, float* patches, const float* intrins
   // The accumulators are zeroed once per (workspace, U_max, N): afterwards the solve / retract kernels leave
   // them zero, so the steady-state call enqueues no memset.
   bool fresh;
+  int32_t token_base = 0;
   int32_t* counters = nullptr;
   {
     std::lock_guard<std::mutex> lk(g_ws_mutex);
     WsState& st = g_ws_state[ba_ws];
     fresh = !(st.valid && st.U_max == U_max && st.N == N && st.bytes == ba_ws_bytes);
-    st = WsState{true, U_max, N, ba_ws_bytes};
+    const int32_t tok0 = (fresh || st.token > 0x7ffffff0 - 4 * (iterations > 0 ? iterations : 1)) ? 0 : st.token;
+    token_base = tok0;
+    st = WsState{true, U_max, N, ba_ws_bytes, tok0 + (iterations > 0 ? iterations : 1)};
     auto it = g_ws_counters.find(ba_ws);
     if (it != g_ws_counters.end()) counters = it->second;
   }
@@ -993,9 +999,22 @@ extern "C" int cdv_ba_forward(float* poses, float* patches, const float* intrins
     wa.Cg = Cg; wa.ug = ug; wa.qg = qg; wa.Edg = Edg; wa.dXg = dXg;
     wa.U_stride = (int)L.U_stride; wa.U_max = (int)L.U_max; wa.n_ck_cap = (int)L.n_ck;
     wa.info = info; wa.counters = counters;
+    wa.pose_next = (float*)(b + L.pnext); wa.pose_src = nullptr;
+    wa.dbg = nullptr;
+    wa.token = token_base + 1;
+    // CDV_BA_FUSE=1: two iterations as THREE launches (ba_win.hip cdv_ba_window_two_iterations: the first solve and the
+    // second chunk pass share a grid).  Measured on the default graph: 12.8 + 26.3 + 15.8 us against 2 x (12.7 + 14.9), the
+    // same 9,880 updates/s -- the chunk pass cannot start before dX exists, so only its load levels overlap the solver and
+    // the saved launch boundary is given back in polling.  Kept as an option (and tested against the plain sequence), off
+    // by default.
+    const char* fuse_env = getenv("CDV_BA_FUSE");
+    const bool fuse = fuse_env != nullptr && atoi(fuse_env) == 1;
+    if (N <= WIN_N && iterations == 2 && dbg == nullptr && fuse && cdv_ba_window_can_fuse(wa))
+      return cdv_ba_window_two_iterations(wa, s);
     for (int itr = 0; itr < iterations; itr++) {
       wa.dbg = (dbg && itr == 0) ? dbg : nullptr;
       wa.first = itr == 0 ? 1 : 0;
+      wa.token = token_base + 1 + itr;
       const int rc = N <= WIN_N ? cdv_ba_window_iteration(wa, s) : cdv_ba_mid_iteration(wa, s);
       if (rc != CDV_OK) return rc;
     }

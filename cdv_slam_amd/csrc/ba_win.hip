@@ -44,6 +44,8 @@ constexpr int SN = WIN_SN;
 constexpr int TRI = WIN_TRI;
 constexpr int SLAB = WIN_SLAB;
 constexpr int EDL = CK + 1;                // row stride of the chunk's [E; u] block in LDS
+constexpr int FUS_POSE0 = 64;              // first dX granule that carries a retracted pose component in a fused launch
+static_assert(FUS_POSE0 + 7 * WIN_N <= MID_GRAN, "granules");
 constexpr int LDS_CHUNK_FLOATS = CKW * SLAB + 64 * EDL + CKW * 8 * CK + 2 * CK;
 
 // one reduced value of frame pair (ci, cj) (free-pose indices or -1) into the wave's packed copy of [S | y]
@@ -61,7 +63,300 @@ __device__ __forceinline__ void pair_emit(float total, int code, int ci, int cj,
   if (ok) lds_add(&Sw[idx], v);
 }
 
-template <bool HAS_II, bool TABLE>
+// ---------------------------------------------------------------------------------------------------------
+// finish: reduce -> solve -> retract
+// ---------------------------------------------------------------------------------------------------------
+
+typedef float cdv_float2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float ld_agent(const float* p) {   // global_load_dword sc1: past this CU's L1
+  return __int_as_float((int)__hip_atomic_load(reinterpret_cast<const uint32_t*>(p), __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// Reduce share of workgroup b of RW: threads 0..255 work (`act`), any further threads of the workgroup only keep the
+// barriers company (the fused launch runs this inside 512-thread workgroups with the very same thread roles, so that
+// its sums are the plain finish launch's bit for bit).
+__device__ __forceinline__ void reduce_slabs(const BaWinArgs& A, int b, int RW, int U, int tid, bool flag_it) {
+  const bool act = tid < 256;
+// ---- reduce the chunk slabs.  A CU streams ~10 B per cycle, so the 1.5 MB of slabs want many CUs: a workgroup takes
+  //         FOUR 16-byte columns, thread = (column, one of 64 interleaved slab subsets: 16 in the lanes of a DPP row x the 4
+  //         waves).  Per-thread sums in slab order, the row's 16 partials by DPP row shifts, the four waves' partials in
+  //         LDS: a fixed tree that depends on nothing but the number of slabs -- reproducible bits whatever the launch
+  //         geometry. ----
+  {
+    const int nsl = (U + CK - 1) / CK;
+    const int g = tid & 15, cs = (tid >> 4) & 3, w = (tid >> 6) & 3;
+    __shared__ cdv_float4 s_part[4][4];
+    const int token = A.token;
+    for (int col0 = b * 4; col0 < SLAB / 4; col0 += RW * 4) {   // workgroup-uniform trip count
+      const int col = col0 + cs;
+      const bool mine = act && col < SLAB / 4;
+      cdv_float4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      if (mine) {
+        const cdv_float4* src = reinterpret_cast<const cdv_float4*>(A.slabs) + col;
+        for (int s0 = g + 16 * w; s0 < nsl; s0 += 8 * 64) {   // 8 loads in flight: 512 slabs per memory round trip
+          cdv_float4 v[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            const int sidx = s0 + 64 * u;
+            v[u] = (sidx < nsl) ? src[(size_t)sidx * (SLAB / 4)] : cdv_float4{0.f, 0.f, 0.f, 0.f};
+          }
+#pragma unroll
+          for (int u = 0; u < 8; u++) acc[u & 1] += v[u];
+        }
+      }
+      cdv_float4 tot = acc[0] + acc[1];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {   // lane g = 0 of the row collects the 16 partials with DPP row shifts
+        float t = tot[j];
+        t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x101, 0xf, 0xf, true));   // row_shl:1
+        t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x102, 0xf, 0xf, true));   // row_shl:2
+        t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x104, 0xf, 0xf, true));   // row_shl:4
+        t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x108, 0xf, 0xf, true));   // row_shl:8
+        tot[j] = t;
+      }
+      if (act && g == 0) s_part[w][cs] = tot;
+      __syncthreads();
+      if (w == 0 && g == 0 && mine) {
+        const cdv_float4 t4 = ((s_part[0][cs] + s_part[1][cs]) + s_part[2][cs]) + s_part[3][cs];
+        // written through (8-byte agent-scope stores): the solver reads them past its L1
+        uint64_t* dst = reinterpret_cast<uint64_t*>(A.ared + 4 * col);
+        __hip_atomic_store(dst, ((uint64_t)(uint32_t)__float_as_int(t4[1]) << 32) | (uint32_t)__float_as_int(t4[0]),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(dst + 1, ((uint64_t)(uint32_t)__float_as_int(t4[3]) << 32) | (uint32_t)__float_as_int(t4[2]),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (col0 + RW * 4 < SLAB / 4) __syncthreads();   // another trip reuses s_part (workgroup-uniform)
+    }
+    if (tid < 64 && flag_it) {   // wave 0 holds every store of this workgroup: it drains, then raises the flag (no barrier needed)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (tid == 0) __hip_atomic_store(&A.arrive[16 + b], token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// (Measured and rejected: a second wave on another SIMD applying the published columns to columns [34, 60) until the
+// chain wave gets there -- half the rank-1 work per wave -- left the factorisation at 14.4k cycles: a lone wave issues a
+// v_pk_fma_f32 every 8 cycles and a ds_read_b128 every ~8, and the ~30 instructions of a column step, chain included,
+// are paid per column whoever does the bulk of the update.)
+// The 60 x 60 system in the registers of ONE wave.  Lane r holds row r of [S ; y^T] (lane 60 = the right-hand side).
+template <bool FUSED>
+__device__ __forceinline__ void solve_wave(const BaWinArgs& A, int RW) {
+  __shared__ __attribute__((aligned(16))) float colb[64];          // the column being broadcast
+  __shared__ __attribute__((aligned(16))) float Lt[(SN + 1) * 68]; // L for the back substitution (row stride 68)
+  const int lane = threadIdx.x;
+  const int n = 6 * A.N;
+  CDV_IF_STAMPS(const int sslot = 4000;)
+  CDV_STAMP(baw, sslot, 0);
+  CDV_STAMP_RT(baw, sslot, 14);
+  // ---- wait for the reduce workgroups: each stores the launch's token into its own flag word once its part of the
+  // reduced system is written through -- no shared counter (same-address atomics serialise, ~90 ns each).  Bounded: a
+  // lost hand-off must not hang the device. ----
+  const int token = A.token;
+  bool ok = false;
+  for (int spins = 0; spins < (1 << 20); spins++) {
+    const int f0 = lane < RW ? __hip_atomic_load(&A.arrive[16 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : token;
+    const int f1 = lane + 64 < RW ? __hip_atomic_load(&A.arrive[16 + 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : token;
+    if (__all(f0 == token && f1 == token)) { ok = true; break; }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  if (!ok) {
+    if (lane == 0) ba_flag(A.info, BI_HANDOFF, 1);
+    return;   // the retract workgroups time out on the dX granules and leave the state untouched
+  }
+  CDV_STAMP(baw, sslot, 1);
+  // ---- the reduced system: coalesced 8-byte write-through loads (every lane 15 of them, one memory round trip) into
+  // LDS, then my row from there.  The packed rows follow each other, so a row is read at full length: its tail (the
+  // head of the next rows) sits where the upper triangle would be, which lane r computes on but nobody ever reads (a
+  // pivot is lane k's own a[k][k], a broadcast value lane c's a[c][k], c > k) ----
+  {
+    uint64_t v[SLAB / 128 + 1];
+    const uint64_t* src = reinterpret_cast<const uint64_t*>(A.ared);
+#pragma unroll
+    for (int i = 0; i < SLAB / 128 + 1; i++)
+      v[i] = (64 * i + lane < SLAB / 2) ? __hip_atomic_load(src + 64 * i + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    uint64_t* dst = reinterpret_cast<uint64_t*>(Lt);   // (SN + 1) * 68 floats >= SLAB
+#pragma unroll
+    for (int i = 0; i < SLAB / 128 + 1; i++)
+      if (64 * i + lane < SLAB / 2) dst[64 * i + lane] = v[i];
+  }
+  wave_lds_sync();
+  const int row = min(lane, SN);
+  const float* rp = Lt + ((row < SN) ? tri_index(row, 0) : TRI);
+  cdv_float2 a2[SN / 2];     // the row as 30 float2 registers: rank-1 updates run two columns per v_pk_fma_f32
+#pragma unroll
+  for (int c = 0; c < SN; c++) {
+    float v = rp[c];
+    if (c == row) v += 1e-4f * v + 1.0f;             // S += I (1e-4 S + 1.0)  (ba_cuda.cu:589 semantics); rows >= 6 N: identity
+    a2[c >> 1][c & 1] = v;
+  }
+  wave_lds_sync();   // Lt is reused for L below
+  if (A.dbg && lane <= SN) {                          // damped S (both triangles) and y of iteration 0
+#pragma unroll
+    for (int c = 0; c < SN; c++) {
+      const float v = a2[c >> 1][c & 1];
+      if (lane < n && c <= lane) { A.dbg[(size_t)lane * n + c] = v; A.dbg[(size_t)c * n + lane] = v; }
+      if (lane == SN && c < n) A.dbg[(size_t)n * n + c] = v;
+    }
+  }
+  CDV_IF_STAMPS(asm volatile("v_nop" :: "v"(a2[29][1] + a2[0][0]));)
+  CDV_STAMP(baw, sslot, 2);
+  // ---- right-looking Cholesky, column k broadcast through LDS one column ahead of its rank-1 update ----
+  int badk = 0;
+  float Lk;
+  {
+    const float piv = readlane_f(a2[0][0], 0);
+    if (!(piv > 0.f)) badk = 1;
+    Lk = a2[0][0] * __builtin_amdgcn_rsqf(piv);
+    a2[0][0] = Lk;
+    colb[lane] = Lk;
+  }
+  cdv_float2 bcur[SN / 2], bnxt[SN / 2];   // column k / column k + 1 of L, the same in every lane (pairs of columns)
+#pragma unroll
+  for (int c4 = 0; c4 < SN / 4; c4++) {
+    const cdv_float4 v = *reinterpret_cast<const cdv_float4*>(&colb[4 * c4]);
+    bcur[2 * c4] = cdv_float2{v[0], v[1]};
+    bcur[2 * c4 + 1] = cdv_float2{v[2], v[3]};
+  }
+#pragma unroll
+  for (int k = 0; k < SN; k++) {
+    float Ln = 0.f;
+    if (k + 1 < SN) {
+      // column k + 1 first: its one update from column k, pivot, scale, broadcast request
+      // L[k+1][k] straight from lane k + 1 (the LDS copy of column k only feeds the rest of the update: the chain
+      // pivot -> scale -> next pivot never waits for an LDS round trip)
+      float an = fmaf(-Lk, readlane_f(Lk, k + 1), a2[(k + 1) >> 1][(k + 1) & 1]);
+      const float piv = readlane_f(an, k + 1);
+      if (!(piv > 0.f) && badk == 0) badk = (k + 1) / 6 + 1;        // wave-uniform
+      Ln = an * __builtin_amdgcn_rsqf(piv);
+      a2[(k + 1) >> 1][(k + 1) & 1] = Ln;
+      colb[lane] = Ln;      // in-order LDS: the reads of column k were issued before this write
+#pragma unroll
+      for (int c4 = (k + 2) / 4; c4 < SN / 4; c4++) {
+        const cdv_float4 v = *reinterpret_cast<const cdv_float4*>(&colb[4 * c4]);
+        bnxt[2 * c4] = cdv_float2{v[0], v[1]};
+        bnxt[2 * c4 + 1] = cdv_float2{v[2], v[3]};
+      }
+    }
+    // the rest of column k's rank-1 update (columns k + 2 ..) runs while column k + 1 travels through LDS
+    if (((k + 2) & 1) && k + 2 < SN)
+      a2[(k + 2) >> 1][1] = fmaf(-Lk, bcur[(k + 2) >> 1][1], a2[(k + 2) >> 1][1]);
+    const cdv_float2 nLk = {-Lk, -Lk};
+#pragma unroll
+    for (int pp = (k + 3) >> 1; pp < SN / 2; pp++) a2[pp] = __builtin_elementwise_fma(nLk, bcur[pp], a2[pp]);
+    Lk = Ln;
+#pragma unroll
+    for (int pp = (k + 2) >> 1; pp < SN / 2; pp++) bcur[pp] = bnxt[pp];
+  }
+  float a[SN];
+#pragma unroll
+  for (int c = 0; c < SN; c++) a[c] = a2[c >> 1][c & 1];
+  CDV_STAMP(baw, sslot, 3);
+  // ---- L back to LDS, then lane k picks up COLUMN k: col[r] = L[r][k].  Entries above the diagonal (r < k) are
+  // whatever the row held there: lane k folds them into its z only AFTER x_k has been taken from it ----
+  wave_lds_sync();
+  if (lane <= SN) {
+#pragma unroll
+    for (int c4 = 0; c4 < SN / 4; c4++)
+      *reinterpret_cast<cdv_float4*>(&Lt[lane * 68 + 4 * c4]) =
+          cdv_float4{a[4 * c4], a[4 * c4 + 1], a[4 * c4 + 2], a[4 * c4 + 3]};
+  }
+  wave_lds_sync();
+  const int kc = min(lane, SN - 1);
+  float col[SN];
+#pragma unroll
+  for (int r = 0; r < SN; r++) col[r] = Lt[r * 68 + kc];
+  float z = Lt[SN * 68 + kc];                       // z = L^-1 y
+  const float invd = 1.0f / Lt[kc * 68 + kc];
+  // back substitution L^T x = z: x_r = z_r / L[r][r] once every x_j, j > r, has been folded into z
+  float x = 0.f;
+#pragma unroll
+  for (int r = SN - 1; r >= 0; r--) {
+    const float xr = readlane_f(z * invd, r);
+    x = (lane == r) ? xr : x;
+    z = fmaf(-col[r], xr, z);
+  }
+  CDV_STAMP(baw, sslot, 4);
+  if (lane < n) {
+    // the data IS the flag: one 8-byte {tag = this launch's token, value} granule per unknown, written through; the retract workgroups
+    // poll the tags of the granules they read (CDNA programming guide, Guideline 16, recipe R2)
+    __hip_atomic_store(&A.granX[lane], ((uint64_t)(uint32_t)token << 32) | (uint64_t)(uint32_t)__float_as_int(x),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    A.dXg[lane] = x;
+    if (A.dbg) A.dbg[(size_t)n * n + n + lane] = x;
+  }
+  if (lane == 0 && badk) ba_flag(A.info, BI_CHOL, badk);
+  if (FUSED) {
+    // The poses of the free frames, retracted ONCE, here: published as granules FUS_POSE0 + 7 t + c for the chunk workgroups
+    // of this launch (the poses in place are not written during it: whoever reads them reads iteration 0's), and put
+    // aside in pose_next for the finish launch that follows.
+    wave_lds_sync();
+    colb[lane] = x;
+    wave_lds_sync();
+    if (lane < A.N) {
+      const float* p = A.poses + 7 * (size_t)(A.t0 + lane);
+      float pose[7], xi[6];
+#pragma unroll
+      for (int c = 0; c < 7; c++) pose[c] = p[c];
+#pragma unroll
+      for (int c = 0; c < 6; c++) xi[c] = colb[6 * lane + c];
+      se3_retract_raw(xi, pose);
+#pragma unroll
+      for (int c = 0; c < 7; c++) {
+        __hip_atomic_store(&A.granX[FUS_POSE0 + 7 * lane + c],
+                           ((uint64_t)(uint32_t)token << 32) | (uint64_t)(uint32_t)__float_as_int(pose[c]), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        A.pose_next[7 * lane + c] = pose[c];
+      }
+    }
+  }
+  CDV_STAMP(baw, sslot, 5);
+  CDV_STAMP_RT(baw, sslot, 15);
+}
+
+// dX and the retracted poses of the fused launch's solver -> sdx[64], spose[7 N], as the retract workgroups of the finish
+// launch take dX (bounded poll of the tagged granules: wave 0 the unknowns, waves 1 and 2 the pose components); false: no
+// solution arrived (status word raised) -- the caller goes on with dX = 0 and the poses as they stand
+__device__ __forceinline__ bool fused_wait(const BaWinArgs& A, float* sdx, float* spose, int* s_ok, int tid) {
+  // ONE wave polls (lane l: granules l, 64 + l, 128 + l), with long sleeps: 144 workgroups hammering the same lines would
+  // stand in the way of the solver's own loads and stores
+  if (tid < 64) {
+    const int n6 = 6 * A.N, n7 = 7 * A.N;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+    bool k0 = tid >= n6, k1 = tid >= n7, k2 = 64 + tid >= n7;
+    // the pose components are published last: wait for the lane's LAST needed granule first, the others are there then
+    for (int spins = 0; spins < (1 << 19); spins++) {
+      if (!k2) { const uint64_t g = __hip_atomic_load(&A.granX[FUS_POSE0 + 64 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                 if ((uint32_t)(g >> 32) == (uint32_t)A.token) { v2 = __int_as_float((int)(uint32_t)g); k2 = true; } }
+      if (!k1) { const uint64_t g = __hip_atomic_load(&A.granX[FUS_POSE0 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                 if ((uint32_t)(g >> 32) == (uint32_t)A.token) { v1 = __int_as_float((int)(uint32_t)g); k1 = true; } }
+      if (!k0) { const uint64_t g = __hip_atomic_load(&A.granX[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                 if ((uint32_t)(g >> 32) == (uint32_t)A.token) { v0 = __int_as_float((int)(uint32_t)g); k0 = true; } }
+      if (__all(k0 && k1 && k2)) break;
+      __builtin_amdgcn_s_sleep(8);
+    }
+    const bool all_ok = __all(k0 && k1 && k2);
+    if (!all_ok && tid == 0) ba_flag(A.info, BI_HANDOFF, 1);
+    if (tid == 0) *s_ok = all_ok ? 1 : 0;
+    sdx[tid] = all_ok ? v0 : 0.f;
+    if (tid < n7) spose[tid] = v1;
+    if (64 + tid < n7) spose[64 + tid] = v2;
+  }
+  __syncthreads();
+  return *s_ok != 0;
+}
+
+// FUSED: ONE launch = the solve of the previous iteration + this iteration's chunk systems.  Workgroup 0 is the solver
+// wave; workgroup 1 + c first does its share of the slab reduce of the previous iteration (the finish launch's reduce,
+// thread for thread), then requests everything chunk c needs -- records, the poses and depths as they stand, targets,
+// weights, and its own E columns / q / u of the previous iteration -- and only then waits for dX; it applies the
+// previous iteration's update to what it holds (its 16 depths, written back; the poses of its edges replaced by the ones
+// the solver retracted and published) and goes on as the plain chunk kernel does.  Saves a launch boundary, the
+// poll-and-retract tail of the finish launch and the load levels of the chunk kernel, which now fly under the solver.
+// Results are the plain sequence's up to the multiply-add contractions the compiler chooses in the two instantiations
+// (last-bit differences; tests/test_graph_table.py), and identical from run to run.
+template <bool HAS_II, bool TABLE, bool FUSED>
 __global__ __launch_bounds__(64 * CKW) void ba_chunk_kernel(BaWinArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Sc = smem;                           // [CKW][SLAB] per-wave packed copies of [S | y] (B and v parts)
@@ -75,14 +370,23 @@ __global__ __launch_bounds__(64 * CKW) void ba_chunk_kernel(BaWinArgs A) {
   const PatchSpan sp = patch_span<TABLE>(A);
   const int gerr = graph_error_of(gmeta, TABLE);
   const int U = sp.U;
-  if (blockIdx.x == 0) {
-    if (tid == 0) {
-      ba_begin_status(A.info, A.counters, A.first, gerr, U > A.U_max);
-      A.arrive[1] = A.arrive[1] + 1;              // token of the finish launch that follows: its arrival flags carry it
+  __shared__ __attribute__((aligned(16))) float f_sdx[64];
+  __shared__ float f_eold[FUSED ? SN * CK : 1], f_pd[FUSED ? CK : 1], f_pose[FUSED ? 7 * WIN_N : 1];
+  __shared__ int f_ok;
+  if (FUSED) {
+    if (blockIdx.x == 1 && tid == 0) ba_begin_status(A.info, A.counters, 0, gerr, U > A.U_max);
+    if (gerr || U > A.U_max) return;
+    const int RWf = min((int)gridDim.x - 1, (SLAB / 4 + 3) / 4);   // workgroups that own columns of the reduce
+    if (blockIdx.x == 0) {
+      if (tid < 64) solve_wave<true>(A, RWf);
+      return;
     }
-    if (tid < 64) A.granX[tid] = 0ull;
+    const int bq = (int)blockIdx.x - 1;
+    reduce_slabs(A, bq, RWf, U, tid, bq < RWf);
+  } else {
+    if (blockIdx.x == 0 && tid == 0) ba_begin_status(A.info, A.counters, A.first, gerr, U > A.U_max);
+    if (gerr || U > A.U_max) return;
   }
-  if (gerr || U > A.U_max) return;
   const int N = A.N, t0 = A.t0, P = A.P;
   const int n6 = 6 * N;
   const int PP = P * P;
@@ -103,10 +407,10 @@ __global__ __launch_bounds__(64 * CKW) void ba_chunk_kernel(BaWinArgs A) {
   }
   const int n_chunks = (U + CK - 1) / CK;
 
-  CDV_IF_STAMPS(const int sslot = (int)blockIdx.x * CKW + wave; unsigned long long t_fac = 0, t_ej = 0, t_xw = 0, t_rd = 0, t_mf = 0, t_em = 0, t_x;)
+  CDV_IF_STAMPS(const int sslot = ((int)blockIdx.x - (FUSED ? 1 : 0)) * CKW + wave; unsigned long long t_fac = 0, t_ej = 0, t_xw = 0, t_rd = 0, t_mf = 0, t_em = 0, t_x;)
   CDV_STAMP(baw, sslot, 0);
   CDV_STAMP_RT(baw, sslot, 14);
-  for (int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+  for (int chunk = (int)blockIdx.x - (FUSED ? 1 : 0); chunk < n_chunks; chunk += FUSED ? n_chunks : (int)gridDim.x) {
     const int r0 = chunk * CK;
     const int r = r0 + p;
     const bool live = r < U;
@@ -156,7 +460,49 @@ __global__ __launch_bounds__(64 * CKW) void ba_chunk_kernel(BaWinArgs A) {
     maxdeg = __builtin_amdgcn_readfirstlane(maxdeg);
     const int a0 = ix_patch - t0;
     const int ixf_patch = (deg > 0 && a0 >= 0 && a0 < N) ? a0 : -1;
+    // FUSED: this chunk's own rows of the PREVIOUS iteration (E columns, q, u) and the depth its update starts from
+    // (pixel [0][0], ba_cuda.cu:218 semantics): requested with level 2, used once dX is there
+    float eo0 = 0.f, eo1 = 0.f, qold = 0.f, uold = 0.f, d00 = 0.f;
+    if (FUSED) {
+      if (tid < n6 * CK) eo0 = A.Edg[(size_t)(tid / CK) * A.U_stride + r0 + (tid % CK)];
+      if (tid + 64 * CKW < n6 * CK) eo1 = A.Edg[(size_t)((tid + 64 * CKW) / CK) * A.U_stride + r0 + ((tid + 64 * CKW) % CK)];
+      if (tid < CK) { qold = A.qg[r0 + tid]; uold = A.ug[r0 + tid]; d00 = pk[2 * PP]; }
+    }
     lds_barrier();   // accumulators are zero (LDS only: the loads above stay in flight)
+    if (FUSED) {
+      if (tid < n6 * CK) f_eold[tid] = eo0;
+      if (tid + 64 * CKW < n6 * CK) f_eold[tid + 64 * CKW] = eo1;
+      const bool have = fused_wait(A, f_sdx, f_pose, &f_ok, tid);   // barriers inside: f_eold / f_sdx / f_pose complete behind it
+      if (tid < 4 * CK) {
+        // dZ = Q (u - E^T dX), depth update with the clamps of patch_retr (ba_cuda.cu:592,209-229 semantics): the finish
+        // launch's arithmetic, term for term -- its four interleaved partial sums are four lanes here (lane = 4 patch + j)
+        const int pt = tid >> 2, j = tid & 3;
+        float sj = 0.f;
+#pragma unroll
+        for (int c4 = 0; c4 < SN / 4; c4++)
+          sj = __builtin_fmaf((4 * c4 + j < n6) ? f_eold[(4 * c4 + j) * CK + pt] : 0.f, f_sdx[4 * c4 + j], sj);
+        const float s1 = __shfl_xor(sj, 1);
+        const float pair = (j & 1) ? s1 + sj : sj + s1;              // (sacc[0] + sacc[1]) resp. (sacc[2] + sacc[3]): a + b = b + a
+        const float other = __shfl_xor(pair, 2);
+        const float tot = (j & 2) ? other + pair : pair + other;
+        // patch pt's q, u, d00, degree and id sit in lane pt of wave 0
+        const float qo = __shfl(qold, pt), uo = __shfl(uold, pt), d0o = __shfl(d00, pt), pdo = __shfl(pd, pt);
+        const int dego = __shfl(deg, pt);
+        const int64_t ido = __shfl(kxr, pt);
+        const float dz = __fmul_rn(qo, uo - tot);   // (no contraction with the add below)
+        float d = __fadd_rn(d0o, dz);
+        d = (d > 20.f) ? 1.0f : d;
+        d = fmaxf(d, 1e-4f);
+        const bool upd = have && (r0 + pt) < U && dego > 0;
+        if (j == 0) f_pd[pt] = upd ? d : pdo;
+        if (upd) {
+          float* pw = A.patches + ido * 3 * PP + 2 * PP;
+          for (int a = j; a < PP; a += 4) pw[a] = d;
+        }
+      }
+      __syncthreads();
+    }
+    const float pdu = FUSED ? f_pd[p] : pd;
     CDV_STAMP(baw, sslot, 1);
 
     float Cacc = 0.f, uacc = 0.f;
@@ -169,7 +515,18 @@ __global__ __launch_bounds__(64 * CKW) void ba_chunk_kernel(BaWinArgs A) {
       if (more) raw_nxt = reinterpret_cast<const int4*>(A.prec)[(tb + step + so < deg) ? plo + tb + step + so : 0];
       CDV_IF_STAMPS(t_x = cdv_now();)
       EdgeFactor J;
-      fastba_factor(in.pi, in.pj, px, py, pd, in.tx, in.ty, in.wx, in.wy, fx, fy, cx, cy, J);
+      if (FUSED && f_ok) {   // the previous iteration's poses of the free frames: the solver's, from its granules
+        const int fa = cur.ix - t0, fb = cur.jx - t0;
+        if (fa >= 0 && fa < N) {
+#pragma unroll
+          for (int c = 0; c < 7; c++) in.pi[c] = f_pose[7 * fa + c];
+        }
+        if (fb >= 0 && fb < N) {
+#pragma unroll
+          for (int c = 0; c < 7; c++) in.pj[c] = f_pose[7 * fb + c];
+        }
+      }
+      fastba_factor(in.pi, in.pj, px, py, pdu, in.tx, in.ty, in.wx, in.wy, fx, fy, cx, cy, J);
       CDV_IF_STAMPS(asm volatile("v_nop" :: "v"(J.Ji[11] + J.Jz[1])); { const unsigned long long t_y = cdv_now(); t_fac += t_y - t_x; t_x = t_y; })
       if (more) {   // rare: this wave's next round (its record was requested above)
         rec = settle_rec<HAS_II>(A, raw_nxt, tb + step + so < deg, safe);
@@ -332,170 +689,6 @@ __global__ __launch_bounds__(64 * CKW) void ba_chunk_kernel(BaWinArgs A) {
   CDV_STAMP_RT(baw, sslot, 15);
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// finish: reduce -> solve -> retract
-// ---------------------------------------------------------------------------------------------------------
-
-typedef float cdv_float2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ float ld_agent(const float* p) {   // global_load_dword sc1: past this CU's L1
-  return __int_as_float((int)__hip_atomic_load(reinterpret_cast<const uint32_t*>(p), __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_AGENT));
-}
-
-// (Measured and rejected: a second wave on another SIMD applying the published columns to columns [34, 60) until the
-// chain wave gets there -- half the rank-1 work per wave -- left the factorisation at 14.4k cycles: a lone wave issues a
-// v_pk_fma_f32 every 8 cycles and a ds_read_b128 every ~8, and the ~30 instructions of a column step, chain included,
-// are paid per column whoever does the bulk of the update.)
-// The 60 x 60 system in the registers of ONE wave.  Lane r holds row r of [S ; y^T] (lane 60 = the right-hand side).
-__device__ __forceinline__ void solve_wave(const BaWinArgs& A, int RW) {
-  __shared__ __attribute__((aligned(16))) float colb[64];          // the column being broadcast
-  __shared__ __attribute__((aligned(16))) float Lt[(SN + 1) * 68]; // L for the back substitution (row stride 68)
-  const int lane = threadIdx.x;
-  const int n = 6 * A.N;
-  CDV_IF_STAMPS(const int sslot = 4000;)
-  CDV_STAMP(baw, sslot, 0);
-  CDV_STAMP_RT(baw, sslot, 14);
-  // ---- wait for the reduce workgroups: each stores the launch's token into its own flag word once its part of the
-  // reduced system is written through -- no shared counter (same-address atomics serialise, ~90 ns each).  Bounded: a
-  // lost hand-off must not hang the device. ----
-  const int token = A.arrive[1];
-  bool ok = false;
-  for (int spins = 0; spins < (1 << 20); spins++) {
-    const int f0 = lane < RW ? __hip_atomic_load(&A.arrive[16 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : token;
-    const int f1 = lane + 64 < RW ? __hip_atomic_load(&A.arrive[16 + 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : token;
-    if (__all(f0 == token && f1 == token)) { ok = true; break; }
-    __builtin_amdgcn_s_sleep(1);
-  }
-  if (!ok) {
-    if (lane == 0) ba_flag(A.info, BI_HANDOFF, 1);
-    return;   // the retract workgroups time out on the dX granules and leave the state untouched
-  }
-  CDV_STAMP(baw, sslot, 1);
-  // ---- the reduced system: coalesced 8-byte write-through loads (every lane 15 of them, one memory round trip) into
-  // LDS, then my row from there.  The packed rows follow each other, so a row is read at full length: its tail (the
-  // head of the next rows) sits where the upper triangle would be, which lane r computes on but nobody ever reads (a
-  // pivot is lane k's own a[k][k], a broadcast value lane c's a[c][k], c > k) ----
-  {
-    uint64_t v[SLAB / 128 + 1];
-    const uint64_t* src = reinterpret_cast<const uint64_t*>(A.ared);
-#pragma unroll
-    for (int i = 0; i < SLAB / 128 + 1; i++)
-      v[i] = (64 * i + lane < SLAB / 2) ? __hip_atomic_load(src + 64 * i + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-    uint64_t* dst = reinterpret_cast<uint64_t*>(Lt);   // (SN + 1) * 68 floats >= SLAB
-#pragma unroll
-    for (int i = 0; i < SLAB / 128 + 1; i++)
-      if (64 * i + lane < SLAB / 2) dst[64 * i + lane] = v[i];
-  }
-  wave_lds_sync();
-  const int row = min(lane, SN);
-  const float* rp = Lt + ((row < SN) ? tri_index(row, 0) : TRI);
-  cdv_float2 a2[SN / 2];     // the row as 30 float2 registers: rank-1 updates run two columns per v_pk_fma_f32
-#pragma unroll
-  for (int c = 0; c < SN; c++) {
-    float v = rp[c];
-    if (c == row) v += 1e-4f * v + 1.0f;             // S += I (1e-4 S + 1.0)  (ba_cuda.cu:589 semantics); rows >= 6 N: identity
-    a2[c >> 1][c & 1] = v;
-  }
-  wave_lds_sync();   // Lt is reused for L below
-  if (A.dbg && lane <= SN) {                          // damped S (both triangles) and y of iteration 0
-#pragma unroll
-    for (int c = 0; c < SN; c++) {
-      const float v = a2[c >> 1][c & 1];
-      if (lane < n && c <= lane) { A.dbg[(size_t)lane * n + c] = v; A.dbg[(size_t)c * n + lane] = v; }
-      if (lane == SN && c < n) A.dbg[(size_t)n * n + c] = v;
-    }
-  }
-  CDV_IF_STAMPS(asm volatile("v_nop" :: "v"(a2[29][1] + a2[0][0]));)
-  CDV_STAMP(baw, sslot, 2);
-  // ---- right-looking Cholesky, column k broadcast through LDS one column ahead of its rank-1 update ----
-  int badk = 0;
-  float Lk;
-  {
-    const float piv = readlane_f(a2[0][0], 0);
-    if (!(piv > 0.f)) badk = 1;
-    Lk = a2[0][0] * __builtin_amdgcn_rsqf(piv);
-    a2[0][0] = Lk;
-    colb[lane] = Lk;
-  }
-  cdv_float2 bcur[SN / 2], bnxt[SN / 2];   // column k / column k + 1 of L, the same in every lane (pairs of columns)
-#pragma unroll
-  for (int c4 = 0; c4 < SN / 4; c4++) {
-    const cdv_float4 v = *reinterpret_cast<const cdv_float4*>(&colb[4 * c4]);
-    bcur[2 * c4] = cdv_float2{v[0], v[1]};
-    bcur[2 * c4 + 1] = cdv_float2{v[2], v[3]};
-  }
-#pragma unroll
-  for (int k = 0; k < SN; k++) {
-    float Ln = 0.f;
-    if (k + 1 < SN) {
-      // column k + 1 first: its one update from column k, pivot, scale, broadcast request
-      // L[k+1][k] straight from lane k + 1 (the LDS copy of column k only feeds the rest of the update: the chain
-      // pivot -> scale -> next pivot never waits for an LDS round trip)
-      float an = fmaf(-Lk, readlane_f(Lk, k + 1), a2[(k + 1) >> 1][(k + 1) & 1]);
-      const float piv = readlane_f(an, k + 1);
-      if (!(piv > 0.f) && badk == 0) badk = (k + 1) / 6 + 1;        // wave-uniform
-      Ln = an * __builtin_amdgcn_rsqf(piv);
-      a2[(k + 1) >> 1][(k + 1) & 1] = Ln;
-      colb[lane] = Ln;      // in-order LDS: the reads of column k were issued before this write
-#pragma unroll
-      for (int c4 = (k + 2) / 4; c4 < SN / 4; c4++) {
-        const cdv_float4 v = *reinterpret_cast<const cdv_float4*>(&colb[4 * c4]);
-        bnxt[2 * c4] = cdv_float2{v[0], v[1]};
-        bnxt[2 * c4 + 1] = cdv_float2{v[2], v[3]};
-      }
-    }
-    // the rest of column k's rank-1 update (columns k + 2 ..) runs while column k + 1 travels through LDS
-    if (((k + 2) & 1) && k + 2 < SN)
-      a2[(k + 2) >> 1][1] = fmaf(-Lk, bcur[(k + 2) >> 1][1], a2[(k + 2) >> 1][1]);
-    const cdv_float2 nLk = {-Lk, -Lk};
-#pragma unroll
-    for (int pp = (k + 3) >> 1; pp < SN / 2; pp++) a2[pp] = __builtin_elementwise_fma(nLk, bcur[pp], a2[pp]);
-    Lk = Ln;
-#pragma unroll
-    for (int pp = (k + 2) >> 1; pp < SN / 2; pp++) bcur[pp] = bnxt[pp];
-  }
-  float a[SN];
-#pragma unroll
-  for (int c = 0; c < SN; c++) a[c] = a2[c >> 1][c & 1];
-  CDV_STAMP(baw, sslot, 3);
-  // ---- L back to LDS, then lane k picks up COLUMN k: col[r] = L[r][k].  Entries above the diagonal (r < k) are
-  // whatever the row held there: lane k folds them into its z only AFTER x_k has been taken from it ----
-  wave_lds_sync();
-  if (lane <= SN) {
-#pragma unroll
-    for (int c4 = 0; c4 < SN / 4; c4++)
-      *reinterpret_cast<cdv_float4*>(&Lt[lane * 68 + 4 * c4]) =
-          cdv_float4{a[4 * c4], a[4 * c4 + 1], a[4 * c4 + 2], a[4 * c4 + 3]};
-  }
-  wave_lds_sync();
-  const int kc = min(lane, SN - 1);
-  float col[SN];
-#pragma unroll
-  for (int r = 0; r < SN; r++) col[r] = Lt[r * 68 + kc];
-  float z = Lt[SN * 68 + kc];                       // z = L^-1 y
-  const float invd = 1.0f / Lt[kc * 68 + kc];
-  // back substitution L^T x = z: x_r = z_r / L[r][r] once every x_j, j > r, has been folded into z
-  float x = 0.f;
-#pragma unroll
-  for (int r = SN - 1; r >= 0; r--) {
-    const float xr = readlane_f(z * invd, r);
-    x = (lane == r) ? xr : x;
-    z = fmaf(-col[r], xr, z);
-  }
-  CDV_STAMP(baw, sslot, 4);
-  if (lane < n) {
-    // the data IS the flag: one 8-byte {tag = 1, value} granule per unknown, written through; the retract workgroups
-    // poll the tags of the granules they read (CDNA programming guide, Guideline 16, recipe R2)
-    __hip_atomic_store(&A.granX[lane], (1ull << 32) | (uint64_t)(uint32_t)__float_as_int(x), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-    A.dXg[lane] = x;
-    if (A.dbg) A.dbg[(size_t)n * n + n + lane] = x;
-  }
-  if (lane == 0 && badk) ba_flag(A.info, BI_CHOL, badk);
-  CDV_STAMP(baw, sslot, 5);
-  CDV_STAMP_RT(baw, sslot, 15);
-}
 
 template <bool TABLE>
 __global__ __launch_bounds__(256) void ba_finish_kernel(BaWinArgs A) {
@@ -506,68 +699,14 @@ __global__ __launch_bounds__(256) void ba_finish_kernel(BaWinArgs A) {
   const int RW = (int)gridDim.x - 1;
   const int tid = threadIdx.x;
   if (blockIdx.x == 0) {
-    if (tid < 64) solve_wave(A, RW);
+    if (tid < 64) solve_wave<false>(A, RW);
     return;
   }
   const int b = (int)blockIdx.x - 1;
   CDV_IF_STAMPS(const int sslot = 4100 + b * 4 + (tid >> 6);)
   CDV_STAMP(baw, sslot, 0);
   CDV_STAMP_RT(baw, sslot, 14);
-  // ---- 1. reduce the chunk slabs.  A CU streams ~10 B per cycle, so the 1.5 MB of slabs want many CUs: a workgroup takes
-  //         FOUR 16-byte columns, thread = (column, one of 64 interleaved slab subsets: 16 in the lanes of a DPP row x the 4
-  //         waves).  Per-thread sums in slab order, the row's 16 partials by DPP row shifts, the four waves' partials in
-  //         LDS: a fixed tree that depends on nothing but the number of slabs -- reproducible bits whatever the launch
-  //         geometry. ----
-  {
-    const int nsl = (U + CK - 1) / CK;
-    const int g = tid & 15, cs = (tid >> 4) & 3, w = tid >> 6;
-    __shared__ cdv_float4 s_part[4][4];
-    const int token = A.arrive[1];
-    for (int col0 = b * 4; col0 < SLAB / 4; col0 += RW * 4) {   // workgroup-uniform trip count
-      const int col = col0 + cs;
-      const bool mine = col < SLAB / 4;
-      cdv_float4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-      if (mine) {
-        const cdv_float4* src = reinterpret_cast<const cdv_float4*>(A.slabs) + col;
-        for (int s0 = g + 16 * w; s0 < nsl; s0 += 8 * 64) {   // 8 loads in flight: 512 slabs per memory round trip
-          cdv_float4 v[8];
-#pragma unroll
-          for (int u = 0; u < 8; u++) {
-            const int sidx = s0 + 64 * u;
-            v[u] = (sidx < nsl) ? src[(size_t)sidx * (SLAB / 4)] : cdv_float4{0.f, 0.f, 0.f, 0.f};
-          }
-#pragma unroll
-          for (int u = 0; u < 8; u++) acc[u & 1] += v[u];
-        }
-      }
-      cdv_float4 tot = acc[0] + acc[1];
-#pragma unroll
-      for (int j = 0; j < 4; j++) {   // lane g = 0 of the row collects the 16 partials with DPP row shifts
-        float t = tot[j];
-        t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x101, 0xf, 0xf, true));   // row_shl:1
-        t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x102, 0xf, 0xf, true));   // row_shl:2
-        t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x104, 0xf, 0xf, true));   // row_shl:4
-        t += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x108, 0xf, 0xf, true));   // row_shl:8
-        tot[j] = t;
-      }
-      if (g == 0) s_part[w][cs] = tot;
-      __syncthreads();
-      if (w == 0 && g == 0 && mine) {
-        const cdv_float4 t4 = ((s_part[0][cs] + s_part[1][cs]) + s_part[2][cs]) + s_part[3][cs];
-        // written through (8-byte agent-scope stores): the solver reads them past its L1
-        uint64_t* dst = reinterpret_cast<uint64_t*>(A.ared + 4 * col);
-        __hip_atomic_store(dst, ((uint64_t)(uint32_t)__float_as_int(t4[1]) << 32) | (uint32_t)__float_as_int(t4[0]),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(dst + 1, ((uint64_t)(uint32_t)__float_as_int(t4[3]) << 32) | (uint32_t)__float_as_int(t4[2]),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      if (col0 + RW * 4 < SLAB / 4) __syncthreads();   // another trip reuses s_part (workgroup-uniform)
-    }
-    if (w == 0) {   // wave 0 holds every store of this workgroup: it drains, then raises the flag (no barrier needed)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (tid == 0) __hip_atomic_store(&A.arrive[16 + b], token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
+  reduce_slabs(A, b, RW, U, tid, true);
   // only the first RT workgroups go on to the retraction (256 patches each per pass); the others were here for the reduce
   const int RT = min(RW, max(1, (U + 255) / 256));
   if (b >= RT) return;
@@ -599,7 +738,7 @@ __global__ __launch_bounds__(256) void ba_finish_kernel(BaWinArgs A) {
     for (int spins = 0; spins < (1 << 21); spins++) {
       if (!ok) {
         const uint64_t g = __hip_atomic_load(&A.granX[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((uint32_t)(g >> 32) == 1u) { xv = __int_as_float((int)(uint32_t)g); ok = true; }
+        if ((uint32_t)(g >> 32) == (uint32_t)A.token) { xv = __int_as_float((int)(uint32_t)g); ok = true; }
       }
       if (__all(ok)) break;
       __builtin_amdgcn_s_sleep(2);
@@ -615,9 +754,10 @@ __global__ __launch_bounds__(256) void ba_finish_kernel(BaWinArgs A) {
   // ---- 4. pose retraction T <- Exp(dX_i) T: the first retract workgroup's first N lanes ----
   if (b == 0 && tid < N) {
     float* p = A.poses + 7 * (size_t)(A.t0 + tid);
+    const float* ps = A.pose_src ? A.pose_src + 7 * tid : p;   // after a fused launch: the poses its solver put aside
     float pose[7], xi[6];
 #pragma unroll
-    for (int c = 0; c < 7; c++) pose[c] = p[c];
+    for (int c = 0; c < 7; c++) pose[c] = ps[c];
 #pragma unroll
     for (int c = 0; c < 6; c++) xi[c] = sdx[6 * tid + c];
     se3_retract_raw(xi, pose);
@@ -632,11 +772,11 @@ __global__ __launch_bounds__(256) void ba_finish_kernel(BaWinArgs A) {
       for (int c4 = 0; c4 < SN / 4; c4++) {
         const cdv_float4 x4 = *reinterpret_cast<const cdv_float4*>(&sdx[4 * c4]);
 #pragma unroll
-        for (int j = 0; j < 4; j++) sacc[j] += ev[4 * c4 + j] * x4[j];
+        for (int j = 0; j < 4; j++) sacc[j] = __builtin_fmaf(ev[4 * c4 + j], x4[j], sacc[j]);
       }
-      const float dz = qv * (uv - ((sacc[0] + sacc[1]) + (sacc[2] + sacc[3])));
+      const float dz = __fmul_rn(qv, uv - ((sacc[0] + sacc[1]) + (sacc[2] + sacc[3])));   // the fused launch's arithmetic, term for term
       if (A.dbg) A.dbg[(size_t)36 * N * N + 12 * N + r] = dz;
-      float d = d0 + dz;
+      float d = __fadd_rn(d0, dz);
       d = (d > 20.f) ? 1.0f : d;
       d = fmaxf(d, 1e-4f);
       for (int a = 0; a < PP; a++) pk[a] = d;
@@ -659,32 +799,75 @@ __global__ __launch_bounds__(256) void ba_finish_kernel(BaWinArgs A) {
 
 }  // namespace
 
-int cdv::cdv_ba_window_iteration(const BaWinArgs& a, hipStream_t s) {
+namespace {
+
+hipError_t win_attrs() {
   static hipError_t attr_err = [] {
     hipError_t e = hipSuccess, x;
     const int lds = (int)(sizeof(float) * LDS_CHUNK_FLOATS);
-    if ((x = hipFuncSetAttribute((const void*)ba_chunk_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess) e = x;
-    if ((x = hipFuncSetAttribute((const void*)ba_chunk_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess) e = x;
-    if ((x = hipFuncSetAttribute((const void*)ba_chunk_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess) e = x;
-    if ((x = hipFuncSetAttribute((const void*)ba_chunk_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess) e = x;
+#define CDV_ATTR(...) if ((x = hipFuncSetAttribute((const void*)ba_chunk_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess) e = x;
+    CDV_ATTR(true, false, false) CDV_ATTR(false, false, false) CDV_ATTR(true, true, false) CDV_ATTR(false, true, false)
+    CDV_ATTR(true, false, true) CDV_ATTR(false, false, true) CDV_ATTR(true, true, true) CDV_ATTR(false, true, true)
+#undef CDV_ATTR
     return e;
   }();
-  CDV_HIP_CHECK(attr_err);
-  const int n_ck = a.n_ck_cap < WIN_MAX_GRID ? a.n_ck_cap : WIN_MAX_GRID;
+  return attr_err;
+}
+
+template <bool FUSED>
+void launch_chunk_win(const BaWinArgs& a, int grid, hipStream_t s) {
   const bool table = a.tab_cap > 0;
   const size_t lds = sizeof(float) * LDS_CHUNK_FLOATS;
-  if (a.has_ii && table) hipLaunchKernelGGL((ba_chunk_kernel<true, true>), dim3(n_ck), dim3(64 * CKW), lds, s, a);
-  else if (a.has_ii) hipLaunchKernelGGL((ba_chunk_kernel<true, false>), dim3(n_ck), dim3(64 * CKW), lds, s, a);
-  else if (table) hipLaunchKernelGGL((ba_chunk_kernel<false, true>), dim3(n_ck), dim3(64 * CKW), lds, s, a);
-  else hipLaunchKernelGGL((ba_chunk_kernel<false, false>), dim3(n_ck), dim3(64 * CKW), lds, s, a);
+  if (a.has_ii && table) hipLaunchKernelGGL((ba_chunk_kernel<true, true, FUSED>), dim3(grid), dim3(64 * CKW), lds, s, a);
+  else if (a.has_ii) hipLaunchKernelGGL((ba_chunk_kernel<true, false, FUSED>), dim3(grid), dim3(64 * CKW), lds, s, a);
+  else if (table) hipLaunchKernelGGL((ba_chunk_kernel<false, true, FUSED>), dim3(grid), dim3(64 * CKW), lds, s, a);
+  else hipLaunchKernelGGL((ba_chunk_kernel<false, false, FUSED>), dim3(grid), dim3(64 * CKW), lds, s, a);
+}
+
+void launch_finish_win(const BaWinArgs& a, hipStream_t s) {
   // reduce workgroups: one per four 16-byte columns of a slab (119), at least one per 256 patches of capacity for the
   // retraction the first of them go on to, at most WIN_MAX_RW (their arrival flags)
   int RW = cdv_div_up(WIN_SLAB / 4, 4);
   const int rw_p = cdv_div_up(a.U_max, 256);
   RW = RW < rw_p ? rw_p : RW;
   RW = RW > WIN_MAX_RW ? WIN_MAX_RW : RW;
-  if (table) hipLaunchKernelGGL(ba_finish_kernel<true>, dim3(1 + RW), dim3(256), 0, s, a);
+  if (a.tab_cap > 0) hipLaunchKernelGGL(ba_finish_kernel<true>, dim3(1 + RW), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(ba_finish_kernel<false>, dim3(1 + RW), dim3(256), 0, s, a);
+}
+
+}  // namespace
+
+// one Gauss-Newton iteration as two launches: chunk systems, then reduce + solve + retract
+int cdv::cdv_ba_window_iteration(const BaWinArgs& a, hipStream_t s) {
+  CDV_HIP_CHECK(win_attrs());
+  const int n_ck = a.n_ck_cap < WIN_MAX_GRID ? a.n_ck_cap : WIN_MAX_GRID;
+  launch_chunk_win<false>(a, n_ck, s);
+  launch_finish_win(a, s);
+  CDV_LAUNCH_CHECK();
+  return CDV_OK;
+}
+
+// the fused launch sits between a chunk launch and a finish launch: can this workspace / call take it?
+// (every workgroup of the fused launch must be resident at once -- the chunk workgroups wait for the solver, the solver for
+// the reduce shares of the first 119 of them: one 512-thread workgroup per CU, so at most 240 of them on the 256 CUs)
+bool cdv::cdv_ba_window_can_fuse(const BaWinArgs& a) {
+  return a.n_ck_cap + 1 <= 240 && a.n_ck_cap >= 1 && a.dbg == nullptr;
+}
+
+// TWO Gauss-Newton iterations (what every caller of fastba.BA asks for, slam.py:514) as three launches:
+//   chunk systems of iteration 1 | solve of iteration 1 + chunk systems of iteration 2 | reduce + solve + retract of 2
+// `a.token` .. `a.token + 1` are consumed.
+int cdv::cdv_ba_window_two_iterations(const BaWinArgs& a0, hipStream_t s) {
+  CDV_HIP_CHECK(win_attrs());
+  BaWinArgs a = a0;
+  const int n_ck = a.n_ck_cap;
+  a.first = 1; a.pose_src = nullptr;
+  launch_chunk_win<false>(a, n_ck, s);
+  a.first = 0;
+  launch_chunk_win<true>(a, n_ck + 1, s);          // workgroup 0: the solver of iteration 1
+  a.token = a0.token + 1;
+  a.pose_src = a.pose_next;                        // iteration 1's poses of the free frames, put aside by that solver
+  launch_finish_win(a, s);
   CDV_LAUNCH_CHECK();
   return CDV_OK;
 }

@@ -39,7 +39,7 @@ __host__ __device__ inline int solve_ld(int n) { return (n + 27) / 32 * 32 + 4; 
 enum { BI_CHOL = 0, BI_OVERFLOW = 1, BI_HANDOFF = 2, BI_GRAPH = 3 };
 
 struct BaLayout {
-  size_t sy, C, u, Ed, cmask, zero_bytes, q, dX, info, Abig, slabs, ared, hand, total;
+  size_t sy, C, u, Ed, cmask, zero_bytes, q, dX, info, Abig, slabs, ared, hand, pnext, total;
   int64_t npad;                         // global-BA path: 6 N rounded up to the Cholesky block (0: not used)
   int64_t U_max, U_stride, sy_stride;   // sy_stride: floats between two copies of [S | y]
   int64_t n_ck;                         // window path: chunk slabs
@@ -69,7 +69,7 @@ inline BaLayout ba_layout(int64_t U_max, int N_max) {
     o = align256(o + sizeof(float) * (size_t)(L.npad + 1) * (size_t)L.npad);
   }
   // window path: one partial system per chunk of 16 patches, the reduced system, the arrival counter
-  L.n_ck = 0; L.slabs = o; L.ared = o; L.hand = o;
+  L.n_ck = 0; L.slabs = o; L.ared = o; L.hand = o; L.pnext = o;
   if (N_max >= 1 && N_max <= MID_N) {
     const size_t slab = N_max <= WIN_N ? (size_t)WIN_SLAB : (size_t)mid_slab(N_max);
     L.n_ck = (U_max + WIN_CK - 1) / WIN_CK;
@@ -78,6 +78,7 @@ inline BaLayout ba_layout(int64_t U_max, int N_max) {
     const size_t ared = N_max <= WIN_N ? slab : (size_t)(6 * N_max + 1) * (size_t)solve_ld(6 * N_max);
     L.ared = o;  o = align256(o + sizeof(float) * ared);
     L.hand = o;  o = align256(o + sizeof(int32_t) * HAND_WORDS);
+    L.pnext = o; o = align256(o + sizeof(float) * 7 * WIN_N);
   }
   L.total = o;
   return L;
@@ -106,12 +107,18 @@ struct BaWinArgs {
   int32_t* info;
   int32_t* counters;                 // optional host-visible event counters (cdv_ba_bind_status_counters), may be NULL
   float* dbg;                        // iteration-0 dump (see cdv_ba_forward), may be NULL
+  int token;                         // tag of this launch's in-launch hand-offs (arrival flags, dX granules): never 0, new per launch
+  float* pose_next;                  // [WIN_N][7]: where a fused launch's solver puts the retracted poses of the free frames
+  const float* pose_src;             // finish launch: read the free frames' poses from here (after a fused launch), NULL: in place
   int first;                         // first iteration of a call: clears the sticky status words
   int has_ii;                        // the graph's records carry the source frames (it was built with ii)
 };
 
 // one Gauss-Newton iteration of the window path: two launches on `s`
 int cdv_ba_window_iteration(const BaWinArgs& a, hipStream_t s);
+// two iterations as three launches (the middle one fuses the first solve with the second chunk pass); uses two tokens
+bool cdv_ba_window_can_fuse(const BaWinArgs& a);
+int cdv_ba_window_two_iterations(const BaWinArgs& a, hipStream_t s);
 // the same for 10 < N <= MID_N (ba_mid.hip)
 int cdv_ba_mid_iteration(const BaWinArgs& a, hipStream_t s);
 

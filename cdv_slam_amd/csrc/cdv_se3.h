@@ -318,6 +318,7 @@ __device__ __forceinline__ void se3_row_times_adj_raw(const float* t, const floa
 
 // pose retraction T <- Exp(xi) T, xi = (tau, phi), in place on a stored pose (ba_cuda.cu:178-206 semantics)
 __device__ __forceinline__ void se3_retract_raw(const float* xi, float* P) {
+  CDV_NOCONTRACT   // the same bits wherever it is inlined: the fused BA launch retracts per lane what the finish launch stores
   const float* tau = xi;
   const float* phi = xi + 3;
   const float th2 = phi[0] * phi[0] + phi[1] * phi[1] + phi[2] * phi[2];
