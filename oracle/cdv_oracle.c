@@ -15,13 +15,16 @@
  *   fastba neighbors                        cdvslam/fastba/ba.cpp:59-97
  *   torch::_unique(sorted, inverse)         ATen (pytorch 2.3.1, not in the reference tree):
  *                                           sorted unique values + inverse index
- *   EfficentE bookkeeping                   cdvslam/fastba/block_e.cu:38-144
+ *   (the block-sparse E storage of cdvslam/fastba/block_e.cu is NOT restated: the oracle keeps the
+ *    dense E, which yields the same S, y, dX, dZ)
  *
  * PARITY STATUS: the reference ships no golden vectors or tests for altcorr / fastba /
  * projective_ops, and its CUDA/Eigen sources cannot be built in this image (no nvcc, Eigen
  * 3.4.0 not vendored).  => "parity unpinned" for corr, fastba, neighbors; the Lie ops are pinned
  * by the reference's own property tests (lietorch/run_tests.py:16-52) and pops.transform / ba.py
  * by executing the reference's Python files under a shimmed import (tests/golden/make_golden.py).
+ * Since round 3 the fastba restatement is additionally anchored on a RUN of the reference's ba.py at
+ * benchmark size (tests/golden/ba_py_pr1.npz: one fastba iteration == one ba.py call at ep = 1.0).
  */
 
 #include <math.h>
