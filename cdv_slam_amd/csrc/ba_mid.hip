@@ -175,6 +175,7 @@ __global__ __launch_bounds__(64 * MKW) void ba_mid_chunk_kernel(BaWinArgs A) {
 #pragma unroll
       for (int o = 8; o > 0; o >>= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, o));
       maxdeg = __builtin_amdgcn_readfirstlane(maxdeg);
+      CDV_STAMP(bam, sslot, 12);
       const int a0 = ix_patch - t0;
       const int ixf_patch = (deg > 0 && a0 >= 0 && a0 < N) ? a0 : -1;
       // ---- the free source frames of the chunk's edges: every edge's, so that an edge list which gives one patch two
@@ -194,6 +195,7 @@ __global__ __launch_bounds__(64 * MKW) void ba_mid_chunk_kernel(BaWinArgs A) {
         }
         if (mbits) atomicOr(&smask[par], mbits);
       }
+      CDV_STAMP(bam, sslot, 13);
       lds_barrier();   // accumulators are zero, the mask is complete (LDS only: the loads above stay in flight)
       const uint32_t mask = smask[par];
       if (pass == 0) npass = max(1, (__popc(mask) + 1) >> 1);
@@ -301,6 +303,7 @@ __global__ __launch_bounds__(64 * MKW) void ba_mid_chunk_kernel(BaWinArgs A) {
         if (wave == 0 && sub == 0) ixp[p] = ixf_patch;
       }
       lds_barrier();
+      CDV_STAMP(bam, sslot, 9);
       // the wave copies of the footprint summed in fixed order into copy 0 (each thread its own 16-byte columns)
       {
         cdv_float4* s4 = reinterpret_cast<cdv_float4*>(Fw);
@@ -332,7 +335,9 @@ __global__ __launch_bounds__(64 * MKW) void ba_mid_chunk_kernel(BaWinArgs A) {
           part[6 * CK + pp] = Ct;      // (wave 0's slot, consumed above) kept for the stores at the end of the pass
         }
       }
+      CDV_STAMP(bam, sslot, 10);
       lds_barrier();
+      CDV_STAMP(bam, sslot, 11);
       // ---- fold the source-frame parts onto the diagonal blocks of copy 0: F_jj[i_s] += F_ii[s], and a self pair
       // (i_s -> i_s) contributes B_ij + B_ij^T to its diagonal block ----
       if (tid < 54) {
@@ -366,30 +371,63 @@ __global__ __launch_bounds__(64 * MKW) void ba_mid_chunk_kernel(BaWinArgs A) {
       if (tid < slabf - (TRI_N + n6)) Sd[TRI_N + n6 + tid] = 0.f;
       const int T16 = ER / 16, ntile = T16 * (T16 + 1) / 2;
       const float* Fij0 = Fw + 54 + 27 * N;
-      for (int pidx = wave; pidx < ntile; pidx += MKW) {
-        int ti = (int)((sqrtf(8.0f * (float)pidx + 1.0f) - 1.0f) * 0.5f);   // lower-triangular tile pair (ti >= tj)
-        if (((ti + 1) * (ti + 2)) >> 1 <= pidx) ti++;
-        if ((ti * (ti + 1)) >> 1 > pidx) ti--;
-        const int tj = pidx - ((ti * (ti + 1)) >> 1);
-        cdv_float4 acc = {0.f, 0.f, 0.f, 0.f};
+      // three tiles of a wave in flight together (operand reads, the four dependent MFMA steps and the scattered writes of
+      // one tile are ~1,500 cycles of latency when taken alone; 45 tiles at N = 22 are six per wave)
+      constexpr int TU = 3;
+      float qk[4];
+#pragma unroll
+      for (int st = 0; st < 4; st++) qk[st] = qs[4 * st + g4];
+      for (int p0 = wave; p0 < ntile; p0 += TU * MKW) {
+        int ti[TU], tj[TU];
+        bool on[TU];   // wave-uniform
+#pragma unroll
+        for (int u = 0; u < TU; u++) {
+          const int pidx = p0 + u * MKW;
+          on[u] = pidx < ntile;
+          const int pc = on[u] ? pidx : p0;
+          int t = (int)((sqrtf(8.0f * (float)pc + 1.0f) - 1.0f) * 0.5f);   // lower-triangular tile pair (ti >= tj)
+          if (((t + 1) * (t + 2)) >> 1 <= pc) t++;
+          if ((t * (t + 1)) >> 1 > pc) t--;
+          ti[u] = t;
+          tj[u] = pc - ((t * (t + 1)) >> 1);
+        }
+        cdv_float4 acc[TU];
+#pragma unroll
+        for (int u = 0; u < TU; u++) acc[u] = cdv_float4{0.f, 0.f, 0.f, 0.f};
         if (pass == 0) {
-          const float* pa = Ed + (16 * ti + c16) * EDL;
-          const float* pb = Ed + (16 * tj + c16) * EDL;
+          float av[TU][4], bv[TU][4];
+#pragma unroll
+          for (int u = 0; u < TU; u++) {
+            const float* pa = Ed + (16 * ti[u] + c16) * EDL;
+            const float* pb = Ed + (16 * tj[u] + c16) * EDL;
+#pragma unroll
+            for (int st = 0; st < 4; st++) {
+              av[u][st] = pa[4 * st + g4];
+              bv[u][st] = pb[4 * st + g4];
+            }
+          }
 #pragma unroll
           for (int st = 0; st < 4; st++) {
-            const int k = 4 * st + g4;
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[k], qs[k] * pb[k], acc, 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < TU; u++)
+              acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][st], qk[st] * bv[u][st], acc[u], 0, 0, 0);
           }
         }
-        const int Cc = 16 * tj + c16;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const int R = 16 * ti + 4 * g4 + q;
-          if (R > n6 || Cc >= n6 || (R < n6 && Cc > R)) continue;   // row 6N = y; column 6N only duplicates it
-          Sd[(R < n6) ? tri_index(R, Cc) : TRI_N + Cc] = -acc[q];
+        for (int u = 0; u < TU; u++) {
+          if (!on[u]) continue;
+          const int Cc = 16 * tj[u] + c16;
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const int R = 16 * ti[u] + 4 * g4 + q;
+            if (R > n6 || Cc >= n6 || (R < n6 && Cc > R)) continue;   // row 6N = y; column 6N only duplicates it
+            Sd[(R < n6) ? tri_index(R, Cc) : TRI_N + Cc] = -acc[u][q];
+          }
         }
       }
+      CDV_STAMP(bam, sslot, 7);
       lds_barrier();   // LDS only: the E stores above drain in the background
+      CDV_STAMP(bam, sslot, 8);
       // ---- the B part: every entry of the folded footprint onto its slab entry.  Each slab entry has at most one addend
       // (the diagonal blocks and v from F_jj; block (i_s, j) from F_ij[s][j], self pairs and the transposed pair of the
       // two source frames having been folded away above): plain read-modify-write, one owner each.  A tile-side lookup
@@ -628,6 +666,35 @@ __device__ __forceinline__ void mid_solve(const BaWinArgs& A, float* smem) {
             if (j < wb) *reinterpret_cast<cdv_float4*>(rp + j) = cdv_float4{o[j], o[j + 1], o[j + 2], o[j + 3]};
         }
       }
+    } else if (wv == FT / 64 - 1 && kb > 0) {
+      // ---- the last wave (never a panel wave: 6N + 1 <= 5 PROWS) has nothing to do during a panel: it inverts the
+      // PREVIOUS diagonal block, final since that step's barrier.  W = L_bb^-1, lane j = column j by forward substitution
+      // on e_j with the block's rows as uniform (broadcast) LDS reads; W^T goes into the block's strictly upper triangle,
+      // which nobody reads (W's diagonal is the inverted diagonal already stored).  The back substitution below then
+      // solves a block by a 24 x 24 product instead of a chain of 24 dependent steps. ----
+      const int cb = NB * (kb - 1);
+      float w[NB];
+#pragma unroll
+      for (int k = 0; k < NB; k++) {
+        const float* lr = &Am[(cb + k) * LD + cb];
+        float s0 = (k == lane) ? 1.0f : 0.f, s1 = 0.f;
+#pragma unroll
+        for (int m = 0; m < k; m++) {
+          if (m & 1) s1 = fmaf(-lr[m], w[m], s1);
+          else s0 = fmaf(-lr[m], w[m], s0);
+        }
+        w[k] = (s0 + s1) * lr[k];
+      }
+      if (lane < NB) {
+        float* rp = &Am[(cb + lane) * LD + cb];
+#pragma unroll
+        for (int jq = 0; jq < NB; jq += 4) {
+          cdv_float4 v = *reinterpret_cast<const cdv_float4*>(rp + jq);
+#pragma unroll
+          for (int h = 0; h < 4; h++) v[h] = (jq + h > lane) ? w[jq + h] : v[h];
+          *reinterpret_cast<cdv_float4*>(rp + jq) = v;
+        }
+      }
     }
     CDV_IF_STAMPS(if (wv == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t_ps += cdv_now() - t_x; })
     __syncthreads();
@@ -637,36 +704,55 @@ __device__ __forceinline__ void mid_solve(const BaWinArgs& A, float* smem) {
       const int c16 = lane & 15, g4 = lane >> 4;
       const int T16 = (nrows + 15) >> 4;
       const int ntile = T16 * (T16 + 1) / 2;
-      for (int pidx = wv; pidx < ntile; pidx += FT / 64) {
-        const int tt = __builtin_amdgcn_readfirstlane(ttab[pidx]);
-        const int ti = tt >> 8, tj = tt & 255;
-        const int ra = 16 * ti + c16, rb = 16 * tj + c16;
-        const float* pa = &Am[(R0 + min(ra, nrows - 1)) * LD + c0];
-        const float* pb = &Am[(R0 + min(rb, nrows - 1)) * LD + c0];
-        // the k index of an MFMA step is ours to choose (the same for both operands): lane group g4 takes columns
-        // 6 g4 .. 6 g4 + 5 of the panel, so each operand is three 8-byte reads; k >= wb is padding
-        float av[NB / 4], bv[NB / 4];
+      // (two tiles of a wave in flight together, as in the chunk kernel's tile loop, measured here: 22.9k against 19.4k
+      // cycles over the six steps -- the read-modify-writes of two tiles queue behind each other in the LDS pipe)
+      constexpr int TU = 1;
+      for (int p0 = wv; p0 < ntile; p0 += TU * (FT / 64)) {
+        int ti[TU], tj[TU];
+        bool on[TU];   // wave-uniform
+        float av[TU][NB / 4], bv[TU][NB / 4];
+#pragma unroll
+        for (int u = 0; u < TU; u++) {
+          const int pidx = p0 + u * (FT / 64);
+          on[u] = pidx < ntile;
+          const int tt = __builtin_amdgcn_readfirstlane(ttab[on[u] ? pidx : p0]);
+          ti[u] = tt >> 8; tj[u] = tt & 255;
+          const int ra = 16 * ti[u] + c16, rb = 16 * tj[u] + c16;
+          const float* pa = &Am[(R0 + min(ra, nrows - 1)) * LD + c0];
+          const float* pb = &Am[(R0 + min(rb, nrows - 1)) * LD + c0];
+          // the k index of an MFMA step is ours to choose (the same for both operands): lane group g4 takes columns
+          // 6 g4 .. 6 g4 + 5 of the panel, so each operand is three 8-byte reads; k >= wb is padding
+#pragma unroll
+          for (int st = 0; st < NB / 4; st += 2) {
+            const int k = (NB / 4) * g4 + st;
+            const float2 a2 = *reinterpret_cast<const float2*>(pa + min(k, wb - 2));
+            const float2 b2 = *reinterpret_cast<const float2*>(pb + min(k, wb - 2));
+            av[u][st] = (ra < nrows && k < wb) ? a2.x : 0.f; av[u][st + 1] = (ra < nrows && k + 1 < wb) ? a2.y : 0.f;
+            bv[u][st] = (rb < nrows && k < wb) ? b2.x : 0.f; bv[u][st + 1] = (rb < nrows && k + 1 < wb) ? b2.y : 0.f;
+          }
+        }
+        cdv_float4 acc0[TU], acc1[TU];
+#pragma unroll
+        for (int u = 0; u < TU; u++) { acc0[u] = cdv_float4{0.f, 0.f, 0.f, 0.f}; acc1[u] = cdv_float4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
         for (int st = 0; st < NB / 4; st += 2) {
-          const int k = (NB / 4) * g4 + st;
-          const float2 a2 = *reinterpret_cast<const float2*>(pa + min(k, wb - 2));
-          const float2 b2 = *reinterpret_cast<const float2*>(pb + min(k, wb - 2));
-          av[st] = (ra < nrows && k < wb) ? a2.x : 0.f; av[st + 1] = (ra < nrows && k + 1 < wb) ? a2.y : 0.f;
-          bv[st] = (rb < nrows && k < wb) ? b2.x : 0.f; bv[st + 1] = (rb < nrows && k + 1 < wb) ? b2.y : 0.f;
-        }
-        cdv_float4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int st = 0; st < NB / 4; st += 2) {
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[st], bv[st], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[st + 1], bv[st + 1], acc1, 0, 0, 0);
+          for (int u = 0; u < TU; u++) {
+            acc0[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][st], bv[u][st], acc0[u], 0, 0, 0);
+            acc1[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][st + 1], bv[u][st + 1], acc1[u], 0, 0, 0);
+          }
         }
-        const cdv_float4 acc = acc0 + acc1;
-        // D: row = 16 ti + 4 g4 + q, col = 16 tj + c16
-        const int cc = 16 * tj + c16;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const int rr = 16 * ti + 4 * g4 + q;
-          if (rr < nrows && cc < n - R0 && cc <= rr) Am[(R0 + rr) * LD + R0 + cc] -= acc[q];   // (ds_add_f32 here: 2.5 x slower)
+        for (int u = 0; u < TU; u++) {
+          if (!on[u]) continue;
+          const cdv_float4 acc = acc0[u] + acc1[u];
+          // D: row = 16 ti + 4 g4 + q, col = 16 tj + c16
+          const int cc = 16 * tj[u] + c16;
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const int rr = 16 * ti[u] + 4 * g4 + q;
+            if (rr < nrows && cc < n - R0 && cc <= rr) Am[(R0 + rr) * LD + R0 + cc] -= acc[q];   // (ds_add_f32 here: 2.5 x slower)
+          }
         }
       }
     }
@@ -680,15 +766,19 @@ __device__ __forceinline__ void mid_solve(const BaWinArgs& A, float* smem) {
   CDV_STAMP_VAL(bam, sslot, 11, t_pc);
   CDV_STAMP_VAL(bam, sslot, 12, t_ps);
   // ---- row n of A now holds z = L^-1 y.  Back substitution L^T x = z inside ONE wave, no barrier: lane l keeps
-  // components l, 64 + l, 128 + l of z in three registers; from the last unknown down, x_k = z_k / L[k][k] is broadcast by
-  // v_readlane and row k of L (contiguous in LDS, requested a step ahead: it does not depend on the chain) folds it into
-  // the components before it.  (Block by block with the other waves' help: two barriers per block, 6,000 cycles each.) ----
+  // components l, 64 + l, 128 + l of z in three registers.  The LAST block (6 .. 24 wide, not inverted) goes unknown by
+  // unknown: x_k = z_k / L[k][k] is broadcast by v_readlane and row k of L (contiguous in LDS, requested a step ahead: it
+  // does not depend on the chain) folds it into the components before it.  Every block before it, last to first, is
+  // x_b = W_b^T z_b -- lane c sums its own row of the block (W^T) against the block's z as broadcast reads, four partial
+  // sums -- followed by z -= L[b][:]^T x_b with x from v_readlane: ~1,200 cycles per block of 24 against 3,400 for the
+  // chain.  (Block by block with the other waves' help: two barriers per block, 6,000 cycles each.) ----
   float* z = Am + (size_t)n * LD;
   if (wv == 0) {
     float zr[3], xr[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int q = 0; q < 3; q++) zr[q] = (64 * q + lane < n) ? z[64 * q + lane] : 0.f;
-    // two unknowns per step (n and the group sizes are even): the chain fma -> v_readlane (~40 cycles to a dependent
+    const int cl = NB * (nblk - 1);   // first unknown of the last block
+    // two unknowns per step (n and the block sizes are even): the chain fma -> v_readlane (~40 cycles to a dependent
     // vector instruction) -> three scalar-operand instructions is paid once per pair
     float La[3], Lb[3], Na[3], Nb[3];   // rows k, k - 1 in use; the next pair's, requested a step ahead
 #pragma unroll
@@ -698,7 +788,7 @@ __device__ __forceinline__ void mid_solve(const BaWinArgs& A, float* smem) {
     }
 #pragma unroll
     for (int r = 2; r >= 0; r--) {
-      for (int k = min(n, 64 * (r + 1)) - 1; k >= 64 * r; k -= 2) {
+      for (int k = min(n, 64 * (r + 1)) - 1; k >= max(64 * r, cl); k -= 2) {
 #pragma unroll
         for (int q = 0; q < 3; q++) { La[q] = Na[q]; Lb[q] = Nb[q]; }
         const int ka = max(k - 2, 0), kb2 = max(k - 3, 0);
@@ -721,7 +811,40 @@ __device__ __forceinline__ void mid_solve(const BaWinArgs& A, float* smem) {
     }
 #pragma unroll
     for (int q = 0; q < 3; q++)
-      if (64 * q + lane < n) z[64 * q + lane] = xr[q];
+      if (64 * q + lane >= cl && 64 * q + lane < n) z[64 * q + lane] = xr[q];
+    for (int kb = nblk - 2; kb >= 0; kb--) {
+      const int c0 = NB * kb;
+      // the block's z out of the registers (components past the block are dead: they hold garbage since their solve)
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        const int comp = 64 * q + lane;
+        if (comp >= c0 && comp < c0 + NB) z[comp] = zr[q];
+      }
+      const int c = min(lane, NB - 1);
+      const float* wr = &Am[(size_t)(c0 + c) * LD + c0];   // row c of the block: L left of the diagonal, W^T from it on
+      const float* zb = z + c0;
+      float ps[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int jq = 0; jq < NB; jq += 4) {
+        const cdv_float4 w4 = *reinterpret_cast<const cdv_float4*>(wr + jq);
+        const cdv_float4 z4 = *reinterpret_cast<const cdv_float4*>(zb + jq);
+#pragma unroll
+        for (int h = 0; h < 4; h++) ps[h] = fmaf((jq + h >= c) ? w4[h] : 0.f, z4[h], ps[h]);
+      }
+      const float xv = (ps[0] + ps[1]) + (ps[2] + ps[3]);
+      if (lane < NB) z[c0 + lane] = xv;   // x over the block's z, which nobody needs any more
+      // z of the earlier components -= L[block rows][:]^T x  (components >= c0 receive garbage: dead)
+      float acc[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+      for (int r = 0; r < NB; r++) {
+        const float xs = readlane_f(xv, r);
+        const float* lrow = &Am[(size_t)(c0 + r) * LD];
+#pragma unroll
+        for (int q = 0; q < 3; q++) acc[q][r & 1] = fmaf(lrow[min(64 * q + lane, LD - 1)], xs, acc[q][r & 1]);
+      }
+#pragma unroll
+      for (int q = 0; q < 3; q++) zr[q] -= acc[q][0] + acc[q][1];
+    }
   }
   __syncthreads();
   CDV_STAMP(bam, sslot, 4);
