@@ -5,18 +5,10 @@
 // Dispatch on the number of free poses N:
 //   1 <= N <= 10    ba_win.hip   two launches per iteration, no float atomics, bitwise reproducible
 //   10 < N <= 32    ba_mid.hip   three launches per iteration, the same properties
-//   N > 32 (<=1024) this file    dense E in HBM; per iteration:
-//     1. ba_assemble_kernel: workgroup = (chunk of 64 unique patches, group of target slots) through the patch CSR.  A wave
-//        owns ONE "target slot" t: lane = patch, edge = t-th edge of that patch in (jj, edge id) order.  Patches of one
-//        source frame share their target list, so the 64 edges of a wave belong to (almost always) ONE frame pair (i, j):
-//          - B blocks and v: the 13x13 Gram matrix of the wave's 128 residual rows [Ji | Jj | r], weighted by w, is ONE
-//            16x16 f32 MFMA tile with K = 128; one atomic per entry per wave adds it into one of four copies of [S | y];
-//          - E, C, u: lanes are consecutive unique patches, so every atomic wave-instruction is one contiguous 256-byte
-//            row segment of E (the shape the memory-side atomic units run at full rate).
-//     2. ba_big_schur_kernel: panel-sparse Schur products on the matrix cores; 3. fold + blocked multi-workgroup Cholesky +
-//        back substitution; 4. ba_retract_kernel: dZ = Q (u - E^T dX), depth and pose update (ba_cuda.cu:178-229, 592).
-//     (Float atomics: results agree with the oracle to the stated tolerances, not bit for bit between runs.)
-//   N = 0           assemble + ba_schur_kernel (q only) + retract: depths alone.
+//   N > 32 (<=1024) this file    dense E in HBM; per iteration: patch owners (E, C, u), frame-pair owners (B, v), pose owners
+//                                (diagonal blocks), tile owners (Schur products on the matrix cores), blocked multi-workgroup
+//                                Cholesky, retract -- one owner and a fixed order for every sum here too (see below)
+//   N = 0           ba_patch_kernel + q + retract: depths alone.
 #include <stdlib.h>
 
 #include <mutex>
@@ -31,16 +23,8 @@ CDV_STAMP_TU(ba)
 
 namespace {
 
-constexpr int BIG_PB = 32;        // poses per panel of the panel-sparse Schur products (192 rows; <= 32 panels: one mask word)
-constexpr int BIG_PR = 6 * BIG_PB;
 constexpr int XLD = 17;           // floats per residual row in the Gram staging buffer (16 + 1 pad)
-constexpr int PAIR_LDS_FLOATS = 128 * XLD + 64;  // per wave: [128][XLD] rows + 64 per-edge pair keys
-constexpr int ELD = BA_CHUNK + 4; // row stride of the chunk's E block in LDS (2-way bank conflicts at most)
-constexpr int ASM_WAVES = 1;      // waves per assemble workgroup, one target slot each (the waves are independent;
-                                  // single-wave workgroups spread the atomics of the busy chunks over all CUs)
-constexpr int ASM_SG = 32;        // slot groups (workgroups) per chunk of 64 patches: 32 slots per pass (48, one pass for every patch of the
-                                  // steady-state graph, measured: no change)
-constexpr int ASM_THREADS = 64 * ASM_WAVES;
+constexpr int ELD = BA_CHUNK + 4; // row stride of a chunk's E panel in LDS (2-way bank conflicts at most)
 
 struct WsState {
   bool valid;
@@ -97,108 +81,120 @@ __device__ __forceinline__ void ba_edge(const EdgeIn& in, float fx, float fy, fl
   fastba_factor(in.pi, in.pj, in.px, in.py, in.pd, in.tx, in.ty, in.wx, in.wy, fx, fy, cx, cy, o);
 }
 
-// one entry (row, col) of the 13x13 Gram matrix G = sum_k w_k X[k] X[k]^T, X[k] = [Ji | Jj | r]
-__device__ __forceinline__ void pair_emit(float val, int row, int col, int ixf, int jxf, int n6,
-                                          float* __restrict__ S, float* __restrict__ y) {
-  if (row >= 12 || col >= 13 || val == 0.0f) return;  // row 12 duplicates column 12; (12,12) = sum w r^2
-  const bool ri = row < 6;                             // row block: i (Ji) or j (Jj)
-  const int rb = ri ? ixf : jxf;
-  if (rb < 0) return;
-  const int r = 6 * rb + (ri ? row : row - 6);
-  // column 12: v[i] -= w r Ji ; v[j] += w r Jj  (ba_cuda.cu:393-398); y follows S in memory, so one atomic
-  // instruction serves both.  Other columns: B[ii] += w Ji Ji^T, B[jj] += w Jj Jj^T, B[ij] -= w Ji Jj^T,
-  // B[ji] -= (w Ji Jj^T)^T   (ba_cuda.cu:364-377)
-  const bool isv = col == 12;
-  const bool ci = col < 6;
-  const int cb = isv ? 0 : (ci ? ixf : jxf);
-  if (cb < 0) return;
-  const int c = 6 * cb + (ci ? col : col - 6);
-  const bool neg = isv ? ri : (ri != ci);
-  float* dst = isv ? &y[r] : &S[r * n6 + c];
-  atomicAdd(dst, neg ? -val : val);
-}
+// =========================================================================================================
+// Systems with more than 32 free poses (the global bundle adjustment; slam.py:460-478 calls fastba.BA(..., eff_impl=True)
+// over the active and the inactive edges), and the structure-only call (no free pose).  The reference switches to a
+// block-sparse E (block_e.cu) because a dense [6N x U] E does not fit its GPUs' budget; the numbers it computes -- S = B - E Q E^T,
+// y = v - E Q u, dX, dZ -- are those of the dense path (ba_cuda.cu:567-580 vs :583-592).  On a 288 GB part the dense E stays in
+// HBM.  EVERY sum below has ONE owner and a fixed order -- no float atomic, results identical from run to run:
+//   ba_patch_kernel   E, C, u: a wave owns 64 unique patches (lane = patch) and walks each patch's edge list in its order;
+//   ba_pair_kernel    B, v: a wave owns a FRAME PAIR {a, b} and walks its edges in edge order (the pair index: an ordinary
+//                     patch-graph index built once per call over the key (a, b)); the 13 x 13 Gram matrix of the pair's
+//                     residual rows [Ja | Jb | r] is one 16 x 16 f32 MFMA tile accumulated over the edges; the off-diagonal
+//                     block goes straight into S, the two diagonal parts into the pair's slots of a scratch array;
+//   ba_diag_kernel    a wave owns a free pose: its diagonal block and v = the pair partials in pair order;
+//   ba_schur_kernel   a workgroup owns a 48 x 48 tile of S (two panels of 8 poses) and walks the chunks of 64 patches in
+//                     which both panels have a non-zero E block (mask words written by ba_patch_kernel), K = 64 per chunk
+//                     on the matrix cores; the panel pairs nobody sees together cost one look at the mask words;
+//   then fold (damping, padding), the blocked multi-workgroup Cholesky with the right-hand side as an extra row, back
+//   substitution, and ba_retract_kernel: dZ = Q (u - E^T dX), depth and pose update (ba_cuda.cu:178-229, 592).
+// =========================================================================================================
 
-struct AsmArgs {
+struct PatchArgs {
   const float *poses, *patches, *intr, *target, *weight;
-  const int64_t *ii, *jj, *kk;
+  const int64_t* ii;
   int P, t0, N;
-  const int32_t *gmeta, *pcsr, *koff_u;
-  float* sy;
-  int sy_stride;
+  const int32_t *gmeta, *prec, *koff_u;
+  const int64_t* kx;
   float *Cg, *ug, *Edg;
   int U_stride, U_max;
   int32_t* info;
-  uint32_t* cmask;
+  uint32_t* cmask;     // [chunks][BIG_MW] panel bits, or NULL (no free pose)
   int32_t* counters;   // optional host-visible event counters of the workspace (may be NULL)
   int first;           // first iteration of a call
 };
 
-__device__ __forceinline__ void assemble_body(const AsmArgs& A, int bid, float* smem) {
-  const float* __restrict__ poses = A.poses;
-  const float* __restrict__ patches = A.patches;
-  const float* __restrict__ intr = A.intr;
-  const float* __restrict__ target = A.target;
-  const float* __restrict__ weight = A.weight;
-  const int64_t* __restrict__ ii = A.ii;
-  const int64_t* __restrict__ jj = A.jj;
-  const int64_t* __restrict__ kk = A.kk;
-  const int P = A.P, t0 = A.t0, N = A.N;
+struct RecIn {
+  int e, ix, jx;
+  float pi[7], pj[7], tx, ty, wx, wy;
+};
+
+// record p of a CSR ({edge, ii, jj, 0}: one 16-byte load) and what the edge needs of the state
+__device__ __forceinline__ int4 rec_load(const int32_t* __restrict__ prec, int p) {
+  return *reinterpret_cast<const int4*>(prec + 4 * (size_t)p);
+}
+__device__ __forceinline__ RecIn rec_inputs(const int4 rec, const int64_t* __restrict__ ii, const float* __restrict__ poses,
+                                            const float* __restrict__ target, const float* __restrict__ weight) {
+  RecIn o;
+  o.e = rec.x;
+  o.ix = rec.y >= 0 ? rec.y : (int)ii[rec.x];   // an index built without source frames: one more dependent load
+  o.jx = rec.z;
+#pragma unroll
+  for (int a = 0; a < 7; a++) { o.pi[a] = poses[7 * (int64_t)o.ix + a]; o.pj[a] = poses[7 * (int64_t)o.jx + a]; }
+  const float2 t = *reinterpret_cast<const float2*>(target + 2 * (int64_t)o.e);
+  const float2 w = *reinterpret_cast<const float2*>(weight + 2 * (int64_t)o.e);
+  o.tx = t.x; o.ty = t.y; o.wx = w.x; o.wy = w.y;
+  return o;
+}
+
+// six entries of one pose's rows of E for patch r: stored, or added onto what is there (see ba_patch_kernel)
+__device__ __forceinline__ void e_rows_out(float* __restrict__ Edg, int U_stride, int r, int b, const float (&v)[6], bool add) {
+#pragma unroll
+  for (int c = 0; c < 6; c++) {
+    float* p = &Edg[(size_t)(6 * b + c) * U_stride + r];
+    *p = add ? *p + v[c] : v[c];
+  }
+}
+
+// E, C, u (ba_cuda.cu:380-390, 401-402 semantics).  One wave per chunk of 64 unique patches, lane = patch, the patch's
+// edges one after the other in the order of its list -- (target frame, edge id), so the edges to one target frame are
+// neighbours.  A lane sums in registers: C, u, the six E entries of the patch's source frame, and the six of the target
+// frame in hand, which leave as plain stores when the target changes (E is kept zero between iterations by the retract
+// kernel: a first write needs no read).  An edge from the patch's frame to itself folds into the source-frame sum.  A patch
+// whose edges name more than one source frame (slam.py builds none) switches its lane to read-modify-writes: correct
+// whatever the list, one lane, program order.  Lanes are consecutive unique patches: every store instruction of the wave
+// writes contiguous 256-byte row segments of E.  Loads run one edge ahead (records two ahead).
+__global__ __launch_bounds__(64) void ba_patch_kernel(PatchArgs A) {
   const int32_t* __restrict__ gmeta = A.gmeta;
-  const int32_t* __restrict__ pcsr = A.pcsr;
-  const int32_t* __restrict__ koff_u = A.koff_u;
-  float* __restrict__ sy = A.sy;
-  const int sy_stride = A.sy_stride;
-  float* __restrict__ Cg = A.Cg;
-  float* __restrict__ ug = A.ug;
-  float* __restrict__ Edg = A.Edg;
-  const int U_stride = A.U_stride, U_max = A.U_max;
-  int32_t* __restrict__ info = A.info;
-  uint32_t* __restrict__ cmask = A.cmask;
   const int gerr = gmeta[GM_ERROR];
   const int U = gmeta[GM_U];
-  if (threadIdx.x == 0 && bid == 0) ba_begin_status(info, A.counters, A.first, gerr, U > U_max);
-  if (gerr || U > U_max) return;   // no index / workspace too small: BA is skipped, the status words say so
-  // workgroup = (chunk of 64 unique patches, slot group): wave w takes target slot t = 8 sg + w (+ 32 per pass)
-  const int chunk = bid / ASM_SG, sg = bid - chunk * ASM_SG;
-  const int r0 = chunk * BA_CHUNK;
+  if (threadIdx.x == 0 && blockIdx.x == 0) ba_begin_status(A.info, A.counters, A.first, gerr, U > A.U_max);
+  if (gerr || U > A.U_max) return;   // no index / workspace too small: BA is skipped, the status words say so
+  const int chunk = (int)blockIdx.x, r0 = chunk * BA_CHUNK;
   if (r0 >= U) return;
-  const int n6 = 6 * N;
-  const int PP = P * P;
-  const int centre = (P > 1) ? (P + 1) : 0;
-  const float fx = intr[0], fy = intr[1], cx = intr[2], cy = intr[3];  // ba_cuda.cu:253-259
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float* S = sy + (size_t)(bid % BA_REPL) * sy_stride;
-  float* y = S + (size_t)n6 * n6;
-  CDV_IF_STAMPS(const int sslot = bid * ASM_WAVES + wave;)
-  CDV_STAMP(ba, sslot, 0);
-  CDV_STAMP_RT(ba, sslot, 8);
-  float* X = smem + (size_t)wave * PAIR_LDS_FLOATS;    // per wave [128][XLD]
-  int* keys = reinterpret_cast<int*>(X + 128 * XLD);   // per wave [64]
-
+  const int lane = threadIdx.x;
+  const int N = A.N, t0 = A.t0, PP = A.P * A.P;
+  const int centre = (A.P > 1) ? (A.P + 1) : 0;
+  const float fx = A.intr[0], fy = A.intr[1], cx = A.intr[2], cy = A.intr[3];  // ba_cuda.cu:253-259
   const int r = r0 + lane;
-  const int plo = (r < U) ? koff_u[r] : 0;
-  const int deg = (r < U) ? koff_u[r + 1] - plo : 0;
+  const bool live = r < U;
+  const int plo = live ? A.koff_u[r] : 0;
+  const int deg = live ? A.koff_u[r + 1] - plo : 0;
   int maxdeg = deg;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, o));
   maxdeg = __builtin_amdgcn_readfirstlane(maxdeg);
-  const int c16 = lane & 15, g4 = lane >> 4;
   const int pdef = (deg > 0) ? plo : 0;
+  const float* pk = A.patches + (live ? A.kx[r] : 0) * 3 * PP;
+  const float px = pk[centre], py = pk[PP + centre], pd = pk[2 * PP + centre];
   float Cacc = 0.f, uacc = 0.f;
-  for (int t = sg * ASM_WAVES + wave; t < maxdeg; t += ASM_SG * ASM_WAVES) {
+  float eacc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, jacc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int icur = -1, jcur = -1;   // free-pose numbers of the rows being summed (-1: none)
+  int ifirst = -2;            // source frame of the patch's first edge (-2: no edge yet)
+  bool multi = false;         // this patch's edges name more than one source frame
+  uint32_t pm[BIG_MW] = {0u, 0u, 0u, 0u};
+  int4 rec1 = rec_load(A.prec, (1 < deg) ? plo + 1 : pdef);
+  RecIn in0 = rec_inputs(rec_load(A.prec, pdef), A.ii, A.poses, A.target, A.weight);
+  for (int t = 0; t < maxdeg; t++) {
     const bool active = t < deg;
-    const EdgeIdx idx = load_idx(pcsr, ii, jj, kk, active ? plo + t : pdef);
-    const EdgeIn in = load_in(poses, patches, target, weight, idx, PP, centre);
+    const int4 rec2 = rec_load(A.prec, (t + 2 < deg) ? plo + t + 2 : pdef);
+    const RecIn in1 = rec_inputs(rec1, A.ii, A.poses, A.target, A.weight);
     EdgeJ J;
-    ba_edge(in, fx, fy, cx, cy, J);
-    int ixf = -1, jxf = -1;
+    fastba_factor(in0.pi, in0.pj, px, py, pd, in0.tx, in0.ty, in0.wx, in0.wy, fx, fy, cx, cy, J);
     if (active) {
-      const int a = idx.ix - t0, b = idx.jx - t0;
-      ixf = (a >= 0 && a < N) ? a : -1;
-      jxf = (b >= 0 && b < N) ? b : -1;
-
-      // E, C, u of this lane's patch (ba_cuda.cu:380-390, 401-402).  Lanes are consecutive unique patches, so
-      // every atomic wave-instruction below is one contiguous 256-byte row segment of E.
+      const int a = in0.ix - t0, b = in0.jx - t0;
+      const int ixf = (a >= 0 && a < N) ? a : -1;
+      const int jxf = (b >= 0 && b < N) ? b : -1;
       float ei[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ej[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int row = 0; row < 2; row++) {
@@ -209,33 +205,144 @@ __device__ __forceinline__ void assemble_body(const AsmArgs& A, int bid, float* 
 #pragma unroll
         for (int c = 0; c < 6; c++) { ei[c] -= wz * J.Ji[6 * row + c]; ej[c] += wz * J.Jj[6 * row + c]; }
       }
+      if (ifirst == -2) ifirst = ixf;
+      else if (ixf != ifirst) multi = true;
       if (ixf >= 0) {
+        if (ixf != icur) {   // (only a patch with several source frames gets here with a sum in hand)
+          if (icur >= 0) e_rows_out(A.Edg, A.U_stride, r, icur, eacc, true);
+          icur = ixf;
 #pragma unroll
-        for (int c = 0; c < 6; c++) atomicAdd(&Edg[(size_t)(6 * ixf + c) * U_stride + r], ei[c]);
+          for (int c = 0; c < 6; c++) eacc[c] = 0.f;
+        }
+#pragma unroll
+        for (int c = 0; c < 6; c++) eacc[c] += ei[c];
       }
       if (jxf >= 0) {
+        if (jxf == icur) {
 #pragma unroll
-        for (int c = 0; c < 6; c++) atomicAdd(&Edg[(size_t)(6 * jxf + c) * U_stride + r], ej[c]);
+          for (int c = 0; c < 6; c++) eacc[c] += ej[c];
+        } else {
+          if (jxf != jcur) {
+            if (jcur >= 0) e_rows_out(A.Edg, A.U_stride, r, jcur, jacc, multi);
+            jcur = jxf;
+#pragma unroll
+            for (int c = 0; c < 6; c++) jacc[c] = 0.f;
+          }
+#pragma unroll
+          for (int c = 0; c < 6; c++) jacc[c] += ej[c];
+        }
+      }
+#pragma unroll
+      for (int wd = 0; wd < BIG_MW; wd++) {   // panel = pose / 8, word = panel / 32
+        if (ixf >= 0 && (ixf >> 8) == wd) pm[wd] |= 1u << ((ixf >> 3) & 31);
+        if (jxf >= 0 && (jxf >> 8) == wd) pm[wd] |= 1u << ((jxf >> 3) & 31);
       }
     }
-    if (cmask) {   // global-BA path: which 32-pose panels have a non-zero E block in this chunk (wave-uniform branch)
-      unsigned pm = (ixf >= 0 ? 1u << (ixf >> 5) : 0u) | (jxf >= 0 ? 1u << (jxf >> 5) : 0u);
+    in0 = in1;
+    rec1 = rec2;
+  }
+  if (jcur >= 0) e_rows_out(A.Edg, A.U_stride, r, jcur, jacc, multi);
+  if (icur >= 0) e_rows_out(A.Edg, A.U_stride, r, icur, eacc, multi);
+  if (live) {
+    A.Cg[r] = Cacc;
+    A.ug[r] = uacc;
+  }
+  if (A.cmask) {   // which 8-pose panels have a non-zero E block in this chunk
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) pm |= __shfl_xor(pm, o);
-      if (pm && lane == 0) atomicOr(&cmask[chunk], pm);
+    for (int wd = 0; wd < BIG_MW; wd++) {
+      uint32_t m = pm[wd];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) m |= __shfl_xor(m, o);
+      if (lane == 0) A.cmask[(size_t)chunk * BIG_MW + wd] = m;
     }
-    CDV_STAMP(ba, sslot, 3);
-    if (N > 0) {
-      // ---- B and v of this wave's frame pair(s): Gram matrix on the matrix cores --------------------
-      const int key = (ixf + 1) * (N + 1) + (jxf + 1);
-      keys[lane] = active ? key : 0;
+  }
+}
+
+// q = 1 / (C + lambda) of every patch (ba_cuda.cu:548): the structure-only call, whose retract kernel reads it
+__global__ __launch_bounds__(256) void ba_q_kernel(const float* __restrict__ lmbda, const int32_t* __restrict__ gmeta,
+                                                   const float* __restrict__ Cg, float* __restrict__ qg,
+                                                   const int32_t* __restrict__ info) {
+  if (gmeta[GM_ERROR] || info[1]) return;
+  const int U = gmeta[GM_U];
+  const float lm = lmbda[0];
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < U; r += gridDim.x * blockDim.x) qg[r] = 1.0f / (Cg[r] + lm);
+}
+
+// ---- the frame-pair index ------------------------------------------------------------------------------------------
+// key of an edge: its two poses as free-pose numbers + 1 (0: a fixed pose), smaller first
+__global__ __launch_bounds__(256) void ba_pair_key_kernel(const int64_t* __restrict__ ii, const int64_t* __restrict__ jj,
+                                                          int32_t E, int t0, int N, int64_t* __restrict__ keys) {
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) {
+    const int a = (int)ii[e] - t0, b = (int)jj[e] - t0;
+    const int ra = (a >= 0 && a < N) ? a + 1 : 0, rb = (b >= 0 && b < N) ? b + 1 : 0;
+    keys[e] = (int64_t)min(ra, rb) * (N + 1) + max(ra, rb);
+  }
+}
+
+// (a, b) -> pair number + 1 (the table was zeroed: 0 = no such pair)
+__global__ __launch_bounds__(256) void ba_pair_table_kernel(const int32_t* __restrict__ pmeta, const int64_t* __restrict__ pkx,
+                                                            int32_t* __restrict__ ptab) {
+  if (pmeta[GM_ERROR]) return;
+  const int Up = pmeta[GM_U];
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < Up; p += gridDim.x * blockDim.x) ptab[pkx[p]] = p + 1;
+}
+
+struct PairArgs {
+  const float *poses, *patches, *intr, *target, *weight;
+  const int64_t *ii, *kk;
+  int P, t0, N;
+  const int32_t *gmeta;                    // of the patch index (its error state gates the whole BA)
+  const int32_t *pmeta, *pprec, *pkoff;    // the pair index
+  const int64_t* pkx;
+  float* sy;                               // [S | y]
+  float* pdiag;                            // [pairs][2][PDIAG]
+  int32_t pair_cap;
+  int32_t* info;
+};
+
+// B and v (ba_cuda.cu:364-377, 393-398 semantics).  One wave per frame pair {a, b}, a <= b (pose numbers + 1, 0 = fixed):
+// 64 of the pair's edges at a time (lane = edge, in edge order), each lane's two residual rows
+//     X = [s_a J_a | s_b J_b | r],   s = -1 for the pose the edge starts from, +1 for the one it points to
+// go to LDS, and the Gram matrix G = sum_k w_k X_k X_k^T is ONE 16 x 16 f32 MFMA tile (K = 128 rows per batch) that stays
+// in the accumulators across the batches.  With those signs G holds everything at once, whichever way an edge runs:
+//     G[0:6, 0:6] -> B_aa, G[6:12, 6:12] -> B_bb, G[0:6, 6:12] -> B_ab, G[0:6, 12] -> v_a, G[6:12, 12] -> v_b.
+// B_ab is written to S by its only owner (this wave); the diagonal parts wait in the pair's scratch slots for ba_diag_kernel.
+// a == b (an edge inside one frame): everything lands on the one diagonal block, folded here.
+__global__ __launch_bounds__(64) void ba_pair_kernel(PairArgs A) {
+  if (A.gmeta[GM_ERROR] || A.pmeta[GM_ERROR] || A.info[1]) return;
+  __shared__ float X[128 * XLD];
+  __shared__ float G[16 * XLD];
+  const int lane = threadIdx.x;
+  const int c16 = lane & 15, g4 = lane >> 4;
+  const int N = A.N, t0 = A.t0, PP = A.P * A.P, n6 = 6 * N;
+  const int centre = (A.P > 1) ? (A.P + 1) : 0;
+  const float fx = A.intr[0], fy = A.intr[1], cx = A.intr[2], cy = A.intr[3];
+  const int Up = min(A.pmeta[GM_U], A.pair_cap);
+  float* S = A.sy;
+  for (int p = (int)blockIdx.x; p < Up; p += (int)gridDim.x) {
+    const int64_t key = A.pkx[p];
+    const int pa = (int)(key / (N + 1)), pb = (int)(key - (int64_t)pa * (N + 1));
+    if (pb == 0) continue;   // both poses fixed: nothing of B or v
+    const int lo = A.pkoff[p], hi = A.pkoff[p + 1];
+    cdv_float4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    for (int base = lo; base < hi; base += 64) {
+      const bool active = base + lane < hi;
+      const RecIn in = rec_inputs(rec_load(A.pprec, active ? base + lane : lo), A.ii, A.poses, A.target, A.weight);
+      const float* pk = A.patches + A.kk[in.e] * 3 * PP;
+      EdgeJ J;
+      fastba_factor(in.pi, in.pj, pk[centre], pk[PP + centre], pk[2 * PP + centre], in.tx, in.ty, in.wx, in.wy, fx, fy, cx, cy, J);
+      // which way the edge runs: forward = it starts from pose a (for a == b both ends are pose a: forward)
+      const int ai = in.ix - t0;
+      const int ri = (ai >= 0 && ai < N) ? ai + 1 : 0;
+      const bool fwd = ri == pa;
 #pragma unroll
       for (int row = 0; row < 2; row++) {
         float* xr = X + (2 * lane + row) * XLD;
 #pragma unroll
         for (int c = 0; c < 6; c++) {
-          xr[c] = active ? J.Ji[6 * row + c] : 0.f;
-          xr[6 + c] = active ? J.Jj[6 * row + c] : 0.f;
+          const float vi = -J.Ji[6 * row + c], vj = J.Jj[6 * row + c];
+          xr[c] = active ? (fwd ? vi : vj) : 0.f;
+          xr[6 + c] = active ? (fwd ? vj : vi) : 0.f;
         }
         xr[12] = active ? J.r[row] : 0.f;
         xr[13] = 0.f;
@@ -243,309 +350,202 @@ __device__ __forceinline__ void assemble_body(const AsmArgs& A, int bid, float* 
         xr[15] = active ? J.w[row] : 0.f;
       }
       wave_lds_sync();
-      CDV_STAMP(ba, sslot, 4);
-      unsigned long long todo = __ballot(active && key != 0);
-      CDV_IF_STAMPS(unsigned long long npass = 0, t_rd = 0, t_mf = 0, t_em = 0, t_x;)
-      if (todo) {
-        CDV_IF_STAMPS(t_x = cdv_now();)
-        // this lane's MFMA operands of all 32 k-steps, read once (unconditional, batched LDS reads): column c16 of
-        // row k = 4 st + g4, with the row's weight and its edge's pair key
-        float xa[32], xw[32];
-        int xk[32];
+      const int nrow = 2 * min(64, hi - base);   // rows of this batch that carry an edge (the rest are zero: skipped)
 #pragma unroll
-        for (int st = 0; st < 32; st++) {
-          const int k = 4 * st + g4;
-          xa[st] = X[k * XLD + c16];
-          xw[st] = X[k * XLD + 15];
-          xk[st] = keys[k >> 1];
-        }
-        CDV_IF_STAMPS(asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t_rd = cdv_now() - t_x;)
-        while (todo) {
-          CDV_IF_STAMPS(npass++; t_x = cdv_now();)
-          const int leader = __ffsll((long long)todo) - 1;
-          const int kcur = __shfl(key, leader);
-          const int ci = __shfl(ixf, leader), cj = __shfl(jxf, leader);
-          // two accumulators: consecutive f32 MFMAs do not wait on each other's result
-          cdv_float4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-          const unsigned long long match = __ballot(active && key == kcur);
-#pragma unroll
-          for (int st = 0; st < 32; st += 2) {
-            // k-steps st, st + 1 hold the rows of edges (lanes) 2 st .. 2 st + 3: skipped when none is of this pair
-            // (wave-uniform test; a chunk that straddles two source frames then costs one pass in total, not two)
-            if (((match >> (2 * st)) & 15ull) == 0) continue;
-            const float w0 = (xk[st] == kcur) ? xw[st] : 0.f;
-            const float w1 = (xk[st + 1] == kcur) ? xw[st + 1] : 0.f;
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[st], w0 * xa[st], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[st + 1], w1 * xa[st + 1], acc1, 0, 0, 0);
-          }
-          CDV_IF_STAMPS(asm volatile("v_nop" :: "v"(acc0[0] + acc1[0])); t_mf += cdv_now() - t_x; t_x = cdv_now();)
-          // D layout: col = lane & 15, row = 4 * (lane >> 4) + reg
-#pragma unroll
-          for (int q = 0; q < 4; q++) pair_emit(acc0[q] + acc1[q], 4 * g4 + q, c16, ci, cj, n6, S, y);
-          CDV_IF_STAMPS(t_em += cdv_now() - t_x;)
-          todo &= ~match;
-        }
+      for (int st = 0; st < 32; st += 2) {
+        if (4 * st >= nrow) break;               // wave-uniform
+        const int k0 = 4 * st + g4, k1 = k0 + 4;
+        const float a0 = X[k0 * XLD + c16], w0 = X[k0 * XLD + 15];
+        const float a1 = X[k1 * XLD + c16], w1 = X[k1 * XLD + 15];
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, w0 * a0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, w1 * a1, acc1, 0, 0, 0);
       }
-      CDV_STAMP(ba, sslot, 5);
-      CDV_STAMP_VAL(ba, sslot, 6, npass);
-      CDV_STAMP_VAL(ba, sslot, 10, t_rd);
-      CDV_STAMP_VAL(ba, sslot, 11, t_mf);
-      CDV_STAMP_VAL(ba, sslot, 12, t_em);
-      wave_lds_sync();  // the next slot overwrites X
+      wave_lds_sync();   // the next batch overwrites X
     }
-  }
-  if (r < U && (Cacc != 0.f || uacc != 0.f)) {
-    atomicAdd(&Cg[r], Cacc);
-    atomicAdd(&ug[r], uacc);
-  }
-  CDV_STAMP(ba, sslot, 2);
-  CDV_STAMP_RT(ba, sslot, 9);
-}
-
-__global__ __launch_bounds__(ASM_THREADS) void ba_assemble_kernel(AsmArgs A) {
-  extern __shared__ float smem[];
-  assemble_body(A, (int)blockIdx.x, smem);
-}
-
-// Schur products of one chunk of 64 patches, after E, C, u are complete in global memory:
-//   q = 1 / (C + lambda);  S -= Ed diag(q) Ed^T;  y -= Ed (q .* u)      (ba_cuda.cu:548, 583-587)
-// as [Ed; u] diag(q) [Ed; u]^T on the matrix cores (K = 64 patches, v_mfma_f32_16x16x4_f32).
-struct SchurArgs {
-  const float* lmbda;
-  int N;
-  const int32_t* gmeta;
-  float* sy;
-  int sy_stride;
-  const float *Cg, *ug;
-  float* qg;
-  const float* Edg;
-  int U_stride;
-  int32_t* info;
-};
-
-// chunk: the 64-patch chunk; nthreads: workgroup size (256 as a launch of its own, 64 as a rider of the assemble launch)
-__device__ __forceinline__ void schur_body(const SchurArgs& A, int chunk, int nthreads, float* smem) {
-  const float* __restrict__ lmbda = A.lmbda;
-  const int N = A.N;
-  const int32_t* __restrict__ gmeta = A.gmeta;
-  float* __restrict__ sy = A.sy;
-  const int sy_stride = A.sy_stride;
-  const float* __restrict__ Cg = A.Cg;
-  const float* __restrict__ ug = A.ug;
-  float* __restrict__ qg = A.qg;
-  const float* __restrict__ Edg = A.Edg;
-  const int U_stride = A.U_stride;
-  const int U = gmeta[GM_U];
-  const int r0 = chunk * BA_CHUNK;
-  if (r0 >= U) return;
-  const int n6 = 6 * N, nrow = n6 + 1;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = nthreads >> 6;
-  const int c16 = lane & 15, g4 = lane >> 4;
-  CDV_IF_STAMPS(const int sslot = 5000 + chunk * 4 + wave;)
-  CDV_STAMP(ba, sslot, 0);
-  CDV_STAMP_RT(ba, sslot, 8);
-  const int T16 = (nrow + 15) / 16;
-  float* Ed = smem;                          // [16 T16][ELD], row n6 = u, rows beyond it zero
-  float* qs = Ed + (size_t)16 * T16 * ELD;   // [64]
-  const float lm = lmbda[0];
-  if (threadIdx.x < BA_CHUNK) {
-    const int rr = r0 + threadIdx.x;
-    const float q = (rr < U) ? 1.0f / (Cg[rr] + lm) : 0.f;
-    qs[threadIdx.x] = q;
-    if (rr < U) qg[rr] = q;
-    Ed[n6 * ELD + threadIdx.x] = (rr < U) ? ug[rr] : 0.f;
-  }
-  // E rows of the chunk -> LDS: float4 loads, all of a thread's loads in flight together; rows nrow .. 16 T16 - 1
-  // are zero so that the tile reads below need no bounds checks
-  {
-    const int tot4 = n6 * (BA_CHUNK / 4), pad4 = 16 * T16 * (BA_CHUNK / 4);
-    const cdv_float4 z4 = {0.f, 0.f, 0.f, 0.f};
-    for (int base = 0; base < pad4; base += 4 * nthreads) {
-      cdv_float4 v[4];
+    // G: lane (c16, g4) holds rows 4 g4 + q, column c16
 #pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const int i4 = base + i * nthreads + (int)threadIdx.x;
-        const int row = i4 >> 4, k4 = (i4 & 15) * 4;
-        // U_stride is a multiple of 64 and the columns beyond U are kept zero by the retract kernel
-        v[i] = (i4 < tot4) ? *reinterpret_cast<const cdv_float4*>(Edg + (size_t)row * U_stride + r0 + k4) : z4;
-      }
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const int i4 = base + i * nthreads + (int)threadIdx.x;
-        const int row = i4 >> 4, k4 = (i4 & 15) * 4;
-        if (i4 < pad4 && row != n6) *reinterpret_cast<cdv_float4*>(Ed + row * ELD + k4) = v[i];
-      }
-    }
-  }
-  __syncthreads();
-  CDV_STAMP(ba, sslot, 1);
-  if (N == 0) return;
-  float* S = sy + (size_t)(chunk % BA_REPL) * sy_stride;
-  float* y = S + (size_t)n6 * n6;
-  const int npairs = T16 * (T16 + 1) / 2;
-  for (int pidx = wave; pidx < npairs; pidx += nwaves) {
-    int ti = 0, acc_rows = 0;  // lower-triangular tile pair (ti >= tj)
-    while (acc_rows + ti + 1 <= pidx) { acc_rows += ti + 1; ti++; }
-    const int tj = pidx - acc_rows;
-    const float* pa = Ed + (size_t)(16 * ti + c16) * ELD;
-    const float* pb = Ed + (size_t)(16 * tj + c16) * ELD;
-    float a[16], bq[16];
-#pragma unroll
-    for (int st = 0; st < 16; st++) {
-      const int k = 4 * st + g4;
-      a[st] = pa[k];
-      bq[st] = qs[k] * pb[k];
-    }
-    cdv_float4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int st = 0; st < 16; st += 2) {
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[st], bq[st], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[st + 1], bq[st + 1], acc1, 0, 0, 0);
-    }
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int R = 16 * ti + 4 * g4 + q, Cc = 16 * tj + c16;
-      const float v = acc0[q] + acc1[q];
-      if (v == 0.f || R >= nrow || Cc >= n6) continue;  // column n6 (u) only duplicates row n6
-      if (R == n6) {
-        atomicAdd(&y[Cc], -v);
+    for (int q = 0; q < 4; q++) G[(4 * g4 + q) * XLD + c16] = acc0[q] + acc1[q];
+    wave_lds_sync();
+    float* slot0 = A.pdiag + (size_t)p * 2 * PDIAG;
+    float* slot1 = slot0 + PDIAG;
+    if (lane < 42) {
+      // entry `lane` of a diagonal part: 36 of the 6 x 6 block (row-major), then the 6 of v
+      const int rr = lane < 36 ? lane / 6 : lane - 36, cc = lane < 36 ? lane - 6 * (lane / 6) : 12;
+      const float da = G[rr * XLD + cc], db = G[(6 + rr) * XLD + (cc == 12 ? 12 : 6 + cc)];
+      if (pa == pb) {
+        const float cross = lane < 36 ? G[rr * XLD + 6 + cc] + G[cc * XLD + 6 + rr] : 0.f;
+        slot0[lane] = (da + db) + cross;
+        slot1[lane] = 0.f;
       } else {
-        atomicAdd(&S[R * n6 + Cc], -v);
-        if (ti != tj) atomicAdd(&S[Cc * n6 + R], -v);
+        slot0[lane] = da;    // pose a's part (never read when a is the fixed pose 0)
+        slot1[lane] = db;
       }
     }
+    if (pa != pb && pa >= 1 && lane < 36) {
+      // B_ab: rows of pose b, columns of pose a in the lower triangle (b > a)
+      const int ra = lane / 6, cb = lane - 6 * ra;
+      S[(size_t)(6 * (pb - 1) + cb) * n6 + 6 * (pa - 1) + ra] = G[ra * XLD + 6 + cb];
+    }
+    wave_lds_sync();   // the next pair overwrites G
   }
-  CDV_STAMP(ba, sslot, 2);
-  CDV_STAMP_RT(ba, sslot, 9);
 }
 
-__global__ __launch_bounds__(1024) void ba_schur_kernel(SchurArgs A) {
-  if (A.gmeta[GM_ERROR] || A.info[1]) return;
-  // the dX granules {tag, value} of the following solve + retract launch (its retract workgroups poll the tags)
-  if (blockIdx.x == 0 && threadIdx.x < 64) reinterpret_cast<uint64_t*>(A.info + 16)[threadIdx.x] = 0ull;
-  extern __shared__ float smem[];
-  schur_body(A, (int)blockIdx.x, (int)blockDim.x, smem);
+// Diagonal block and v of free pose x (block x of the grid): the parts of every pair that holds x, in a fixed order --
+// lane l takes the partner poses m = l, l + 64, .. (the pair (m, x + 1) for m <= x, (x + 1, m) beyond; looked up in the pair
+// table), sums them in increasing m, and the 64 lane sums meet in a fixed tree.
+__global__ __launch_bounds__(64) void ba_diag_kernel(const int32_t* __restrict__ gmeta, const int32_t* __restrict__ pmeta,
+                                                     const int32_t* __restrict__ ptab, const float* __restrict__ pdiag,
+                                                     int N, float* __restrict__ sy, const int32_t* __restrict__ info) {
+  if (gmeta[GM_ERROR] || pmeta[GM_ERROR] || info[1]) return;
+  const int lane = threadIdx.x;
+  const int x1 = (int)blockIdx.x + 1;   // pose number + 1
+  const int n6 = 6 * N;
+  float acc[42];
+#pragma unroll
+  for (int i = 0; i < 42; i++) acc[i] = 0.f;
+  for (int m = lane; m <= N; m += 64) {
+    const int a = min(m, x1), b = max(m, x1);
+    const int p1 = ptab[(size_t)a * (N + 1) + b];
+    if (p1 == 0) continue;
+    // the pair's slot 0 belongs to its smaller pose, slot 1 to the larger (a pair (x, x) has everything in slot 0)
+    const float* src = pdiag + ((size_t)(p1 - 1) * 2 + (m < x1 ? 1 : 0)) * PDIAG;
+#pragma unroll
+    for (int i4 = 0; i4 < 40; i4 += 4) {
+      const cdv_float4 v = *reinterpret_cast<const cdv_float4*>(src + i4);
+#pragma unroll
+      for (int h = 0; h < 4; h++) acc[i4 + h] += v[h];
+    }
+    acc[40] += src[40];
+    acc[41] += src[41];
+  }
+  float* S = sy;
+  float* y = S + (size_t)n6 * n6;
+#pragma unroll
+  for (int i = 0; i < 42; i++) {
+    float v = acc[i];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o);   // butterfly: every lane ends with the same total, same tree
+    if (lane == i) {
+      if (i < 36) S[(size_t)(6 * (x1 - 1) + i / 6) * n6 + 6 * (x1 - 1) + (i % 6)] = v;
+      else y[6 * (x1 - 1) + (i - 36)] = v;
+    }
+  }
 }
 
-// =========================================================================================================
-// Global bundle adjustment (N > 32 free poses; slam.py:460-478 calls fastba.BA(..., eff_impl=True) over the active
-// and the inactive edges).  The reference switches to a block-sparse E (block_e.cu) because a dense [6N x U] E does
-// not fit its GPUs' budget; the numbers it computes -- S = B - E Q E^T, y = v - E Q u, dX, dZ -- are those of the
-// dense path (ba_cuda.cu:567-580 vs :583-592).  On a 288 GB part the dense E simply stays in HBM (assemble and
-// retract are unchanged); what changes is where zeros would be multiplied:
-//   * the Schur products run per (chunk of 64 patches, pair of 32-pose panels), and only for panels in which the chunk
-//     has a non-zero E block (one mask word per chunk, set by the assemble kernel) -- a patch is seen from ~25-40 of
-//     the hundreds of free poses;
-//   * the 6N x 6N system is factored by a right-looking blocked Cholesky over many workgroups (two launches per
-//     64-column block: diagonal block + panel, trailing update on the matrix cores), the right-hand side carried as
-//     an extra row, then one back-substitution launch.
-// =========================================================================================================
-
-// S -= E_pa diag(q) E_pb^T (lower part), y -= E_pa (q .* u) for one chunk and one pair of pose panels.
-__global__ __launch_bounds__(256) void ba_big_schur_kernel(const float* __restrict__ lmbda, int N,
-                                                           const int32_t* __restrict__ gmeta, float* __restrict__ sy,
-                                                           int sy_stride, const float* __restrict__ Cg,
-                                                           const float* __restrict__ ug, const float* __restrict__ Edg,
-                                                           int U_stride, const uint32_t* __restrict__ cmask, int npair,
-                                                           const int32_t* __restrict__ info) {
+// S -= E Q E^T, y -= E Q u (ba_cuda.cu:583-587), lower triangle.  Workgroup = a pair of 8-pose panels (pa >= pb): the 48 x 48
+// tile of S it owns is nine 16 x 16 MFMA tiles dealt to four waves, accumulated over the chunks of 64 patches whose mask
+// words have both panels, in chunk order (K = 64 per chunk); q = 1 / (C + lambda) per chunk (ba_cuda.cu:548).  A diagonal
+// workgroup also owns its 48 entries of y.  At the end the tile is subtracted from S (B is there already), one owner per entry.
+constexpr int SPR = 6 * BIG_PP;   // rows of a panel
+__global__ __launch_bounds__(256) void ba_schur_kernel(const float* __restrict__ lmbda, int N, const int32_t* __restrict__ gmeta,
+                                                       float* __restrict__ sy, const float* __restrict__ Cg,
+                                                       const float* __restrict__ ug, const float* __restrict__ Edg,
+                                                       int U_stride, const uint32_t* __restrict__ cmask, int n_chunks,
+                                                       const int32_t* __restrict__ info) {
   if (gmeta[GM_ERROR] || info[1]) return;
   const int U = gmeta[GM_U];
-  // workgroup (chunk, slot): the chunk's ACTIVE panel pairs (pa >= pb, both bits set) are dealt round-robin to
-  // BIG_SLOTS workgroups -- a chunk touches 2-3 of the up to 32 panels, so almost every one of the 528 possible pairs
-  // would be an empty workgroup if each had its own
-  const int chunk = blockIdx.x / npair, slot = blockIdx.x - chunk * npair;   // npair == BIG_SLOTS here
-  const int r0 = chunk * BA_CHUNK;
-  if (r0 >= U) return;
-  const uint32_t mask = cmask[chunk];
-  const int n6 = 6 * N;
-  int pair_idx = 0;
-  for (int pa = 0; pa < 32; pa++) {
-    if (!((mask >> pa) & 1u)) continue;
-    for (int pb = 0; pb <= pa; pb++) {
-      if (!((mask >> pb) & 1u)) continue;
-      const bool mine = (pair_idx % npair) == slot;
-      pair_idx++;
-      if (!mine) continue;
-      __syncthreads();   // the previous pair's tiles are done with the LDS panels
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Ea = smem;                          // [BIG_PR][ELD]
-  float* Eb = Ea + (size_t)BIG_PR * ELD;     // [BIG_PR][ELD]  (aliases Ea when pa == pb)
-  float* qs = Eb + (size_t)BIG_PR * ELD;     // [64]
-  float* qu = qs + BA_CHUNK;                 // [64] q .* u
-  if (pa == pb) Eb = Ea;
-  const float lm = lmbda[0];
-  if (threadIdx.x < BA_CHUNK) {
-    const int rr = r0 + threadIdx.x;
-    const float q = (rr < U) ? 1.0f / (Cg[rr] + lm) : 0.f;
-    qs[threadIdx.x] = q;
-    qu[threadIdx.x] = (rr < U) ? q * ug[rr] : 0.f;
-  }
-  const cdv_float4 z4 = {0.f, 0.f, 0.f, 0.f};
-  for (int half = 0; half < (pa == pb ? 1 : 2); half++) {
-    float* dstE = half == 0 ? Ea : Eb;
-    const int rowbase = BIG_PR * (half == 0 ? pa : pb);
-    for (int i4 = threadIdx.x; i4 < BIG_PR * (BA_CHUNK / 4); i4 += 256) {
-      const int row = i4 >> 4, k4 = (i4 & 15) * 4;
-      const int grow = rowbase + row;
-      const cdv_float4 v = (grow < n6) ? *reinterpret_cast<const cdv_float4*>(Edg + (size_t)grow * U_stride + r0 + k4) : z4;
-      *reinterpret_cast<cdv_float4*>(dstE + row * ELD + k4) = v;
-    }
-  }
-  __syncthreads();
-  float* S = sy + (size_t)(blockIdx.x % BA_REPL) * sy_stride;
-  float* y = S + (size_t)n6 * n6;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nck = min(n_chunks, (U + BA_CHUNK - 1) / BA_CHUNK);
+  // (pa, pb) of this workgroup: lower-triangular pair number blockIdx.x
+  int pa = (int)((sqrtf(8.0f * (float)blockIdx.x + 1.0f) - 1.0f) * 0.5f);
+  if (((pa + 1) * (pa + 2)) >> 1 <= (int)blockIdx.x) pa++;
+  if ((pa * (pa + 1)) >> 1 > (int)blockIdx.x) pa--;
+  const int pb = (int)blockIdx.x - ((pa * (pa + 1)) >> 1);
+  __shared__ __attribute__((aligned(16))) float Ea[SPR * ELD];
+  __shared__ __attribute__((aligned(16))) float Eb[SPR * ELD];
+  __shared__ float qs[BA_CHUNK], qu[BA_CHUNK];
+  __shared__ int lst[256];
+  __shared__ int wcnt[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c16 = lane & 15, g4 = lane >> 4;
-  constexpr int TT = BIG_PR / 16;   // 12 tiles per panel side
-  const int ntile = (pa == pb) ? TT * (TT + 1) / 2 : TT * TT;
-  for (int tix = wave; tix < ntile; tix += 4) {
-    int ti, tj;
-    if (pa == pb) {
-      ti = 0; int ar = 0;
-      while (ar + ti + 1 <= tix) { ar += ti + 1; ti++; }
-      tj = tix - ar;
-    } else {
-      ti = tix / TT; tj = tix - ti * TT;
-    }
-    const float* pra = Ea + (size_t)(16 * ti + c16) * ELD;
-    const float* prb = Eb + (size_t)(16 * tj + c16) * ELD;
-    float a[16], bq[16];
+  const int n6 = 6 * N;
+  const float lm = lmbda[0];
+  const uint32_t bita = 1u << (pa & 31), bitb = 1u << (pb & 31);
+  const int wa = pa >> 5, wb = pb >> 5;
+  const float* Ebp = (pa == pb) ? Ea : Eb;
+  cdv_float4 acc[3];
 #pragma unroll
-    for (int st = 0; st < 16; st++) {
-      const int k = 4 * st + g4;
-      a[st] = pra[k];
-      bq[st] = qs[k] * prb[k];
-    }
-    cdv_float4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  for (int u = 0; u < 3; u++) acc[u] = cdv_float4{0.f, 0.f, 0.f, 0.f};
+  float yacc = 0.f;
+  const cdv_float4 z4 = {0.f, 0.f, 0.f, 0.f};
+  for (int base = 0; base < nck; base += 256) {   // workgroup-uniform
+    // the chunks of this batch that hold both panels, in chunk order
+    const int c = base + tid;
+    const bool hit = c < nck && (cmask[(size_t)c * BIG_MW + wa] & bita) && (cmask[(size_t)c * BIG_MW + wb] & bitb);
+    const unsigned long long bal = __ballot(hit);
+    if (lane == 0) wcnt[wave] = __popcll(bal);
+    __syncthreads();
+    int before = 0, total = 0;
 #pragma unroll
-    for (int st = 0; st < 16; st += 2) {
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[st], bq[st], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[st + 1], bq[st + 1], acc1, 0, 0, 0);
+    for (int w = 0; w < 4; w++) { const int n = wcnt[w]; before += (w < wave) ? n : 0; total += n; }
+    if (hit) lst[before + __popcll(bal & ((1ull << lane) - 1ull))] = c;
+    __syncthreads();
+    for (int i = 0; i < total; i++) {
+      const int chunk = lst[i];
+      const int r0 = chunk * BA_CHUNK;
+      if (tid < BA_CHUNK) {
+        const int rr = r0 + tid;
+        const float q = (rr < U) ? 1.0f / (Cg[rr] + lm) : 0.f;
+        qs[tid] = q;
+        qu[tid] = (rr < U) ? q * ug[rr] : 0.f;
+      }
+      for (int half = 0; half < (pa == pb ? 1 : 2); half++) {
+        float* dstE = half == 0 ? Ea : Eb;
+        const int rowbase = SPR * (half == 0 ? pa : pb);
+        for (int i4 = tid; i4 < SPR * (BA_CHUNK / 4); i4 += 256) {
+          const int row = i4 >> 4, k4 = (i4 & 15) * 4;
+          const int grow = rowbase + row;
+          const cdv_float4 v = (grow < n6) ? *reinterpret_cast<const cdv_float4*>(Edg + (size_t)grow * U_stride + r0 + k4) : z4;
+          *reinterpret_cast<cdv_float4*>(dstE + row * ELD + k4) = v;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < 3; u++) {
+        const int tix = wave + 4 * u;   // tiles 0 .. 8: (ti, tj) = (tix / 3, tix % 3)
+        if (tix >= 9) continue;
+        const int ti = tix / 3, tj = tix - 3 * ti;
+        if (pa == pb && tj > ti) continue;
+        const float* pra = Ea + (size_t)(16 * ti + c16) * ELD;
+        const float* prb = Ebp + (size_t)(16 * tj + c16) * ELD;
+        cdv_float4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int st = 0; st < 16; st += 2) {
+          const int k0 = 4 * st + g4, k1 = k0 + 4;
+          t0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pra[k0], qs[k0] * prb[k0], t0, 0, 0, 0);
+          t1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pra[k1], qs[k1] * prb[k1], t1, 0, 0, 0);
+        }
+        acc[u] += t0 + t1;
+      }
+      if (pa == pb && tid < SPR) {
+        float sacc = 0.f;
+        const float* pr = Ea + (size_t)tid * ELD;
+#pragma unroll 8
+        for (int k = 0; k < BA_CHUNK; k++) sacc += pr[k] * qu[k];
+        yacc += sacc;
+      }
+      __syncthreads();   // the next chunk overwrites the panels
     }
+  }
+  float* S = sy;
+  float* y = S + (size_t)n6 * n6;
+#pragma unroll
+  for (int u = 0; u < 3; u++) {
+    const int tix = wave + 4 * u;
+    if (tix >= 9) continue;
+    const int ti = tix / 3, tj = tix - 3 * ti;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-      const int R = BIG_PR * pa + 16 * ti + 4 * g4 + q, Cc = BIG_PR * pb + 16 * tj + c16;
-      const float v = acc0[q] + acc1[q];
+      const int R = SPR * pa + 16 * ti + 4 * g4 + q, Cc = SPR * pb + 16 * tj + c16;
+      const float v = acc[u][q];
       if (v == 0.f || R >= n6 || Cc > R) continue;   // lower triangle only: the blocked Cholesky reads nothing else
-      atomicAdd(&S[(size_t)R * n6 + Cc], -v);
+      S[(size_t)R * n6 + Cc] -= v;
     }
   }
-  if (pa == pb && threadIdx.x < BIG_PR) {
-    const int R = BIG_PR * pa + threadIdx.x;
-    if (R < n6) {
-      float sacc = 0.f;
-      const float* pr = Ea + (size_t)threadIdx.x * ELD;
-#pragma unroll 8
-      for (int k = 0; k < BA_CHUNK; k++) sacc += pr[k] * qu[k];
-      if (sacc != 0.f) atomicAdd(&y[R], -sacc);
-    }
-  }
-    }
-  }
+  if (pa == pb && tid < SPR && SPR * pa + tid < n6 && yacc != 0.f) y[SPR * pa + tid] -= yacc;
 }
 
-// copies of [S | y] -> working matrix A [(npad + 1)][npad]: rows 0..n-1 = S with the damping of ba_cuda.cu:589, identity
-// on the padded diagonal, row npad = y^T; re-zeroes the copies.
+// [S | y] -> working matrix A [(npad + 1)][npad]: rows 0..n-1 = S with the damping of ba_cuda.cu:589, identity
+// on the padded diagonal, row npad = y^T; re-zeroes [S | y] (its owners write only the blocks that exist).
 __global__ __launch_bounds__(256) void ba_big_fold_kernel(float* __restrict__ sy, int sy_stride, int n, int npad,
                                                           float* __restrict__ A, const int32_t* __restrict__ gmeta,
                                                           float* __restrict__ dbg, const int32_t* __restrict__ info) {
@@ -556,12 +556,9 @@ __global__ __launch_bounds__(256) void ba_big_fold_kernel(float* __restrict__ sy
     float v = 0.f;
     if (b < n && (a < n || a == npad)) {
       const size_t src = (a < n) ? (size_t)a * n + b : (size_t)n * n + b;
-#pragma unroll
-      for (int rep = 0; rep < BA_REPL; rep++) {
-        float* p = sy + (size_t)rep * sy_stride + src;
-        v += *p;
-        *p = 0.f;
-      }
+      float* p = sy + src;
+      v = *p;
+      *p = 0.f;
       if (a == b) v += 1e-4f * v + 1.0f;
       if (dbg) dbg[src] = v;
     } else if (a == b) {
@@ -826,13 +823,16 @@ __global__ __launch_bounds__(64 * RET_RG) void ba_retract_kernel(float* __restri
   if (gmeta[GM_ERROR] || info[1]) return;
   const int U = gmeta[GM_U];
   const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
-  // global-BA path: a workgroup is one chunk of 64 patches; its panel mask says which 32-pose panels of E are non-zero
+  // global-BA path: a workgroup is one chunk of 64 patches; its panel mask says which 8-pose panels of E are non-zero
   // (the rest of the column is zero and stays zero: not read, not rewritten); the mask is consumed here
-  uint32_t pmask = 0xffffffffu;
+  uint32_t pmask[BIG_MW];
+#pragma unroll
+  for (int wd = 0; wd < BIG_MW; wd++) pmask[wd] = 0xffffffffu;
   if (cmask) {
-    pmask = ((int)blockIdx.x < n_chunks) ? cmask[blockIdx.x] : 0u;
+#pragma unroll
+    for (int wd = 0; wd < BIG_MW; wd++) pmask[wd] = ((int)blockIdx.x < n_chunks) ? cmask[(size_t)blockIdx.x * BIG_MW + wd] : 0u;
     __syncthreads();
-    if (threadIdx.x == 0 && (int)blockIdx.x < n_chunks) cmask[blockIdx.x] = 0u;
+    if (threadIdx.x < BIG_MW && (int)blockIdx.x < n_chunks) cmask[(size_t)blockIdx.x * BIG_MW + threadIdx.x] = 0u;
   }
   // pose_retr_kernel (ba_cuda.cu:178-206): T <- Exp(dX_i) T, one lane per free pose, in wave 0 of the last workgroups
   // (the first ones carry the longest E-column sweeps)
@@ -856,7 +856,10 @@ __global__ __launch_bounds__(64 * RET_RG) void ba_retract_kernel(float* __restri
   float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (r < U) {
     for (int b = g; b < N; b += RET_RG) {
-      if (!((pmask >> (b >> 5)) & 1u)) continue;
+      uint32_t word = pmask[0];
+#pragma unroll
+      for (int wd = 1; wd < BIG_MW; wd++) word = ((b >> 8) == wd) ? pmask[wd] : word;
+      if (!((word >> ((b >> 3) & 31)) & 1u)) continue;
 #pragma unroll
       for (int c = 0; c < 6; c++) {
         float* ep = &Edg[(size_t)(6 * b + c) * U_stride + r];
@@ -913,11 +916,11 @@ extern "C" int cdv_ba_workspace_init(void* ba_ws, void* stream) {
 }
 
 extern "C" size_t cdv_ba_workspace_bytes(int64_t E_max, int64_t U_max, int N_max) {
-  (void)E_max;
+  if (E_max < 1) E_max = 1;
   if (U_max < 1) U_max = 1;
   if (N_max < 1) N_max = 1;
   if (N_max > BA_NBIG) N_max = BA_NBIG;
-  return ba_layout(U_max, N_max).total;
+  return ba_layout(U_max, N_max, E_max).total;
 }
 
 extern "C" int cdv_ba_forward(float* poses, float* patches, const float* intrinsics, const float* target,
@@ -937,7 +940,7 @@ extern "C" int cdv_ba_forward(float* poses, float* patches, const float* intrins
   CDV_REQUIRE(GL.E_max >= E, CDV_ERR_ARG, "cdv_ba_forward: graph was built for fewer edges");
   const GraphView gv = graph_view((void*)graph_ws, GL);
   CDV_REQUIRE(U_max >= 1, CDV_ERR_ARG, "cdv_ba_forward: U_max must be >= 1");
-  const BaLayout L = ba_layout(U_max, N > 0 ? N : 1);
+  const BaLayout L = ba_layout(U_max, N > 0 ? N : 1, E);
   CDV_REQUIRE(L.total <= ba_ws_bytes, CDV_ERR_WORKSPACE, "cdv_ba_forward: workspace too small for (U_max, N)");
   char* b = (char*)ba_ws;
   float* sy = (float*)(b + L.sy);
@@ -1022,36 +1025,42 @@ extern "C" int cdv_ba_forward(float* poses, float* patches, const float* intrins
   }
 
   const int n_chunks = cdv_div_up(L.U_max, BA_CHUNK);
-  const size_t smem_asm = sizeof(float) * ASM_WAVES * (size_t)PAIR_LDS_FLOATS;
-  const size_t smem_sch = sizeof(float) * ((size_t)((n6i + 1 + 15) / 16 * 16) * ELD + BA_CHUNK);
-  // raise the dynamic-LDS limits once (not a stream operation: kept out of the per-call path so that the
-  // call sequence can be captured into a hipGraph)
-  static std::once_flag attr_once;
-  static hipError_t attr_err = hipSuccess;
-  std::call_once(attr_once, [] {
-    hipError_t e4 = hipFuncSetAttribute((const void*)ba_big_schur_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        112 * 1024);
-    if (e4 != hipSuccess) { attr_err = e4; return; }
-    hipError_t e1 = hipFuncSetAttribute((const void*)ba_assemble_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        96 * 1024);
-    hipError_t e2 = hipFuncSetAttribute((const void*)ba_schur_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        64 * 1024);
-    attr_err = e1 != hipSuccess ? e1 : e2;
-  });
-  CDV_HIP_CHECK(attr_err);
   const int rb = cdv_div_up(L.U_max > N ? L.U_max : N, 64);
-  const int npair = 6;   // workgroups per chunk that share its active panel pairs (ba_big_schur_kernel)
   const int npad = (int)L.npad, nbk = npad / CNB;
-  const size_t smem_bsch = sizeof(float) * (2 * (size_t)BIG_PR * ELD + 2 * BA_CHUNK);
+  if (big) {
+    // the frame-pair index of this call's edges (both iterations use it): keys, an ordinary index build over them, the
+    // (a, b) -> pair table
+    int64_t* pkeys = (int64_t*)(b + L.pkeys);
+    void* pws = b + L.pgraph;
+    if (fresh) {
+      const int rc0 = cdv_graph_workspace_init(pws, L.pgraph_bytes, L.E_max, L.pair_range, stream);
+      if (rc0 != CDV_OK) return rc0;
+    }
+    hipLaunchKernelGGL(ba_pair_key_kernel, dim3(cdv_div_up(E, 256) < 2048 ? (int)cdv_div_up(E, 256) : 2048), dim3(256), 0, s, ii, jj,
+                       (int32_t)E, t0, N, pkeys);
+    const int rc1 = cdv_graph_build_edges(ii, jj, pkeys, E, pws, L.pgraph_bytes, L.E_max, L.pair_range, nullptr, nullptr, stream);
+    if (rc1 != CDV_OK) return rc1;
+    const GraphView pv = graph_view(pws, graph_layout(L.E_max, L.pair_range));
+    int32_t* ptab = (int32_t*)(b + L.ptab);
+    CDV_HIP_CHECK(hipMemsetAsync(ptab, 0, sizeof(int32_t) * (size_t)L.pair_range, s));
+    hipLaunchKernelGGL(ba_pair_table_kernel, dim3(256), dim3(256), 0, s, pv.meta, pv.kx, ptab);
+  }
   for (int itr = 0; itr < iterations; itr++) {
     float* d = (dbg && itr == 0) ? dbg : nullptr;
-    const AsmArgs aa{poses, patches, intrinsics, target, weight, ii, jj, kk, P, t0, N, gv.meta, gv.pcsr, gv.koff_u, sy,
-                     (int)L.sy_stride, Cg, ug, Edg, (int)L.U_stride, (int)L.U_max, info, cmask, counters, itr == 0 ? 1 : 0};
-    const SchurArgs sa{lmbda, N, gv.meta, sy, (int)L.sy_stride, Cg, ug, qg, Edg, (int)L.U_stride, info};
-    hipLaunchKernelGGL(ba_assemble_kernel, dim3(n_chunks * ASM_SG), dim3(ASM_THREADS), smem_asm, s, aa);
+    const PatchArgs pa{poses, patches, intrinsics, target, weight, ii, P, t0, N, gv.meta, gv.prec, gv.koff_u, gv.kx, Cg, ug, Edg,
+                       (int)L.U_stride, (int)L.U_max, info, cmask, counters, itr == 0 ? 1 : 0};
+    hipLaunchKernelGGL(ba_patch_kernel, dim3(n_chunks), dim3(64), 0, s, pa);
     if (big) {
-      hipLaunchKernelGGL(ba_big_schur_kernel, dim3(n_chunks * npair), dim3(256), smem_bsch, s, lmbda, N, gv.meta, sy,
-                         (int)L.sy_stride, Cg, ug, Edg, (int)L.U_stride, cmask, npair, info);
+      const GraphView pv = graph_view(b + L.pgraph, graph_layout(L.E_max, L.pair_range));
+      const PairArgs qa{poses, patches, intrinsics, target, weight, ii, kk, P, t0, N, gv.meta, pv.meta, pv.prec, pv.koff_u, pv.kx,
+                        sy, (float*)(b + L.pdiag), (int32_t)L.pair_cap, info};
+      const int pgrid = (int)(L.pair_cap < 16384 ? L.pair_cap : 16384);
+      hipLaunchKernelGGL(ba_pair_kernel, dim3(pgrid), dim3(64), 0, s, qa);
+      hipLaunchKernelGGL(ba_diag_kernel, dim3(N), dim3(64), 0, s, gv.meta, pv.meta, (const int32_t*)(b + L.ptab),
+                         (const float*)(b + L.pdiag), N, sy, info);
+      const int npan = cdv_div_up(N, BIG_PP);
+      hipLaunchKernelGGL(ba_schur_kernel, dim3(npan * (npan + 1) / 2), dim3(256), 0, s, lmbda, N, gv.meta, sy, Cg, ug, Edg,
+                         (int)L.U_stride, cmask, n_chunks, info);
       hipLaunchKernelGGL(ba_big_fold_kernel, dim3(1024), dim3(256), 0, s, sy, (int)L.sy_stride, n6i, npad, Abig, gv.meta,
                          d, info);
       for (int kb = 0; kb < nbk; kb++) {
@@ -1065,8 +1074,9 @@ extern "C" int cdv_ba_forward(float* poses, float* patches, const float* intrins
         hipLaunchKernelGGL(ba_big_backstep_kernel, dim3(kb > 0 ? cdv_div_up(CNB * kb, 256) : 1), dim3(256), 0, s, Abig, npad,
                            n6i, kb, dXg, gv.meta, d, info);
     } else {
-      // only N = 0 gets here (no free pose: depths alone are refined): q = 1 / (C + lambda) per chunk
-      hipLaunchKernelGGL(ba_schur_kernel, dim3(n_chunks), dim3(256), smem_sch, s, sa);
+      // only N = 0 gets here (no free pose: depths alone are refined): q = 1 / (C + lambda)
+      hipLaunchKernelGGL(ba_q_kernel, dim3(cdv_div_up(L.U_max, 256) < 1024 ? (int)cdv_div_up(L.U_max, 256) : 1024), dim3(256), 0, s,
+                         lmbda, gv.meta, Cg, qg, info);
     }
     // dbg layout: [S n6^2 | y n6 | dX n6 | dZ U_stride | C U_stride | u U_stride | E n6*U_stride]
     float* dbgp = d ? d + (size_t)n6i * n6i + 2 * n6i : nullptr;

@@ -13,7 +13,9 @@ constexpr int BA_CHUNK = 64;      // unique patches per workgroup of the N > 10 
 constexpr int BA_NMAX = 32;       // free poses supported by the single-workgroup solver
 constexpr int BA_NBIG = 1024;     // free poses supported by the global-BA path (dense E in HBM, blocked Cholesky)
 constexpr int CNB = 64;           // block size of the multi-workgroup Cholesky
-constexpr int BA_REPL = 4;        // copies of [S | y] the N > 10 assemble / schur workgroups spread their atomics over
+constexpr int BIG_PP = 8;         // poses per panel of the global path's Schur products (48 rows; <= 128 panels: four mask words)
+constexpr int BIG_MW = 4;         // mask words per chunk of 64 patches: which panels have a non-zero E block in it
+constexpr int PDIAG = 48;         // floats per (frame pair, side) partial of a diagonal block: 36 (6 x 6) + 6 (v), padded
 
 // ---- window path (N <= 10): no float atomics anywhere, bitwise reproducible ---------------------------------
 constexpr int WIN_N = 10;                        // free poses
@@ -39,26 +41,27 @@ __host__ __device__ inline int solve_ld(int n) { return (n + 27) / 32 * 32 + 4; 
 enum { BI_CHOL = 0, BI_OVERFLOW = 1, BI_HANDOFF = 2, BI_GRAPH = 3 };
 
 struct BaLayout {
-  size_t sy, C, u, Ed, cmask, zero_bytes, q, dX, info, Abig, slabs, ared, hand, pnext, total;
+  size_t sy, C, u, Ed, cmask, zero_bytes, q, dX, info, Abig, slabs, ared, hand, pnext, ptab, pdiag, pkeys, pgraph, pgraph_bytes, total;
+  int64_t E_max, pair_cap, pair_range;  // global path: edges the pair index is sized for, frame pairs it can hold, key range
   int64_t npad;                         // global-BA path: 6 N rounded up to the Cholesky block (0: not used)
   int64_t U_max, U_stride, sy_stride;   // sy_stride: floats between two copies of [S | y]
   int64_t n_ck;                         // window path: chunk slabs
   int N_max;
 };
 
-inline BaLayout ba_layout(int64_t U_max, int N_max) {
+inline BaLayout ba_layout(int64_t U_max, int N_max, int64_t E_max = 1) {
   BaLayout L;
-  L.U_max = U_max; L.N_max = N_max;
+  L.U_max = U_max; L.N_max = N_max; L.E_max = E_max < 1 ? 1 : E_max;
   L.U_stride = (U_max + BA_CHUNK - 1) / BA_CHUNK * BA_CHUNK;
   const size_t n6 = 6 * (size_t)N_max;
   size_t o = 0;
   // accumulators of the N > 10 path: zeroed once, then kept zero by their consumers
-  L.sy_stride = (int64_t)((n6 * n6 + n6 + 1023) / 1024 * 1024);   // 4 KB multiples: copies start on different channels
-  L.sy = o;   o = align256(o + sizeof(float) * (size_t)L.sy_stride * BA_REPL);
+  L.sy_stride = (int64_t)((n6 * n6 + n6 + 1023) / 1024 * 1024);
+  L.sy = o;   o = align256(o + sizeof(float) * (size_t)L.sy_stride);   // [S | y] of the global path: one owner per entry
   L.C = o;    o = align256(o + sizeof(float) * (size_t)L.U_stride);
   L.u = o;    o = align256(o + sizeof(float) * (size_t)L.U_stride);
   L.Ed = o;   o = align256(o + sizeof(float) * n6 * (size_t)L.U_stride);
-  L.cmask = o; o = align256(o + sizeof(uint32_t) * (size_t)(L.U_stride / BA_CHUNK));   // active pose panels per chunk
+  L.cmask = o; o = align256(o + sizeof(uint32_t) * BIG_MW * (size_t)(L.U_stride / BA_CHUNK));   // active pose panels per chunk
   L.zero_bytes = o;
   L.q = o;    o = align256(o + sizeof(float) * (size_t)L.U_stride);
   L.dX = o;   o = align256(o + sizeof(float) * (n6 + 8));
@@ -79,6 +82,24 @@ inline BaLayout ba_layout(int64_t U_max, int N_max) {
     L.ared = o;  o = align256(o + sizeof(float) * ared);
     L.hand = o;  o = align256(o + sizeof(int32_t) * HAND_WORDS);
     L.pnext = o; o = align256(o + sizeof(float) * 7 * WIN_N);
+  }
+  // global path (N > 32): the frame-pair index of the edges -- an ordinary patch-graph index (cdv_graph.h) built over the
+  // key (a, b) = the two poses of an edge as free-pose numbers + 1 (0: fixed), a <= b --, the pair table (a, b) -> pair
+  // number + 1, and the per-pair partials of the diagonal blocks.  LAST in the layout: everything before it keeps its
+  // offset whatever the number of edges.
+  L.ptab = o; L.pdiag = o; L.pkeys = o; L.pgraph = o; L.pgraph_bytes = 0; L.pair_cap = 0; L.pair_range = 0;
+  if (N_max > BA_NMAX) {
+    const int64_t np1 = (int64_t)N_max + 1;
+    L.pair_range = np1 * np1;
+    const int64_t allp = np1 * (np1 + 1) / 2;
+    L.pair_cap = L.E_max < allp ? L.E_max : allp;
+    L.ptab = o;   o = align256(o + sizeof(int32_t) * (size_t)L.pair_range);
+    // (the index first: its address -- the key of the index registry -- then depends on (U_max, N) only, and a call with
+    // another number of edges is seen as a change of ITS layout, which re-initialises it)
+    L.pgraph_bytes = graph_layout(L.E_max, L.pair_range).total;
+    L.pgraph = o; o = align256(o + L.pgraph_bytes);
+    L.pkeys = o;  o = align256(o + sizeof(int64_t) * (size_t)L.E_max);
+    L.pdiag = o;  o = align256(o + sizeof(float) * 2 * PDIAG * (size_t)L.pair_cap);
   }
   L.total = o;
   return L;

@@ -193,6 +193,101 @@ __device__ __forceinline__ void transform_body(const TfArgs& A, int64_t n) {
 }
 
 // ---- patch-id histogram over (id mod R) + min / max of kk, jj (graph.hip, launch 1 of the index build) ----
+// The same scan for a launch of its own (1024 threads, AFTER the histogram launch: plain loads see its atomics): wave w takes
+// the w-th sixteenth of the id range, 64 consecutive bins at a time -- coalesced, where graph_scan_body gives every thread a
+// contiguous run of bins (fine for the few thousand ids of a frame-to-frame graph, 250 us for the 10^5 frame-pair keys of
+// a global bundle adjustment).
+__device__ __forceinline__ void graph_scan_wide_body(int32_t* meta, const int32_t* __restrict__ stage, int nstage,
+                                                     int32_t* khist, int32_t* kcount, int32_t* krank, int32_t E,
+                                                     int64_t k_cap, int T, int t) {
+  constexpr int IMAX = 0x7fffffff, IMIN = (int)0x80000000;
+  __shared__ int32_t w_sum[16], w_cnt[16];
+  __shared__ int32_t w_mm[16][4];
+  int kmin = IMAX, kmax = IMIN, jmin = IMAX, jmax = IMIN;
+  for (int i = t; i < nstage; i += T) {
+    kmin = min(kmin, stage[4 * i]); kmax = max(kmax, stage[4 * i + 1]);
+    jmin = min(jmin, stage[4 * i + 2]); jmax = max(jmax, stage[4 * i + 3]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    kmin = min(kmin, __shfl_xor(kmin, o)); kmax = max(kmax, __shfl_xor(kmax, o));
+    jmin = min(jmin, __shfl_xor(jmin, o)); jmax = max(jmax, __shfl_xor(jmax, o));
+  }
+  const int lane = t & 63, wv = t >> 6, nw = T >> 6;
+  if (lane == 0) { w_mm[wv][0] = kmin; w_mm[wv][1] = kmax; w_mm[wv][2] = jmin; w_mm[wv][3] = jmax; }
+  __syncthreads();
+  for (int w = 0; w < nw; w++) {
+    kmin = min(kmin, w_mm[w][0]); kmax = max(kmax, w_mm[w][1]);
+    jmin = min(jmin, w_mm[w][2]); jmax = max(jmax, w_mm[w][3]);
+  }
+  const int64_t krange = (E > 0) ? (int64_t)kmax - kmin + 1 : 0;
+  const bool bad = E > 0 && (kmin < 0 || krange > k_cap);
+  if (t == 0) {
+    meta[GM_KMIN] = kmin; meta[GM_KMAX] = kmax; meta[GM_JMIN] = jmin; meta[GM_JMAX] = jmax;
+    meta[GM_E] = E;
+    meta[GM_ERROR] = bad ? 1 : 0;
+    meta[GM_KRANGE] = bad ? 0 : (int32_t)krange;
+    if (bad || E == 0) meta[GM_U] = 0;
+  }
+  const int R = (int)k_cap;
+  if (bad || E == 0) {
+    for (int i = t; i < R; i += T) khist[i] = 0;   // a failed build leaves a clean histogram too
+    return;
+  }
+  const int b0 = kmin % R;
+  const int n = (int)krange;
+  const int seg = ((n + nw - 1) / nw + 63) / 64 * 64;   // bins per wave, whole groups of 64
+  const int lo = min(wv * seg, n), hi = min(lo + seg, n);
+  int32_t sum = 0, cnt = 0;
+  for (int i0 = lo; i0 < hi; i0 += 4 * 64) {   // four coalesced loads in flight
+    int32_t v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int i = i0 + 64 * u + lane;
+      int bin = b0 + min(i, hi - 1); bin = (bin >= R) ? bin - R : bin;
+      v[u] = khist[bin];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (i0 + 64 * u + lane < hi) { sum += v[u]; cnt += (v[u] > 0); }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o); cnt += __shfl_xor(cnt, o); }
+  if (lane == 0) { w_sum[wv] = sum; w_cnt[wv] = cnt; }
+  __syncthreads();
+  int32_t run = 0, rk = 0, tot = 0, totc = 0;
+  for (int w = 0; w < nw; w++) {
+    if (w < wv) { run += w_sum[w]; rk += w_cnt[w]; }
+    tot += w_sum[w]; totc += w_cnt[w];
+  }
+  for (int i0 = lo; i0 < hi; i0 += 64) {
+    const int i = i0 + lane;
+    const bool in = i < hi;
+    int bin = b0 + min(i, hi - 1); bin = (bin >= R) ? bin - R : bin;
+    const int32_t v = in ? khist[bin] : 0;
+    int32_t is = v, ic = (v > 0);
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int32_t a1 = __shfl_up(is, o), c1 = __shfl_up(ic, o);
+      if (lane >= o) { is += a1; ic += c1; }
+    }
+    if (in) {
+      khist[bin] = 0;
+      kcount[i] = run + is - v;
+      krank[i] = rk + ic - (v > 0);
+    }
+    run += __shfl(is, 63);
+    rk += __shfl(ic, 63);
+  }
+  if (t == 0) { kcount[n] = tot; meta[GM_U] = totc; }
+}
+
+// An index build over more than GRAPH_WIDE_EDGES edges (a global bundle adjustment: 10^6 edges, an id range of 10^4 .. 10^5
+// bins) leaves the scan of the histogram to a launch of its own with four times the threads (cdv_graph_finish) instead of
+// the last workgroup of the histogram launch: hundreds of bins per thread of ONE 256-thread workgroup are hundreds of
+// microseconds, and one more launch is nothing there.  The per-frame builds stay at one launch.
+constexpr int GRAPH_WIDE_EDGES = 200000;
+
 struct HistArgs {
   const int64_t *jj, *kk;
   int32_t E;
@@ -265,10 +360,18 @@ __device__ __forceinline__ void graph_scan_body(int32_t* meta, const int32_t* __
 #pragma unroll
     for (int u = 0; u < PERMAX; u++) { sum += vals[u]; cnt += (vals[u] > 0); }
   } else {
-    for (int64_t i = lo; i < hi; i++) {
-      int bin = b0 + (int)i; bin = (bin >= R) ? bin - R : bin;
-      const int32_t v = __hip_atomic_load(&khist[bin], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      sum += v; cnt += (v > 0);
+    // a wide id range (the frame-pair index of a global bundle adjustment: ~10^5 bins, hundreds per thread): sixteen loads in
+    // flight at a time -- one by one they were 350 dependent microseconds
+    for (int64_t i0 = lo; i0 < hi; i0 += 16) {
+      int32_t v[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) {
+        int bin = b0 + (int)min(i0 + u, hi - 1); bin = (bin >= R) ? bin - R : bin;
+        v[u] = __hip_atomic_load(&khist[bin], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+      for (int u = 0; u < 16; u++)
+        if (i0 + u < hi) { sum += v[u]; cnt += (v[u] > 0); }
     }
   }
   // inclusive scan of the 1024 per-thread partials: shuffle scan inside each wave, then the 16 wave totals
@@ -310,19 +413,49 @@ __device__ __forceinline__ void graph_scan_body(int32_t* meta, const int32_t* __
       }
     }
   } else {
-    for (int64_t i = lo; i < hi; i++) {
-      int bin = b0 + (int)i; bin = (bin >= R) ? bin - R : bin;
-      const int32_t v = __hip_atomic_load(&khist[bin], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      khist[bin] = 0;
-      kcount[i] = run;
-      krank[i] = rk;
-      run += v; rk += (v > 0);
+    for (int64_t i0 = lo; i0 < hi; i0 += 16) {
+      int32_t v[16];
+      int bins[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) {
+        int bin = b0 + (int)min(i0 + u, hi - 1); bin = (bin >= R) ? bin - R : bin;
+        bins[u] = bin;
+        v[u] = __hip_atomic_load(&khist[bin], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+      for (int u = 0; u < 16; u++) {
+        if (i0 + u < hi) {
+          khist[bins[u]] = 0;
+          kcount[i0 + u] = run;
+          krank[i0 + u] = rk;
+          run += v[u]; rk += (v[u] > 0);
+        }
+      }
     }
   }
   if (t == T - 1) { kcount[n] = s_sum[t]; meta[GM_U] = s_cnt[t]; }
 }
 
 
+
+// One atomic per RUN of equal bins among the consecutive lanes of a wave (consecutive lanes hold consecutive edges): a list
+// that keeps the edges of a frame pair together -- the key of the bundle adjustment's pair index -- has runs of 64, and
+// same-address atomics serialise at ~90 ns each.  Every lane of the wave must call; `in` false: the lane has no edge.
+// Returns the value the run's counter had before (+ the lane's offset in the run): the lane's own slot.
+__device__ __forceinline__ int run_atomic_add(int32_t* counters, int bin, bool in, int lane) {
+  const int prev = __shfl_up(in ? bin : -1, 1);
+  const bool head = in && (lane == 0 || prev != bin);
+  const unsigned long long bound = __ballot(head || !in);
+  int base = 0;
+  if (head) {
+    const unsigned long long rest = lane == 63 ? 0ull : bound >> (lane + 1);
+    const int len = rest ? __ffsll((long long)rest) : 64 - lane;
+    base = atomicAdd(&counters[bin], len);
+  }
+  const unsigned long long heads_le = __ballot(head) & (~0ull >> (63 - lane));
+  const int hl = heads_le ? 63 - __clzll((long long)heads_le) : lane;   // lane of this run's head
+  return __shfl(base, in ? hl : lane) + (lane - hl);
+}
 
 __device__ __forceinline__ void graph_hist_body(const HistArgs& a, int bid, int nblocks, int nthreads_per_block, int tid) {
   constexpr int IMAXV = 0x7fffffff, IMINV = (int)0x80000000;
@@ -332,19 +465,22 @@ __device__ __forceinline__ void graph_hist_body(const HistArgs& a, int bid, int 
   __shared__ int s_obin[ORD_BINS];
   if (tid < ORD_BINS) s_obin[tid] = 0;
   __syncthreads();
-  for (int e = bid * nthreads_per_block + tid; e < a.E; e += nblocks * nthreads_per_block) {
-    const int k = (int)a.kk[e], j = (int)a.jj[e];
-    atomicAdd(&s_obin[j & (ORD_BINS - 1)], 1);
-    kmin = min(kmin, k); kmax = max(kmax, k);
-    jmin = min(jmin, j); jmax = max(jmax, j);
-    if (k >= 0) {
+  const int hl = tid & 63;
+  for (int e = bid * nthreads_per_block + tid; e - hl < a.E; e += nblocks * nthreads_per_block) {   // wave-uniform trip count
+    const bool in = e < a.E;
+    const int k = in ? (int)a.kk[e] : -1, j = in ? (int)a.jj[e] : 0;
+    int m = 0;
+    if (in) {
+      atomicAdd(&s_obin[j & (ORD_BINS - 1)], 1);
+      kmin = min(kmin, k); kmax = max(kmax, k);
+      jmin = min(jmin, j); jmax = max(jmax, j);
       // k mod R without an integer division: float quotient estimate, then one correction step each way
-      int q = (int)((float)k * rinv);
-      int m = k - q * R;
+      const int q = (int)((float)k * rinv);
+      m = k - q * R;
       m = (m < 0) ? m + R : m;
       m = (m >= R) ? m - R : m;
-      atomicAdd(&a.khist[m], 1);
     }
+    run_atomic_add(a.khist, m, in && k >= 0, hl);
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -382,6 +518,7 @@ __device__ __forceinline__ void graph_hist_body(const HistArgs& a, int bid, int 
   }
   __syncthreads();
   if (!s_last) return;
+  if (a.E > GRAPH_WIDE_EDGES) return;   // scanned by a launch of its own (see GRAPH_WIDE_EDGES)
   graph_scan_body(a.meta, a.stage, nblocks, a.khist, a.kcount, a.krank, a.E, (int64_t)a.R, nthreads_per_block, tid);
 }
 

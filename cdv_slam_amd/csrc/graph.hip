@@ -69,12 +69,12 @@ __global__ __launch_bounds__(256) void graph_hist_kernel(cdv::HistArgs a) {
   cdv::graph_hist_body(a, (int)blockIdx.x, (int)gridDim.x, (int)blockDim.x, (int)threadIdx.x);
 }
 
-// exclusive scan of the histogram as a launch of its own: only when there are no edges (no histogram launch whose last
-// workgroup would do it) -- body in cdv_parts.h
+// exclusive scan of the histogram as a launch of its own: when there are no edges (no histogram launch whose last
+// workgroup would do it), and for the wide builds (GRAPH_WIDE_EDGES) -- body in cdv_parts.h
 __global__ __launch_bounds__(1024) void graph_scan_kernel(int32_t* meta, const int32_t* __restrict__ stage,
                                                           int nstage, int32_t* khist, int32_t* kcount,
                                                           int32_t* krank, int32_t E, int64_t k_cap) {
-  cdv::graph_scan_body(meta, stage, nstage, khist, kcount, krank, E, k_cap, (int)blockDim.x, (int)threadIdx.x);
+  cdv::graph_scan_wide_body(meta, stage, nstage, khist, kcount, krank, E, k_cap, (int)blockDim.x, (int)threadIdx.x);
 }
 
 // index % modulus with the host's reciprocal (as the correlation kernel reduces kk / jj itself when it reads them)
@@ -115,11 +115,14 @@ __global__ __launch_bounds__(256) void graph_fill_kernel(const int64_t* __restri
   const int err = meta[GM_ERROR];
   const int krange = meta[GM_KRANGE], kmin = meta[GM_KMIN];
   int d_first = 0, p_first = 0, kc_first = 0, kr_first = 0;
-  if (!err && t_first < E) {
-    d_first = (int)kk_first - kmin;
-    p_first = atomicAdd(&kcursor[d_first], 1);
-    kc_first = kcount[d_first];
-    kr_first = krank[d_first];
+  const int flane = threadIdx.x & 63;
+  if (!err) {   // (workgroup-uniform; one cursor atomic per run of equal ids among the wave's consecutive edges)
+    d_first = t_first < E ? (int)kk_first - kmin : 0;
+    p_first = cdv::run_atomic_add(kcursor, d_first, t_first < E, flane);
+    if (t_first < E) {
+      kc_first = kcount[d_first];
+      kr_first = krank[d_first];
+    }
   }
   if (do_order) {
     __shared__ int s_tot[32][ORD_BINS + 1], s_pre[32][ORD_BINS + 1];
@@ -197,7 +200,10 @@ __global__ __launch_bounds__(256) void graph_fill_kernel(const int64_t* __restri
   }
   if (err) return;
   const int n = max(E, krange + 1);
-  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t - flane < n; t += gridDim.x * blockDim.x) {   // wave-uniform trip count
+    const bool first = t == t_first;   // (the whole wave's first trip, or nobody's)
+    int p_run = 0;
+    if (!first) p_run = cdv::run_atomic_add(kcursor, t < E ? (int)kk[t] - kmin : 0, t < E, flane);
     if (t <= krange) {  // dense bins -> unique ranks
       if (t == krange) {
         koff_u[meta[GM_U]] = kcount[krange];
@@ -208,10 +214,9 @@ __global__ __launch_bounds__(256) void graph_fill_kernel(const int64_t* __restri
       }
     }
     if (t < E) {
-      const bool first = t == t_first;
       const int d = first ? d_first : (int)kk[t] - kmin;
       const int jt = first ? (int)jj_first : (int)jj[t];
-      const int p = first ? p_first : atomicAdd(&kcursor[d], 1);
+      const int p = first ? p_first : p_run;
       // what the segment sort needs of the edge, in one 16-byte entry: it then walks the lists without going back to
       // kk / jj (three dependent load levels instead of five)
       *reinterpret_cast<int4*>(pcsr_tmp + 4 * (size_t)((first ? kc_first : kcount[d]) + p)) = make_int4(t, jt, d, 0);
@@ -716,7 +721,7 @@ int cdv_graph_finish(const int64_t* ii, const int64_t* jj, const int64_t* kk, in
   const int32_t En = (int32_t)E;
   const int tb = 256;
   const int fb = grid_for(E, tb, GRAPH_MAX_BLOCKS);
-  if (hist_blocks == 0)   // otherwise the last workgroup of the histogram launch has done the scan
+  if (hist_blocks == 0 || E > cdv::GRAPH_WIDE_EDGES)   // otherwise the last workgroup of the histogram launch has done the scan
     hipLaunchKernelGGL(graph_scan_kernel, dim3(1), dim3(1024), 0, s, v.meta, v.stage, hist_blocks, v.khist, v.kcount,
                        v.krank, En, k_range);
   if (E > 0) {

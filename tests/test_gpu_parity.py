@@ -1332,3 +1332,17 @@ def test_ba_dropin_inplace_contract():
 def test_update_path_end_to_end():
     import __graft_entry__ as ge
     ge.smoke()
+
+
+def test_global_ba_is_bitwise_reproducible():
+    """more than 32 free poses: every sum has one owner and a fixed order here too (patch owners for E, C, u; frame-pair
+    owners for B, v; pose owners for the diagonal blocks; tile owners for the Schur products) -- two runs, the same bits"""
+    st = synth.make_state("global", features=False)
+    assert st.n - st.t0 > 32
+    a = _run_ba(st, iterations=2)
+    b = _run_ba(st, iterations=2)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    _, _, d1 = _run_ba(st, iterations=1, debug=True)
+    _, _, d2 = _run_ba(st, iterations=1, debug=True)
+    for key in ("S", "y", "dX", "E", "C", "u"):
+        assert torch.equal(d1[key], d2[key]), key
