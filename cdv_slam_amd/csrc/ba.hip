@@ -709,49 +709,203 @@ __global__ __launch_bounds__(64) void ba_big_panel_kernel(float* __restrict__ A,
     *reinterpret_cast<cdv_float4*>(rowp + 4 * c4) = cdv_float4{x[4 * c4], x[4 * c4 + 1], x[4 * c4 + 2], x[4 * c4 + 3]};
 }
 
-// Block step kb, part 2: trailing update A[rb][cb] -= P_rb P_cb^T for kb < cb <= rb (and the right-hand-side row
-// against every cb) on the matrix cores; every target block is owned by one workgroup (no atomics).
-__global__ __launch_bounds__(256) void ba_big_update_kernel(float* __restrict__ A, int npad, int kb,
-                                                            const int32_t* __restrict__ gmeta,
-                                                            const int32_t* __restrict__ info) {
+// Block step kb >= 1 as ONE launch, the trailing update delayed by a step: what step kb - 1 owes the matrix is applied
+//   * to block column kb by the panel workgroups themselves, each to its own block and (redundantly) to the diagonal block,
+//     on the matrix cores, straight into the LDS the panel wave then reads its rows from;
+//   * to the blocks right of column kb by update workgroups, as in ba_big_update_kernel;
+// both need only panel kb - 1 (the previous launch) and touch disjoint blocks, so the panel chain of step kb (one wave,
+// ~18 us) no longer waits for a trailing-update launch of its own: 29 x (20 + 14.5 us + two launch gaps) became 29 x ~23.
+// Workgroups 0 .. nb - kb: panel (0 = diagonal block, last = the right-hand-side row); the rest: updates.
+constexpr int STEP_T = 512;   // threads of a step workgroup: eight waves share the 16 (update) or 32 (panel) tiles
+__global__ __launch_bounds__(STEP_T) void ba_big_step_kernel(float* __restrict__ A, int npad, int kb,
+                                                             const int32_t* __restrict__ gmeta, int32_t* __restrict__ info) {
   if (gmeta[GM_ERROR] || info[1]) return;
-  __shared__ float Pr[CNB * CLD];
-  __shared__ float Pc[CNB * CLD];
-  const int t = threadIdx.x;
+  __shared__ __attribute__((aligned(16))) float Pr[CNB * CLD];
+  __shared__ __attribute__((aligned(16))) float Pc[CNB * CLD];
+  __shared__ __attribute__((aligned(16))) float Ls[CNB * CLD];
+  __shared__ __attribute__((aligned(16))) float colb[CNB];
+  typedef float cdv_float2 __attribute__((ext_vector_type(2)));
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, c16 = lane & 15, g4 = lane >> 4;
   const int nb = npad / CNB;
-  const int T = nb - kb - 1;                 // trailing block rows / columns
-  const int ntri = T * (T + 1) / 2;
-  int rb, cb;
-  bool rhs = false;
-  if ((int)blockIdx.x < ntri) {
-    int ri = 0, ar = 0;
-    while (ar + ri + 1 <= (int)blockIdx.x) { ar += ri + 1; ri++; }
-    rb = kb + 1 + ri; cb = kb + 1 + ((int)blockIdx.x - ar);
-  } else {
-    rhs = true; rb = nb; cb = kb + 1 + ((int)blockIdx.x - ntri);
-  }
   const size_t lda = (size_t)npad;
-  const int c0 = CNB * kb;
-  for (int i = t; i < CNB * CNB; i += 256) {
-    const int r = i >> 6, c = i & 63;
-    Pr[r * CLD + c] = rhs ? (r == 0 ? A[(size_t)npad * lda + c0 + c] : 0.f) : A[(size_t)(CNB * rb + r) * lda + c0 + c];
-    Pc[r * CLD + c] = A[(size_t)(CNB * cb + r) * lda + c0 + c];
+  const int c0 = CNB * kb, cp = CNB * (kb - 1);   // columns of this step's panel / of the panel whose update is due
+  const int nA = nb - kb + 1;
+  if ((int)blockIdx.x >= nA) {
+    // ---- update role: block (rb, cb), cb > kb, or the right-hand-side row against column block cb ----
+    const int idx = (int)blockIdx.x - nA;
+    const int T = nb - kb - 1;
+    const int ntri = T * (T + 1) / 2;
+    int rb, cb;
+    bool rhs = false;
+    if (idx < ntri) {
+      int ri = 0, ar = 0;
+      while (ar + ri + 1 <= idx) { ar += ri + 1; ri++; }
+      rb = kb + 1 + ri; cb = kb + 1 + (idx - ar);
+    } else {
+      rhs = true; rb = nb; cb = kb + 1 + (idx - ntri);
+    }
+    for (int i = t; i < CNB * CNB; i += STEP_T) {
+      const int r = i >> 6, c = i & 63;
+      Pr[r * CLD + c] = rhs ? (r == 0 ? A[(size_t)npad * lda + cp + c] : 0.f) : A[(size_t)(CNB * rb + r) * lda + cp + c];
+      Pc[r * CLD + c] = A[(size_t)(CNB * cb + r) * lda + cp + c];
+    }
+    __syncthreads();
+    for (int tix = wave; tix < 16; tix += STEP_T / 64) {
+      const int ti = tix >> 2, tj = tix & 3;
+      const cdv_float4 acc = tile64_xyt(Pr, Pc, ti, tj, c16, g4);
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int r = 16 * ti + 4 * g4 + q, c = 16 * tj + c16;
+        if (rhs) {
+          if (r == 0) A[(size_t)npad * lda + CNB * cb + c] -= acc[q];
+        } else {
+          A[(size_t)(CNB * rb + r) * lda + CNB * cb + c] -= acc[q];
+        }
+      }
+    }
+    return;
   }
-  __syncthreads();
-  const int lane = t & 63, wave = t >> 6, c16 = lane & 15, g4 = lane >> 4;
-  for (int tix = wave; tix < 16; tix += 4) {
-    const int ti = tix >> 2, tj = tix & 3;
-    const cdv_float4 acc = tile64_xyt(Pr, Pc, ti, tj, c16, g4);
+  // ---- panel role ----
+  const int rb = kb + (int)blockIdx.x;          // block row handled here; rb == nb: the right-hand-side row
+  const bool rhs = rb == nb;
+  const bool diag = blockIdx.x == 0;
+  // panel kb - 1: this workgroup's rows (Pr) and the rows of block row kb (Pc); and, in the same round trip, the entries of
+  // the own block and of the diagonal block this wave's tiles will be subtracted from
+  constexpr int TU = 16 / (STEP_T / 64);   // tiles of each of the two blocks per wave
+  float o[TU][4], d[TU][4];
+#pragma unroll
+  for (int u = 0; u < TU; u++) {
+    const int tix = wave + (STEP_T / 64) * u, ti = tix >> 2, tj = tix & 3;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       const int r = 16 * ti + 4 * g4 + q, c = 16 * tj + c16;
-      if (rhs) {
-        if (r == 0) A[(size_t)npad * lda + CNB * cb + c] -= acc[q];
-      } else {
-        A[(size_t)(CNB * rb + r) * lda + CNB * cb + c] -= acc[q];
-      }
+      o[u][q] = rhs ? (r == 0 ? A[(size_t)npad * lda + c0 + c] : 0.f) : A[(size_t)(CNB * rb + r) * lda + c0 + c];
+      d[u][q] = A[(size_t)(c0 + r) * lda + c0 + c];
     }
   }
+  for (int i = t; i < CNB * CNB; i += STEP_T) {
+    const int r = i >> 6, c = i & 63;
+    Pr[r * CLD + c] = rhs ? (r == 0 ? A[(size_t)npad * lda + cp + c] : 0.f) : A[(size_t)(CNB * rb + r) * lda + cp + c];
+    Pc[r * CLD + c] = A[(size_t)(CNB * kb + r) * lda + cp + c];
+  }
+  __syncthreads();
+  // the 16 tiles of the own block and the 16 of the diagonal block, dealt to the waves: products in registers ...
+  cdv_float4 own[TU], dia[TU];
+#pragma unroll
+  for (int u = 0; u < TU; u++) {
+    const int tix = wave + (STEP_T / 64) * u, ti = tix >> 2, tj = tix & 3;
+    own[u] = tile64_xyt(Pr, Pc, ti, tj, c16, g4);
+    dia[u] = tile64_xyt(Pc, Pc, ti, tj, c16, g4);
+  }
+  __syncthreads();   // everybody is done reading the panels
+  // ... subtracted from the blocks, the results parked where the panels were: Pr <- own block (the right-hand side: its
+  // row 0), Pc <- diagonal block
+#pragma unroll
+  for (int u = 0; u < TU; u++) {
+    const int tix = wave + (STEP_T / 64) * u, ti = tix >> 2, tj = tix & 3;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int r = 16 * ti + 4 * g4 + q, c = 16 * tj + c16;
+      Pr[r * CLD + c] = o[u][q] - own[u][q];
+      Pc[r * CLD + c] = d[u][q] - dia[u][q];
+    }
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  // ---- from here on: ba_big_panel_kernel's single wave, its rows read from LDS ----
+  cdv_float2 a2[CNB / 2];
+#pragma unroll
+  for (int c4 = 0; c4 < CNB / 4; c4++) {
+    const cdv_float4 q = *reinterpret_cast<const cdv_float4*>(&Pc[lane * CLD + 4 * c4]);
+    a2[2 * c4] = cdv_float2{q[0], q[1]};
+    a2[2 * c4 + 1] = cdv_float2{q[2], q[3]};
+  }
+  float* rowp = A + (size_t)(rhs ? npad : CNB * min(rb, nb - 1) + lane) * lda + c0;
+  float x[CNB];
+#pragma unroll
+  for (int c4 = 0; c4 < CNB / 4; c4++) {
+    const cdv_float4 q = *reinterpret_cast<const cdv_float4*>(&Pr[(rhs ? 0 : lane) * CLD + 4 * c4]);
+    x[4 * c4] = q[0]; x[4 * c4 + 1] = q[1]; x[4 * c4 + 2] = q[2]; x[4 * c4 + 3] = q[3];
+  }
+  bool bad = false;
+  float Lk;
+  {
+    const float piv = readlane_f(a2[0][0], 0);
+    bad = !(piv > 0.f);
+    Lk = a2[0][0] * __builtin_amdgcn_rsqf(piv);
+    a2[0][0] = Lk;
+    colb[lane] = Lk;
+  }
+  cdv_float2 bcur[CNB / 2], bnxt[CNB / 2];
+#pragma unroll
+  for (int c4 = 0; c4 < CNB / 4; c4++) {
+    const cdv_float4 v = *reinterpret_cast<const cdv_float4*>(&colb[4 * c4]);
+    bcur[2 * c4] = cdv_float2{v[0], v[1]};
+    bcur[2 * c4 + 1] = cdv_float2{v[2], v[3]};
+  }
+#pragma unroll
+  for (int k = 0; k < CNB; k++) {
+    float Ln = 0.f;
+    if (k + 1 < CNB) {
+      const float an = fmaf(-Lk, readlane_f(Lk, k + 1), a2[(k + 1) >> 1][(k + 1) & 1]);
+      const float piv = readlane_f(an, k + 1);
+      bad = bad || !(piv > 0.f);                          // wave-uniform
+      Ln = an * __builtin_amdgcn_rsqf(piv);
+      a2[(k + 1) >> 1][(k + 1) & 1] = Ln;
+      colb[lane] = Ln;
+#pragma unroll
+      for (int c4 = (k + 2) / 4; c4 < CNB / 4; c4++) {
+        const cdv_float4 v = *reinterpret_cast<const cdv_float4*>(&colb[4 * c4]);
+        bnxt[2 * c4] = cdv_float2{v[0], v[1]};
+        bnxt[2 * c4 + 1] = cdv_float2{v[2], v[3]};
+      }
+    }
+    if (((k + 2) & 1) && k + 2 < CNB)
+      a2[(k + 2) >> 1][1] = fmaf(-Lk, bcur[(k + 2) >> 1][1], a2[(k + 2) >> 1][1]);
+    const cdv_float2 nLk = {-Lk, -Lk};
+#pragma unroll
+    for (int pp = (k + 3) >> 1; pp < CNB / 2; pp++) a2[pp] = __builtin_elementwise_fma(nLk, bcur[pp], a2[pp]);
+    Lk = Ln;
+#pragma unroll
+    for (int pp = (k + 2) >> 1; pp < CNB / 2; pp++) bcur[pp] = bnxt[pp];
+  }
+#pragma unroll
+  for (int c4 = 0; c4 < CNB / 4; c4++) {
+    cdv_float4 q;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int c = 4 * c4 + j;
+      q[j] = (c <= lane) ? a2[c >> 1][c & 1] : 0.f;
+    }
+    *reinterpret_cast<cdv_float4*>(&Ls[lane * CLD + 4 * c4]) = q;
+    if (diag) {
+      float* dst = A + (size_t)(c0 + lane) * lda + c0 + 4 * c4;
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if (4 * c4 + j <= lane) dst[j] = q[j];
+    }
+  }
+  if (diag) {
+    if (lane == 0 && bad && info[BI_CHOL] == 0) ba_flag(info, BI_CHOL, kb + 1);
+    return;
+  }
+  wave_lds_sync();
+  if (rhs && lane > 0) return;                    // the right-hand side is one row
+#pragma unroll
+  for (int c = 0; c < CNB; c++) {
+    float sacc = x[c];
+#pragma unroll
+    for (int j4 = 0; j4 < (c + 3) / 4; j4++) {
+      const cdv_float4 l = *reinterpret_cast<const cdv_float4*>(&Ls[c * CLD + 4 * j4]);
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if (4 * j4 + j < c) sacc = fmaf(-x[4 * j4 + j], l[j], sacc);
+    }
+    x[c] = sacc / Ls[c * CLD + c];
+  }
+#pragma unroll
+  for (int c4 = 0; c4 < CNB / 4; c4++)
+    *reinterpret_cast<cdv_float4*>(rowp + 4 * c4) = cdv_float4{x[4 * c4], x[4 * c4 + 1], x[4 * c4 + 2], x[4 * c4 + 3]};
 }
 
 // L^T x = z (z = row npad of A after the factorisation), one launch per 64-block from the bottom.  Every workgroup of
@@ -1063,12 +1217,12 @@ extern "C" int cdv_ba_forward(float* poses, float* patches, const float* intrins
                          (int)L.U_stride, cmask, n_chunks, info);
       hipLaunchKernelGGL(ba_big_fold_kernel, dim3(1024), dim3(256), 0, s, sy, (int)L.sy_stride, n6i, npad, Abig, gv.meta,
                          d, info);
-      for (int kb = 0; kb < nbk; kb++) {
-        hipLaunchKernelGGL(ba_big_panel_kernel, dim3(nbk - kb + 1), dim3(64), 0, s, Abig, npad, kb, gv.meta, info);
+      // block step 0: the panel alone; block step kb >= 1: the panel together with what step kb - 1 owes the matrix
+      hipLaunchKernelGGL(ba_big_panel_kernel, dim3(nbk + 1), dim3(64), 0, s, Abig, npad, 0, gv.meta, info);
+      for (int kb = 1; kb < nbk; kb++) {
         const int T = nbk - kb - 1;
-        if (T > 0)
-          hipLaunchKernelGGL(ba_big_update_kernel, dim3(T * (T + 1) / 2 + T), dim3(256), 0, s, Abig, npad, kb, gv.meta,
-                             info);
+        hipLaunchKernelGGL(ba_big_step_kernel, dim3(nbk - kb + 1 + T * (T + 1) / 2 + T), dim3(STEP_T), 0, s, Abig, npad, kb, gv.meta,
+                           info);
       }
       for (int kb = nbk - 1; kb >= 0; kb--)
         hipLaunchKernelGGL(ba_big_backstep_kernel, dim3(kb > 0 ? cdv_div_up(CNB * kb, 256) : 1), dim3(256), 0, s, Abig, npad,
