@@ -479,26 +479,39 @@ __global__ __launch_bounds__(256) void ba_schur_kernel(const float* __restrict__
     for (int w = 0; w < 4; w++) { const int n = wcnt[w]; before += (w < wave) ? n : 0; total += n; }
     if (hit) lst[before + __popcll(bal & ((1ull << lane) - 1ull))] = c;
     __syncthreads();
-    for (int i = 0; i < total; i++) {
-      const int chunk = lst[i];
+    // the panels of a chunk travel memory -> registers -> LDS, one chunk ahead of the products (a chunk's MFMA work is
+    // shorter than its memory round trip)
+    constexpr int LPT = SPR * (BA_CHUNK / 4) / 256;   // 16-byte loads per thread and panel (3)
+    cdv_float4 ra[LPT], rbv[LPT];
+    float rq = 0.f, rqu = 0.f;
+    const auto fetch = [&](int chunk) {
       const int r0 = chunk * BA_CHUNK;
       if (tid < BA_CHUNK) {
         const int rr = r0 + tid;
-        const float q = (rr < U) ? 1.0f / (Cg[rr] + lm) : 0.f;
-        qs[tid] = q;
-        qu[tid] = (rr < U) ? q * ug[rr] : 0.f;
+        rq = (rr < U) ? 1.0f / (Cg[rr] + lm) : 0.f;
+        rqu = (rr < U) ? rq * ug[rr] : 0.f;
       }
-      for (int half = 0; half < (pa == pb ? 1 : 2); half++) {
-        float* dstE = half == 0 ? Ea : Eb;
-        const int rowbase = SPR * (half == 0 ? pa : pb);
-        for (int i4 = tid; i4 < SPR * (BA_CHUNK / 4); i4 += 256) {
-          const int row = i4 >> 4, k4 = (i4 & 15) * 4;
-          const int grow = rowbase + row;
-          const cdv_float4 v = (grow < n6) ? *reinterpret_cast<const cdv_float4*>(Edg + (size_t)grow * U_stride + r0 + k4) : z4;
-          *reinterpret_cast<cdv_float4*>(dstE + row * ELD + k4) = v;
-        }
+#pragma unroll
+      for (int l = 0; l < LPT; l++) {
+        const int i4 = tid + 256 * l;
+        const int row = i4 >> 4, k4 = (i4 & 15) * 4;
+        const int ga = SPR * pa + row, gb = SPR * pb + row;
+        ra[l] = (ga < n6) ? *reinterpret_cast<const cdv_float4*>(Edg + (size_t)ga * U_stride + r0 + k4) : z4;
+        rbv[l] = (pa != pb && gb < n6) ? *reinterpret_cast<const cdv_float4*>(Edg + (size_t)gb * U_stride + r0 + k4) : z4;
+      }
+    };
+    if (total > 0) fetch(lst[0]);
+    for (int i = 0; i < total; i++) {
+      if (tid < BA_CHUNK) { qs[tid] = rq; qu[tid] = rqu; }
+#pragma unroll
+      for (int l = 0; l < LPT; l++) {
+        const int i4 = tid + 256 * l;
+        const int row = i4 >> 4, k4 = (i4 & 15) * 4;
+        *reinterpret_cast<cdv_float4*>(Ea + row * ELD + k4) = ra[l];
+        if (pa != pb) *reinterpret_cast<cdv_float4*>(Eb + row * ELD + k4) = rbv[l];
       }
       __syncthreads();
+      if (i + 1 < total) fetch(lst[i + 1]);   // in flight during the products
 #pragma unroll
       for (int u = 0; u < 3; u++) {
         const int tix = wave + 4 * u;   // tiles 0 .. 8: (ti, tj) = (tix / 3, tix % 3)
