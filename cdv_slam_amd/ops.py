@@ -719,8 +719,8 @@ class _LevelPairing:
             shadow = _nhwc.get(fmap2)          # in step already (synchronised by the first call; the version has not moved)
             N2, H2, W2 = fmap2.shape[1], fmap2.shape[3], fmap2.shape[4]
             C = fmap1.shape[2]
-            g = fmap1[0].contiguous()
-            rc = lib.cdv_corr_level_checked_interleaved(_p(g), _p(shadow[0]), _p(coords), _p(pend["coords"]), 1.0 / pend["ratio"],
+            g = fmap1 if fmap1.is_contiguous() else fmap1[0].contiguous()    # batch 1: the same bytes either way
+            rc = lib.cdv_corr_level_checked_interleaved(_p(g), _p(shadow), _p(coords), _p(pend["coords"]), 1.0 / pend["ratio"],
                                                         _p(ii), _p(jj), _p(pend["buf"]), 1, E, g.numel() // (C * 9), N2, C, H2, W2,
                                                         1.0, 0, 0, 0, _stream())
             _lib.check(rc, "cdv_corr_level_checked_interleaved")
@@ -962,11 +962,15 @@ def ba_forward(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, PP
     dev = poses.device
     if E == 0:
         return []
-    target = target.reshape(-1, 2).float().contiguous()
-    weight = weight.reshape(-1, 2).float().contiguous()
+    # only pointers travel: a contiguous float32 tensor goes as it is (the reshapes / casts below cost 2 us each on the host)
+    if target.dtype != torch.float32 or not target.is_contiguous():
+        target = target.reshape(-1, 2).float().contiguous()
+    if weight.dtype != torch.float32 or not weight.is_contiguous():
+        weight = weight.reshape(-1, 2).float().contiguous()
     if not torch.is_tensor(lmbda):
         lmbda = torch.tensor([float(lmbda)], dtype=torch.float32, device=dev)
-    lmbda = lmbda.reshape(-1).float().contiguous().to(dev)
+    if lmbda.dtype != torch.float32 or not lmbda.is_contiguous() or lmbda.device != dev:
+        lmbda = lmbda.reshape(-1).float().contiguous().to(dev)
     ii, jj, kk = ii.contiguous(), jj.contiguous(), kk.contiguous()
     g = graph if graph is not None else _device_graph(dev)
     g.index_for_ba(jj, kk, ii, N)

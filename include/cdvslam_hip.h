@@ -306,8 +306,9 @@ int cdv_neighbors(const void* ws, int64_t E, int64_t* ix, int64_t* jx, void* str
  * fastba  (replaces cuda_ba.forward, ba.cpp:31-45, ba_cuda.cu:462-611)
  * ---------------------------------------------------------------------------------------------- */
 
-/* bytes of device workspace for up to U_max unique patches and N_max <= 1024 free poses (the dense E,
- * 6 N_max x round_up(U_max, 64) floats, dominates: 2.4 GB at N = 1024, U = 100k) */
+/* bytes of device workspace for up to E_max edges, U_max unique patches and N_max <= 1024 free poses (the dense E,
+ * 6 N_max x round_up(U_max, 64) floats, dominates: 2.4 GB at N = 1024, U = 100k; for N_max > 32 the workspace also holds
+ * the frame-pair index of the call's edges, ~250 bytes per edge, which is where E_max counts) */
 size_t cdv_ba_workspace_bytes(int64_t E_max, int64_t U_max, int N_max);
 
 /*
@@ -326,9 +327,10 @@ size_t cdv_ba_workspace_bytes(int64_t E_max, int64_t U_max, int N_max);
  *   dbg (optional, NULL): receives iteration-0 values, with n = 6N and Us = round_up(U_max, 64):
  *             [S n*n (damped) | y n | dX n | dZ Us | C Us | u Us | E n*Us]
  *             (N > 32: only the lower triangle of S is accumulated)
- * 1 <= N = t1 - t0 <= 10 (the optimisation window): two launches per iteration, no float atomics -- results are
- * bitwise reproducible; <= 32: single-workgroup LDS Cholesky; <= 1024 (global BA, slam.py:460-478): Schur products per
- * (64-patch chunk, pair of 32-pose panels with non-zero E), blocked multi-workgroup Cholesky.  More: CDV_ERR_UNSUPPORTED.
+ * Every path sums with one owner and a fixed order per entry -- no float atomic anywhere, results bitwise reproducible:
+ * 1 <= N = t1 - t0 <= 10 (the optimisation window): two launches per iteration; <= 32: three, a single-workgroup LDS Cholesky;
+ * <= 1024 (global BA, slam.py:460-478): patch / frame-pair / pose / tile owners (the pair index is built inside the call),
+ * blocked multi-workgroup Cholesky.  More: CDV_ERR_UNSUPPORTED.
  * Failures inside the launches (not positive definite, U_max exceeded, ...) are reported by cdv_ba_status.
  */
 int cdv_ba_forward(float* poses, float* patches, const float* intrinsics, const float* target, const float* weight,
