@@ -282,7 +282,7 @@ def main():
     if st.fmap1 is not None and not args.no_dropin:
         from cdv_slam_amd.update import DropinPath
         dp = DropinPath(st, dev)
-        nd = max(10, min(args.steps, 100))
+        nd = 100                      # its own fixed count: the sub-records do not depend on --steps
         for _ in range(5):
             dp.step()
         torch.cuda.synchronize()
@@ -307,7 +307,7 @@ def main():
             for _ in range(30):
                 up2.step()
             torch.cuda.synchronize()
-            n2 = max(20, min(args.steps, 200))
+            n2 = 200
             t2 = time.perf_counter()
             for _ in range(n2):
                 up2.step()
@@ -324,8 +324,10 @@ def main():
             run = StreamRunner(dev)
             for _ in range(45):       # reach the steady state (E = 47,712 at the default window)
                 run.frame(drop=False)
+            for f in range(9):        # ... and the removal path's first-use costs (allocations, lazily loaded kernels)
+                run.frame(drop=(f % 3 == 2))
             torch.cuda.synchronize()
-            nf = max(30, min(args.steps, 300))
+            nf = 200
             ts = time.perf_counter()
             for f in range(nf):
                 n_kf, E_s = run.frame(drop=(f % 3 == 2))

@@ -1346,3 +1346,43 @@ def test_global_ba_is_bitwise_reproducible():
     _, _, d2 = _run_ba(st, iterations=1, debug=True)
     for key in ("S", "y", "dX", "E", "C", "u"):
         assert torch.equal(d1[key], d2[key]), key
+
+
+def test_global_ba_irregular_graph():
+    """more than 32 free poses on edge lists the front-end never builds but the API admits: a third of the edges dropped,
+    the order shuffled, duplicated edges (the same patch to the same target frame twice: neighbours in the patch's list),
+    self edges (i == j), and patches whose edges name TWO source frames (the patch owner of E switches its lane to
+    read-modify-writes; the pair index simply files the edge under another pair) -- intermediates against the float64
+    oracle, and the same bits from run to run"""
+    st = synth.make_state("global", features=False)
+    N = st.n - st.t0
+    assert N > 32
+    rng = np.random.default_rng(23)
+    sel = np.flatnonzero(rng.random(st.E) > 0.33)
+    sel = np.concatenate([sel, sel[rng.integers(0, len(sel), 60)]])      # duplicates
+    rng.shuffle(sel)
+    st.ii, st.jj, st.kk = st.ii[sel].copy(), st.jj[sel].copy(), st.kk[sel].copy()
+    st.target, st.weight = st.target[sel].copy(), st.weight[sel].copy()
+    # self edges of free frames, and a second source frame for some edges (free and fixed ones)
+    pick = rng.choice(len(sel), 80, replace=False)
+    st.jj[pick[:30]] = st.ii[pick[:30]]
+    st.ii[pick[30:70]] = rng.integers(st.t0, st.n, 40)
+    st.ii[pick[70:]] = rng.integers(0, max(st.t0, 1), 10)
+    assert ((st.ii == st.jj) & (st.ii >= st.t0)).any()
+    _, _, dbg = _run_ba(st, iterations=1, debug=True)
+    _, _, info, o = O.fastba(st.poses, st.patches, st.intrinsics[0], st.target, st.weight, st.lmbda, st.ii, st.jj,
+                             st.kk, st.t0, st.n, 1, np.float64, debug=True)
+    assert info == 0
+    U = len(o["kx"])
+    S = np.tril(dbg["S"].cpu().numpy())
+    assert np.abs(S - np.tril(o["S"])).max() <= 1e-4 * np.abs(o["S"]).max()
+    for key, got, want in (("y", dbg["y"], o["y"]), ("C", dbg["C"][:U], o["C"]), ("u", dbg["u"][:U], o["u"]),
+                           ("E", dbg["E"][:, :U], o["E"])):
+        assert np.abs(got.cpu().numpy() - want).max() <= 1e-4 * np.abs(want).max(), key
+    _, _, dbg2 = _run_ba(st, iterations=1, debug=True)
+    for key in ("S", "y", "dX", "E", "C", "u"):
+        assert torch.equal(dbg[key], dbg2[key]), key
+    a = _run_ba(st, iterations=2)
+    b = _run_ba(st, iterations=2)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert np.isfinite(a[0]).all() and np.isfinite(a[1]).all()
