@@ -100,3 +100,17 @@ def test_synth_graph_sizes():
         assert len(ii) == E and len(np.unique(kk)) == U
     st = synth.make_state("default", features=False)
     assert st.n - st.t0 == 10
+
+
+def test_ba_workspace_accounts_for_the_pair_index():
+    """the global bundle adjustment (more than 32 free poses) builds a frame-pair index of the call's edges inside its
+    workspace: cdv_ba_workspace_bytes grows with E_max there, and only there (host arithmetic, no GPU call)"""
+    from cdv_slam_amd import _lib
+    lib = _lib.load()
+    small = [lib.cdv_ba_workspace_bytes(E, 4096, 10) for E in (1000, 1000000)]
+    assert small[0] == small[1]
+    big = [lib.cdv_ba_workspace_bytes(E, 4096, 64) for E in (1000, 100000, 1000000)]
+    assert big[0] < big[1] < big[2]
+    # ~250 bytes per edge of index workspace + 8 of keys, and at most (N + 1)(N + 2) / 2 pair slots of 384 bytes
+    per_edge = (big[2] - big[1]) / 900000.0
+    assert 100.0 < per_edge < 600.0

@@ -102,3 +102,31 @@ def test_iproj_proj_pinhole_maps():
         fx, fy, cx, cy = intr[0, n]
         assert torch.allclose(uv[0, n, ..., 0], fx * (d[0, n] * Y[0, n, ..., 0]) + cx)
         assert torch.allclose(uv[0, n, ..., 1], fy * (d[0, n] * Y[0, n, ..., 1]) + cy)
+
+
+def test_switches_are_read_live():
+    """the environment switches (CDV_CHECK, CDV_INDEX, CDV_PAIR_LEVELS, CDV_TABLE_CAPACITY) are documented as live: a change
+    of os.environ is seen by the next call, although they are read without os.environ's encode / decode round trip"""
+    import os
+    from cdv_slam_amd import ops
+    keep = {k: os.environ.get(k) for k in ("CDV_CHECK", "CDV_PAIR_LEVELS", "CDV_INDEX")}
+    try:
+        os.environ["CDV_CHECK"] = "1"
+        assert ops._sync_check()
+        os.environ["CDV_CHECK"] = "0"
+        assert not ops._sync_check()
+        os.environ.pop("CDV_PAIR_LEVELS", None)
+        assert ops.pair_levels_enabled()
+        os.environ["CDV_PAIR_LEVELS"] = "0"
+        assert not ops.pair_levels_enabled()
+        os.environ["CDV_INDEX"] = "ranked"
+        assert not ops.prefer_table()
+        del os.environ["CDV_INDEX"]
+        assert ops.prefer_table()
+        assert ops._env("CDV_NO_SUCH_SWITCH", "dflt") == "dflt"
+    finally:
+        for k, v in keep.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
