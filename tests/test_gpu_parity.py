@@ -1386,3 +1386,62 @@ def test_global_ba_irregular_graph():
     b = _run_ba(st, iterations=2)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     assert np.isfinite(a[0]).all() and np.isfinite(a[1]).all()
+
+
+# ---------------------------------------------------------------------------------------------------
+# size-independent properties at the benchmark sizes (no oracle run needed: they hold bit for bit)
+# ---------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("name", ["default", "stress"])
+def test_corr_properties_at_benchmark_size(name):
+    """linearity and equivariance of the fused correlation on the benchmark workloads (E = 47,712 / 97,412).
+    (1) Doubling every feature map doubles every output: products and sums scale by a power of two without rounding
+    (f16 storage, f32 accumulation, f16 raw volume, bilinear blend), except where a value passes through half precision's
+    SUBNORMAL range, whose spacing (6e-8) is absolute -- so: equal to within one unit in the last place + two subnormal
+    steps, and bit for bit on more than 99 % of the outputs; any dropped or doubly counted term breaks it.  (2) Permuting the edge list permutes the output rows, bit for bit -- through the index-independent direct call
+    and with the processing order of a permuted list's own index.  (3) A patch tile of zeros gives zeros."""
+    from cdv_slam_amd.update import UpdatePath
+    st = synth.make_state(name)
+    up = UpdatePath(st, torch.device(DEV))
+    coords = _gpu_coords(st)
+    base = ops.corr_fused(up.gmap, up.fmap1, up.fmap2, coords, up.kk, up.jj, kmod=up.kmod, jmod=up.jmod)
+    torch.cuda.synchronize()
+    assert base.shape == (1, st.E, 882) and bool(torch.isfinite(base.float()).all())
+    assert float(base.float().abs().max()) < 2.0 ** 14          # doubling stays inside half precision
+    # (1) linearity in the maps
+    twice = ops.corr_fused(up.gmap, up.fmap1 * 2, up.fmap2 * 2, coords, up.kk, up.jj, kmod=up.kmod, jmod=up.jmod)
+    def doubled(t):
+        want = (base * 2).float()
+        diff = (t.float() - want).abs()
+        assert bool((diff <= want.abs() * 2.0 ** -10 + 2.4e-7).all())
+        assert float((diff == 0).float().mean()) > 0.99
+    doubled(twice)
+    # ... and in the patch tiles
+    doubled(ops.corr_fused(up.gmap * 2, up.fmap1, up.fmap2, coords, up.kk, up.jj, kmod=up.kmod, jmod=up.jmod))
+    # (2) edge permutation
+    perm = torch.randperm(st.E, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))
+    pc, pk, pj = coords[:, perm].contiguous(), up.kk[perm].contiguous(), up.jj[perm].contiguous()
+    permuted = ops.corr_fused(up.gmap, up.fmap1, up.fmap2, pc, pk, pj, kmod=up.kmod, jmod=up.jmod)
+    assert torch.equal(permuted, base[:, perm])
+    g = ops.GraphIndex(torch.device(DEV), E_cap=st.E, k_range=len(st.patches))
+    g.build(pj, pk, force=True)
+    ordered = ops.corr_fused(up.gmap, up.fmap1, up.fmap2, pc, pk, pj, kmod=up.kmod, jmod=up.jmod,
+                             order_ptr=g.corr_order_ptr())
+    assert torch.equal(ordered, base[:, perm])
+    # (3) zero tiles
+    zeros = ops.corr_fused(torch.zeros_like(up.gmap), up.fmap1, up.fmap2, coords, up.kk, up.jj, kmod=up.kmod, jmod=up.jmod)
+    assert float(zeros.float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("name", ["default", "stress", "global"])
+def test_ba_with_zero_weights_changes_nothing(name):
+    """a bundle adjustment whose residuals all carry weight zero has B = 0, v = 0, E = 0, u = 0: the damped system is
+    the identity with a zero right-hand side, dX = 0, dZ = 0 -- poses and patches must come back BIT FOR BIT (Exp(0) T = T,
+    d + 0 = d), on all three paths (10, 22 and 79 free poses) at their full sizes; the status words stay clear"""
+    st = synth.make_state(name, features=False)
+    st.weight = np.zeros_like(st.weight)
+    assert st.patches[np.unique(st.kk), 2].max() < 20.0 and st.patches[np.unique(st.kk), 2].min() > 1e-4   # no clamp fires
+    poses, patches, _ = _run_ba(st, iterations=2)
+    assert np.array_equal(poses, st.poses)
+    assert np.array_equal(patches, st.patches)
+    assert ops.ba_status(torch.device(DEV)) == (0, 0, 0, 0)
