@@ -921,52 +921,114 @@ __global__ __launch_bounds__(STEP_T) void ba_big_step_kernel(float* __restrict__
     *reinterpret_cast<cdv_float4*>(rowp + 4 * c4) = cdv_float4{x[4 * c4], x[4 * c4 + 1], x[4 * c4 + 2], x[4 * c4 + 3]};
 }
 
-// L^T x = z (z = row npad of A after the factorisation), one launch per 64-block from the bottom.  Every workgroup of
-// step kb loads L_kk and z_kb and solves the 64 unknowns in wave 0's registers (redundantly; lane k holds column k of
-// L_kk: one v_readlane + FMA per unknown); workgroup 0 publishes x_kb, workgroup w folds it into the z of its 256
-// columns to the left of the block (every column is owned by one workgroup: no atomics).
-__global__ __launch_bounds__(256) void ba_big_backstep_kernel(float* __restrict__ A, int npad, int n, int kb,
-                                                              float* __restrict__ dXg, const int32_t* __restrict__ gmeta,
-                                                              float* __restrict__ dbg, const int32_t* __restrict__ info) {
+// L^T x = z as ONE launch: workgroup w owns columns 256 w .. 256 w + 255 of z, one per thread, IN REGISTERS for the whole
+// sweep.  Step kb (from the bottom): the wave whose 64 columns are block kb solves its 64 unknowns (lane k holds column k of
+// L_kk: one v_readlane + FMA per unknown) and publishes them as {launch token, value} granules, written through; every
+// workgroup picks them up (the poll is the load) and folds them into its columns left of the block -- all 64 row loads
+// of a thread in flight together.  The next block's L_kk is fetched before the wait.  29 launches of 8.7 us became one
+// chain of ~5 us steps.  Bounded polls: a lost hand-off raises the hand-off word and leaves dX at what was written.
+__global__ __launch_bounds__(256) void ba_big_backsolve_kernel(float* __restrict__ A, int npad, int n,
+                                                               float* __restrict__ dXg, uint64_t* __restrict__ xg, int token,
+                                                               const int32_t* __restrict__ gmeta, float* __restrict__ dbg,
+                                                               int32_t* __restrict__ info) {
   if (gmeta[GM_ERROR] || info[1]) return;
   __shared__ __attribute__((aligned(16))) float Lb[CNB * CLD];
   __shared__ float xs[CNB];
-  const int t = threadIdx.x;
+  __shared__ int s_ok;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const size_t lda = (size_t)npad;
-  const int c0 = CNB * kb;
-  float* zrow = A + (size_t)npad * lda;
-  for (int i = t; i < CNB * CNB; i += 256) {
-    const int r = i >> 6, c = i & 63;
-    Lb[r * CLD + c] = (c <= r) ? A[(size_t)(c0 + r) * lda + c0 + c] : 0.f;
+  const int nb = npad / CNB;
+  const int cc = (int)blockIdx.x * 256 + t;        // this thread's column of z
+  const float* zrow = A + (size_t)npad * lda;
+  float z = cc < npad ? zrow[cc] : 0.f;
+  // L_kk of the first block this workgroup solves, if it is the very first step's (no step before it to hide the load in)
+  {
+    const int c0 = CNB * (nb - 1);
+    if ((c0 >> 8) == (int)blockIdx.x)
+      for (int i = t; i < CNB * CNB; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        Lb[r * CLD + c] = (c <= r) ? A[(size_t)(c0 + r) * lda + c0 + c] : 0.f;
+      }
   }
-  __syncthreads();
-  if (t < 64) {   // x_r = z_r / L[r][r] once every x_j, j > r, has been folded into z (as in ba_solve60_kernel)
-    float col[CNB];
+  for (int kb = nb - 1; kb >= 0; kb--) {
+    const int c0 = CNB * kb;
+    if (c0 + CNB <= (int)blockIdx.x * 256) break;   // this block and all that follow lie left of my columns: nothing of
+                                                     // them folds into mine (workgroup-uniform)
+    const bool owner = (c0 >> 8) == (int)blockIdx.x;   // block kb lies inside this workgroup's columns
+    const bool owner_next = kb > 0 && ((c0 - CNB) >> 8) == (int)blockIdx.x;
+    // requested BEFORE the wait, neither depends on x: the rows of L this thread folds with, and (the next step's owner) the
+    // next diagonal block
+    float l[CNB];
 #pragma unroll
-    for (int r = 0; r < CNB; r++) col[r] = Lb[r * CLD + t];   // column t of L_kk: L[r][t], zero for r < t
-    float z = zrow[c0 + t];
-    const float invd = 1.0f / Lb[t * CLD + t];
-    float x = 0.f;
+    for (int r = 0; r < CNB; r++) l[r] = (cc < c0) ? A[(size_t)(c0 + r) * lda + cc] : 0.f;
+    float pre[CNB * CNB / 256];
+    if (owner_next) {
 #pragma unroll
-    for (int r = CNB - 1; r >= 0; r--) {
-      const float xr = readlane_f(z * invd, r);
-      x = (t == r) ? xr : x;
-      z = fmaf(-col[r], xr, z);
+      for (int u = 0; u < CNB * CNB / 256; u++) {
+        const int i = t + 256 * u, r = i >> 6, c = i & 63;
+        pre[u] = (c <= r) ? A[(size_t)(c0 - CNB + r) * lda + c0 - CNB + c] : 0.f;
+      }
     }
-    xs[t] = x;
-    if (blockIdx.x == 0 && c0 + t < n) {
-      dXg[c0 + t] = x;
-      if (dbg) dbg[(size_t)n * n + n + c0 + t] = x;
+    if (t == 0) s_ok = 1;
+    __syncthreads();   // Lb holds L_kk (written a step ago, or above)
+    if (owner) {
+      if (wave == ((c0 & 255) >> 6)) {   // this wave's z IS block kb's: x_r = z_r / L[r][r] once every x_j, j > r, is folded in
+        float col[CNB];
+#pragma unroll
+        for (int r = 0; r < CNB; r++) col[r] = Lb[r * CLD + lane];   // column `lane` of L_kk: L[r][lane], zero for r < lane
+        const float invd = 1.0f / Lb[lane * CLD + lane];
+        float zz = z, x = 0.f;
+#pragma unroll
+        for (int r = CNB - 1; r >= 0; r--) {
+          const float xr = readlane_f(zz * invd, r);
+          x = (lane == r) ? xr : x;
+          zz = fmaf(-col[r], xr, zz);
+        }
+        xs[lane] = x;
+        __hip_atomic_store(&xg[c0 + lane], ((uint64_t)(uint32_t)token << 32) | (uint64_t)(uint32_t)__float_as_int(x),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (c0 + lane < n) {
+          dXg[c0 + lane] = x;
+          if (dbg) dbg[(size_t)n * n + n + c0 + lane] = x;
+        }
+      }
+    } else if (wave == 0) {
+      float xv = 0.f;
+      bool ok = false;
+      for (int spins = 0; spins < (1 << 20); spins++) {
+        if (!ok) {
+          const uint64_t g = __hip_atomic_load(&xg[c0 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((uint32_t)(g >> 32) == (uint32_t)token) { xv = __int_as_float((int)(uint32_t)g); ok = true; }
+        }
+        if (__all(ok)) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      xs[lane] = xv;
+      if (!ok) s_ok = 0;
     }
-  }
-  __syncthreads();
-  // z[c'] -= sum_r L[c0 + r][c'] x_r for this workgroup's columns left of the block
-  const int cc = (int)blockIdx.x * 256 + t;
-  if (cc < c0) {
-    float sacc = 0.f;
-#pragma unroll 16
-    for (int r = 0; r < CNB; r++) sacc += A[(size_t)(c0 + r) * lda + cc] * xs[r];
-    zrow[cc] -= sacc;
+    __syncthreads();
+    if (!s_ok) {
+      if (t == 0) ba_flag(info, BI_HANDOFF, 1);
+      return;
+    }
+    // z[cc] -= sum_r L[c0 + r][cc] x_r (zero rows for a column that is not left of the block)
+    {
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+      for (int r = 0; r < CNB; r += 4) {
+        s0 = fmaf(l[r], xs[r], s0); s1 = fmaf(l[r + 1], xs[r + 1], s1);
+        s2 = fmaf(l[r + 2], xs[r + 2], s2); s3 = fmaf(l[r + 3], xs[r + 3], s3);
+      }
+      z -= (s0 + s1) + (s2 + s3);
+    }
+    __syncthreads();   // xs and Lb are rewritten
+    if (owner_next) {
+#pragma unroll
+      for (int u = 0; u < CNB * CNB / 256; u++) {
+        const int i = t + 256 * u, r = i >> 6, c = i & 63;
+        Lb[r * CLD + c] = pre[u];
+      }
+    }
   }
 }
 
@@ -1147,6 +1209,7 @@ extern "C" int cdv_ba_forward(float* poses, float* patches, const float* intrins
     if (!window) CDV_HIP_CHECK(hipMemsetAsync(b + L.sy, 0, L.zero_bytes, s));   // the window path keeps no accumulators
     CDV_HIP_CHECK(hipMemsetAsync(info, 0, sizeof(int32_t) * 16 + sizeof(uint64_t) * MID_GRAN, s));
     if (window) CDV_HIP_CHECK(hipMemsetAsync(b + L.hand, 0, sizeof(int32_t) * HAND_WORDS, s));   // token 0, no flag set
+    if (big) CDV_HIP_CHECK(hipMemsetAsync(b + L.xgran, 0, sizeof(uint64_t) * (size_t)L.npad, s));   // no granule carries a token
   }
   if (window) {
     BaWinArgs wa;
@@ -1237,9 +1300,8 @@ extern "C" int cdv_ba_forward(float* poses, float* patches, const float* intrins
         hipLaunchKernelGGL(ba_big_step_kernel, dim3(nbk - kb + 1 + T * (T + 1) / 2 + T), dim3(STEP_T), 0, s, Abig, npad, kb, gv.meta,
                            info);
       }
-      for (int kb = nbk - 1; kb >= 0; kb--)
-        hipLaunchKernelGGL(ba_big_backstep_kernel, dim3(kb > 0 ? cdv_div_up(CNB * kb, 256) : 1), dim3(256), 0, s, Abig, npad,
-                           n6i, kb, dXg, gv.meta, d, info);
+      hipLaunchKernelGGL(ba_big_backsolve_kernel, dim3(cdv_div_up(npad, 256)), dim3(256), 0, s, Abig, npad, n6i, dXg,
+                         (uint64_t*)(b + L.xgran), token_base + 1 + itr, gv.meta, d, info);
     } else {
       // only N = 0 gets here (no free pose: depths alone are refined): q = 1 / (C + lambda)
       hipLaunchKernelGGL(ba_q_kernel, dim3(cdv_div_up(L.U_max, 256) < 1024 ? (int)cdv_div_up(L.U_max, 256) : 1024), dim3(256), 0, s,

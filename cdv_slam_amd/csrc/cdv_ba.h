@@ -41,7 +41,7 @@ __host__ __device__ inline int solve_ld(int n) { return (n + 27) / 32 * 32 + 4; 
 enum { BI_CHOL = 0, BI_OVERFLOW = 1, BI_HANDOFF = 2, BI_GRAPH = 3 };
 
 struct BaLayout {
-  size_t sy, C, u, Ed, cmask, zero_bytes, q, dX, info, Abig, slabs, ared, hand, pnext, ptab, pdiag, pkeys, pgraph, pgraph_bytes, total;
+  size_t sy, C, u, Ed, cmask, zero_bytes, q, dX, info, Abig, xgran, slabs, ared, hand, pnext, ptab, pdiag, pkeys, pgraph, pgraph_bytes, total;
   int64_t E_max, pair_cap, pair_range;  // global path: edges the pair index is sized for, frame pairs it can hold, key range
   int64_t npad;                         // global-BA path: 6 N rounded up to the Cholesky block (0: not used)
   int64_t U_max, U_stride, sy_stride;   // sy_stride: floats between two copies of [S | y]
@@ -66,10 +66,12 @@ inline BaLayout ba_layout(int64_t U_max, int N_max, int64_t E_max = 1) {
   L.q = o;    o = align256(o + sizeof(float) * (size_t)L.U_stride);
   L.dX = o;   o = align256(o + sizeof(float) * (n6 + 8));
   L.info = o; o = align256(o + sizeof(int32_t) * 16 + sizeof(uint64_t) * MID_GRAN);   // 16 words + the dX granules of the solve -> retract hand-off
-  L.npad = 0; L.Abig = o;
+  L.npad = 0; L.Abig = o; L.xgran = o;
   if (N_max > BA_NMAX) {   // working copy of [S ; y^T] for the blocked Cholesky, padded with identity to 64-blocks
     L.npad = (int64_t)((n6 + CNB - 1) / CNB * CNB);
     o = align256(o + sizeof(float) * (size_t)(L.npad + 1) * (size_t)L.npad);
+    // the solution as {launch token, value} granules: the hand-off between the workgroups of the back-substitution launch
+    L.xgran = o; o = align256(o + sizeof(uint64_t) * (size_t)L.npad);
   }
   // window path: one partial system per chunk of 16 patches, the reduced system, the arrival counter
   L.n_ck = 0; L.slabs = o; L.ared = o; L.hand = o; L.pnext = o;
