@@ -452,7 +452,8 @@ __global__ __launch_bounds__(256) void ba_schur_kernel(const float* __restrict__
   const int pb = (int)blockIdx.x - ((pa * (pa + 1)) >> 1);
   __shared__ __attribute__((aligned(16))) float Ea[SPR * ELD];
   __shared__ __attribute__((aligned(16))) float Eb[SPR * ELD];
-  __shared__ float qs[BA_CHUNK], qu[BA_CHUNK];
+  __shared__ __attribute__((aligned(16))) float qs[BA_CHUNK];
+  __shared__ float qu[BA_CHUNK];
   __shared__ int lst[256];
   __shared__ int wcnt[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -520,12 +521,19 @@ __global__ __launch_bounds__(256) void ba_schur_kernel(const float* __restrict__
         if (pa == pb && tj > ti) continue;
         const float* pra = Ea + (size_t)(16 * ti + c16) * ELD;
         const float* prb = Ebp + (size_t)(16 * tj + c16) * ELD;
+        // the k index of an MFMA step is ours to choose (the same for both operands): lane group g4 takes the 16 patches
+        // 16 g4 .. 16 g4 + 15 of the chunk, so every operand is four 16-byte reads instead of sixteen 4-byte ones
         cdv_float4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int st = 0; st < 16; st += 2) {
-          const int k0 = 4 * st + g4, k1 = k0 + 4;
-          t0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pra[k0], qs[k0] * prb[k0], t0, 0, 0, 0);
-          t1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pra[k1], qs[k1] * prb[k1], t1, 0, 0, 0);
+        for (int s4 = 0; s4 < 4; s4++) {
+          const int k = 16 * g4 + 4 * s4;
+          const cdv_float4 av = *reinterpret_cast<const cdv_float4*>(pra + k);
+          const cdv_float4 bv = *reinterpret_cast<const cdv_float4*>(prb + k);
+          const cdv_float4 qv = *reinterpret_cast<const cdv_float4*>(qs + k);
+          t0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], qv[0] * bv[0], t0, 0, 0, 0);
+          t1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], qv[1] * bv[1], t1, 0, 0, 0);
+          t0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], qv[2] * bv[2], t0, 0, 0, 0);
+          t1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], qv[3] * bv[3], t1, 0, 0, 0);
         }
         acc[u] += t0 + t1;
       }
@@ -587,12 +595,17 @@ constexpr int CLD = CNB + 4;
 __device__ __forceinline__ cdv_float4 tile64_xyt(const float* X, const float* Y, int ti, int tj, int c16, int g4) {
   const float* pa = X + (size_t)(16 * ti + c16) * CLD;
   const float* pb = Y + (size_t)(16 * tj + c16) * CLD;
+  // (lane group g4 takes columns 16 g4 .. 16 g4 + 15: four 16-byte reads per operand; rows are 16-byte aligned, CLD = 68)
   cdv_float4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int st = 0; st < 16; st += 2) {
-    const int k0 = 4 * st + g4, k1 = k0 + 4;
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[k0], pb[k0], acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[k1], pb[k1], acc1, 0, 0, 0);
+  for (int s4 = 0; s4 < 4; s4++) {
+    const int k = 16 * g4 + 4 * s4;
+    const cdv_float4 av = *reinterpret_cast<const cdv_float4*>(pa + k);
+    const cdv_float4 bv = *reinterpret_cast<const cdv_float4*>(pb + k);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv[0], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bv[1], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bv[2], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bv[3], acc1, 0, 0, 0);
   }
   return acc0 + acc1;
 }
