@@ -1129,7 +1129,7 @@ __global__ __launch_bounds__(64 * RET_RG) void ba_retract_kernel(float* __restri
   d = d + dz;
   d = (d > 20.f) ? 1.0f : d;
   d = fmaxf(d, 1e-4f);
-  for (int a = 0; a < PP; a++) pk[a] = d;
+  store_depth(pk, PP, d);
 }
 
 }  // namespace

@@ -1039,7 +1039,7 @@ __global__ __launch_bounds__(FT) void ba_mid_finish_kernel(BaWinArgs A) {
       float d = d0 + dz;
       d = (d > 20.f) ? 1.0f : d;
       d = fmaxf(d, 1e-4f);
-      for (int a = 0; a < PP; a++) pk[a] = d;
+      store_depth(pk, PP, d);
     }
     r += RT * FT;
     if (r - tid >= U) { CDV_STAMP(bam, sslot, 4); CDV_STAMP_RT(bam, sslot, 15); break; }          // workgroup-uniform

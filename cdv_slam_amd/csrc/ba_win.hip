@@ -779,7 +779,7 @@ __global__ __launch_bounds__(256) void ba_finish_kernel(BaWinArgs A) {
       float d = __fadd_rn(d0, dz);
       d = (d > 20.f) ? 1.0f : d;
       d = fmaxf(d, 1e-4f);
-      for (int a = 0; a < PP; a++) pk[a] = d;
+      store_depth(pk, PP, d);
     }
     // more patches than one pass of the retract workgroups covers: the next block of 256 (loaded now, dX is known)
     r += RT * 256;

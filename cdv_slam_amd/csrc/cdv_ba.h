@@ -174,6 +174,20 @@ __device__ __forceinline__ void ba_flag(int32_t* info, int which, int value) {
   }
 }
 
+// the P x P inverse-depth pixels of a patch, all set to d (ba_cuda.cu:223-227): 36 contiguous bytes on a 4-byte boundary when
+// P = 3 -- two 16-byte stores and one 4-byte store instead of nine 4-byte ones (global memory takes unaligned 16-byte accesses)
+__device__ __forceinline__ void store_depth(float* __restrict__ pk, int PP, float d) {
+  if (PP == 9) {
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    const f4u v = {d, d, d, d};
+    *reinterpret_cast<f4u*>(pk) = v;
+    *reinterpret_cast<f4u*>(pk + 4) = v;
+    pk[8] = d;
+  } else {
+    for (int a = 0; a < PP; a++) pk[a] = d;
+  }
+}
+
 // status handling of the first launch of an iteration (one thread): sticky words cleared by the first iteration of a
 // call; overflow / graph error rewritten by every iteration, so a workspace recovers on the next well-sized call
 __device__ __forceinline__ void ba_begin_status(int32_t* info, int32_t* counters, int first, int gerr, bool overflow) {
