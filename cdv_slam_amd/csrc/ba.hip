@@ -569,8 +569,12 @@ __global__ __launch_bounds__(256) void ba_schur_kernel(const float* __restrict__
 // on the padded diagonal, row npad = y^T; re-zeroes [S | y] (its owners write only the blocks that exist).
 __global__ __launch_bounds__(256) void ba_big_fold_kernel(float* __restrict__ sy, int sy_stride, int n, int npad,
                                                           float* __restrict__ A, const int32_t* __restrict__ gmeta,
-                                                          float* __restrict__ dbg, const int32_t* __restrict__ info) {
+                                                          float* __restrict__ dbg, const int32_t* __restrict__ info,
+                                                          uint64_t* __restrict__ xg) {
   if (gmeta[GM_ERROR] || info[1]) return;
+  // the granules of the back-substitution launch lose their tags (per-launch tokens from host state at enqueue time: a
+  // captured hipGraph replays the same ones)
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npad; i += gridDim.x * blockDim.x) xg[i] = 0ull;
   const int64_t total = (int64_t)(npad + 1) * npad;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     const int a = (int)(idx / npad), b = (int)(idx - (int64_t)a * npad);
@@ -1305,7 +1309,7 @@ extern "C" int cdv_ba_forward(float* poses, float* patches, const float* intrins
       hipLaunchKernelGGL(ba_schur_kernel, dim3(npan * (npan + 1) / 2), dim3(256), 0, s, lmbda, N, gv.meta, sy, Cg, ug, Edg,
                          (int)L.U_stride, cmask, n_chunks, info);
       hipLaunchKernelGGL(ba_big_fold_kernel, dim3(1024), dim3(256), 0, s, sy, (int)L.sy_stride, n6i, npad, Abig, gv.meta,
-                         d, info);
+                         d, info, (uint64_t*)(b + L.xgran));
       // block step 0: the panel alone; block step kb >= 1: the panel together with what step kb - 1 owes the matrix
       hipLaunchKernelGGL(ba_big_panel_kernel, dim3(nbk + 1), dim3(64), 0, s, Abig, npad, 0, gv.meta, info);
       for (int kb = 1; kb < nbk; kb++) {

@@ -385,6 +385,13 @@ __global__ __launch_bounds__(64 * CKW) void ba_chunk_kernel(BaWinArgs A) {
     reduce_slabs(A, bq, RWf, U, tid, bq < RWf);
   } else {
     if (blockIdx.x == 0 && tid == 0) ba_begin_status(A.info, A.counters, A.first, gerr, U > A.U_max);
+    // the hand-off words of the finish launch that follows (arrival flags, dX granules) lose their tags here: the tags are
+    // per-launch tokens taken from host state when the call is ENQUEUED, so a captured hipGraph replays the same tokens --
+    // with the words reset by the launch in front, a replay never meets a tag of its own from the time before
+    if (blockIdx.x == 0) {
+      for (int i = tid; i < HAND_WORDS - 16; i += (int)blockDim.x) A.arrive[16 + i] = 0;
+      for (int i = tid; i < 64; i += (int)blockDim.x) A.granX[i] = 0ull;
+    }
     if (gerr || U > A.U_max) return;
   }
   const int N = A.N, t0 = A.t0, P = A.P;

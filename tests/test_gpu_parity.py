@@ -1445,3 +1445,48 @@ def test_ba_with_zero_weights_changes_nothing(name):
     assert np.array_equal(poses, st.poses)
     assert np.array_equal(patches, st.patches)
     assert ops.ba_status(torch.device(DEV)) == (0, 0, 0, 0)
+
+
+@pytest.mark.parametrize("iterations", [1, 2])
+def test_update_captured_as_a_hipgraph_replays_bit_for_bit(iterations):
+    """a whole update -- ring ingest, table build, reprojection, two-level correlation, neighbors, BA -- captured into a
+    hipGraph (every entry point only enqueues on the given stream) and replayed: the same bits as the eager launches, replay
+    after replay.  The hand-off tags between the BA's launches are per-launch tokens taken from host state when a call is
+    enqueued, so a replay carries the tokens of the capture: each iteration's first launch therefore clears the tags of the
+    launch that follows (an odd number of iterations per call would otherwise meet its own tags from the replay before)."""
+    from cdv_slam_amd.update import UpdatePath
+    st = synth.make_state("small")
+    dev = torch.device(DEV)
+
+    def run(up, stepper, n):
+        outs = []
+        up.reset()
+        for _ in range(n):
+            r = stepper()
+            torch.cuda.synchronize()
+            outs.append((up.poses.clone(), up.patches.clone(), r["corr"].clone(), r["ix"].clone(), r["jx"].clone()))
+        return outs
+
+    eager = UpdatePath(st, dev)
+    want = run(eager, lambda: eager.step(iterations=iterations), 3)
+    cap = UpdatePath(st, dev)
+    for _ in range(3):
+        cap.step(iterations=iterations)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    os.environ["CDV_CHECK"] = "0"      # (CDV_CHECK=1 reads the status words back after every BA: a synchronisation, not capturable)
+    try:
+        with torch.cuda.graph(g):
+            held = cap.step(iterations=iterations)
+    finally:
+        os.environ["CDV_CHECK"] = "1"
+    torch.cuda.synchronize()
+
+    def replay():
+        g.replay()
+        return held
+    got = run(cap, replay, 3)
+    for a, b in zip(want, got):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    assert ops.ba_status(dev) == (0, 0, 0, 0)
