@@ -1490,3 +1490,34 @@ def test_update_captured_as_a_hipgraph_replays_bit_for_bit(iterations):
         for x, y in zip(a, b):
             assert torch.equal(x, y)
     assert ops.ba_status(dev) == (0, 0, 0, 0)
+
+
+def test_global_path_just_above_the_mid_path():
+    """35 free poses -- the smallest systems the global path serves (the mid path ends at 32): five 8-pose panels with a
+    ragged last one, a 210-unknown system padded to four 64-blocks.  Intermediates against the float64 oracle, the solve's
+    backward error, the same bits from run to run."""
+    st = synth.make_state("small", features=False, frames=40, opt_window=35, removal_window=40, buffer_size=48)
+    N = st.n - st.t0
+    assert 32 < N < 40
+    _, _, dbg = _run_ba(st, iterations=1, debug=True)
+    _, _, info, o = O.fastba(st.poses, st.patches, st.intrinsics[0], st.target, st.weight, st.lmbda, st.ii, st.jj,
+                             st.kk, st.t0, st.n, 1, np.float64, debug=True)
+    assert info == 0
+    U = len(o["kx"])
+    S = np.tril(dbg["S"].cpu().numpy())
+    assert np.abs(S - np.tril(o["S"])).max() <= 1e-4 * np.abs(o["S"]).max()
+    for key, got, want in (("y", dbg["y"], o["y"]), ("C", dbg["C"][:U], o["C"]), ("u", dbg["u"][:U], o["u"]),
+                           ("E", dbg["E"][:, :U], o["E"])):
+        assert np.abs(got.cpu().numpy() - want).max() <= 1e-4 * np.abs(want).max(), key
+    # the kernel's own solve: S dX = y to float32 accuracy (S symmetric from its lower triangle)
+    Sg = dbg["S"].cpu().numpy().astype(np.float64)
+    Sg = np.tril(Sg) + np.tril(Sg, -1).T
+    dX = dbg["dX"].cpu().numpy().astype(np.float64).reshape(-1)
+    y = dbg["y"].cpu().numpy().astype(np.float64)
+    assert np.linalg.norm(Sg @ dX - y) <= 2e-5 * (np.linalg.norm(Sg, 2) * np.linalg.norm(dX) + np.linalg.norm(y))
+    _, _, dbg2 = _run_ba(st, iterations=1, debug=True)
+    for key in ("S", "y", "dX", "E", "C", "u"):
+        assert torch.equal(dbg[key], dbg2[key]), key
+    a, b = _run_ba(st, iterations=2), _run_ba(st, iterations=2)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert ops.ba_status(torch.device(DEV)) == (0, 0, 0, 0)
