@@ -76,8 +76,13 @@ __device__ __forceinline__ int nth_bit(uint32_t m, int k) {
   return m ? __ffs((int)m) - 1 : -1;
 }
 
+#ifdef CDV_MID_WPE
+#define CDV_MID_OCC __attribute__((amdgpu_waves_per_eu(CDV_MID_WPE, CDV_MID_WPE)))
+#else
+#define CDV_MID_OCC
+#endif
 template <bool HAS_II, int MKW, bool TABLE>
-__global__ __launch_bounds__(64 * MKW) void ba_mid_chunk_kernel(BaWinArgs A) {
+__global__ __launch_bounds__(64 * MKW) CDV_MID_OCC void ba_mid_chunk_kernel(BaWinArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int N = A.N, t0 = A.t0, P = A.P;
   const int n6 = 6 * N;
@@ -1089,6 +1094,10 @@ int cdv::cdv_ba_mid_iteration(const BaWinArgs& a, hipStream_t s) {
     if ((x = chunk_attr<false, 8, false>()) != hipSuccess) e = x;
     if ((x = chunk_attr<true, 8, true>()) != hipSuccess) e = x;
     if ((x = chunk_attr<false, 8, true>()) != hipSuccess) e = x;
+    if ((x = chunk_attr<true, 7, false>()) != hipSuccess) e = x;
+    if ((x = chunk_attr<false, 7, false>()) != hipSuccess) e = x;
+    if ((x = chunk_attr<true, 7, true>()) != hipSuccess) e = x;
+    if ((x = chunk_attr<false, 7, true>()) != hipSuccess) e = x;
     if ((x = chunk_attr<true, 4, false>()) != hipSuccess) e = x;
     if ((x = chunk_attr<false, 4, false>()) != hipSuccess) e = x;
     if ((x = chunk_attr<true, 4, true>()) != hipSuccess) e = x;
@@ -1110,12 +1119,15 @@ int cdv::cdv_ba_mid_iteration(const BaWinArgs& a, hipStream_t s) {
   const int n_ck = a.n_ck_cap < WIN_MAX_GRID ? a.n_ck_cap : WIN_MAX_GRID;
   const bool table = a.tab_cap > 0;
   static const int mkw_env = getenv("CDV_MID_WAVES") ? atoi(getenv("CDV_MID_WAVES")) : 8;
-  const int mkw = mkw_env == 4 ? 4 : 8;
+  const int mkw = mkw_env == 4 ? 4 : (mkw_env == 7 ? 7 : 8);
   const size_t lds = chunk_lds_bytes(N, mkw);
   CDV_REQUIRE(lds <= 160 * 1024 - 256, CDV_ERR_UNSUPPORTED, "cdv_ba_forward: chunk footprint exceeds LDS");
   if (mkw == 8) {
     if (table) launch_chunk<8, true>(a, n_ck, lds, s);
     else launch_chunk<8, false>(a, n_ck, lds, s);
+  } else if (mkw == 7) {
+    if (table) launch_chunk<7, true>(a, n_ck, lds, s);
+    else launch_chunk<7, false>(a, n_ck, lds, s);
   } else {
     if (table) launch_chunk<4, true>(a, n_ck, lds, s);
     else launch_chunk<4, false>(a, n_ck, lds, s);
