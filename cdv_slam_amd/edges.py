@@ -11,7 +11,7 @@ import ctypes
 import torch
 
 from . import _lib
-from .ops import _p, _stream
+from .ops import _p, _stream, touched
 
 
 class EdgeStore:
@@ -50,6 +50,7 @@ class EdgeStore:
         rc = self.lib.cdv_edges_frame(_p(self._ii[c]), _p(self._jj[c]), _p(self._kk[c]), _p(ix), self.E, self.cap, int(n),
                                       int(M), int(r), ctypes.byref(added), _stream())
         _lib.check(rc, "cdv_edges_frame")
+        touched(self._ii, self._jj, self._kk)      # written through raw pointers: whoever keys a cache on these views must see it
         self._zero_tail(added.value)
         self.E += added.value
         return added.value
@@ -62,6 +63,7 @@ class EdgeStore:
         rc = self.lib.cdv_edges_append(_p(self._ii[c]), _p(self._jj[c]), _p(self._kk[c]), _p(ix), _p(new_k.contiguous()),
                                        _p(new_j.contiguous()), self.E, n, self.cap, _stream())
         _lib.check(rc, "cdv_edges_append")
+        touched(self._ii, self._jj, self._kk)
         self._zero_tail(n)
         self.E += n
 
@@ -92,6 +94,7 @@ class EdgeStore:
             _p(self.target_inac) if store else None, _p(self.weight_inac) if store else None, self.E_inac,
             ctypes.c_void_p(self._counts.data_ptr()), _stream())
         _lib.check(rc, "cdv_edges_remove")
+        touched(self._ii, self._jj, self._kk, self._target, self._weight)
         torch.cuda.current_stream().synchronize()
         kept, removed = int(self._counts[0]), int(self._counts[1])
         self.cur, self.E = o, kept
@@ -104,6 +107,7 @@ class EdgeStore:
         c = self.cur
         _lib.check(self.lib.cdv_edges_keyframe_shift(_p(self._ii[c]), _p(self._jj[c]), _p(self._kk[c]), self.E, int(k),
                                                      int(M), _stream()), "cdv_edges_keyframe_shift")
+        touched(self._ii, self._jj, self._kk)
 
     def keyframe(self, k, n, M, ix, removal_window, loop_closure=False, opt_window=10, drop=True):
         """the edge part of SLAM.keyframe() (slam.py:408-458): if `drop`, frame k leaves the graph (its edges removed

@@ -6,7 +6,6 @@ library or a non-CUDA(ROCm) tensor raises.
 """
 import ctypes
 import os
-import weakref
 
 import torch
 
@@ -52,6 +51,28 @@ def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+def _ident(t):
+    """What a tensor IS for the caches below: the memory it views (address, shape, strides, dtype) and the version counter of
+    that memory.  NOT the Python object: the reference hands over fresh views of its buffers at every access (SLAM.gmap,
+    .poses, .patches are properties that call .view(), cdvslam/slam.py:237-251) and fresh edge tensors every frame
+    (torch.cat, slam.py:331-337); a view shares its base's version counter, so `same ident` means `same bytes` as long as
+    whoever compares also HOLDS a tensor on that storage (a freed address can be handed out again -- every cache below
+    keeps the tensor it took the ident from).  A write through an alias with a version counter of its own (`t.data`,
+    from_blob, dlpack) is invisible here, as it is to autograd."""
+    return (t.data_ptr(), t._version, t.shape, t.stride(), t.dtype)
+
+
+def _place(t):
+    """_ident without the version: the place, whatever it holds at the moment"""
+    return (t.data_ptr(), t.shape, t.stride(), t.dtype)
+
+
+def touched(*ts):
+    """tell the version counters that a kernel wrote these tensors through their raw pointers"""
+    for t in ts:
+        torch.autograd.graph.increment_version(t)
+
+
 def _need_cuda(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
@@ -85,6 +106,7 @@ class GraphIndex:
         self._key = None
         self.E = 0
         self.is_table = False
+        self.n_builds = 0          # index builds enqueued on this workspace (diagnostics, tests)
         self._reserve(E_cap)
 
     def _reserve(self, E):
@@ -103,10 +125,11 @@ class GraphIndex:
 
     @staticmethod
     def _make_key(jj, kk, ii):
-        """identity + version of every tensor whose CONTENT is baked into the index: jj, kk, and ii when the build was
+        """memory + version (_ident) of every tensor whose CONTENT is baked into the index: jj, kk, and ii when the build was
         given it (the per-patch edge records carry the source frames the N <= 32 bundle adjustment reads).  Strong
-        references pin the tensors, so identity + version implies content."""
-        return (jj, kk, jj._version, kk._version, ii, None if ii is None else ii._version)
+        references pin the storages, so the same ident implies the same content -- for the very objects and for any other
+        view of the same memory (slam.py hands the same edge tensors to neighbors() and BA(), EdgeStore fresh views)."""
+        return (_ident(jj), _ident(kk), None if ii is None else _ident(ii), (jj, kk, ii))
 
     def _same_key(self, key):
         """is the index in the workspace the one `key` describes?  A build WITH ii also serves a request without it
@@ -114,11 +137,11 @@ class GraphIndex:
         cuda_ba.forward then reads ii per edge: one more dependent load instead of a second build); a build with another or
         a modified ii does not serve a request with ii."""
         k = self._key
-        if k is None or k[0] is not key[0] or k[1] is not key[1] or k[2] != key[2] or k[3] != key[3]:
+        if k is None or k[0] != key[0] or k[1] != key[1]:
             return False
-        if key[4] is None or k[4] is None:
+        if key[2] is None or k[2] is None:
             return True      # nothing of ii is baked into an index built without it: the bundle adjustment reads ii itself then
-        return k[4] is key[4] and k[5] == key[5]
+        return k[2] == key[2]
 
     def corr_order_ptr(self):
         """device pointer (ctypes.c_void_p) of the correlation's processing order of the index currently in the
@@ -175,6 +198,7 @@ class GraphIndex:
         rc = self.lib.cdv_graph_build_edges(_p(ii), _p(jj), _p(kk), E, _p(self.ws), self.ws_bytes, self.E_cap,
                                             self.k_range, _p(ix), _p(jx), _stream())
         _lib.check(rc, "cdv_graph_build_edges")
+        self.n_builds += 1
         self._key = key  # strong refs pin the tensors so that identity implies content
         self.E = E
         if _sync_check():
@@ -221,6 +245,7 @@ class GraphIndex:
         rc = self.lib.cdv_graph_build_table(_p(ii), _p(jj), _p(kk), E, _p(self.ws), self.ws_bytes, self.E_cap, self.k_range,
                                             self.table_capacity, _p(ix), _p(jx), _stream())
         _lib.check(rc, "cdv_graph_build_table")
+        self.n_builds += 1
         self._key = key
         self.E = E
         self.is_table = True
@@ -263,8 +288,8 @@ class GraphIndex:
     def unique(self):
         """(kx, ku) == torch._unique(kk, sorted=True, return_inverse=True); one host sync for U."""
         if self.is_table:      # a table has no ranks: rebuild as the ranked index from the tensors it was built from
-            k = self._key
-            self.build(k[0], k[1], force=True, ii=k[4])
+            jj, kk, ii = self._key[3]
+            self.build(jj, kk, force=True, ii=ii)
         U = self.meta()[0] if self.E else 0
         kx = torch.empty(U, dtype=torch.int64, device=self.device)
         ku = torch.empty(self.E, dtype=torch.int64, device=self.device)
@@ -299,6 +324,7 @@ def update_prologue(graph, fmap_chw, fmap1_nhwc, fmap2_nhwc, slot, gmap, gmap_pm
                                  _p(intrinsics), _p(ii), _p(jj), _p(kk), E, 1 if layout_e2pp else 0, _p(coords),
                                  _p(graph.ws), graph.ws_bytes, graph.E_cap, graph.k_range, _p(ix), _p(jx), _stream())
     _lib.check(rc, "cdv_update_prologue")
+    graph.n_builds += 1
     graph._key = graph._make_key(jj, kk, ii)
     graph.E = E
     graph.is_table = False
@@ -332,6 +358,7 @@ def update_prologue_table(graph, fmap_chw, fmap1_nhwc, fmap2_nhwc, slot, gmap, g
                                        _p(intrinsics), _p(ii), _p(jj), _p(kk), E, _p(coords), _p(graph.ws), graph.ws_bytes,
                                        graph.E_cap, graph.k_range, graph.table_capacity, _p(ix), _p(jx), _stream())
     _lib.check(rc, "cdv_update_prologue_table")
+    graph.n_builds += 1
     graph._key = graph._make_key(jj, kk, ii) + ("table",)
     graph.E = E
     graph.is_table = True
@@ -477,15 +504,16 @@ class NhwcCache:
         self.max_entries = max_entries
 
     def get(self, fmap):
+        place = _place(fmap)
         for ent in self.entries:
-            if ent["src"] is fmap:
+            if ent["place"] == place:      # the same memory, through whichever view object (ent["src"] pins the storage)
                 if ent["version"] != fmap._version:
                     self._sync(ent)
                 return ent["shadow"]
         C, H, W = fmap.shape[-3:]
         N = fmap.numel() // (C * H * W)
         lib = _lib.load()
-        ent = {"src": fmap, "version": None, "parity": 0,
+        ent = {"src": fmap, "place": place, "version": None, "parity": 0,
                "shadow": torch.zeros(fmap.shape[:-3] + (H + 2 * FMAP_PADY, W + 2 * FMAP_PADX, C), dtype=fmap.dtype,
                                      device=fmap.device),
                "ws": torch.zeros(lib.cdv_fmap_sync_workspace_bytes(N), dtype=torch.uint8, device=fmap.device)}
@@ -508,8 +536,9 @@ class NhwcCache:
 
     def converted_slots(self, fmap):
         """diagnostics: slots converted so far for this ring (synchronises)"""
+        place = _place(fmap)
         for ent in self.entries:
-            if ent["src"] is fmap:
+            if ent["place"] == place:
                 return int(ent["ws"][-64:-60].view(torch.int32).item())
         return 0
 
@@ -522,14 +551,19 @@ class TileCache:
     gmap_): re-converted when the tensor's version counter has moved (1.5 MB in, 1.5 MB out at the default sizes)."""
 
     def __init__(self):
-        self.src, self.version, self.shadow = None, None, None
+        self.src, self.ident, self.shadow = None, None, None
+        self.n_converted = 0
 
     def get(self, gmap):
-        if self.src is not gmap or self.version != gmap._version or self.shadow is None:
+        """keyed on the memory + version (_ident), not on the Python object: slam.py's `gmap` property is a fresh view of
+        gmap_ at every access (slam.py:249-251) and SLAM.corr reads it twice (:321-322)"""
+        idn = _ident(gmap)
+        if self.ident != idn or self.shadow is None:
             g = gmap[0] if gmap.dim() == 5 else gmap
-            self.shadow = gmap_to_pixel_major(g.contiguous(), out=self.shadow if (self.shadow is not None and self.src is gmap)
-                                              else None)
-            self.src, self.version = gmap, gmap._version
+            same_place = self.ident is not None and self.ident[0] == idn[0] and self.ident[2:] == idn[2:]
+            self.shadow = gmap_to_pixel_major(g.contiguous(), out=self.shadow if (self.shadow is not None and same_place) else None)
+            self.src, self.ident = gmap, idn      # src pins the storage the ident speaks of
+            self.n_converted += 1
         return self.shadow
 
 
@@ -667,12 +701,14 @@ class _LevelPairing:
     torch.stack of the two along a new last axis returns the buffer they share.
 
     What is assumed, and what guards it (a documented mode, CDV_PAIR_LEVELS=0 turns all of it off):
-      * the speculative level-1 result is only handed out to the call that IMMEDIATELY follows, with the very same
-        tensor objects (patch tiles, ii, jj: identity AND version counter -- held alive by `pending`, so an address
-        the allocator recycles cannot impersonate them) on the ring that was learned as the partner, unchanged since
-        (identity + version); any other call in between -- a third caller -- drops the pending result;
-      * the learned partnership is keyed by the identity of ring A (a weak reference that must still resolve to the
-        very object), re-validated (shapes, dtype, contiguity, ratio) before every paired launch;
+      * the speculative level-1 result is only handed out to the call that IMMEDIATELY follows, on the very same
+        memory at the same version (_ident: address, shape, strides, dtype, version counter of patch tiles, ii, jj -- NOT
+        the Python objects: slam.py's `gmap` is a property that returns a fresh view per access, slam.py:249-251,321-322;
+        the tensors of the first call are held alive by `pending`, so an address the allocator recycles cannot
+        impersonate them) on the ring that was learned as the partner, unchanged since; any other call in between -- a
+        third caller -- drops the pending result;
+      * the learned partnership is keyed by the memory of ring A (at most four partnerships are remembered, each holding
+        its two rings), re-validated (shapes, dtype, contiguity, ratio) before every paired launch;
       * the coords are checked per edge on the device, so a caller whose second call is not coords / ratio gets the
         recomputed values;
       * the stack shortcut needs the two views of one buffer, levels (0, 1), new last axis -- anything else is a real stack.
@@ -680,7 +716,7 @@ class _LevelPairing:
     `n_stacked` the stacks answered with the shared buffer."""
 
     def __init__(self):
-        self.learned = {}      # id(ring A) -> (weakref ring A, weakref ring B, ratio)
+        self.learned = {}      # _place(ring A) -> (ring A, ring B, ratio); insertion order = age
         self.last = None       # the previous call when it was an ordinary one
         self.pending = None
         self.n_fused = 0
@@ -688,21 +724,18 @@ class _LevelPairing:
 
     @staticmethod
     def _same(held, now):
-        """every (tensor, version) pair recorded at the first call is the very object, unmodified"""
-        return all(t is u and v == u._version for (t, v), u in zip(held, now))
+        """every tensor recorded at the first call views the same memory, unmodified since (the held tensor pins it)"""
+        return all(idn == _ident(u) for (t, idn), u in zip(held, now))
 
     @staticmethod
     def _hold(*ts):
-        return tuple((t, t._version) for t in ts)
+        return tuple((t, _ident(t)) for t in ts)
 
     def _partner(self, ringA):
-        ent = self.learned.get(id(ringA))
+        ent = self.learned.get(_place(ringA))
         if ent is None:
             return None, 0
-        ra, rb, ratio = ent[0](), ent[1](), ent[2]
-        if ra is not ringA or rb is None:          # the id was recycled by another tensor, or the partner is gone
-            del self.learned[id(ringA)]
-            return None, 0
+        rb, ratio = ent[1], ent[2]
         ok = (rb.is_contiguous() and rb.dtype == torch.float16 and rb.shape[:3] == ringA.shape[:3]
               and rb.shape[3] * ratio == ringA.shape[3] and rb.shape[4] * ratio == ringA.shape[4])
         return (rb, ratio) if ok else (None, 0)
@@ -737,13 +770,14 @@ class _LevelPairing:
         # ---- an ordinary call: remember it, and learn the pairing from two in a row on the same tiles and indices
         if last is not None and E == last["E"] and self._same(last["held"], (fmap1, ii, jj)):
             ra = last["ring"]
-            if ra is not fmap2 and ra.shape[:3] == fmap2.shape[:3] and fmap2.dtype == torch.float16:
+            if _place(ra) != _place(fmap2) and ra.shape[:3] == fmap2.shape[:3] and fmap2.dtype == torch.float16:
                 h, w, H, W = fmap2.shape[3], fmap2.shape[4], ra.shape[3], ra.shape[4]
                 ratio = H // h if h > 0 else 0
                 if ratio >= 2 and (ratio & (ratio - 1)) == 0 and h * ratio == H and w * ratio == W:
-                    if len(self.learned) >= 16:    # rings that died since
-                        self.learned = {k: v for k, v in self.learned.items() if v[0]() is not None and v[1]() is not None}
-                    self.learned[id(ra)] = (weakref.ref(ra), weakref.ref(fmap2), ratio)
+                    self.learned.pop(_place(ra), None)
+                    while len(self.learned) >= 4:      # the oldest partnership goes (and with it the hold on its rings)
+                        self.learned.pop(next(iter(self.learned)))
+                    self.learned[_place(ra)] = (ra, fmap2, ratio)
         self.last = {"held": self._hold(fmap1, ii, jj), "E": E, "ring": fmap2}
         return None
 

@@ -58,6 +58,13 @@ def transform(poses, patches, intrinsics, ii, jj, kk, depth=False, valid=False, 
     (coords, (Z > 0.2) at the centre [1,E], (Ji [1,E,2,6], Jj [1,E,2,6], Jz [1,E,2,1]))."""
     if depth:
         raise NotImplementedError("transform(depth=True) is not on the update path")
+    if not (valid or jacobian):
+        # every inference caller turns the result into [1,E,2,P,P] at once (`.permute(0, 1, 4, 2, 3).contiguous()`,
+        # slam.py:328-329, loop_closure/long_term.py:118-129): the kernel writes THAT layout and the [1,E,P,P,2] tensor handed
+        # back is a permuted view of it -- same values, same shape, and the caller's permute + contiguous() is then the
+        # buffer itself instead of a 3.4 MB copy kernel
+        return ops.transform(_kernel_pose_rows(poses, "transform"), patches, intrinsics, ii, jj, kk, layout_e2pp=True,
+                             tonly=tonly).permute(0, 1, 3, 4, 2)
     return ops.transform(_kernel_pose_rows(poses, "transform"), patches, intrinsics, ii, jj, kk, layout_e2pp=False,
                          valid=valid, jacobian=jacobian, tonly=tonly)
 

@@ -198,12 +198,36 @@ class UpdatePath:
         return res
 
 
+class _CorrLayer(torch.autograd.Function):
+    """the reference routes every correlation through a torch.autograd.Function that calls the extension
+    (cdvslam/altcorr/correlation.py:4-13, `altcorr.corr` = CorrLayer.apply); this is that hop, own wording, forward only"""
+
+    @staticmethod
+    def forward(ctx, fmap1, fmap2, coords, ii, jj, radius, dropout, ext):
+        out, = ext.forward(fmap1, fmap2, coords, ii, jj, radius)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        raise NotImplementedError("training path (out of scope)")
+
+
 class DropinPath:
     """The SAME update written the way the reference writes it -- SLAM.reproject / SLAM.corr (slam.py:316-329), the
     per-frame ring writes (slam.py:679-682), Update's fastba.neighbors (net_cdv.py:102) and fastba.BA (slam.py:512-515,
     fastba/ba.py:8) -- against the module names it imports (cuda_corr, cuda_ba, lietorch_backends, registered by
-    install_dropin()) and on the reference's state layouts (planar rings [1,mem,C,h,w], gmap [1,pmem*M,C,3,3]).  What an
-    unchanged slam.py gets; tests compare it with UpdatePath.step(), bench.py times it as `dropin_fps`."""
+    install_dropin()) and on the reference's state layouts (planar rings [1,mem,C,h,w], gmap_ [pmem,M,C,3,3]).
+
+    Round 4: what the unchanged caller really hands over, so that nothing here is easier than slam.py --
+      * `gmap`, `poses`, `patches`, `intrinsics` are PROPERTIES returning a fresh .view() per access (slam.py:237-251;
+        SLAM.corr reads `self.gmap` twice, :321-322);
+      * the edge tensors are NEW objects every step: slam.py appends with torch.cat (:331-337), here the newest frame's
+        edges are cut off and appended again -- same content, fresh storage, so the index is built once per step;
+      * `ii % (M * pmem)`, `jj % mem`, `coords / 1`, `coords / 4` are computed per call as SLAM.corr does;
+      * the two correlation calls go through an autograd.Function under autocast and no_grad (slam.py:486,
+        altcorr/correlation.py:4-13,74-75); `lmbda` is made per call (slam.py:492);
+      * the new frame's tiles are written into gmap_ every step (slam.py:676), so the tile shadow is converted once per step.
+    What an unchanged slam.py gets; tests compare it with UpdatePath.step(), bench.py times it as `dropin_fps`."""
 
     def __init__(self, st, device):
         import importlib
@@ -217,47 +241,72 @@ class DropinPath:
         self.pops, self.SE3 = pops, SE3
         t = lambda a: torch.as_tensor(a, device=device)
         cfg = st.cfg
-        self.M, self.mem, self.pmem, self.n, self.t0 = cfg.M, cfg.mem, cfg.pmem, st.n, st.t0
-        N = cfg.buffer_size
-        self.poses_ = t(st.poses).clone()
-        self.patches_ = t(st.patches).clone()
-        self.poses = self.poses_.view(1, N, 7)
-        self.patches = self.patches_.view(1, N * self.M, 3, 3, 3)
-        self.intrinsics = t(st.intrinsics).view(1, N, 4)
+        self.dev = device
+        self.M, self.mem, self.pmem, self.n, self.t0, self.C = cfg.M, cfg.mem, cfg.pmem, st.n, st.t0, cfg.C
+        self.N = cfg.buffer_size
+        self.poses_ = t(st.poses).clone()                                  # pg.poses_ [N,7]
+        self.patches_ = t(st.patches).clone().view(self.N, self.M, 3, 3, 3)    # pg.patches_ [N,M,3,3,3]
+        self.intrinsics_ = t(st.intrinsics).clone()
         self.ii, self.jj, self.kk = t(st.ii), t(st.jj), t(st.kk)
         self.target, self.weight = t(st.target)[None].contiguous(), t(st.weight)[None].contiguous()
-        self.lmbda = torch.as_tensor([st.lmbda], dtype=torch.float32, device=device)
         self.fmap1_ = t(st.fmap1)[None].contiguous()                       # [1, mem, C, h, w]
         self.fmap2_ = torch.nn.functional.avg_pool2d(self.fmap1_[0], 4, 4)[None].contiguous()
         self.pyramid = (self.fmap1_, self.fmap2_)
-        self.gmap = t(st.gmap).view(1, self.pmem * self.M, cfg.C, 3, 3)
+        self.gmap_ = t(st.gmap).clone().view(self.pmem, self.M, cfg.C, 3, 3)
         self.new_frame = self.fmap1_[0, (st.n - 1) % self.mem].clone()
+        self.new_tiles = self.gmap_[(st.n - 1) % self.pmem].clone()
+        self.n_new = max(1, min(2 * cfg.patch_lifetime * cfg.M, st.E // 2))     # one frame's forward + backward edges
         self._poses0, self._patches0 = self.poses_.clone(), self.patches_.clone()
+
+    # slam.py:237-251: every access is a fresh view object of the persistent buffer
+    poses = property(lambda s: s.poses_.view(1, s.N, 7))
+    patches = property(lambda s: s.patches_.view(1, s.N * s.M, 3, 3, 3))
+    intrinsics = property(lambda s: s.intrinsics_.view(1, s.N, 4))
+    gmap = property(lambda s: s.gmap_.view(1, s.pmem * s.M, s.C, 3, 3))
 
     def reset(self):
         self.poses_.copy_(self._poses0)
         self.patches_.copy_(self._patches0)
 
+    def reproject(self):
+        """SLAM.reproject (slam.py:325-329)"""
+        coords = self.pops.transform(self.SE3(self.poses), self.patches, self.intrinsics, self.ii, self.jj, self.kk)
+        return coords.permute(0, 1, 4, 2, 3).contiguous()
+
+    def corr(self, coords):
+        """SLAM.corr (slam.py:316-323), altcorr.corr = CorrLayer.apply (altcorr/correlation.py:74-75)"""
+        ii1 = self.kk % (self.M * self.pmem)
+        jj1 = self.jj % self.mem
+        corr1 = _CorrLayer.apply(self.gmap, self.pyramid[0], coords / 1, ii1, jj1, 3, 1, self.cuda_corr)
+        corr2 = _CorrLayer.apply(self.gmap, self.pyramid[1], coords / 4, ii1, jj1, 3, 1, self.cuda_corr)
+        return torch.stack([corr1, corr2], -1).view(1, len(ii1), -1)
+
+    def append_again(self):
+        """the edge lists as a frame's append_factors leaves them (slam.py:331-337): new tensors from torch.cat"""
+        c = self.ii.numel() - self.n_new
+        self.jj = torch.cat([self.jj[:c], self.jj[c:]])
+        self.kk = torch.cat([self.kk[:c], self.kk[c:]])
+        self.ii = torch.cat([self.ii[:c], self.ii[c:]])
+
+    @torch.no_grad()
     def step(self, ingest=True, iterations=2, pooled=None):
         """pooled: the new frame's level-1 map, if the caller wants a particular rounding of the 4x4 average (tests);
         default torch's avg_pool2d as slam.py:682"""
         out = {}
-        if ingest:   # slam.py:679-682
+        if ingest:   # slam.py:676-682
             slot = (self.n - 1) % self.mem
+            self.gmap_[(self.n - 1) % self.pmem] = self.new_tiles
             self.fmap1_[:, slot] = self.new_frame
             self.fmap2_[:, slot] = torch.nn.functional.avg_pool2d(self.new_frame[None], 4, 4)[0] if pooled is None else pooled
-        # SLAM.reproject
-        coords = self.pops.transform(self.SE3(self.poses), self.patches, self.intrinsics, self.ii, self.jj, self.kk)
-        coords = coords.permute(0, 1, 4, 2, 3).contiguous()
-        # SLAM.corr
-        ii1, jj1 = self.kk % (self.M * self.pmem), self.jj % self.mem
-        corr1, = self.cuda_corr.forward(self.gmap, self.pyramid[0], coords / 1, ii1, jj1, 3)
-        corr2, = self.cuda_corr.forward(self.gmap, self.pyramid[1], coords / 4, ii1, jj1, 3)
-        out["corr"] = torch.stack([corr1, corr2], -1).view(1, len(self.ii), -1)
+            self.append_again()
+        coords = self.reproject()
+        with torch.autocast("cuda", enabled=True):      # slam.py:486
+            out["corr"] = self.corr(coords)
+            # Update.forward (net_cdv.py:102)
+            out["ix"], out["jx"] = self.cuda_ba.neighbors(self.kk, self.jj)
         out["coords"] = coords
-        # Update.forward
-        out["ix"], out["jx"] = self.cuda_ba.neighbors(self.kk, self.jj)
-        # fastba.BA
+        lmbda = torch.as_tensor([1e-4], device=self.dev)       # slam.py:492
+        # fastba.BA (fastba/ba.py:8)
         out["ba"] = self.cuda_ba.forward(self.poses.data, self.patches, self.intrinsics, self.target, self.weight,
-                                         self.lmbda, self.ii, self.jj, self.kk, self.M, self.t0, self.n, iterations, False)
+                                         lmbda, self.ii, self.jj, self.kk, self.M, self.t0, self.n, iterations, False)
         return out

@@ -275,8 +275,87 @@ def bench_size():
     print("benchmark-size fixtures written:", out)
 
 
+def corr_pin():
+    """Round 4: the correlation pinned as far as anything of the reference that RUNS here allows.
+    corr_forward_kernel + corr_cuda_forward (altcorr/correlation_kernel.cu:82-136,193-233) are CUDA; the one piece of the
+    reference that executes in this container and shares their sampling convention is `altcorr.patchify(net, coords, r,
+    'bilinear')` (altcorr/correlation.py:51-71): floor(coords) - r .. + r + 1 integer samples, out-of-range samples zero,
+    then the four-slice blend with the SAME weights and the same roles of dx / dy as correlation_kernel.cu:213-230.  The
+    correlation is linear in the feature map, so
+
+        corr[e, y_off, x_off, i0, j0] = sum_c gmap[ii[e], c, i0, j0] * patchify(fmap[jj[e]], coords[e, :, i0, j0] / s, 3)[c, y_off, x_off]
+
+    with patchify's blend computed BY THE REFERENCE'S PYTHON in float64, contracted here, and permuted to [x_off][y_off] as
+    correlation_kernel.cu:232 returns it.  cuda_corr.patchify_forward (a CUDA kernel, correlation_kernel.cu:16-47) is
+    stood in for by the torch gather below (integer samples, zero outside) -- that gather is this repository's reading,
+    everything after it is the reference executing.  -> corr_pin.npz (inputs + float64 result, both pyramid levels)"""
+    _install_shims()
+    sys.path.insert(0, REF)
+
+    def patchify_forward(net, coords, radius):
+        B, C, H, W = net.shape
+        M, D = coords.shape[1], 2 * radius + 2
+        fx, fy = torch.floor(coords[..., 0]).long(), torch.floor(coords[..., 1]).long()
+        out = torch.zeros((B, M, C, D, D), dtype=net.dtype)
+        bidx = torch.arange(B)[:, None].expand(B, M)
+        for a in range(D):
+            for b in range(D):
+                i, j = fy + (a - radius), fx + (b - radius)
+                ok = (i >= 0) & (i < H) & (j >= 0) & (j < W)
+                v = net[bidx, :, i.clamp(0, H - 1), j.clamp(0, W - 1)]          # [B, M, C]
+                out[:, :, :, a, b] = torch.where(ok[..., None], v, torch.zeros_like(v))
+        return [out]
+
+    sys.modules["cuda_corr"].patchify_forward = patchify_forward
+    from cdvslam.altcorr import correlation as refcorr
+
+    rng = np.random.default_rng(20261004)
+    mem, C, H, W, Ng, E = 4, 24, 24, 32, 40, 144
+    fmap1 = (rng.standard_normal((mem, C, H, W)) / 4).astype(np.float16)
+    # the level-1 map as slam.py:682 makes it: 4x4 average of the level-0 map, stored in half
+    fmap2 = torch.nn.functional.avg_pool2d(torch.from_numpy(fmap1).float(), 4, 4).half().numpy()
+    gmap = (rng.standard_normal((Ng, C, 3, 3)) / 4).astype(np.float16)
+    cx, cy = rng.uniform(4, W - 4, E), rng.uniform(4, H - 4, E)
+    sc = rng.uniform(0.5, 1.6, E)
+    # borders, corners, half-outside, far outside, integer coordinates, a degenerate patch
+    cx[:12] = [0.0, W - 1.0, -0.25, W - 0.5, 1.5, W - 2.5, -3.0, W + 2.75, -40.0, 3.0 * W, 10.0, 11.0]
+    cy[:12] = [0.0, H - 1.0, H - 0.5, -0.25, -2.0, H + 1.25, 5.5, 7.25, 6.0, -3.0 * H, 12.0, 13.0]
+    off = np.arange(3.0) - 1
+    coords = np.empty((E, 2, 3, 3), np.float32)
+    coords[:, 0] = cx[:, None, None] + sc[:, None, None] * off[None, None, :]
+    coords[:, 1] = cy[:, None, None] + sc[:, None, None] * off[None, :, None]
+    coords[10] = np.round(coords[10])                   # dx = dy = 0
+    coords[11] = coords[11, :, 1:2, 1:2]                # all nine pixels on one point
+    # a rotated / sheared patch: x depends on the row, y on the column (the roles of i0 / j0 must not be swapped)
+    coords[12, 0] = 14.3 + 0.9 * off[None, None, :] + 0.4 * off[None, :, None]
+    coords[12, 1] = 9.6 - 0.3 * off[None, None, :] + 1.1 * off[None, :, None]
+    ii = rng.integers(0, Ng, E).astype(np.int64)
+    jj = rng.integers(0, mem, E).astype(np.int64)
+
+    res = {}
+    with torch.no_grad():
+        for lvl, (fm, s) in enumerate(((fmap1, 1.0), (fmap2, 4.0))):
+            net = torch.from_numpy(fm).double()
+            g = torch.from_numpy(gmap).double()
+            out = torch.zeros((E, 7, 7, 3, 3), dtype=torch.float64)
+            c = torch.from_numpy(coords) / s              # float32 division, as slam.py:321-322 does it
+            for e in range(E):
+                pts = c[e].reshape(2, 9).T[None].contiguous()          # [1, 9, (x, y)]: pixel p = i0 * 3 + j0
+                samp = refcorr.patchify(net[jj[e]][None], pts, 3, mode="bilinear")[0]       # [9, C, 7 (y_off), 7 (x_off)]
+                f1 = g[ii[e]].reshape(C, 9)                              # [C, p]
+                blended = torch.einsum("cp,pcyx->yxp", f1, samp)        # [y_off, x_off, p]
+                out[e] = blended.permute(1, 0, 2).reshape(7, 7, 3, 3)   # correlation_kernel.cu:232: (x_off, y_off, i0, j0)
+            res["corr%d" % lvl] = out.numpy()
+    np.savez_compressed(os.path.join(HERE, "corr_pin.npz"), fmap1=fmap1, fmap2=fmap2, gmap=gmap, coords=coords, ii=ii, jj=jj,
+                        **res)
+    print("corr_pin.npz", os.path.getsize(os.path.join(HERE, "corr_pin.npz")), "bytes;",
+          "max |corr0| %.3f, max |corr1| %.3f" % (np.abs(res["corr0"]).max(), np.abs(res["corr1"]).max()))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "bench-size":
         bench_size()
+    elif len(sys.argv) > 1 and sys.argv[1] == "corr-pin":
+        corr_pin()
     else:
         main()

@@ -282,6 +282,41 @@ def test_corr_fused_vs_oracle(name):
     assert np.abs(got - truth).mean() <= 0.1 * tol
 
 
+def test_corr_vs_reference_run_pin(golden_dir):
+    """Rows a1 / a2 on the GPU against `corr_pin.npz` (the reference's own patchify blend executed in this repository's
+    container, contracted with the patch features: tests/golden/make_golden.py corr-pin): cuda_corr.forward per level on
+    half and on float32 maps, and the fused two-level launch of the update path on channels-last rings with pixel-major
+    and planar tiles.  Half storage: |d| <= 2^-8 max|corr| + 2^-10; float32: 1e-5 relative."""
+    z = np.load(os.path.join(golden_dir, "corr_pin.npz"))
+    E = len(z["ii"])
+    gmap, f1, f2 = T(z["gmap"]), T(z["fmap1"]), T(z["fmap2"])
+    coords, ii, jj = T(z["coords"])[None], T(z["ii"]), T(z["jj"])
+    saved, ops._pairing = ops._pairing, ops._LevelPairing()
+    try:
+        for lvl, (fm, s) in enumerate(((f1, 1.0), (f2, 4.0))):
+            want = z["corr%d" % lvl]
+            top = np.abs(want).max()
+            got = ops.corr_forward(gmap[None], fm[None], coords / s, ii, jj, 3)
+            assert got.dtype == torch.float16 and tuple(got.shape) == (1, E, 7, 7, 3, 3)
+            assert np.abs(got[0].float().cpu().numpy() - want).max() <= 2.0 ** -8 * top + 2.0 ** -10
+            got32 = ops.corr_forward(gmap[None].float(), fm[None].float(), coords / s, ii, jj, 3)
+            assert got32.dtype == torch.float32
+            assert np.abs(got32[0].cpu().numpy() - want).max() <= 1e-5 * top
+            assert not got[0, 8].any() and not got[0, 9].any()          # far outside the map
+    finally:
+        ops._pairing = saved
+    mem, C, H, W = z["fmap1"].shape
+    r1, r2 = ops.alloc_fmap_ring(mem, C, H, W, DEV), ops.alloc_fmap_ring(mem, C, H // 4, W // 4, DEV)
+    ops.fmap_interior(r1).copy_(f1.permute(0, 2, 3, 1))
+    ops.fmap_interior(r2).copy_(f2.permute(0, 2, 3, 1))       # the fixture's own level-1 map (torch's pooling, slam.py:682)
+    want = np.stack([z["corr0"], z["corr1"]], -1).reshape(E, -1)
+    tol = _corr_tol(want)
+    for tiles, pm in ((gmap, False), (ops.gmap_to_pixel_major(gmap), True)):
+        out = ops.corr_fused(tiles, r1, r2, coords, ii, jj, pixel_major=pm)
+        assert np.abs(out[0].float().cpu().numpy() - want).max() <= tol
+        assert np.abs(out[0].float().cpu().numpy() - want).mean() <= 0.1 * tol
+
+
 def test_corr_processing_order_beyond_one_trip():
     """the same order on a graph whose per-edge launches loop (E = 705,024 > 1,024 workgroups x 256 edges): still a
     permutation grouped by target bin"""
@@ -459,7 +494,7 @@ def test_reference_call_sequence_through_the_dropin_names():
     # the bundle adjustment: the same sums in the same order, but through other instantiations of the kernels (the drop-in's
     # index carries no source frames, its workspace is sized for every patch of the buffer and so takes the four-launch
     # sequence): equal up to the compiler's multiply-add contractions
-    same_state = lambda: (float((dp.poses_ - up.poses).abs().max()) < 1e-6 and float((dp.patches_ - up.patches).abs().max()) < 1e-5)
+    same_state = lambda: (float((dp.poses_ - up.poses).abs().max()) < 1e-6 and float((dp.patches_.view_as(up.patches) - up.patches).abs().max()) < 1e-5)
     assert same_state()
     assert not torch.equal(dp.poses_, T(st.poses))
     # a second frame: only the ring slot that was written is converted again (fingerprint-gated shadow sync)
@@ -474,6 +509,71 @@ def test_reference_call_sequence_through_the_dropin_names():
     assert torch.equal(got["coords"], want["coords"]) or float((got["coords"] - want["coords"]).abs().max()) < 1e-4
     assert float((got["corr"].float() - want["corr"].float()).abs().max()) <= 2.0 ** -8 * float(want["corr"].float().abs().max()) + 2.0 ** -10
     assert same_state()
+
+
+def test_dropin_fast_path_under_the_unchanged_caller():
+    """What the round-3 review found missing: the reference's SLAM object hands over a FRESH view of gmap_ at every access
+    (slam.py:249-251; SLAM.corr reads it twice, :321-322), fresh views of poses / patches / intrinsics, NEW edge tensors
+    every frame (torch.cat, slam.py:331-337), and calls the extension through an autograd.Function under autocast
+    (altcorr/correlation.py:4-13, slam.py:486).  DropinPath now does all of that; the caches are keyed on memory + version,
+    not on Python identity.  Per update, from the second on: the two per-level calls are served by ONE fused launch
+    (n_fused + 1), the stack of the two results is the shared buffer (n_stacked + 1), the tile shadow is converted exactly
+    once, the patch-graph index is built exactly once (neighbors + BA share it), and everything equals UpdatePath.step()
+    from the same state: coordinates, correlation, neighbors bit for bit, the state after the BA to rounding."""
+    from cdv_slam_amd.update import DropinPath, UpdatePath
+    st = synth.make_state("default")
+    dev = torch.device(DEV)
+    up = UpdatePath(st, dev)
+    dp = DropinPath(st, dev)
+    assert dp.gmap is not dp.gmap and dp.poses is not dp.poses and dp.patches is not dp.patches     # property-style views
+    level1 = lambda: ops.fmap_interior(up.fmap2).permute(0, 3, 1, 2).contiguous()
+    dp.fmap2_.copy_(level1()[None])
+    ops._pairing, ops._tiles = ops._LevelPairing(), ops.TileCache()
+    g = ops._device_graph(dev)
+    for it in range(4):
+        # a new frame every step: other features, other tiles
+        up.new_frame = (up.new_frame.float() * 0.75 + 0.03125 * it).half()
+        dp.new_frame = up.new_frame.clone()
+        tiles = (dp.new_tiles.float() * 0.5 + 0.0625 * it).half()
+        dp.new_tiles = tiles
+        up.gmap[up.new_tiles:up.new_tiles + up.M] = tiles
+        dp.poses_.copy_(up.poses)                      # both paths start the step from the same state
+        dp.patches_.copy_(up.patches.view_as(dp.patches_))
+        want = up.step()
+        f0, s0, c0, b0 = ops._pairing.n_fused, ops._pairing.n_stacked, ops._tiles.n_converted, g.n_builds
+        old = (dp.ii, dp.jj, dp.kk)
+        got = dp.step(pooled=level1()[up.new_slot])
+        torch.cuda.synchronize()
+        assert dp.ii is not old[0] and dp.jj is not old[1] and dp.kk is not old[2]      # fresh edge tensors, as torch.cat leaves
+        assert dp.ii.data_ptr() != old[0].data_ptr() and torch.equal(dp.ii, old[0])
+        if it > 0:      # step 0 taught the pairing
+            assert ops._pairing.n_fused == f0 + 1 and ops._pairing.n_stacked == s0 + 1, it
+            assert ops._tiles.n_converted == c0 + 1, it
+        assert g.n_builds == b0 + 1, it
+        assert type(got["corr"]) is torch.Tensor and got["corr"].shape == want["corr"].shape
+        assert torch.equal(got["coords"], want["coords"]), it
+        assert torch.equal(got["corr"], want["corr"]), it
+        assert torch.equal(got["ix"], want["ix"]) and torch.equal(got["jx"], want["jx"]), it
+        assert float((dp.poses_ - up.poses).abs().max()) < 1e-6, it
+        assert float((dp.patches_.view_as(up.patches) - up.patches).abs().max()) < 1e-5, it
+    # the same tensors once more, nothing written in between: the index is not rebuilt, the tiles not reconverted
+    b0, c0 = g.n_builds, ops._tiles.n_converted
+    dp.step(ingest=False)
+    assert g.n_builds == b0 and ops._tiles.n_converted == c0
+    # gmap_ written through ANOTHER view between the two calls of a pair: the second call must not be served from the pair
+    coords = dp.reproject()
+    ii1, jj1 = dp.kk % (dp.M * dp.pmem), dp.jj % dp.mem
+    f0 = ops._pairing.n_fused
+    a, = dp.cuda_corr.forward(dp.gmap, dp.pyramid[0], coords / 1, ii1, jj1, 3)
+    dp.gmap_[3] = dp.gmap_[4]
+    b, = dp.cuda_corr.forward(dp.gmap, dp.pyramid[1], coords / 4, ii1, jj1, 3)
+    assert ops._pairing.n_fused == f0 and not isinstance(b, ops.PairedLevel)
+    saved, ops._pairing = ops._pairing, ops._LevelPairing()
+    try:
+        assert torch.equal(b, ops.corr_forward(dp.gmap, dp.pyramid[1], coords / 4, ii1, jj1, 3))
+    finally:
+        ops._pairing = saved
+    ops._pairing, ops._tiles = ops._LevelPairing(), ops.TileCache()
 
 
 def test_corr_pixel_major_tiles_bit_identical():

@@ -194,3 +194,38 @@ def test_pops_small_golden():
         assert np.allclose(a, b, rtol=2e-4, atol=2e-5 * np.abs(b).max())
     c3, vpx = O.transform(*args, valid=True, dtype=np.float32)
     assert np.array_equal(vpx, g["validpx"])
+
+
+def test_corr_oracle_vs_reference_run_pin(golden_dir):
+    """Rows a1 / a2: the correlation oracle against `corr_pin.npz` -- the reference's own `altcorr.patchify(..., 'bilinear')`
+    (cdvslam/altcorr/correlation.py:51-71, executed by tests/golden/make_golden.py corr-pin) contracted with the patch
+    features: its blend weights, its roles of dx / dy, its zero for out-of-range integer samples, the [x][y] order of
+    correlation_kernel.cu:232 -- on borders, corners, far-outside, integer and sheared patches, both pyramid levels.
+    Still unpinned by anything that runs: the half-precision accumulate order of correlation_kernel.cu:121-131 and the
+    cast of dx / dy to half (:218-219); mode "ref" restates those and is only held inside the half envelope here."""
+    z = np.load(os.path.join(golden_dir, "corr_pin.npz"))
+    g32 = z["gmap"].astype(np.float32)
+    for lvl, (fm, s) in enumerate(((z["fmap1"], 1.0), (z["fmap2"], 4.0))):
+        c = (z["coords"] / np.float32(s)).astype(np.float32)
+        want = z["corr%d" % lvl]
+        top = np.abs(want).max()
+        assert top > 0.2
+        # float64 accumulation of the same products (the half maps are exact in float32); the reference's weights are
+        # float32 products (1 - dy) * (1 - dx), hence 1e-7 and not 1e-15
+        truth = O.corr(g32, fm.astype(np.float32), c, z["ii"], z["jj"], 3, "truth")
+        assert truth.shape == want.shape == (len(z["ii"]), 7, 7, 3, 3)
+        assert np.abs(truth - want).max() <= 2e-7 * top
+        # the [x][y] order and the i0 / j0 roles are really pinned: the transposed readings are far off
+        assert np.abs(truth.transpose(0, 2, 1, 3, 4) - want).max() > 0.1 * top
+        assert np.abs(truth.transpose(0, 1, 2, 4, 3) - want).max() > 0.1 * top
+        f32 = O.corr(g32, fm.astype(np.float32), c, z["ii"], z["jj"], 3, "f32")
+        assert np.abs(f32 - want).max() <= 1e-5 * top
+        half = O.corr(z["gmap"], fm, c, z["ii"], z["jj"], 3, "ref").astype(np.float64)
+        assert np.abs(half - want).max() <= 2.0 ** -8 * top + 2.0 ** -10
+        # far outside the map: exact zeros in every reading
+        for a in (truth, f32, half):
+            assert not a[8].any() and not a[9].any() and not want[8].any()
+    both = O.slam_corr(z["gmap"].astype(np.float32), z["fmap1"].astype(np.float32), z["fmap2"].astype(np.float32), z["coords"],
+                       z["ii"], z["jj"], 3, "truth")
+    want = np.stack([z["corr0"], z["corr1"]], -1).reshape(len(z["ii"]), -1)      # slam.py:323
+    assert np.abs(both - want).max() <= 2e-7 * np.abs(want).max()
