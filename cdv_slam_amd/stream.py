@@ -17,7 +17,7 @@ from .edges import EdgeStore, frames_keyframe_shift
 class StreamRunner:
     def __init__(self, device, M=96, ht=384, wd=512, C=24, mem=36, pmem=36, buffer_size=512, patch_lifetime=13,
                  removal_window=22, opt_window=10, keyframe_index=4, seed=1234, loop_closure=False, max_edge_age=1000,
-                 global_opt_freq=15, backend_thresh=64.0, pose_init=None, record_global=False):
+                 global_opt_freq=15, backend_thresh=64.0, pose_init=None, record_global=False, keyframe_thresh=12.5, gain=0.01):
         """loop_closure: the LOOP_CLOSURE configuration of the reference (default_cdvslam.yaml): the patch ring holds
         MAX_EDGE_AGE frames (slam.py:66-68), proximity loop edges are added every GLOBAL_OPT_FREQ frames
         (slam.py:699-705, patchgraph.py:71-97), edges that close loops survive the removal window (slam.py:453-457) and an
@@ -36,6 +36,8 @@ class StreamRunner:
         self.h, self.w = ht // 4, wd // 4
         self.r, self.rw, self.ow, self.ki = patch_lifetime, removal_window, opt_window, keyframe_index
         self.N = buffer_size
+        self.kthresh, self.gain = keyframe_thresh, gain      # KEYFRAME_THRESH (config.py:20); the operator stub's step
+        self.last_motion = None
         g = torch.Generator(device="cpu").manual_seed(seed)
         self.g = g
         f32 = dict(dtype=torch.float32, device=device)
@@ -67,19 +69,24 @@ class StreamRunner:
         self.pool = [(torch.randn((C, self.h, self.w), generator=g) / 4).half().to(device) for _ in range(4)]
 
     # -- stub of network.patchify (net_cdv.py:355-374): random patch centres, tiles cut out of the frame's features
-    def _new_frame(self):
+    def _new_frame(self, inputs=None):
+        """inputs: (fmap [C,h,w] f16, cx [M], cy [M], d [M]) on the device -- the stubbed network's outputs for this frame
+        (tests hand the same ones to the oracle runner); None: drawn here"""
         M, n = self.M, self.n
-        fmap = self.pool[n % len(self.pool)]
-        cx = torch.rand(M, generator=self.g) * (self.w - 16) + 8
-        cy = torch.rand(M, generator=self.g) * (self.h - 16) + 8
-        d = torch.rand(M, generator=self.g) * 0.75 + 0.25
-        off = torch.tensor([-1.0, 0.0, 1.0])
-        pt = torch.empty((M, 3, 3, 3))
+        if inputs is None:
+            fmap = self.pool[n % len(self.pool)]
+            cx = (torch.rand(M, generator=self.g) * (self.w - 16) + 8).to(self.dev)
+            cy = (torch.rand(M, generator=self.g) * (self.h - 16) + 8).to(self.dev)
+            d = (torch.rand(M, generator=self.g) * 0.75 + 0.25).to(self.dev)
+        else:
+            fmap, cx, cy, d = inputs
+        off = torch.tensor([-1.0, 0.0, 1.0], device=self.dev)
+        pt = torch.empty((M, 3, 3, 3), device=self.dev)
         pt[:, 0] = cx[:, None, None] + off[None, None, :]
         pt[:, 1] = cy[:, None, None] + off[None, :, None]
         pt[:, 2] = d[:, None, None]
-        self.patches[n * M:(n + 1) * M] = pt.to(self.dev)
-        coords = torch.stack([cx, cy], -1)[None].to(self.dev)
+        self.patches[n * M:(n + 1) * M] = pt
+        coords = torch.stack([cx, cy], -1)[None]
         tiles = ops.patchify_blend(fmap[None], coords, 1, "bilinear")[0].half()       # [M,C,3,3]
         t0 = (n % self.pmem) * M
         self.gmap[t0:t0 + M] = tiles
@@ -104,7 +111,7 @@ class StreamRunner:
             corr = ops.corr_fused(self.gmap_pm, self.fmap1, self.fmap2, coords, kk, jj, kmod=M * self.pmem, jmod=self.mem,
                                   pixel_major=True, order_ptr=self.graph.corr_order_ptr())   # edges grouped by target frame
         # stub of the update operator (net_cdv.py:66-107): a small correction that depends on the correlation
-        delta = 0.01 * torch.tanh(corr[0, :, :2].float())
+        delta = self.gain * torch.tanh(corr[0, :, :2].float())
         e.target[0].copy_(coords[0, :, :, 1, 1] + delta)
         e.weight[0].copy_(torch.sigmoid(corr[0, :, 2:4].float()))
         if self.lc and bool((e.ii < n - self.rw - 1).any()) and not self.ran_global_ba.get(n, False):
@@ -151,11 +158,24 @@ class StreamRunner:
                                    (self.fmap1, self.mem), (self.fmap2, self.mem)], k, n)
         self.n = self.edges.keyframe(k, n, M, self.ix, self.rw, loop_closure=self.lc, opt_window=self.ow, drop=drop)
 
-    def frame(self, drop=False):
-        """one incoming frame (slam.py:697-720 for an initialised system)"""
+    def motion(self):
+        """the keyframe test's statistic (slam.py:399-413): mean flow between the frames either side of k = n -
+        KEYFRAME_INDEX, both directions; read back like the reference's two .item() calls"""
+        from . import projective_ops as pops
+        e, n = self.edges, self.n
+        tot = 0.0
+        for i, j in ((n - self.ki - 1, n - self.ki + 1), (n - self.ki + 1, n - self.ki - 1)):
+            k = (e.ii == i) & (e.jj == j)
+            flow, _ = pops.flow_mag(self.poses[None], self.patches[None], self.intrinsics[None], e.ii[k], e.jj[k], e.kk[k], beta=0.5)
+            tot += flow.mean().item()
+        return 0.5 * tot
+
+    def frame(self, drop=False, inputs=None):
+        """one incoming frame (slam.py:697-720 for an initialised system).  drop: True / False = the caller decides
+        whether frame n - KEYFRAME_INDEX leaves; None = the reference's test (mean flow under KEYFRAME_THRESH, slam.py:413)"""
         if self.n + 1 >= self.N:
             raise RuntimeError("StreamRunner: frame buffer full")
-        fmap, tile0 = self._new_frame()
+        fmap, tile0 = self._new_frame(inputs)
         self.n += 1
         self.last_loop_edges = None
         if self.lc and self.n - self.last_global_ba >= self.gof:      # proximity loop edges (slam.py:699-705)
@@ -171,7 +191,11 @@ class StreamRunner:
         self.edges.append_frame(self.ix, self.n, self.M, self.r)
         if self.n >= 8:
             self._update(fmap, tile0)
-            self._keyframe(drop and self.n > self.ki + 2)
+            self.last_motion = None
+            if drop is None:
+                self.last_motion = self.motion()
+                drop = self.last_motion < self.kthresh
+            self._keyframe(bool(drop) and self.n > self.ki + 2)
         else:   # before initialisation only the rings are filled
             ops.fmap_ingest(fmap, self.fmap1, self.fmap2, (self.n - 1) % self.mem, gmap=self.gmap, gmap_pm=self.gmap_pm,
                             gmap_first=tile0, gmap_count=self.M)
