@@ -72,6 +72,7 @@ SIGNATURES = {
                               _i64, _vp, _vp]),
     "cdv_ba_status": (_i32, [_vp, _vp, _vp]),
     "cdv_ba_bind_status_counters": (_i32, [_vp, _vp]),
+    "cdv_ba_test_handoff": (_i32, [_i32]),
     "cdv_lie_op": (_i32, [_i32, _i32, _i32, _i64, _vp, _vp, _vp, _vp]),
 }
 

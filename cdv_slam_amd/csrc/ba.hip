@@ -11,6 +11,7 @@
 //   N = 0           ba_patch_kernel + q + retract: depths alone.
 #include <stdlib.h>
 
+#include <atomic>
 #include <mutex>
 #include <unordered_map>
 
@@ -36,6 +37,7 @@ struct WsState {
 std::mutex g_ws_mutex;
 std::unordered_map<const void*, WsState> g_ws_state;
 std::unordered_map<const void*, int32_t*> g_ws_counters;   // cdv_ba_bind_status_counters
+std::atomic<int> g_handoff_test{0};                        // cdv_ba_test_handoff: fault injection for the in-launch hand-offs
 
 typedef EdgeFactor EdgeJ;   // residual, weights and Jacobian rows of one edge (cdv_se3.h: fastba_factor)
 
@@ -943,11 +945,12 @@ __global__ __launch_bounds__(STEP_T) void ba_big_step_kernel(float* __restrict__
 // L_kk: one v_readlane + FMA per unknown) and publishes them as {launch token, value} granules, written through; every
 // workgroup picks them up (the poll is the load) and folds them into its columns left of the block -- all 64 row loads
 // of a thread in flight together.  The next block's L_kk is fetched before the wait.  29 launches of 8.7 us became one
-// chain of ~5 us steps.  Bounded polls: a lost hand-off raises the hand-off word and leaves dX at what was written.
+// chain of ~5 us steps.  Bounded polls: a lost hand-off raises the hand-off word; dX is then incomplete and the retract launch
+// that follows applies NOTHING of it (it only re-zeroes the accumulators): the update is all-or-nothing.
 __global__ __launch_bounds__(256) void ba_big_backsolve_kernel(float* __restrict__ A, int npad, int n,
                                                                float* __restrict__ dXg, uint64_t* __restrict__ xg, int token,
                                                                const int32_t* __restrict__ gmeta, float* __restrict__ dbg,
-                                                               int32_t* __restrict__ info) {
+                                                               int32_t* __restrict__ info, int test) {
   if (gmeta[GM_ERROR] || info[1]) return;
   __shared__ __attribute__((aligned(16))) float Lb[CNB * CLD];
   __shared__ float xs[CNB];
@@ -1002,8 +1005,9 @@ __global__ __launch_bounds__(256) void ba_big_backsolve_kernel(float* __restrict
           zz = fmaf(-col[r], xr, zz);
         }
         xs[lane] = x;
-        __hip_atomic_store(&xg[c0 + lane], ((uint64_t)(uint32_t)token << 32) | (uint64_t)(uint32_t)__float_as_int(x),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!(test && kb == nb - 2))      // fault injection (tests): the second block's solution never leaves its owner
+          __hip_atomic_store(&xg[c0 + lane], ((uint64_t)(uint32_t)token << 32) | (uint64_t)(uint32_t)__float_as_int(x),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (c0 + lane < n) {
           dXg[c0 + lane] = x;
           if (dbg) dbg[(size_t)n * n + n + c0 + lane] = x;
@@ -1012,7 +1016,7 @@ __global__ __launch_bounds__(256) void ba_big_backsolve_kernel(float* __restrict
     } else if (wave == 0) {
       float xv = 0.f;
       bool ok = false;
-      for (int spins = 0; spins < (1 << 20); spins++) {
+      for (int spins = 0; spins < (test ? (1 << 10) : (1 << 20)); spins++) {
         if (!ok) {
           const uint64_t g = __hip_atomic_load(&xg[c0 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if ((uint32_t)(g >> 32) == (uint32_t)token) { xv = __int_as_float((int)(uint32_t)g); ok = true; }
@@ -1067,6 +1071,9 @@ __global__ __launch_bounds__(64 * RET_RG) void ba_retract_kernel(float* __restri
                                                         const float* __restrict__ lmbda_q, uint32_t* __restrict__ cmask,
                                                         int n_chunks) {
   if (gmeta[GM_ERROR] || info[1]) return;
+  // a lost hand-off in the back-substitution launch (final by now: that launch is over): dX is incomplete, so NOTHING of this
+  // iteration is applied -- poses and depths stay as they are, only the accumulators are re-zeroed for the next call
+  const bool apply = info[BI_HANDOFF] == 0;
   const int U = gmeta[GM_U];
   const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
   // global-BA path: a workgroup is one chunk of 64 patches; its panel mask says which 8-pose panels of E are non-zero
@@ -1083,7 +1090,7 @@ __global__ __launch_bounds__(64 * RET_RG) void ba_retract_kernel(float* __restri
   // pose_retr_kernel (ba_cuda.cu:178-206): T <- Exp(dX_i) T, one lane per free pose, in wave 0 of the last workgroups
   // (the first ones carry the longest E-column sweeps)
   const int gid_rev = (int)(gridDim.x * 64) - 1 - (int)(blockIdx.x * 64 + lane);
-  if (pose_retr && g == 0 && gid_rev < N) {
+  if (pose_retr && apply && g == 0 && gid_rev < N) {
     const int pi = gid_rev;
     float* p = poses + 7 * (size_t)(t0 + pi);
     float pose[7], xi[6];
@@ -1128,6 +1135,7 @@ __global__ __launch_bounds__(64 * RET_RG) void ba_retract_kernel(float* __restri
   if (dbgp) { dbgp[r] = dz; dbgp[U_stride + r] = cv; dbgp[2 * (size_t)U_stride + r] = uv; }
   Cg[r] = 0.f;
   ug[r] = 0.f;
+  if (!apply) return;
   float* pk = patches + kx[r] * 3 * PP + 2 * PP;
   float d = pk[0];                 // patch_retr_kernel reads pixel [0][0]   ba_cuda.cu:218
   d = d + dz;
@@ -1249,18 +1257,9 @@ extern "C" int cdv_ba_forward(float* poses, float* patches, const float* intrins
     wa.Cg = Cg; wa.ug = ug; wa.qg = qg; wa.Edg = Edg; wa.dXg = dXg;
     wa.U_stride = (int)L.U_stride; wa.U_max = (int)L.U_max; wa.n_ck_cap = (int)L.n_ck;
     wa.info = info; wa.counters = counters;
-    wa.pose_next = (float*)(b + L.pnext); wa.pose_src = nullptr;
+    wa.test = g_handoff_test.load();
     wa.dbg = nullptr;
     wa.token = token_base + 1;
-    // CDV_BA_FUSE=1: two iterations as THREE launches (ba_win.hip cdv_ba_window_two_iterations: the first solve and the
-    // second chunk pass share a grid).  Measured on the default graph: 12.8 + 26.3 + 15.8 us against 2 x (12.7 + 14.9), the
-    // same 9,880 updates/s -- the chunk pass cannot start before dX exists, so only its load levels overlap the solver and
-    // the saved launch boundary is given back in polling.  Kept as an option (and tested against the plain sequence), off
-    // by default.
-    const char* fuse_env = getenv("CDV_BA_FUSE");
-    const bool fuse = fuse_env != nullptr && atoi(fuse_env) == 1;
-    if (N <= WIN_N && iterations == 2 && dbg == nullptr && fuse && cdv_ba_window_can_fuse(wa))
-      return cdv_ba_window_two_iterations(wa, s);
     for (int itr = 0; itr < iterations; itr++) {
       wa.dbg = (dbg && itr == 0) ? dbg : nullptr;
       wa.first = itr == 0 ? 1 : 0;
@@ -1318,7 +1317,7 @@ extern "C" int cdv_ba_forward(float* poses, float* patches, const float* intrins
                            info);
       }
       hipLaunchKernelGGL(ba_big_backsolve_kernel, dim3(cdv_div_up(npad, 256)), dim3(256), 0, s, Abig, npad, n6i, dXg,
-                         (uint64_t*)(b + L.xgran), token_base + 1 + itr, gv.meta, d, info);
+                         (uint64_t*)(b + L.xgran), token_base + 1 + itr, gv.meta, d, info, g_handoff_test.load());
     } else {
       // only N = 0 gets here (no free pose: depths alone are refined): q = 1 / (C + lambda)
       hipLaunchKernelGGL(ba_q_kernel, dim3(cdv_div_up(L.U_max, 256) < 1024 ? (int)cdv_div_up(L.U_max, 256) : 1024), dim3(256), 0, s,
@@ -1338,6 +1337,17 @@ extern "C" int cdv_ba_forward(float* poses, float* patches, const float* intrins
 // ---------------------------------------------------------------------------------------------------------
 // status of a workspace
 // ---------------------------------------------------------------------------------------------------------
+
+// Fault injection for the in-launch hand-offs (tests only; process-wide, read by the next cdv_ba_forward calls):
+//   0 off; 1 the solver of the N <= 32 paths stalls BEFORE its commit (the retract workgroups abandon: nothing is applied) --
+//   on the global path the back substitution withholds one block's solution (its readers time out: nothing is applied);
+//   2 the solver stalls AFTER its commit (the retract workgroups lose their patience, learn that the solution is coming and
+//   wait on: the update is applied as usual).  The waits are shortened so that a test takes milliseconds.
+extern "C" int cdv_ba_test_handoff(int mode) {
+  CDV_REQUIRE(mode >= 0 && mode <= 2, CDV_ERR_ARG, "cdv_ba_test_handoff: mode 0, 1 or 2");
+  g_handoff_test.store(mode);
+  return CDV_OK;
+}
 
 extern "C" int cdv_ba_bind_status_counters(void* ba_ws, int32_t* counters) {
   CDV_REQUIRE(ba_ws != nullptr, CDV_ERR_ARG, "cdv_ba_bind_status_counters: workspace is NULL");

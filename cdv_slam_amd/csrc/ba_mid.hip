@@ -106,6 +106,7 @@ __global__ __launch_bounds__(64 * MKW) CDV_MID_OCC void ba_mid_chunk_kernel(BaWi
     if (tid == 0) {
       ba_begin_status(A.info, A.counters, A.first, gerr, U > A.U_max);
       *A.arrive = 0;                              // hand-off words of the finish launch that follows
+      A.arrive[HO_VERDICT] = HO_UNDECIDED;
     }
     for (int i = tid; i < MID_GRAN; i += 64 * MKW) A.granX[i] = 0ull;
   }
@@ -544,8 +545,15 @@ __device__ __forceinline__ void mid_solve(const BaWinArgs& A, float* smem) {
   CDV_STAMP_RT(bam, sslot, 14);
   // lower-triangular tile pairs (ti >= tj) in row-major order: the first T (T + 1) / 2 entries serve any T
   __shared__ int ttab[96];
-  __shared__ int s_read;
-  if (t == 0) s_read = 0;
+  __shared__ int s_read, s_verdict, s_lost;
+  if (t == 0) {
+    s_read = 0;
+    s_lost = 0;
+    // the solver of this path waits for nothing outside its workgroup (the reduce was a launch of its own): it COMMITS to
+    // publishing dX right away -- unless a retract workgroup has already given up on it (cdv_ba.h ho_decide)
+    if (A.test == HO_TEST_STALL_BEFORE) ho_test_stall();
+    s_verdict = ho_decide(&A.arrive[HO_VERDICT], HO_COMMITTED);
+  }
   if (t < 96) {
     int ti = 0, acc_rows = 0;
     while (acc_rows + ti + 1 <= t) { acc_rows += ti + 1; ti++; }
@@ -663,7 +671,7 @@ __device__ __forceinline__ void mid_solve(const BaWinArgs& A, float* smem) {
         }
         // a reader that never checked in: the block is NOT overwritten under it (the factor is then wrong, and said to be:
         // the hand-off word is raised like for every other lost hand-off of this path)
-        if (!copied && lane == 0) ba_flag(A.info, BI_HANDOFF, 1);
+        if (!copied && lane == 0) { ba_flag(A.info, BI_HANDOFF, 1); s_lost = 1; }   // nothing is published below
         if (has && copied) {
           float* rp = &Am[row * LD + c0];
 #pragma unroll
@@ -853,6 +861,18 @@ __device__ __forceinline__ void mid_solve(const BaWinArgs& A, float* smem) {
   }
   __syncthreads();
   CDV_STAMP(bam, sslot, 4);
+  if (A.test == HO_TEST_STALL_AFTER && t == 0) ho_test_stall();
+  if (A.test == HO_TEST_STALL_AFTER) __syncthreads();
+  if (s_verdict != HO_COMMITTED || s_lost) {
+    // a retract workgroup abandoned the launch before the commit (all of them have left or will), or the factor is not to
+    // be trusted (a hand-off inside this workgroup failed): nothing is published, nothing is applied
+    if (t == 0) {
+      ba_flag(A.info, BI_HANDOFF, 1);
+      if (s_verdict == HO_COMMITTED)      // retract workgroups are waiting for a solution that will not come: tell them
+        __hip_atomic_store(&A.arrive[HO_VERDICT], HO_ABANDONED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
   if (t < n) {
     const float x = z[t];
     __hip_atomic_store(&A.granX[t], (1ull << 32) | (uint64_t)(uint32_t)__float_as_int(x), __ATOMIC_RELAXED,
@@ -993,28 +1013,38 @@ __global__ __launch_bounds__(FT) void ba_mid_finish_kernel(BaWinArgs A) {
     d0 = pk[0];                      // the depth is read from pixel [0][0]   (ba_cuda.cu:218 semantics)
   }
   CDV_STAMP(bam, sslot, 2);
-  // ---- 3. wait for the solver (bounded) ----
-  __shared__ int s_bad;
-  if (tid == 0) s_bad = 0;
-  __syncthreads();
-  if (tid < MID_GRAN) {   // thread t polls the granule of unknown t until its tag shows up; the poll is the load of dX
-    float xv = 0.f;
-    bool ok = tid >= n6;
-    for (int spins = 0; spins < (1 << 21); spins++) {
-      if (!ok) {
-        const uint64_t g = __hip_atomic_load(&A.granX[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((uint32_t)(g >> 32) == 1u) { xv = __int_as_float((int)(uint32_t)g); ok = true; }
+  // ---- 3. wait for the solver: all-or-nothing (cdv_ba.h ho_decide; the same protocol as ba_win.hip's finish launch) ----
+  __shared__ int s_bad, s_go;
+  const int patience = A.test ? (1 << 10) : (1 << 21);
+  for (int round = 0; round < 2; round++) {
+    if (tid == 0) { s_bad = 0; s_go = 0; }
+    __syncthreads();
+    if (tid < MID_GRAN) {   // thread t polls the granule of unknown t until its tag shows up; the poll is the load of dX
+      float xv = 0.f;
+      bool ok = tid >= n6;
+      for (int spins = 0; spins < (round == 0 ? patience : (1 << 24)); spins++) {
+        if (!ok) {
+          const uint64_t g = __hip_atomic_load(&A.granX[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((uint32_t)(g >> 32) == 1u) { xv = __int_as_float((int)(uint32_t)g); ok = true; }
+        }
+        if (__all(ok)) break;
+        if ((spins & 255) == 255 &&      // the solver said it will not publish
+            __hip_atomic_load(&A.arrive[HO_VERDICT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == HO_ABANDONED) break;
+        __builtin_amdgcn_s_sleep(2);
       }
-      if (__all(ok)) break;
-      __builtin_amdgcn_s_sleep(2);
+      if (tid < SNP) sdx[tid] = xv;
+      if (!ok) s_bad = 1;
     }
-    if (tid < SNP) sdx[tid] = xv;
-    if (!ok) s_bad = 1;
+    __syncthreads();
+    if (!s_bad) break;
+    // patience ran out: ask for the verdict.  COMMITTED: the solution is coming, wait on (once); otherwise nobody applies it
+    if (tid == 0) s_go = (round == 0 && ho_decide(&A.arrive[HO_VERDICT], HO_ABANDONED) == HO_COMMITTED) ? 1 : 0;
+    __syncthreads();
+    if (!s_go) break;
   }
-  __syncthreads();
   if (s_bad) {
     if (tid == 0) ba_flag(A.info, BI_HANDOFF, 1);
-    return;   // no update without a solution: poses and depths stay as they were
+    return;   // no update without a solution: poses and depths stay as they were -- in EVERY retract workgroup
   }
   CDV_STAMP(bam, sslot, 3);
   // ---- 4. pose retraction T <- Exp(dX_i) T: the first retract workgroup's first N lanes ----

@@ -44,8 +44,6 @@ constexpr int SN = WIN_SN;
 constexpr int TRI = WIN_TRI;
 constexpr int SLAB = WIN_SLAB;
 constexpr int EDL = CK + 1;                // row stride of the chunk's [E; u] block in LDS
-constexpr int FUS_POSE0 = 64;              // first dX granule that carries a retracted pose component in a fused launch
-static_assert(FUS_POSE0 + 7 * WIN_N <= MID_GRAN, "granules");
 constexpr int LDS_CHUNK_FLOATS = CKW * SLAB + 64 * EDL + CKW * 8 * CK + 2 * CK;
 
 // one reduced value of frame pair (ci, cj) (free-pose indices or -1) into the wave's packed copy of [S | y]
@@ -74,9 +72,7 @@ __device__ __forceinline__ float ld_agent(const float* p) {   // global_load_dwo
                                                __HIP_MEMORY_SCOPE_AGENT));
 }
 
-// Reduce share of workgroup b of RW: threads 0..255 work (`act`), any further threads of the workgroup only keep the
-// barriers company (the fused launch runs this inside 512-thread workgroups with the very same thread roles, so that
-// its sums are the plain finish launch's bit for bit).
+// Reduce share of workgroup b of RW.
 __device__ __forceinline__ void reduce_slabs(const BaWinArgs& A, int b, int RW, int U, int tid, bool flag_it) {
   const bool act = tid < 256;
 // ---- reduce the chunk slabs.  A CU streams ~10 B per cycle, so the 1.5 MB of slabs want many CUs: a workgroup takes
@@ -141,7 +137,6 @@ __device__ __forceinline__ void reduce_slabs(const BaWinArgs& A, int b, int RW, 
 // v_pk_fma_f32 every 8 cycles and a ds_read_b128 every ~8, and the ~30 instructions of a column step, chain included,
 // are paid per column whoever does the bulk of the update.)
 // The 60 x 60 system in the registers of ONE wave.  Lane r holds row r of [S ; y^T] (lane 60 = the right-hand side).
-template <bool FUSED>
 __device__ __forceinline__ void solve_wave(const BaWinArgs& A, int RW) {
   __shared__ __attribute__((aligned(16))) float colb[64];          // the column being broadcast
   __shared__ __attribute__((aligned(16))) float Lt[(SN + 1) * 68]; // L for the back substitution (row stride 68)
@@ -161,9 +156,16 @@ __device__ __forceinline__ void solve_wave(const BaWinArgs& A, int RW) {
     if (__all(f0 == token && f1 == token)) { ok = true; break; }
     __builtin_amdgcn_s_sleep(1);
   }
+  if (A.test == HO_TEST_STALL_BEFORE) ho_test_stall();
+  // ---- ONE decision per launch (cdv_ba.h ho_decide): from here on the solver has nothing left to wait for, so it COMMITS to
+  // publishing dX -- unless a retract workgroup has given up first, in which case nothing of this iteration may be
+  // applied by anybody.  The compare-and-swap is issued now and looked at before the granules go out: its round trip
+  // lies under the loads and the factorisation. ----
+  int verdict = HO_ABANDONED;
+  if (lane == 0) verdict = ho_decide(&A.arrive[HO_VERDICT], ok ? HO_COMMITTED : HO_ABANDONED);
   if (!ok) {
     if (lane == 0) ba_flag(A.info, BI_HANDOFF, 1);
-    return;   // the retract workgroups time out on the dX granules and leave the state untouched
+    return;   // the retract workgroups read the verdict and leave the state untouched
   }
   CDV_STAMP(baw, sslot, 1);
   // ---- the reduced system: coalesced 8-byte write-through loads (every lane 15 of them, one memory round trip) into
@@ -278,6 +280,11 @@ __device__ __forceinline__ void solve_wave(const BaWinArgs& A, int RW) {
     z = fmaf(-col[r], xr, z);
   }
   CDV_STAMP(baw, sslot, 4);
+  if (A.test == HO_TEST_STALL_AFTER) ho_test_stall();
+  if (__builtin_amdgcn_readfirstlane(verdict) != HO_COMMITTED) {   // a retract workgroup gave up before the commit: all of them did
+    if (lane == 0) ba_flag(A.info, BI_HANDOFF, 1);
+    return;
+  }
   if (lane < n) {
     // the data IS the flag: one 8-byte {tag = this launch's token, value} granule per unknown, written through; the retract workgroups
     // poll the tags of the granules they read (CDNA programming guide, Guideline 16, recipe R2)
@@ -287,76 +294,11 @@ __device__ __forceinline__ void solve_wave(const BaWinArgs& A, int RW) {
     if (A.dbg) A.dbg[(size_t)n * n + n + lane] = x;
   }
   if (lane == 0 && badk) ba_flag(A.info, BI_CHOL, badk);
-  if (FUSED) {
-    // The poses of the free frames, retracted ONCE, here: published as granules FUS_POSE0 + 7 t + c for the chunk workgroups
-    // of this launch (the poses in place are not written during it: whoever reads them reads iteration 0's), and put
-    // aside in pose_next for the finish launch that follows.
-    wave_lds_sync();
-    colb[lane] = x;
-    wave_lds_sync();
-    if (lane < A.N) {
-      const float* p = A.poses + 7 * (size_t)(A.t0 + lane);
-      float pose[7], xi[6];
-#pragma unroll
-      for (int c = 0; c < 7; c++) pose[c] = p[c];
-#pragma unroll
-      for (int c = 0; c < 6; c++) xi[c] = colb[6 * lane + c];
-      se3_retract_raw(xi, pose);
-#pragma unroll
-      for (int c = 0; c < 7; c++) {
-        __hip_atomic_store(&A.granX[FUS_POSE0 + 7 * lane + c],
-                           ((uint64_t)(uint32_t)token << 32) | (uint64_t)(uint32_t)__float_as_int(pose[c]), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-        A.pose_next[7 * lane + c] = pose[c];
-      }
-    }
-  }
   CDV_STAMP(baw, sslot, 5);
   CDV_STAMP_RT(baw, sslot, 15);
 }
 
-// dX and the retracted poses of the fused launch's solver -> sdx[64], spose[7 N], as the retract workgroups of the finish
-// launch take dX (bounded poll of the tagged granules: wave 0 the unknowns, waves 1 and 2 the pose components); false: no
-// solution arrived (status word raised) -- the caller goes on with dX = 0 and the poses as they stand
-__device__ __forceinline__ bool fused_wait(const BaWinArgs& A, float* sdx, float* spose, int* s_ok, int tid) {
-  // ONE wave polls (lane l: granules l, 64 + l, 128 + l), with long sleeps: 144 workgroups hammering the same lines would
-  // stand in the way of the solver's own loads and stores
-  if (tid < 64) {
-    const int n6 = 6 * A.N, n7 = 7 * A.N;
-    float v0 = 0.f, v1 = 0.f, v2 = 0.f;
-    bool k0 = tid >= n6, k1 = tid >= n7, k2 = 64 + tid >= n7;
-    // the pose components are published last: wait for the lane's LAST needed granule first, the others are there then
-    for (int spins = 0; spins < (1 << 19); spins++) {
-      if (!k2) { const uint64_t g = __hip_atomic_load(&A.granX[FUS_POSE0 + 64 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                 if ((uint32_t)(g >> 32) == (uint32_t)A.token) { v2 = __int_as_float((int)(uint32_t)g); k2 = true; } }
-      if (!k1) { const uint64_t g = __hip_atomic_load(&A.granX[FUS_POSE0 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                 if ((uint32_t)(g >> 32) == (uint32_t)A.token) { v1 = __int_as_float((int)(uint32_t)g); k1 = true; } }
-      if (!k0) { const uint64_t g = __hip_atomic_load(&A.granX[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                 if ((uint32_t)(g >> 32) == (uint32_t)A.token) { v0 = __int_as_float((int)(uint32_t)g); k0 = true; } }
-      if (__all(k0 && k1 && k2)) break;
-      __builtin_amdgcn_s_sleep(8);
-    }
-    const bool all_ok = __all(k0 && k1 && k2);
-    if (!all_ok && tid == 0) ba_flag(A.info, BI_HANDOFF, 1);
-    if (tid == 0) *s_ok = all_ok ? 1 : 0;
-    sdx[tid] = all_ok ? v0 : 0.f;
-    if (tid < n7) spose[tid] = v1;
-    if (64 + tid < n7) spose[64 + tid] = v2;
-  }
-  __syncthreads();
-  return *s_ok != 0;
-}
-
-// FUSED: ONE launch = the solve of the previous iteration + this iteration's chunk systems.  Workgroup 0 is the solver
-// wave; workgroup 1 + c first does its share of the slab reduce of the previous iteration (the finish launch's reduce,
-// thread for thread), then requests everything chunk c needs -- records, the poses and depths as they stand, targets,
-// weights, and its own E columns / q / u of the previous iteration -- and only then waits for dX; it applies the
-// previous iteration's update to what it holds (its 16 depths, written back; the poses of its edges replaced by the ones
-// the solver retracted and published) and goes on as the plain chunk kernel does.  Saves a launch boundary, the
-// poll-and-retract tail of the finish launch and the load levels of the chunk kernel, which now fly under the solver.
-// Results are the plain sequence's up to the multiply-add contractions the compiler chooses in the two instantiations
-// (last-bit differences; tests/test_graph_table.py), and identical from run to run.
-template <bool HAS_II, bool TABLE, bool FUSED>
+template <bool HAS_II, bool TABLE>
 __global__ __launch_bounds__(64 * CKW) void ba_chunk_kernel(BaWinArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Sc = smem;                           // [CKW][SLAB] per-wave packed copies of [S | y] (B and v parts)
@@ -370,30 +312,16 @@ __global__ __launch_bounds__(64 * CKW) void ba_chunk_kernel(BaWinArgs A) {
   const PatchSpan sp = patch_span<TABLE>(A);
   const int gerr = graph_error_of(gmeta, TABLE);
   const int U = sp.U;
-  __shared__ __attribute__((aligned(16))) float f_sdx[64];
-  __shared__ float f_eold[FUSED ? SN * CK : 1], f_pd[FUSED ? CK : 1], f_pose[FUSED ? 7 * WIN_N : 1];
-  __shared__ int f_ok;
-  if (FUSED) {
-    if (blockIdx.x == 1 && tid == 0) ba_begin_status(A.info, A.counters, 0, gerr, U > A.U_max);
-    if (gerr || U > A.U_max) return;
-    const int RWf = min((int)gridDim.x - 1, (SLAB / 4 + 3) / 4);   // workgroups that own columns of the reduce
-    if (blockIdx.x == 0) {
-      if (tid < 64) solve_wave<true>(A, RWf);
-      return;
-    }
-    const int bq = (int)blockIdx.x - 1;
-    reduce_slabs(A, bq, RWf, U, tid, bq < RWf);
-  } else {
-    if (blockIdx.x == 0 && tid == 0) ba_begin_status(A.info, A.counters, A.first, gerr, U > A.U_max);
-    // the hand-off words of the finish launch that follows (arrival flags, dX granules) lose their tags here: the tags are
-    // per-launch tokens taken from host state when the call is ENQUEUED, so a captured hipGraph replays the same tokens --
-    // with the words reset by the launch in front, a replay never meets a tag of its own from the time before
-    if (blockIdx.x == 0) {
-      for (int i = tid; i < HAND_WORDS - 16; i += (int)blockDim.x) A.arrive[16 + i] = 0;
-      for (int i = tid; i < 64; i += (int)blockDim.x) A.granX[i] = 0ull;
-    }
-    if (gerr || U > A.U_max) return;
+  if (blockIdx.x == 0 && tid == 0) ba_begin_status(A.info, A.counters, A.first, gerr, U > A.U_max);
+  // the hand-off words of the finish launch that follows (arrival flags, verdict, dX granules) lose their tags here: the
+  // tags are per-launch tokens taken from host state when the call is ENQUEUED, so a captured hipGraph replays the same
+  // tokens -- with the words reset by the launch in front, a replay never meets a tag of its own from the time before
+  if (blockIdx.x == 0) {
+    for (int i = tid; i < HAND_WORDS - 16; i += (int)blockDim.x) A.arrive[16 + i] = 0;
+    for (int i = tid; i < 64; i += (int)blockDim.x) A.granX[i] = 0ull;
+    if (tid == 0) A.arrive[HO_VERDICT] = HO_UNDECIDED;
   }
+  if (gerr || U > A.U_max) return;
   const int N = A.N, t0 = A.t0, P = A.P;
   const int n6 = 6 * N;
   const int PP = P * P;
@@ -414,10 +342,10 @@ __global__ __launch_bounds__(64 * CKW) void ba_chunk_kernel(BaWinArgs A) {
   }
   const int n_chunks = (U + CK - 1) / CK;
 
-  CDV_IF_STAMPS(const int sslot = ((int)blockIdx.x - (FUSED ? 1 : 0)) * CKW + wave; unsigned long long t_fac = 0, t_ej = 0, t_xw = 0, t_rd = 0, t_mf = 0, t_em = 0, t_x;)
+  CDV_IF_STAMPS(const int sslot = (int)blockIdx.x * CKW + wave; unsigned long long t_fac = 0, t_ej = 0, t_xw = 0, t_rd = 0, t_mf = 0, t_em = 0, t_x;)
   CDV_STAMP(baw, sslot, 0);
   CDV_STAMP_RT(baw, sslot, 14);
-  for (int chunk = (int)blockIdx.x - (FUSED ? 1 : 0); chunk < n_chunks; chunk += FUSED ? n_chunks : (int)gridDim.x) {
+  for (int chunk = (int)blockIdx.x; chunk < n_chunks; chunk += (int)gridDim.x) {
     const int r0 = chunk * CK;
     const int r = r0 + p;
     const bool live = r < U;
@@ -467,49 +395,8 @@ __global__ __launch_bounds__(64 * CKW) void ba_chunk_kernel(BaWinArgs A) {
     maxdeg = __builtin_amdgcn_readfirstlane(maxdeg);
     const int a0 = ix_patch - t0;
     const int ixf_patch = (deg > 0 && a0 >= 0 && a0 < N) ? a0 : -1;
-    // FUSED: this chunk's own rows of the PREVIOUS iteration (E columns, q, u) and the depth its update starts from
-    // (pixel [0][0], ba_cuda.cu:218 semantics): requested with level 2, used once dX is there
-    float eo0 = 0.f, eo1 = 0.f, qold = 0.f, uold = 0.f, d00 = 0.f;
-    if (FUSED) {
-      if (tid < n6 * CK) eo0 = A.Edg[(size_t)(tid / CK) * A.U_stride + r0 + (tid % CK)];
-      if (tid + 64 * CKW < n6 * CK) eo1 = A.Edg[(size_t)((tid + 64 * CKW) / CK) * A.U_stride + r0 + ((tid + 64 * CKW) % CK)];
-      if (tid < CK) { qold = A.qg[r0 + tid]; uold = A.ug[r0 + tid]; d00 = pk[2 * PP]; }
-    }
     lds_barrier();   // accumulators are zero (LDS only: the loads above stay in flight)
-    if (FUSED) {
-      if (tid < n6 * CK) f_eold[tid] = eo0;
-      if (tid + 64 * CKW < n6 * CK) f_eold[tid + 64 * CKW] = eo1;
-      const bool have = fused_wait(A, f_sdx, f_pose, &f_ok, tid);   // barriers inside: f_eold / f_sdx / f_pose complete behind it
-      if (tid < 4 * CK) {
-        // dZ = Q (u - E^T dX), depth update with the clamps of patch_retr (ba_cuda.cu:592,209-229 semantics): the finish
-        // launch's arithmetic, term for term -- its four interleaved partial sums are four lanes here (lane = 4 patch + j)
-        const int pt = tid >> 2, j = tid & 3;
-        float sj = 0.f;
-#pragma unroll
-        for (int c4 = 0; c4 < SN / 4; c4++)
-          sj = __builtin_fmaf((4 * c4 + j < n6) ? f_eold[(4 * c4 + j) * CK + pt] : 0.f, f_sdx[4 * c4 + j], sj);
-        const float s1 = __shfl_xor(sj, 1);
-        const float pair = (j & 1) ? s1 + sj : sj + s1;              // (sacc[0] + sacc[1]) resp. (sacc[2] + sacc[3]): a + b = b + a
-        const float other = __shfl_xor(pair, 2);
-        const float tot = (j & 2) ? other + pair : pair + other;
-        // patch pt's q, u, d00, degree and id sit in lane pt of wave 0
-        const float qo = __shfl(qold, pt), uo = __shfl(uold, pt), d0o = __shfl(d00, pt), pdo = __shfl(pd, pt);
-        const int dego = __shfl(deg, pt);
-        const int64_t ido = __shfl(kxr, pt);
-        const float dz = __fmul_rn(qo, uo - tot);   // (no contraction with the add below)
-        float d = __fadd_rn(d0o, dz);
-        d = (d > 20.f) ? 1.0f : d;
-        d = fmaxf(d, 1e-4f);
-        const bool upd = have && (r0 + pt) < U && dego > 0;
-        if (j == 0) f_pd[pt] = upd ? d : pdo;
-        if (upd) {
-          float* pw = A.patches + ido * 3 * PP + 2 * PP;
-          for (int a = j; a < PP; a += 4) pw[a] = d;
-        }
-      }
-      __syncthreads();
-    }
-    const float pdu = FUSED ? f_pd[p] : pd;
+    const float pdu = pd;
     CDV_STAMP(baw, sslot, 1);
 
     float Cacc = 0.f, uacc = 0.f;
@@ -522,17 +409,6 @@ __global__ __launch_bounds__(64 * CKW) void ba_chunk_kernel(BaWinArgs A) {
       if (more) raw_nxt = reinterpret_cast<const int4*>(A.prec)[(tb + step + so < deg) ? plo + tb + step + so : 0];
       CDV_IF_STAMPS(t_x = cdv_now();)
       EdgeFactor J;
-      if (FUSED && f_ok) {   // the previous iteration's poses of the free frames: the solver's, from its granules
-        const int fa = cur.ix - t0, fb = cur.jx - t0;
-        if (fa >= 0 && fa < N) {
-#pragma unroll
-          for (int c = 0; c < 7; c++) in.pi[c] = f_pose[7 * fa + c];
-        }
-        if (fb >= 0 && fb < N) {
-#pragma unroll
-          for (int c = 0; c < 7; c++) in.pj[c] = f_pose[7 * fb + c];
-        }
-      }
       fastba_factor(in.pi, in.pj, px, py, pdu, in.tx, in.ty, in.wx, in.wy, fx, fy, cx, cy, J);
       CDV_IF_STAMPS(asm volatile("v_nop" :: "v"(J.Ji[11] + J.Jz[1])); { const unsigned long long t_y = cdv_now(); t_fac += t_y - t_x; t_x = t_y; })
       if (more) {   // rare: this wave's next round (its record was requested above)
@@ -706,7 +582,7 @@ __global__ __launch_bounds__(256) void ba_finish_kernel(BaWinArgs A) {
   const int RW = (int)gridDim.x - 1;
   const int tid = threadIdx.x;
   if (blockIdx.x == 0) {
-    if (tid < 64) solve_wave<false>(A, RW);
+    if (tid < 64) solve_wave(A, RW);
     return;
   }
   const int b = (int)blockIdx.x - 1;
@@ -737,20 +613,32 @@ __global__ __launch_bounds__(256) void ba_finish_kernel(BaWinArgs A) {
   }
   CDV_IF_STAMPS(asm volatile("v_nop" :: "v"(ev[0] + ev[59] + d0));)
   CDV_STAMP(baw, sslot, 2);
-  // ---- 3. wait for the solver (bounded) ----
+  // ---- 3. wait for the solver.  All-or-nothing (cdv_ba.h ho_decide): a workgroup whose patience runs out does not simply
+  // leave -- others may already hold the solution -- it asks for the launch's verdict: if the solver has committed, dX WILL
+  // come and the wait goes on; if nobody has decided yet, this workgroup decides ABANDONED, which the solver honours by
+  // publishing nothing, so that every retract workgroup ends here ----
   __shared__ int s_ok;
   if (tid < 64) {   // wave 0: lane t polls the granule of unknown t until its tag shows up; the poll is the load of dX
     float xv = 0.f;
     bool ok = tid >= 6 * N;
-    for (int spins = 0; spins < (1 << 21); spins++) {
-      if (!ok) {
-        const uint64_t g = __hip_atomic_load(&A.granX[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((uint32_t)(g >> 32) == (uint32_t)A.token) { xv = __int_as_float((int)(uint32_t)g); ok = true; }
+    const int patience = A.test ? (1 << 10) : (1 << 21);
+    bool all_ok = false;
+    for (int round = 0; round < 2 && !all_ok; round++) {
+      for (int spins = 0; spins < (round == 0 ? patience : (1 << 24)); spins++) {
+        if (!ok) {
+          const uint64_t g = __hip_atomic_load(&A.granX[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((uint32_t)(g >> 32) == (uint32_t)A.token) { xv = __int_as_float((int)(uint32_t)g); ok = true; }
+        }
+        if (__all(ok)) { all_ok = true; break; }
+        if ((spins & 255) == 255 &&      // the solver may have said it will not publish (its own wait failed)
+            __hip_atomic_load(&A.arrive[HO_VERDICT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == HO_ABANDONED) break;
+        __builtin_amdgcn_s_sleep(2);
       }
-      if (__all(ok)) break;
-      __builtin_amdgcn_s_sleep(2);
+      if (all_ok) break;
+      int verdict = 0;
+      if (tid == 0) verdict = ho_decide(&A.arrive[HO_VERDICT], HO_ABANDONED);
+      if (__builtin_amdgcn_readfirstlane(verdict) != HO_COMMITTED) break;   // abandoned (by this workgroup or before): nobody applies it
     }
-    const bool all_ok = __all(ok);
     if (!all_ok && tid == 0) ba_flag(A.info, BI_HANDOFF, 1);
     if (tid == 0) s_ok = all_ok ? 1 : 0;
     sdx[tid] = xv;
@@ -761,7 +649,7 @@ __global__ __launch_bounds__(256) void ba_finish_kernel(BaWinArgs A) {
   // ---- 4. pose retraction T <- Exp(dX_i) T: the first retract workgroup's first N lanes ----
   if (b == 0 && tid < N) {
     float* p = A.poses + 7 * (size_t)(A.t0 + tid);
-    const float* ps = A.pose_src ? A.pose_src + 7 * tid : p;   // after a fused launch: the poses its solver put aside
+    const float* ps = p;
     float pose[7], xi[6];
 #pragma unroll
     for (int c = 0; c < 7; c++) pose[c] = ps[c];
@@ -781,7 +669,7 @@ __global__ __launch_bounds__(256) void ba_finish_kernel(BaWinArgs A) {
 #pragma unroll
         for (int j = 0; j < 4; j++) sacc[j] = __builtin_fmaf(ev[4 * c4 + j], x4[j], sacc[j]);
       }
-      const float dz = __fmul_rn(qv, uv - ((sacc[0] + sacc[1]) + (sacc[2] + sacc[3])));   // the fused launch's arithmetic, term for term
+      const float dz = __fmul_rn(qv, uv - ((sacc[0] + sacc[1]) + (sacc[2] + sacc[3])));
       if (A.dbg) A.dbg[(size_t)36 * N * N + 12 * N + r] = dz;
       float d = __fadd_rn(d0, dz);
       d = (d > 20.f) ? 1.0f : d;
@@ -813,22 +701,20 @@ hipError_t win_attrs() {
     hipError_t e = hipSuccess, x;
     const int lds = (int)(sizeof(float) * LDS_CHUNK_FLOATS);
 #define CDV_ATTR(...) if ((x = hipFuncSetAttribute((const void*)ba_chunk_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)) != hipSuccess) e = x;
-    CDV_ATTR(true, false, false) CDV_ATTR(false, false, false) CDV_ATTR(true, true, false) CDV_ATTR(false, true, false)
-    CDV_ATTR(true, false, true) CDV_ATTR(false, false, true) CDV_ATTR(true, true, true) CDV_ATTR(false, true, true)
+    CDV_ATTR(true, false) CDV_ATTR(false, false) CDV_ATTR(true, true) CDV_ATTR(false, true)
 #undef CDV_ATTR
     return e;
   }();
   return attr_err;
 }
 
-template <bool FUSED>
 void launch_chunk_win(const BaWinArgs& a, int grid, hipStream_t s) {
   const bool table = a.tab_cap > 0;
   const size_t lds = sizeof(float) * LDS_CHUNK_FLOATS;
-  if (a.has_ii && table) hipLaunchKernelGGL((ba_chunk_kernel<true, true, FUSED>), dim3(grid), dim3(64 * CKW), lds, s, a);
-  else if (a.has_ii) hipLaunchKernelGGL((ba_chunk_kernel<true, false, FUSED>), dim3(grid), dim3(64 * CKW), lds, s, a);
-  else if (table) hipLaunchKernelGGL((ba_chunk_kernel<false, true, FUSED>), dim3(grid), dim3(64 * CKW), lds, s, a);
-  else hipLaunchKernelGGL((ba_chunk_kernel<false, false, FUSED>), dim3(grid), dim3(64 * CKW), lds, s, a);
+  if (a.has_ii && table) hipLaunchKernelGGL((ba_chunk_kernel<true, true>), dim3(grid), dim3(64 * CKW), lds, s, a);
+  else if (a.has_ii) hipLaunchKernelGGL((ba_chunk_kernel<true, false>), dim3(grid), dim3(64 * CKW), lds, s, a);
+  else if (table) hipLaunchKernelGGL((ba_chunk_kernel<false, true>), dim3(grid), dim3(64 * CKW), lds, s, a);
+  else hipLaunchKernelGGL((ba_chunk_kernel<false, false>), dim3(grid), dim3(64 * CKW), lds, s, a);
 }
 
 void launch_finish_win(const BaWinArgs& a, hipStream_t s) {
@@ -848,33 +734,9 @@ void launch_finish_win(const BaWinArgs& a, hipStream_t s) {
 int cdv::cdv_ba_window_iteration(const BaWinArgs& a, hipStream_t s) {
   CDV_HIP_CHECK(win_attrs());
   const int n_ck = a.n_ck_cap < WIN_MAX_GRID ? a.n_ck_cap : WIN_MAX_GRID;
-  launch_chunk_win<false>(a, n_ck, s);
+  launch_chunk_win(a, n_ck, s);
   launch_finish_win(a, s);
   CDV_LAUNCH_CHECK();
   return CDV_OK;
 }
 
-// the fused launch sits between a chunk launch and a finish launch: can this workspace / call take it?
-// (every workgroup of the fused launch must be resident at once -- the chunk workgroups wait for the solver, the solver for
-// the reduce shares of the first 119 of them: one 512-thread workgroup per CU, so at most 240 of them on the 256 CUs)
-bool cdv::cdv_ba_window_can_fuse(const BaWinArgs& a) {
-  return a.n_ck_cap + 1 <= 240 && a.n_ck_cap >= 1 && a.dbg == nullptr;
-}
-
-// TWO Gauss-Newton iterations (what every caller of fastba.BA asks for, slam.py:514) as three launches:
-//   chunk systems of iteration 1 | solve of iteration 1 + chunk systems of iteration 2 | reduce + solve + retract of 2
-// `a.token` .. `a.token + 1` are consumed.
-int cdv::cdv_ba_window_two_iterations(const BaWinArgs& a0, hipStream_t s) {
-  CDV_HIP_CHECK(win_attrs());
-  BaWinArgs a = a0;
-  const int n_ck = a.n_ck_cap;
-  a.first = 1; a.pose_src = nullptr;
-  launch_chunk_win<false>(a, n_ck, s);
-  a.first = 0;
-  launch_chunk_win<true>(a, n_ck + 1, s);          // workgroup 0: the solver of iteration 1
-  a.token = a0.token + 1;
-  a.pose_src = a.pose_next;                        // iteration 1's poses of the free frames, put aside by that solver
-  launch_finish_win(a, s);
-  CDV_LAUNCH_CHECK();
-  return CDV_OK;
-}

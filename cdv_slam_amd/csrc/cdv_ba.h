@@ -25,7 +25,20 @@ constexpr int WIN_SLAB = 1896;                   // floats per partial system: T
 constexpr int WIN_CK = 16;                       // unique patches per chunk workgroup
 constexpr int WIN_MAX_GRID = 1024;               // chunk workgroups per launch (grid-stride over the chunks beyond)
 constexpr int WIN_MAX_RW = 128;                  // reduce workgroups of the finish launch (the first few also retract)
-constexpr int HAND_WORDS = 16 + WIN_MAX_RW;      // hand-off words: [1] launch token, [16 + b] arrival flag of reduce workgroup b
+constexpr int HAND_WORDS = 16 + WIN_MAX_RW;      // hand-off words: [HO_VERDICT] the launch's verdict, [16 + b] arrival flag of reduce workgroup b
+
+// ---- the solve -> retract hand-off inside a finish launch is ALL-OR-NOTHING.  dX travels as tagged granules (the data is the
+// flag); whether it travels at all is ONE word per launch, decided by whoever gets its compare-and-swap in first:
+//   the solver, once it has nothing left to wait for: UNDECIDED -> COMMITTED  (it then publishes, always);
+//   a retract workgroup whose patience has run out:    UNDECIDED -> ABANDONED  (the solver then publishes nothing).
+// A retract workgroup that loses the swap to COMMITTED keeps waiting -- the solution is on its way; one that finds ABANDONED
+// leaves.  So either every retract workgroup applies the update or none does, however the workgroups of the launch are
+// delayed against each other (another stream, another process on the device).  The word is reset by the chunk launch in
+// front (like the flags and the granules, so that a replayed hipGraph starts from UNDECIDED).
+constexpr int HO_VERDICT = 2;                    // index into the hand-off words
+enum { HO_UNDECIDED = 0, HO_COMMITTED = 1, HO_ABANDONED = 2 };
+// test switch (cdv_ba_test_handoff): the solver stalls before / after its commit, the retract workgroups' patience is short
+enum { HO_TEST_OFF = 0, HO_TEST_STALL_BEFORE = 1, HO_TEST_STALL_AFTER = 2 };
 
 // ---- the same design for 10 < N <= BA_NMAX free poses (ba_mid.hip): the slab is the packed triangle of a 6N x 6N system
 constexpr int MID_N = BA_NMAX;
@@ -131,17 +144,13 @@ struct BaWinArgs {
   int32_t* counters;                 // optional host-visible event counters (cdv_ba_bind_status_counters), may be NULL
   float* dbg;                        // iteration-0 dump (see cdv_ba_forward), may be NULL
   int token;                         // tag of this launch's in-launch hand-offs (arrival flags, dX granules): never 0, new per launch
-  float* pose_next;                  // [WIN_N][7]: where a fused launch's solver puts the retracted poses of the free frames
-  const float* pose_src;             // finish launch: read the free frames' poses from here (after a fused launch), NULL: in place
+  int test;                          // HO_TEST_*: hand-off fault injection (tests only), 0 in production
   int first;                         // first iteration of a call: clears the sticky status words
   int has_ii;                        // the graph's records carry the source frames (it was built with ii)
 };
 
 // one Gauss-Newton iteration of the window path: two launches on `s`
 int cdv_ba_window_iteration(const BaWinArgs& a, hipStream_t s);
-// two iterations as three launches (the middle one fuses the first solve with the second chunk pass); uses two tokens
-bool cdv_ba_window_can_fuse(const BaWinArgs& a);
-int cdv_ba_window_two_iterations(const BaWinArgs& a, hipStream_t s);
 // the same for 10 < N <= MID_N (ba_mid.hip)
 int cdv_ba_mid_iteration(const BaWinArgs& a, hipStream_t s);
 
@@ -151,6 +160,18 @@ int cdv_ba_mid_iteration(const BaWinArgs& a, hipStream_t s);
 __device__ __forceinline__ void wave_lds_sync() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
+}
+
+// try to decide the launch's verdict; returns the verdict that holds afterwards (one lane calls it)
+__device__ __forceinline__ int ho_decide(int32_t* word, int want) {
+  int expected = HO_UNDECIDED;
+  __hip_atomic_compare_exchange_strong(word, &expected, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return expected == HO_UNDECIDED ? want : expected;
+}
+
+// fault injection: ~30 ms of sleep (tests only)
+__device__ __forceinline__ void ho_test_stall() {
+  for (int i = 0; i < (1 << 13); i++) __builtin_amdgcn_s_sleep(127);
 }
 
 __device__ __forceinline__ float readlane_f(float v, int l) {

@@ -410,9 +410,28 @@ def _device_graph(dev, **kw):
     return g
 
 
+def _table_still_fits(g, dev):
+    """The table form of the index assumes that the live patch ids fit its capacity (install_dropin(table_capacity=...)).
+    When they do not -- loop-closure or long-range edges, slam.py:507-510 -- the build flags a collision, neighbors() of
+    that update are -1 and its BA is skipped and COUNTED (pinned event counters, no synchronisation).  Seen here before the
+    next build: the workspace then gives the table up for good and goes on with the ranked index, which assumes nothing
+    about the ids."""
+    cnt = _ba_counters.get(dev)
+    if cnt is None or not g.table_capacity:
+        return
+    seen = _ba_seen[dev]
+    if int(cnt[3]) > seen[3]:
+        import warnings
+        warnings.warn("cdv_slam_amd: the patch table (capacity %d) did not hold the live patch ids -- one update was skipped; "
+                      "falling back to the ranked index on %s from now on" % (g.table_capacity, dev), RuntimeWarning, stacklevel=3)
+        g.table_capacity = 0
+        g._key = None
+
+
 def graph_for(jj, kk, ii=None, **kw):
     """Per-device shared GraphIndex, (re)built for (jj, kk) in the preferred form."""
     g = _device_graph(kk.device, **kw)
+    _table_still_fits(g, kk.device)
     key = g._make_key(jj.contiguous(), kk.contiguous(), None if ii is None else ii.contiguous())
     if g._key is not None and g._same_key(key):
         return g
@@ -1007,6 +1026,7 @@ def ba_forward(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, PP
         lmbda = lmbda.reshape(-1).float().contiguous().to(dev)
     ii, jj, kk = ii.contiguous(), jj.contiguous(), kk.contiguous()
     g = graph if graph is not None else _device_graph(dev)
+    _table_still_fits(g, dev)
     g.index_for_ba(jj, kk, ii, N)
     _ba_report_events(dev)
     if U_max is None:

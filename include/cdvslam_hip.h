@@ -330,7 +330,12 @@ size_t cdv_ba_workspace_bytes(int64_t E_max, int64_t U_max, int N_max);
  *   dbg (optional, NULL): receives iteration-0 values, with n = 6N and Us = round_up(U_max, 64):
  *             [S n*n (damped) | y n | dX n | dZ Us | C Us | u Us | E n*Us]
  *             (N > 32: only the lower triangle of S is accumulated)
- * Every path sums with one owner and a fixed order per entry -- no float atomic anywhere, results bitwise reproducible:
+ * Every path sums with one owner and a fixed order per entry and no float atomic reaches HBM.  Results are bitwise
+ * reproducible for patch graphs as slam.py builds them -- one source frame per patch, every (patch, target frame) edge once --
+ * on all three paths, and for ANY edge list on the global path.  On the N <= 32 paths a patch with two source frames or a
+ * duplicated edge sums part of its E column with LDS float atomics (arrival order): correct, reproducible to rounding only.
+ * The solve -> retract hand-off inside a launch is all-or-nothing (one verdict word per launch): a lost hand-off sets the
+ * hand-off status word and leaves poses and patches exactly as they were.
  * 1 <= N = t1 - t0 <= 10 (the optimisation window): two launches per iteration; <= 32: three, a single-workgroup LDS Cholesky;
  * <= 1024 (global BA, slam.py:460-478): patch / frame-pair / pose / tile owners (the pair index is built inside the call),
  * blocked multi-workgroup Cholesky.  More: CDV_ERR_UNSUPPORTED.
@@ -360,6 +365,15 @@ int cdv_ba_status(const void* ba_ws, int32_t* info_host, void* stream);
  * watch them without synchronising any stream.  NULL unbinds.
  */
 int cdv_ba_bind_status_counters(void* ba_ws, int32_t* counters);
+
+/*
+ * Fault injection for the in-launch hand-offs (tests only; process-wide, read by the following cdv_ba_forward calls; no
+ * counterpart in the reference, whose kernels hand nothing over inside a launch):  0 off;  1 the solver of the N <= 32
+ * paths stalls before it commits / the global path's back substitution withholds one block -- the waiting workgroups
+ * give up, the status word `hand-off` is set and NOTHING of the iteration is applied;  2 the solver stalls after its
+ * commit -- the waiting workgroups lose patience, learn that the solution is coming, wait on, and the update is applied.
+ */
+int cdv_ba_test_handoff(int mode);
 
 /* altcorr.patchify(net, coords, radius, mode) -- correlation.py:51-71 -- in one launch: the gather of
  * patchify_forward plus the blend the reference composes from four slice products.
