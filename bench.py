@@ -66,11 +66,11 @@ def closed_loop_ate(dev, frames=126, progress=None):
     test on each side's own state; Sim(3)-aligned ATE-RMSE between the two final trajectories.  Reduced frame size (24
     patches per frame, 256 x 192 images) so that the CPU side takes seconds, not minutes."""
     from cdv_slam_amd import metrics
-    from cdv_slam_amd.stream import StreamRunner
+    from cdv_slam_amd.stream import DeviceStreamRunner
     from oracle.stream_py import StreamOracle, closed_loop
     cfg = dict(M=24, ht=192, wd=256, C=24, buffer_size=256, keyframe_thresh=2.5)
     t0 = time.perf_counter()
-    res = closed_loop(StreamRunner(dev, **cfg), StreamOracle(**cfg), frames=frames, drop="flow", progress=progress)
+    res = closed_loop(DeviceStreamRunner(dev, **cfg), StreamOracle(**cfg), frames=frames, drop="flow", progress=progress)
     ate = metrics.ate_rmse(res["poses_oracle"], res["poses_gpu"])
     return {"value": ate, "unit": "scene units (RMSE of the camera centres, Sim(3)-aligned)", "frames": res["frames"],
             "keyframes": res["keyframes"], "dropped_by_the_keyframe_test": res["dropped"], "edges": res["edges"],
@@ -377,24 +377,32 @@ def main():
         except Exception as ex:      # a sub-record must not take the headline down with it
             extra["stress"] = {"error": repr(ex)}
         try:
-            from cdv_slam_amd.stream import StreamRunner
-            run = StreamRunner(dev)
+            from cdv_slam_amd.stream import DeviceStreamRunner
+            run = DeviceStreamRunner(dev, buffer_size=1024, keyframe_thresh=15.0)
             for _ in range(45):       # reach the steady state (E = 47,712 at the default window)
                 run.frame(drop=False)
-            for f in range(9):        # ... and the removal path's first-use costs (allocations, lazily loaded kernels)
-                run.frame(drop=(f % 3 == 2))
+            for f in range(30):       # ... and the reference's keyframe test deciding on the device
+                run.frame(drop=None)
             torch.cuda.synchronize()
-            nf = 200
+            n_a, _ = run.counts()
+            nf = 600
             ts = time.perf_counter()
             for f in range(nf):
-                n_kf, E_s = run.frame(drop=(f % 3 == 2))
+                run.frame(drop=None)
+            t_enq = time.perf_counter() - ts
             torch.cuda.synchronize()
             ts = time.perf_counter() - ts
+            n_kf, E_s = run.counts()
             extra["stream_fps"] = {"value": nf / ts, "unit": "frames/s", "ms_per_frame": 1e3 * ts / nf, "frames": nf,
-                                   "edges": int(E_s), "keyframes": int(n_kf),
-                                   "what": "SURVEY 8(d)(iii): synthetic 512x384 stream end to end (state write, edge append, update, "
-                                           "keyframe bookkeeping incl. one read-back per removal; every third frame dropped as a "
-                                           "keyframe; stub feature / update networks; Python glue included)"}
+                                   "host_enqueue_ms_per_frame": 1e3 * t_enq / nf, "edges": int(E_s), "keyframes": int(n_kf),
+                                   "keyframes_dropped_in_the_timed_frames": int(nf - (n_kf - n_a)),
+                                   "what": "SURVEY 8(d)(iii): synthetic 512x384 stream end to end with every size on the device "
+                                           "(cdv_slam_amd.stream.DeviceStreamRunner), 17 launches per frame and no read-back: state "
+                                           "write + patch tiles + edge append, ring ingest + index + reprojection, two-level "
+                                           "correlation, operator stub, BA(2), point cloud of the removal window (slam.py:524-526), "
+                                           "keyframe test from flow_mag decided ON THE DEVICE (slam.py:399-413) with the removal, index "
+                                           "shift, frame-buffer shift and removal-window pruning it triggers (slam.py:415-458); stub "
+                                           "feature / update networks; device RNG drawn once; Python glue included"}
             del run
         except Exception as ex:
             extra["stream_fps"] = {"error": repr(ex)}

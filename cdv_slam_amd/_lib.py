@@ -74,6 +74,21 @@ SIGNATURES = {
     "cdv_ba_bind_status_counters": (_i32, [_vp, _vp]),
     "cdv_ba_test_handoff": (_i32, [_i32]),
     "cdv_lie_op": (_i32, [_i32, _i32, _i32, _i64, _vp, _vp, _vp, _vp]),
+    # ---- a frame stream whose sizes live on the device
+    "cdv_update_prologue_table_dyn": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i64, _i64, _vp, _vp, _vp,
+                                             _vp, _vp, _vp, _i64, _vp, _vp, _vp, _sz, _i64, _i64, _i64, _vp]),
+    "cdv_corr_fused_stream_dyn": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _f32,
+                                         _f32, _i32, _vp]),
+    "cdv_ba_forward_dyn": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _i32, _vp, _vp, _sz,
+                                  _i64, _vp]),
+    "cdv_stream_workspace_bytes": (_sz, [_i64, _i32]),
+    "cdv_stream_frame_begin": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp,
+                                      _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp, _vp]),
+    "cdv_stream_operator_stub": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _f32, _i64, _vp]),
+    "cdv_stream_points": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
+    "cdv_stream_keyframe": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                   _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _f32, _i32, _vp, _i32, _vp, _vp, _vp]),
+    "cdv_stream_motion": (_vp, [_vp, _i64, _i32]),
 }
 
 class FrameBuf(ctypes.Structure):

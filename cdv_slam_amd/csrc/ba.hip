@@ -1177,11 +1177,40 @@ extern "C" size_t cdv_ba_workspace_bytes(int64_t E_max, int64_t U_max, int N_max
   return ba_layout(U_max, N_max, E_max).total;
 }
 
+static int ba_forward_impl(float* poses, float* patches, const float* intrinsics, const float* target,
+                           const float* weight, const float* lmbda, const int64_t* ii, const int64_t* jj,
+                           const int64_t* kk, int64_t E, int P, int t0, int t1, int iterations,
+                           const void* graph_ws, void* ba_ws, size_t ba_ws_bytes, int64_t U_max, float* dbg,
+                           void* stream, const int32_t* dyn);
+
 extern "C" int cdv_ba_forward(float* poses, float* patches, const float* intrinsics, const float* target,
                               const float* weight, const float* lmbda, const int64_t* ii, const int64_t* jj,
                               const int64_t* kk, int64_t E, int P, int t0, int t1, int iterations,
                               const void* graph_ws, void* ba_ws, size_t ba_ws_bytes, int64_t U_max, float* dbg,
                               void* stream) {
+  return ba_forward_impl(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, E, P, t0, t1, iterations, graph_ws, ba_ws,
+                         ba_ws_bytes, U_max, dbg, stream, nullptr);
+}
+
+// cdv_ba_forward with the window on the device: the free poses are [dyn[CDV_DYN_T0], + dyn[CDV_DYN_NFREE]) with
+// dyn[CDV_DYN_NFREE] <= N_max <= 10 (the optimisation window of a frame stream, slam.py:512-513: known to the device only
+// when the keyframe decision stays there); E_bound sizes the workspace, the index in graph_ws must be a patch table.
+extern "C" int cdv_ba_forward_dyn(float* poses, float* patches, const float* intrinsics, const float* target, const float* weight,
+                                  const float* lmbda, const int64_t* ii, const int64_t* jj, const int64_t* kk, int64_t E_bound,
+                                  int P, int N_max, const int32_t* dyn, int iterations, const void* graph_ws, void* ba_ws,
+                                  size_t ba_ws_bytes, int64_t U_max, void* stream) {
+  CDV_REQUIRE(dyn != nullptr, CDV_ERR_ARG, "cdv_ba_forward_dyn: NULL dynamic block");
+  CDV_REQUIRE(N_max >= 1 && N_max <= WIN_N, CDV_ERR_UNSUPPORTED, "cdv_ba_forward_dyn: 1 <= N_max <= 10 free poses");
+  CDV_REQUIRE(cdv_graph_is_table(graph_ws), CDV_ERR_UNSUPPORTED, "cdv_ba_forward_dyn: graph_ws must hold a patch table");
+  return ba_forward_impl(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, E_bound, P, 0, N_max, iterations, graph_ws,
+                         ba_ws, ba_ws_bytes, U_max, nullptr, stream, dyn);
+}
+
+static int ba_forward_impl(float* poses, float* patches, const float* intrinsics, const float* target,
+                           const float* weight, const float* lmbda, const int64_t* ii, const int64_t* jj,
+                           const int64_t* kk, int64_t E, int P, int t0, int t1, int iterations,
+                           const void* graph_ws, void* ba_ws, size_t ba_ws_bytes, int64_t U_max, float* dbg,
+                           void* stream, const int32_t* dyn) {
   const int N = t1 - t0;
   CDV_REQUIRE(N >= 0, CDV_ERR_ARG, "cdv_ba_forward: t1 < t0");
   CDV_REQUIRE(N <= BA_NBIG, CDV_ERR_UNSUPPORTED, "cdv_ba_forward: more than 1024 free poses");
@@ -1258,6 +1287,7 @@ extern "C" int cdv_ba_forward(float* poses, float* patches, const float* intrins
     wa.U_stride = (int)L.U_stride; wa.U_max = (int)L.U_max; wa.n_ck_cap = (int)L.n_ck;
     wa.info = info; wa.counters = counters;
     wa.test = g_handoff_test.load();
+    wa.dyn = dyn;
     wa.dbg = nullptr;
     wa.token = token_base + 1;
     for (int itr = 0; itr < iterations; itr++) {

@@ -298,8 +298,20 @@ __device__ __forceinline__ void solve_wave(const BaWinArgs& A, int RW) {
   CDV_STAMP_RT(baw, sslot, 15);
 }
 
+// sizes on the device: the window [t0, t0 + N) of this update comes from the dynamic block (two scalar loads that travel
+// with the first load level)
+__device__ __forceinline__ BaWinArgs with_dyn(const BaWinArgs& a) {
+  BaWinArgs A = a;
+  if (a.dyn) {
+    A.t0 = a.dyn[CDV_DYN_T0];
+    A.N = min(a.dyn[CDV_DYN_NFREE], a.N);
+  }
+  return A;
+}
+
 template <bool HAS_II, bool TABLE>
-__global__ __launch_bounds__(64 * CKW) void ba_chunk_kernel(BaWinArgs A) {
+__global__ __launch_bounds__(64 * CKW) void ba_chunk_kernel(BaWinArgs A_in) {
+  const BaWinArgs A = with_dyn(A_in);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Sc = smem;                           // [CKW][SLAB] per-wave packed copies of [S | y] (B and v parts)
   float* Ed = Sc + CKW * SLAB;                // [64][EDL]   rows 0..59 E, row 60 u, rows 61..63 zero
@@ -574,7 +586,8 @@ __global__ __launch_bounds__(64 * CKW) void ba_chunk_kernel(BaWinArgs A) {
 
 
 template <bool TABLE>
-__global__ __launch_bounds__(256) void ba_finish_kernel(BaWinArgs A) {
+__global__ __launch_bounds__(256) void ba_finish_kernel(BaWinArgs A_in) {
+  const BaWinArgs A = with_dyn(A_in);
   const int32_t* __restrict__ gmeta = A.gmeta;
   const PatchSpan sp = patch_span<TABLE>(A);
   const int U = sp.U;

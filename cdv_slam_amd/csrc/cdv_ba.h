@@ -145,6 +145,7 @@ struct BaWinArgs {
   float* dbg;                        // iteration-0 dump (see cdv_ba_forward), may be NULL
   int token;                         // tag of this launch's in-launch hand-offs (arrival flags, dX granules): never 0, new per launch
   int test;                          // HO_TEST_*: hand-off fault injection (tests only), 0 in production
+  const int32_t* dyn;                // != NULL: t0 and N are dyn[CDV_DYN_T0], dyn[CDV_DYN_NFREE] (sizes on the device; N <= the N above)
   int first;                         // first iteration of a call: clears the sticky status words
   int has_ii;                        // the graph's records carry the source frames (it was built with ii)
 };

@@ -182,7 +182,7 @@ __device__ __forceinline__ int graph_error_of(const int32_t* __restrict__ meta, 
 namespace cdv { struct TFillArgs; }
 int cdv_graph_table_prepare(const int64_t* ii, const int64_t* jj, const int64_t* kk, int64_t E, void* ws, size_t ws_bytes,
                             int64_t E_max, int64_t k_range, int64_t tab_cap, int64_t* ix, int64_t* jx, void* stream,
-                            cdv::TFillArgs* fill, int* fill_blocks);
+                            cdv::TFillArgs* fill, int* fill_blocks, const int32_t* dyn = nullptr);
 int cdv_graph_table_finish(const cdv::TFillArgs& fill, int fill_blocks, void* ws, int64_t E_max, int64_t k_range, int64_t* ix,
                            int64_t* jx, const float* poses, const float* patches, const float* intr, float* coords_out,
                            bool with_stream, void* stream);

@@ -21,6 +21,10 @@ struct IngestArgs {
   _Float16* gdst;          // pixel-major tiles [Ng][9][C]
   int64_t gfirst, gcount;
   int fblocks, gblocks;    // workgroups for the feature maps / for the tiles
+  // sizes on the device (include/cdvslam_hip.h CDV_DYN_*): the newest keyframe is n - 1 with n = dyn[CDV_DYN_N]; its ring slot
+  // is (n - 1) % dyn_mem and its tiles are [((n - 1) % dyn_pmem) * gcount, + gcount) -- `slot` and `gfirst` are then unused
+  const int32_t* dyn = nullptr;
+  int dyn_mem = 0, dyn_pmem = 0;
 };
 
 // patch tiles planar [C][3][3] -> pixel-major [9][C]: one thread per (tile, pixel, 8-channel group)
@@ -44,14 +48,21 @@ __device__ __forceinline__ void gmap_pm_convert(const _Float16* __restrict__ src
 // (F.avg_pool2d(fmap, 4, 4), slam.py:682: f16 in, f32 sum of 16, * 1/16, rounded to f16); blocks
 // [fblocks, fblocks + gblocks) convert the frame's patch tiles to the pixel-major layout instead
 __device__ __forceinline__ void ingest_body(const IngestArgs& a, int bid, int nthreads_per_block, int tid) {
+  int slot_dyn = a.slot;
+  int64_t gfirst = a.gfirst;
+  if (a.dyn) {
+    const int newest = max(a.dyn[CDV_DYN_N] - 1, 0);
+    slot_dyn = newest % a.dyn_mem;
+    gfirst = (int64_t)(newest % a.dyn_pmem) * a.gcount;
+  }
   if (bid >= a.fblocks) {
-    gmap_pm_convert(a.gsrc, a.gdst, a.gfirst, a.gcount, a.C, (int64_t)(bid - a.fblocks) * nthreads_per_block + tid,
+    gmap_pm_convert(a.gsrc, a.gdst, gfirst, a.gcount, a.C, (int64_t)(bid - a.fblocks) * nthreads_per_block + tid,
                     (int64_t)a.gblocks * nthreads_per_block);
     return;
   }
   // one thread per (full-resolution pixel, 8-channel group); the 16 pixels of a 4x4 pooling block are the 16 lanes of a
   // DPP row, so the pooled sum is four row rotations (no LDS, no 128-gather serial loop per thread)
-  const int C = a.C, H = a.H, W = a.W, slot = a.slot;
+  const int C = a.C, H = a.H, W = a.W, slot = slot_dyn;
   const int G = C / 8, H4 = H / 4, W4 = W / 4;
   const int64_t total = (int64_t)H4 * W4 * G * 16;   // a multiple of 64: whole rows of 16 lanes stay together
   for (int64_t idx = (int64_t)bid * nthreads_per_block + tid; idx < total; idx += (int64_t)a.fblocks * nthreads_per_block) {
@@ -539,9 +550,12 @@ struct TFillArgs {
   int32_t *ttab, *tovf, *tprec;
   int32_t* ocnt;                 // [blocks][ORD_BINS]
   int32_t gen;                   // generation of this build (> 0)
+  const int32_t* dyn = nullptr;  // != NULL: the number of edges is dyn[CDV_DYN_E]; E above is an upper bound (launch sizes)
 };
 
-__device__ __forceinline__ void graph_tfill_body(const TFillArgs& a, int bid, int nblocks, int nthreads_per_block, int tid) {
+__device__ __forceinline__ void graph_tfill_body(const TFillArgs& a_in, int bid, int nblocks, int nthreads_per_block, int tid) {
+  TFillArgs a = a_in;
+  if (a.dyn) a.E = min(a.dyn[CDV_DYN_E], a_in.E);
   __shared__ int s_obin[ORD_BINS];
   if (tid < ORD_BINS) s_obin[tid] = 0;
   if (bid == 0 && tid == 0) {     // words the sort launch accumulates into; nobody reads them between the two launches

@@ -483,6 +483,8 @@ struct CorrArgs2 {
   // packed per-edge input stream in PROCESSING order (written by the index build next to `order`): record p =
   // {18 coords, edge id, patch-ring index, frame-ring index (0xFFFFFFFF: invalid), ...} -- cdv_graph.h CORR_REC_WORDS
   const uint32_t* rec;
+  // != NULL: the number of edges is *dynE (include/cdvslam_hip.h CDV_DYN_E); E above bounds it and sized the launch
+  const int32_t* dynE;
 };
 
 constexpr uint32_t FBIAS = 0x4B000000u;   // bit pattern of 2^23
@@ -770,8 +772,14 @@ __global__ __launch_bounds__(256) void corr_fused2_kernel(const CorrArgs2 a) {
   // workgroup b runs on XCD b % 8 and takes 4 consecutive edges of the b % 8-th contiguous eighth of the list.  (Two or
   // three edges per wave, the next edge's coordinates and indices prefetched under the one in progress: measured
   // 10 % slower -- fewer, longer waves.)
-  const int p0 = (((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3)) * 4 + wave;
-  if (p0 >= a.E) return;  // no block-wide barriers below: waves are independent
+  int E = a.E, eighth = (int)gridDim.x >> 3;
+  if (REC && a.dynE) {    // sizes on the device: the contiguous eighths are those of the ACTUAL list, not of the launch
+    E = min(__builtin_amdgcn_readfirstlane(*a.dynE), a.E);
+    eighth = (E + 31) >> 5;
+    if (((int)blockIdx.x >> 3) >= eighth) return;
+  }
+  const int p0 = (((int)blockIdx.x & 7) * eighth + ((int)blockIdx.x >> 3)) * 4 + wave;
+  if (p0 >= E) return;  // no block-wide barriers below: waves are independent
   if (REC) {
     // ---- ONE round trip: record p0 of the packed input stream the index build wrote in processing order -- the 18
     // coordinates as one vector load, edge id and ring indices as scalar loads of the same line (no order[] -> coords /
@@ -1202,7 +1210,7 @@ static int corr_fused_impl(const void* gmap, const void* fmap0_nhwc, const void*
                            int64_t Ng, int64_t slots, int C, int H0, int W0, int H1, int W1, float scale0,
                            float scale1, int nlev, int64_t kmod, int64_t jmod, int gmap_pixel_major, void* stream,
                            int out_stride, int out_off, int out_pitch, const float* coords_ref, float ref_mul, int split,
-                           const uint32_t* rec = nullptr) {
+                           const uint32_t* rec = nullptr, const int32_t* dynE = nullptr) {
   CDV_REQUIRE(nlev == 1 || nlev == 2, CDV_ERR_ARG, "cdv_corr_fused: nlev must be 1 or 2");
   CDV_REQUIRE(C % 8 == 0 && C > 0 && C <= 128, CDV_ERR_UNSUPPORTED, "cdv_corr_fused: C must be a multiple of 8, <= 128");
   CDV_REQUIRE(E >= 0 && E < ((int64_t)1 << 31), CDV_ERR_ARG, "cdv_corr_fused: E out of range");
@@ -1234,7 +1242,7 @@ static int corr_fused_impl(const void* gmap, const void* fmap0_nhwc, const void*
     const CorrArgs2 a{coords, kk, jj, order, (int)E, (uint32_t)kmod, (uint32_t)jmod, kmagic, jmagic, (uint32_t)Ng,
                       (uint32_t)slots, (const char*)gmap, (_Float16*)out, A0,
                       nlev == 2 ? level(fmap1_nhwc, H1, W1, scale1, ex1 - ex0) : A0, C, gmap_pixel_major, exp,
-                      out_stride, out_off, out_pitch, coords_ref, ref_mul, split, rec};
+                      out_stride, out_off, out_pitch, coords_ref, ref_mul, split, rec, dynE};
     const int blocks = 8 * (int)cdv_div_up(E, 32);   // a multiple of 8: the kernel deals contiguous eighths to the XCDs
     if (rec) {   // packed input stream in processing order (cdv_corr_fused_stream)
       CDV_REQUIRE(nlev == 2 && !split && coords_ref == nullptr, CDV_ERR_UNSUPPORTED, "cdv_corr_fused_stream: two fused levels only");
@@ -1281,6 +1289,17 @@ extern "C" int cdv_corr_fused_stream(const void* gmap, const void* fmap0_nhwc, c
   return corr_fused_impl(gmap, fmap0_nhwc, fmap1_nhwc, nullptr, nullptr, nullptr, nullptr, out, E, Ng, slots, C, H0, W0, H1,
                          W1, scale0, scale1, 2, 0, 0, gmap_pixel_major, stream, 1, 0, 441, nullptr, 1.0f, 0,
                          (const uint32_t*)records);
+}
+
+// cdv_corr_fused_stream with the number of edges on the device: *dyn_E edges (at most E_bound, which sizes the launch)
+extern "C" int cdv_corr_fused_stream_dyn(const void* gmap, const void* fmap0_nhwc, const void* fmap1_nhwc, const void* records,
+                                         void* out, int64_t E_bound, const int32_t* dyn, int64_t Ng, int64_t slots, int C, int H0,
+                                         int W0, int H1, int W1, float scale0, float scale1, int gmap_pixel_major, void* stream) {
+  CDV_REQUIRE(records != nullptr && dyn != nullptr, CDV_ERR_ARG, "cdv_corr_fused_stream_dyn: NULL record stream / dynamic block");
+  CDV_REQUIRE(C <= 32, CDV_ERR_UNSUPPORTED, "cdv_corr_fused_stream_dyn: C must be <= 32");
+  return corr_fused_impl(gmap, fmap0_nhwc, fmap1_nhwc, nullptr, nullptr, nullptr, nullptr, out, E_bound, Ng, slots, C, H0, W0,
+                         H1, W1, scale0, scale1, 2, 0, 0, gmap_pixel_major, stream, 1, 0, 441, nullptr, 1.0f, 0,
+                         (const uint32_t*)records, dyn + CDV_DYN_E);
 }
 
 extern "C" int cdv_corr_fused_split(const void* gmap, const void* fmap0_nhwc, const void* fmap1_nhwc, const float* coords,

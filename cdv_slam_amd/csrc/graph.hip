@@ -336,6 +336,7 @@ struct TSortArgs {
   uint32_t* crec;                 // NULL: no packed stream
   const float *poses, *patches, *intr;   // poses != NULL: reproject here and write coords_out [E][2][3][3]
   float* coords_out;
+  const int32_t* dyn;             // != NULL: the number of edges is dyn[CDV_DYN_E], E is an upper bound
 };
 
 constexpr int TS_OVF_MAX = TAB_MAX_DEG;   // edges of one patch the sort launch handles (beyond: range-error state)
@@ -374,7 +375,9 @@ __device__ __forceinline__ void reproject_edge(const TSortArgs& A, int64_t ix, i
   }
 }
 
-__global__ __launch_bounds__(256) void graph_tsort_kernel(const TSortArgs A) {
+__global__ __launch_bounds__(256) void graph_tsort_kernel(const TSortArgs A_in) {
+  TSortArgs A = A_in;
+  if (A.dyn) A.E = min(A.dyn[CDV_DYN_E], A_in.E);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const bool terr = A.meta[GM_TERR] == A.gen;      // written by the fill launch
   if ((int)blockIdx.x >= A.n_patch_wg) {
@@ -751,7 +754,7 @@ int64_t cdv_graph_table_capacity(const void* ws) {
 // finish = the sort launch (patch workgroups + edge workgroups).
 int cdv_graph_table_prepare(const int64_t* ii, const int64_t* jj, const int64_t* kk, int64_t E, void* ws, size_t ws_bytes,
                             int64_t E_max, int64_t k_range, int64_t tab_cap, int64_t* ix, int64_t* jx, void* stream,
-                            cdv::TFillArgs* fill, int* fill_blocks) {
+                            cdv::TFillArgs* fill, int* fill_blocks, const int32_t* dyn) {
   CDV_REQUIRE((ix == nullptr) == (jx == nullptr), CDV_ERR_ARG, "cdv_graph_build_table: give both ix and jx or neither");
   CDV_REQUIRE(ws != nullptr, CDV_ERR_ARG, "cdv_graph_build_table: workspace is NULL");
   CDV_REQUIRE(E >= 0 && E < (int64_t)1 << 31, CDV_ERR_ARG, "cdv_graph_build_table: E out of range");
@@ -778,7 +781,7 @@ int cdv_graph_table_prepare(const int64_t* ii, const int64_t* jj, const int64_t*
   if (need_init)
     hipLaunchKernelGGL(graph_init_kernel, dim3(grid_for(k_range + 1 + GM_WORDS, 256, 2048)), dim3(256), 0,
                        (hipStream_t)stream, v.meta, v.khist, v.kcursor, v.tcur, v.town, k_range);
-  *fill = cdv::TFillArgs{ii, jj, kk, (int32_t)E, (int32_t)tab_cap, v.meta, v.tcur, v.town, v.ttab, v.tovf, v.tprec, v.ocnt, gen};
+  *fill = cdv::TFillArgs{ii, jj, kk, (int32_t)E, (int32_t)tab_cap, v.meta, v.tcur, v.town, v.ttab, v.tovf, v.tprec, v.ocnt, gen, dyn};
   *fill_blocks = grid_for(E, 256, GRAPH_MAX_BLOCKS);   // >= 1: the first workgroup also resets the words of this build
   return CDV_OK;
 }
@@ -805,6 +808,7 @@ int cdv_graph_table_finish(const cdv::TFillArgs& fill, int fill_blocks, void* ws
   A.ii = fill.ii; A.jj = fill.jj; A.kk = fill.kk;
   A.cs = cs; A.crec = stream_ok ? v.crec : nullptr;
   A.poses = poses; A.patches = patches; A.intr = intr; A.coords_out = coords_out;
+  A.dyn = fill.dyn;
   const int n_edge_wg = fill.E > 0 ? fill_blocks : 0;
   hipLaunchKernelGGL(graph_tsort_kernel, dim3(A.n_patch_wg + n_edge_wg), dim3(256), 0, (hipStream_t)stream, A);
   CDV_LAUNCH_CHECK();
@@ -816,7 +820,7 @@ extern "C" int cdv_graph_build_table(const int64_t* ii, const int64_t* jj, const
                                      int64_t* jx, void* stream) {
   cdv::TFillArgs f;
   int fb = 0;
-  const int rc = cdv_graph_table_prepare(ii, jj, kk, E, ws, ws_bytes, E_max, k_range, table_capacity, ix, jx, stream, &f, &fb);
+  const int rc = cdv_graph_table_prepare(ii, jj, kk, E, ws, ws_bytes, E_max, k_range, table_capacity, ix, jx, stream, &f, &fb, nullptr);
   if (rc != CDV_OK) return rc;
   hipLaunchKernelGGL(graph_tfill_kernel, dim3(fb), dim3(256), 0, (hipStream_t)stream, f);
   return cdv_graph_table_finish(f, fb, ws, E_max, k_range, ix, jx, nullptr, nullptr, nullptr, nullptr, true, stream);

@@ -45,12 +45,12 @@ __global__ __launch_bounds__(256) void update_prologue_table_kernel(cdv::IngestA
 
 }  // namespace
 
-extern "C" int cdv_update_prologue_table(
+static int prologue_table_impl(
     const void* fmap_chw, void* fmap1_nhwc, void* fmap2_nhwc, int slot, int C, int H, int W, const void* gmap_planar,
     void* gmap_pm, int64_t Ng, int64_t gmap_first, int64_t gmap_count, const float* poses, const float* patches,
     const float* intrinsics, const int64_t* ii, const int64_t* jj, const int64_t* kk, int64_t E, float* coords,
     void* graph_ws, size_t graph_ws_bytes, int64_t E_max, int64_t k_range, int64_t table_capacity, int64_t* ix, int64_t* jx,
-    void* stream) {
+    void* stream, const int32_t* dyn, int dyn_mem, int dyn_pmem) {
   CDV_REQUIRE(C % 8 == 0 && C > 0, CDV_ERR_ARG, "cdv_update_prologue_table: C must be a multiple of 8");
   CDV_REQUIRE(H % 4 == 0 && W % 4 == 0, CDV_ERR_ARG, "cdv_update_prologue_table: H and W must be multiples of 4");
   CDV_REQUIRE(slot >= 0, CDV_ERR_ARG, "cdv_update_prologue_table: slot");
@@ -62,18 +62,45 @@ extern "C" int cdv_update_prologue_table(
   cdv::TFillArgs fill;
   int n_fill = 0;
   const int rc = cdv_graph_table_prepare(ii, jj, kk, E, graph_ws, graph_ws_bytes, E_max, k_range, table_capacity, ix, jx, stream,
-                                         &fill, &n_fill);
+                                         &fill, &n_fill, dyn);
   if (rc != CDV_OK) return rc;
   const int fblocks = cdv_div_up((int64_t)(H / 4) * (W / 4) * (C / 8) * 16, 256);
   const int gblocks = do_g ? cdv_div_up(gmap_count * 9 * (C / 8), 256) : 0;
   const cdv::IngestArgs ing{(const _Float16*)fmap_chw, (_Float16*)fmap1_nhwc, (_Float16*)fmap2_nhwc, nullptr, nullptr,
                             slot, C, H, W, (const _Float16*)gmap_planar, (_Float16*)gmap_pm, gmap_first, gmap_count,
-                            fblocks, gblocks};
+                            fblocks, gblocks, dyn, dyn_mem, dyn_pmem};
   const int n_ing = fblocks + gblocks;
   hipLaunchKernelGGL(update_prologue_table_kernel, dim3(n_fill + n_ing), dim3(256), 0, (hipStream_t)stream, ing, n_ing, fill,
                      n_fill);
   CDV_LAUNCH_CHECK();
   return cdv_graph_table_finish(fill, n_fill, graph_ws, E_max, k_range, ix, jx, poses, patches, intrinsics, coords, true, stream);
+}
+
+extern "C" int cdv_update_prologue_table(
+    const void* fmap_chw, void* fmap1_nhwc, void* fmap2_nhwc, int slot, int C, int H, int W, const void* gmap_planar,
+    void* gmap_pm, int64_t Ng, int64_t gmap_first, int64_t gmap_count, const float* poses, const float* patches,
+    const float* intrinsics, const int64_t* ii, const int64_t* jj, const int64_t* kk, int64_t E, float* coords,
+    void* graph_ws, size_t graph_ws_bytes, int64_t E_max, int64_t k_range, int64_t table_capacity, int64_t* ix, int64_t* jx,
+    void* stream) {
+  return prologue_table_impl(fmap_chw, fmap1_nhwc, fmap2_nhwc, slot, C, H, W, gmap_planar, gmap_pm, Ng, gmap_first, gmap_count,
+                             poses, patches, intrinsics, ii, jj, kk, E, coords, graph_ws, graph_ws_bytes, E_max, k_range,
+                             table_capacity, ix, jx, stream, nullptr, 0, 0);
+}
+
+// the same with the sizes on the device (include/cdvslam_hip.h "a frame stream whose sizes live on the DEVICE"): the number of
+// edges is dyn[CDV_DYN_E] (E_bound only dimensions the launches), the newest keyframe n - 1 = dyn[CDV_DYN_N] - 1 names the
+// ring slot ((n - 1) % mem) and the tiles ([((n - 1) % pmem) * tiles_per_frame, + tiles_per_frame)) the new frame goes to
+extern "C" int cdv_update_prologue_table_dyn(
+    const void* fmap_chw, void* fmap1_nhwc, void* fmap2_nhwc, int mem, int pmem, int C, int H, int W, const void* gmap_planar,
+    void* gmap_pm, int64_t Ng, int64_t tiles_per_frame, const float* poses, const float* patches, const float* intrinsics,
+    const int64_t* ii, const int64_t* jj, const int64_t* kk, int64_t E_bound, const int32_t* dyn, float* coords, void* graph_ws,
+    size_t graph_ws_bytes, int64_t E_max, int64_t k_range, int64_t table_capacity, void* stream) {
+  CDV_REQUIRE(dyn != nullptr && mem >= 1 && pmem >= 1 && tiles_per_frame >= 1 && (int64_t)pmem * tiles_per_frame <= Ng, CDV_ERR_ARG,
+              "cdv_update_prologue_table_dyn: dyn / ring sizes");
+  CDV_REQUIRE(E_bound >= 1, CDV_ERR_ARG, "cdv_update_prologue_table_dyn: E_bound must be >= 1");
+  return prologue_table_impl(fmap_chw, fmap1_nhwc, fmap2_nhwc, 0, C, H, W, gmap_planar, gmap_pm, Ng, 0, tiles_per_frame, poses,
+                             patches, intrinsics, ii, jj, kk, E_bound, coords, graph_ws, graph_ws_bytes, E_max, k_range,
+                             table_capacity, nullptr, nullptr, stream, dyn, mem, pmem);
 }
 
 extern "C" int cdv_update_prologue(

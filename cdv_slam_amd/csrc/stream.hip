@@ -1,0 +1,588 @@
+// stream.hip -- a frame stream whose sizes live on the device, gfx950.
+//
+// What SLAM.__call__ does around the update for an initialised system (cdvslam/slam.py:697-720) -- the new frame's state
+// write and edges (:676-709), the keyframe test (:399-413), keyframe()'s removals, index shift and buffer shift
+// (:415-458), the point cloud of the updated patches (:524-526) -- WITHOUT the reference's host round trips: its keyframe
+// decision is two .item() read-backs, and every size after it (n, the number of edges left by the mask indexing of
+// remove_factors, :339-354) is a host integer again.  Here the decision is a word on the device, n and E live in a
+// "dynamic block" (include/cdvslam_hip.h CDV_DYN_*), the kernels that change a size read one block and write the next,
+// and every launch is dimensioned by an upper bound: a frame is a fixed sequence of launches with no synchronisation.
+//
+// Edge order is the reference's, bit for bit: appending writes at E, removing is a stable compaction with the removal
+// predicate evaluated in the kernels (no mask tensor), the index shift of a dropped keyframe rides the first compaction.
+#include "cdv_common.h"
+#include "cdv_se3.h"
+
+namespace {
+
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+
+// ------------------------------------------------------------------------------------------------------------------
+// 1. a frame arrives: n <- n + 1, its edges (slam.py:707-709, 528-541), its state
+// ------------------------------------------------------------------------------------------------------------------
+struct BeginArgs {
+  const int32_t* dyn_in;
+  int32_t* dyn_out;
+  int64_t *ii, *jj, *kk;           // active edge lists (capacity `cap`)
+  float *target, *weight;          // [cap][2]: the new edges' rows are zeroed (slam.py:336-337 appends zeros)
+  const int64_t* ix;               // frame of every patch (pg.index_)
+  int64_t cap;
+  int M, r, opt_window, frames_cap;
+  // the (stubbed) network outputs of the new frame: patch centres + inverse depths, the frame's feature map, and where
+  // they go -- patches_[n], gmap_[n % pmem] (net_cdv.py:355-374, slam.py:676-696); all optional (cx == NULL: none)
+  const float *cx, *cy, *d;
+  const _Float16* fmap;            // [C][h][w]
+  _Float16* gmap;                  // [pmem * M][C][3][3]
+  float *poses, *patches;
+  int C, h, w, pmem;
+  float pose_step;                 // initial guess of the new pose: the previous one moved by this much along x
+  float* flow_buf;                 // [4][M]: sums and counts of the keyframe test, zeroed here for this frame
+  int n_edge_blocks, n_tile_blocks;
+};
+
+__global__ __launch_bounds__(256) void stream_begin_kernel(const BeginArgs A) {
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const int n0 = A.dyn_in[CDV_DYN_N], E0 = A.dyn_in[CDV_DYN_E];
+  const int err0 = A.dyn_in[CDV_DYN_ERR];
+  const int n = n0 + 1, M = A.M, r = A.r;
+  const int64_t f0 = (int64_t)M * imax(n - r, 0), f1 = (int64_t)M * imax(n - 1, 0);
+  const int64_t nf = f1 > f0 ? f1 - f0 : 0;
+  const int jb0 = imax(n - r, 0), nbj = n - jb0;
+  const int64_t nb = (int64_t)M * nbj, cnt = nf + nb;
+  const bool full = err0 != 0 || E0 + cnt > A.cap || n >= A.frames_cap;
+  if (b < A.n_edge_blocks) {
+    if (full) return;
+    for (int64_t t = (int64_t)b * 256 + tid; t < cnt; t += (int64_t)A.n_edge_blocks * 256) {
+      int64_t k, j;
+      if (t < nf) { k = f0 + t; j = n - 1; }
+      else { const int64_t u = t - nf; k = (int64_t)M * (n - 1) + u / nbj; j = jb0 + (int)(u % nbj); }
+      A.kk[E0 + t] = k;
+      A.jj[E0 + t] = j;
+      A.ii[E0 + t] = A.ix[k];
+      A.target[2 * (E0 + t)] = 0.f; A.target[2 * (E0 + t) + 1] = 0.f;
+      A.weight[2 * (E0 + t)] = 0.f; A.weight[2 * (E0 + t) + 1] = 0.f;
+    }
+    return;
+  }
+  if (b == A.n_edge_blocks) {
+    // ---- the block of sizes after this frame's arrival, the patch grid, the pose guess ----
+    if (tid == 0) {
+      for (int i = 0; i < CDV_DYN_WORDS; i++) A.dyn_out[i] = A.dyn_in[i];
+      if (!full) {
+        const int t0 = imax(1, n - A.opt_window);
+        A.dyn_out[CDV_DYN_N] = n;
+        A.dyn_out[CDV_DYN_E] = E0 + (int)cnt;
+        A.dyn_out[CDV_DYN_T0] = t0;
+        A.dyn_out[CDV_DYN_NFREE] = n - t0;
+        A.dyn_out[CDV_DYN_FRAME] = A.dyn_in[CDV_DYN_FRAME] + 1;
+      } else {
+        A.dyn_out[CDV_DYN_ERR] = err0 ? err0 : 1;
+      }
+    }
+    if (A.flow_buf) for (int i = tid; i < 4 * M; i += 256) A.flow_buf[i] = 0.f;
+    if (full || A.cx == nullptr) return;
+    for (int m = tid; m < M; m += 256) {
+      float* pk = A.patches + ((int64_t)n0 * M + m) * 27;
+      const float x = A.cx[m], y = A.cy[m], dd = A.d[m];
+#pragma unroll
+      for (int a = 0; a < 9; a++) {
+        pk[a] = x + (float)(a % 3 - 1);
+        pk[9 + a] = y + (float)(a / 3 - 1);
+        pk[18 + a] = dd;
+      }
+    }
+    if (tid == 0 && n0 > 0) {
+      const float* ps = A.poses + 7 * (int64_t)(n0 - 1);
+      float* pd = A.poses + 7 * (int64_t)n0;
+      pd[0] = __fadd_rn(ps[0], A.pose_step);
+#pragma unroll
+      for (int c = 1; c < 7; c++) pd[c] = ps[c];
+    }
+    return;
+  }
+  // ---- the frame's patch tiles: altcorr.patchify(fmap, centres, 1, 'bilinear') as the reference composes it
+  // (correlation_kernel.cu:16-47 gather with zeros outside, correlation.py:55-66: x00 + x01 + x10 + x11, float32 weights)
+  // rounded to half into gmap_[n % pmem] ----
+  if (full || A.cx == nullptr) return;
+  const int C = A.C, H = A.h, W = A.w;
+  const int64_t total = (int64_t)M * C * 9;
+  const int64_t tile0 = (int64_t)(n0 % A.pmem) * M;
+  for (int64_t t = (int64_t)(b - A.n_edge_blocks - 1) * 256 + tid; t < total; t += (int64_t)A.n_tile_blocks * 256) {
+    const int px = (int)(t % 9);
+    const int c = (int)((t / 9) % C);
+    const int m = (int)(t / (9 * C));
+    const float x = A.cx[m], y = A.cy[m];
+    const float fx = floorf(x), fy = floorf(y);
+    const float dx = x - fx, dy = y - fy;
+    const int i0 = (int)fy + (px / 3 - 1), j0 = (int)fx + (px % 3 - 1);
+    const _Float16* src = A.fmap + (int64_t)c * H * W;
+    const auto at = [&](int i, int j) -> float { return (i >= 0 && i < H && j >= 0 && j < W) ? (float)src[(int64_t)i * W + j] : 0.f; };
+    const float omx = 1.0f - dx, omy = 1.0f - dy;
+    const float x00 = __fmul_rn(__fmul_rn(omy, omx), at(i0, j0));
+    const float x01 = __fmul_rn(__fmul_rn(omy, dx), at(i0, j0 + 1));
+    const float x10 = __fmul_rn(__fmul_rn(dy, omx), at(i0 + 1, j0));
+    const float x11 = __fmul_rn(__fmul_rn(dy, dx), at(i0 + 1, j0 + 1));
+    const float v = __fadd_rn(__fadd_rn(__fadd_rn(x00, x01), x10), x11);
+    A.gmap[((tile0 + m) * C + c) * 9 + px] = (_Float16)v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// 2. the stub of the update operator (cdv_slam_amd/stream.py): target = reprojected centre + gain tanh(corr[:2]),
+//    weight = sigmoid(corr[2:4]) -- stands where net_cdv.py's Update runs; only here because its size lives on the device
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stream_operator_stub_kernel(const int32_t* __restrict__ dyn, const float* __restrict__ coords,
+                                                                   const _Float16* __restrict__ corr, int corr_pitch,
+                                                                   float* __restrict__ target, float* __restrict__ weight,
+                                                                   float gain) {
+  const int E = dyn[CDV_DYN_E];
+  for (int e = (int)blockIdx.x * 256 + threadIdx.x; e < E; e += (int)gridDim.x * 256) {
+    const _Float16* c = corr + (size_t)e * corr_pitch;
+    const float c0 = (float)c[0], c1 = (float)c[1], c2 = (float)c[2], c3 = (float)c[3];
+    target[2 * e] = __fadd_rn(coords[(size_t)e * 18 + 4], __fmul_rn(gain, tanhf(c0)));
+    target[2 * e + 1] = __fadd_rn(coords[(size_t)e * 18 + 13], __fmul_rn(gain, tanhf(c1)));
+    weight[2 * e] = 1.0f / (1.0f + expf(-c2));
+    weight[2 * e + 1] = 1.0f / (1.0f + expf(-c3));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// 3. the world points of the patches the update touched (slam.py:524-526 computes ALL m patches every frame; only those of
+//    the frames inside the removal window can have moved): points_[m] = (P^-1 iproj(centre))[:3] / [3]
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stream_points_kernel(const int32_t* __restrict__ dyn, const float* __restrict__ poses,
+                                                            const float* __restrict__ patches, const float* __restrict__ intr,
+                                                            const int64_t* __restrict__ ix, int M, int window_frames,
+                                                            float* __restrict__ points) {
+  const int n = dyn[CDV_DYN_N];
+  const int64_t m0 = (int64_t)imax(n - window_frames, 0) * M, m1 = (int64_t)n * M;
+  for (int64_t m = m0 + (int64_t)blockIdx.x * 256 + threadIdx.x; m < m1; m += (int64_t)gridDim.x * 256) {
+    const int64_t f = ix[m];
+    float Pi[7], Pinv[7], t[3], q[4];
+#pragma unroll
+    for (int a = 0; a < 7; a++) Pi[a] = poses[7 * f + a];
+    cdv::lt_se3_inv(Pi, Pinv);
+    cdv::lt_se3_load(Pinv, t, q);
+    const float* pk = patches + m * 27;
+    float X0[4], X1[4];
+    X0[0] = (pk[4] - intr[4 * f + 2]) / intr[4 * f + 0];
+    X0[1] = (pk[13] - intr[4 * f + 3]) / intr[4 * f + 1];
+    X0[2] = 1.f;
+    X0[3] = pk[22];
+    cdv::lt_act4_loaded(t, q, X0, X1);
+    points[3 * m] = X1[0] / X1[3];
+    points[3 * m + 1] = X1[1] / X1[3];
+    points[3 * m + 2] = X1[2] / X1[3];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// 4. the keyframe test's statistic (slam.py:399-413): mean flow_mag (projective_ops.py:120-130, beta = 0.5) over the edges
+//    i -> j and j -> i with i = n - KI - 1, j = n - KI + 1.  Every matching edge puts the sum over its nine pixels into the
+//    slot of ITS patch (kk - M ii: one edge per patch and direction in a patch graph), so the total is summed later in a
+//    fixed order -- the decision does not depend on which workgroup got where first.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stream_motion_kernel(const int32_t* __restrict__ dyn, const float* __restrict__ poses,
+                                                            const float* __restrict__ patches, const float* __restrict__ intr,
+                                                            const int64_t* __restrict__ ii, const int64_t* __restrict__ jj,
+                                                            const int64_t* __restrict__ kk, int M, int ki, float beta,
+                                                            float* __restrict__ flow_buf) {
+  const int n = dyn[CDV_DYN_N], E = dyn[CDV_DYN_E];
+  const int64_t fi = n - ki - 1, fj = n - ki + 1;
+  for (int e = (int)blockIdx.x * 256 + threadIdx.x; e < E; e += (int)gridDim.x * 256) {
+    const int64_t ix = ii[e], jx = jj[e];
+    const int dir = (ix == fi && jx == fj) ? 0 : ((ix == fj && jx == fi) ? 1 : -1);
+    if (dir < 0) continue;
+    const int64_t kx = kk[e];
+    float Pi[7], Pj[7], Pinv[7], G[3][7];
+#pragma unroll
+    for (int a = 0; a < 7; a++) { Pi[a] = poses[7 * ix + a]; Pj[a] = poses[7 * jx + a]; }
+    cdv::lt_se3_inv(Pi, Pinv);
+    cdv::lt_se3_mul(Pi, Pinv, G[0]);
+    cdv::lt_se3_mul(Pj, Pinv, G[1]);
+#pragma unroll
+    for (int a = 0; a < 3; a++) G[2][a] = G[1][a];
+    G[2][3] = 0.f; G[2][4] = 0.f; G[2][5] = 0.f; G[2][6] = 1.f;   // tonly (projective_ops.py:62)
+    float t[3][3], q[3][4];
+#pragma unroll
+    for (int v = 0; v < 3; v++) cdv::lt_se3_load(G[v], t[v], q[v]);
+    const float fxi = intr[4 * ix + 0], fyi = intr[4 * ix + 1], cxi = intr[4 * ix + 2], cyi = intr[4 * ix + 3];
+    const float fxj = intr[4 * jx + 0], fyj = intr[4 * jx + 1], cxj = intr[4 * jx + 2], cyj = intr[4 * jx + 3];
+    const float* pk = patches + kx * 27;
+    float tot = 0.f;
+#pragma unroll
+    for (int a = 0; a < 9; a++) {
+      float X0[4], X1[4], xy[3][2];
+      X0[0] = (pk[a] - cxi) / fxi;
+      X0[1] = (pk[9 + a] - cyi) / fyi;
+      X0[2] = 1.f;
+      X0[3] = pk[18 + a];
+#pragma unroll
+      for (int v = 0; v < 3; v++) {
+        cdv::lt_act4_loaded(t[v], q[v], X0, X1);
+        const float d = 1.0f / fmaxf(X1[2], 0.1f);
+        const float fx = v == 0 ? fxi : fxj, fy = v == 0 ? fyi : fyj, cx = v == 0 ? cxi : cxj, cy = v == 0 ? cyi : cyj;
+        xy[v][0] = fx * (d * X1[0]) + cx;
+        xy[v][1] = fy * (d * X1[1]) + cy;
+      }
+      const float ax = xy[1][0] - xy[0][0], ay = xy[1][1] - xy[0][1];
+      const float bx = xy[2][0] - xy[0][0], by = xy[2][1] - xy[0][1];
+      tot += beta * sqrtf(ax * ax + ay * ay) + (1.0f - beta) * sqrtf(bx * bx + by * by);
+    }
+    const int slot = (int)(kx - (int64_t)M * ix);
+    if (slot >= 0 && slot < M) {
+      flow_buf[dir * M + slot] = tot;          // one edge per (direction, patch): a plain store
+      flow_buf[(2 + dir) * M + slot] = 9.0f;   // pixels counted
+    }
+  }
+}
+
+// the decision, by one wave, in a fixed order: (mean_ij + mean_ji) / 2 < thresh (slam.py:413); an empty selection gives
+// NaN and no drop, like the reference's mean() of nothing.  force: -1 the test decides, 0 / 1 the caller does.
+__device__ __forceinline__ int keyframe_decision(const float* __restrict__ flow_buf, int M, int n, int ki, float thresh,
+                                                 int force, int lane, float* motion_out) {
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int v = 0; v < 4; v++)
+    for (int i = lane; i < M; i += 64) s[v] += flow_buf[v * M + i];
+#pragma unroll
+  for (int v = 0; v < 4; v++)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s[v] += __shfl_xor(s[v], o);
+  const float motion = 0.5f * (s[0] / s[2] + s[1] / s[3]);
+  if (motion_out) *motion_out = motion;
+  const bool guard = n > ki + 2;
+  if (force >= 0) return (force != 0 && guard) ? 1 : 0;
+  return (motion < thresh && guard) ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// 5. removals as stable compactions with the predicate inside (slam.py:339-354 with the masks of :423, :453)
+// ------------------------------------------------------------------------------------------------------------------
+struct RemoveArgs {
+  const int32_t* dyn_in;
+  int32_t* dyn_out;
+  int pass;                       // 0: frame k = n - KI leaves if the keyframe test says so (slam.py:415-427), 1: removal window (:453-458)
+  int M, ki, removal_window;
+  float thresh;
+  int force;
+  const float* flow_buf;
+  float* motion_out;              // [2]: the statistic and the decision, for whoever wants to look (tests)
+  const int64_t* ix;
+  const int64_t *ii, *jj, *kk;    // source lists
+  const float *target, *weight;
+  int64_t *ii_o, *jj_o, *kk_o;    // kept edges, compacted (the twin buffers)
+  float *target_o, *weight_o;
+  int64_t *ii_r, *jj_r, *kk_r;    // pass 1: removed edges are stored as inactive edges at dyn[EINAC]
+  float *target_r, *weight_r;
+  int64_t inac_cap;
+  int32_t *counts, *meta;         // per-workgroup keep counts -> exclusive offsets; meta[0] kept, [1] removed, [2] arrival
+  int64_t* mirror;                // pinned host word: (frames << 32 | edges) after pass 1 (no synchronisation needed to size launches)
+};
+
+__device__ __forceinline__ bool remove_pred(const RemoveArgs& A, int drop, int n_after, int64_t i, int64_t j, int64_t k,
+                                            int kf) {
+  if (A.pass == 0) return drop && (i == kf || j == kf);
+  return A.ix[k] < n_after - A.removal_window;
+}
+
+__global__ __launch_bounds__(256) void stream_count_kernel(const RemoveArgs A) {
+  __shared__ int s_w[4];
+  __shared__ int s_last, s_drop;
+  const int t = threadIdx.x, b = blockIdx.x;
+  const int n = A.dyn_in[CDV_DYN_N], E = A.dyn_in[CDV_DYN_E];
+  const int kf = n - A.ki;
+  if (A.pass == 0) {
+    if (t < 64) {
+      float motion;
+      const int d = keyframe_decision(A.flow_buf, A.M, n, A.ki, A.thresh, A.force, t, &motion);
+      if (t == 0) {
+        s_drop = d;
+        if (b == 0 && A.motion_out) { A.motion_out[0] = motion; A.motion_out[1] = (float)d; }
+      }
+    }
+    __syncthreads();
+  }
+  const int drop = A.pass == 0 ? s_drop : 0;
+  const int64_t base = (int64_t)b * 1024;
+  int c = 0;
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    const int64_t e = base + u * 256 + t;
+    if (e < E) c += remove_pred(A, drop, n, A.ii[e], A.jj[e], A.kk[e], kf) ? 0 : 1;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+  if ((t & 63) == 0) s_w[t >> 6] = c;
+  __syncthreads();
+  if (t == 0) {
+    const int tot = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    __hip_atomic_store(&A.counts[b], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int prev = __hip_atomic_fetch_add(&A.meta[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = prev == (int)gridDim.x - 1;
+    if (s_last) __hip_atomic_store(&A.meta[2], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!s_last) return;
+  if (t < 64) {   // the last workgroup to arrive: exclusive scan of the keep counts, the sizes after this removal
+    const int nb = (int)gridDim.x;
+    int run = 0;
+    for (int c0 = 0; c0 < nb; c0 += 64) {
+      const int i = c0 + t;
+      const int v = (i < nb) ? __hip_atomic_load(&A.counts[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+      int inc = v;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int a1 = __shfl_up(inc, o);
+        if (t >= o) inc += a1;
+      }
+      if (i < nb) A.counts[i] = run + inc - v;
+      run += __shfl(inc, 63);
+    }
+    if (t == 0) {
+      const int removed = E - run;
+      A.meta[0] = run; A.meta[1] = removed;
+      for (int i = 0; i < CDV_DYN_WORDS; i++) A.dyn_out[i] = A.dyn_in[i];
+      A.dyn_out[CDV_DYN_E] = run;
+      if (A.pass == 0) {
+        A.dyn_out[CDV_DYN_DROP] = drop;
+        A.dyn_out[CDV_DYN_N] = n - drop;
+      } else {
+        const int inac = A.dyn_in[CDV_DYN_EINAC];
+        if ((int64_t)inac + removed > A.inac_cap) A.dyn_out[CDV_DYN_ERR] = 2;   // inactive edges beyond their capacity: not stored
+        else A.dyn_out[CDV_DYN_EINAC] = inac + removed;
+        if (A.mirror)
+          __hip_atomic_store(A.mirror, ((int64_t)A.dyn_in[CDV_DYN_FRAME] << 32) | (int64_t)(uint32_t)run, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void stream_compact_kernel(const RemoveArgs A) {
+  __shared__ int s_pre[4][4];
+  const int t = threadIdx.x, b = blockIdx.x, lane = t & 63, wave = t >> 6;
+  const int n = A.dyn_in[CDV_DYN_N], E = A.dyn_in[CDV_DYN_E];
+  const int drop = A.pass == 0 ? A.dyn_out[CDV_DYN_DROP] : 0;      // written by the count launch in front
+  const int kf = n - A.ki;
+  const int64_t r0 = A.dyn_in[CDV_DYN_EINAC];
+  const bool store = A.pass == 1 && A.ii_r != nullptr && A.dyn_out[CDV_DYN_ERR] == 0;
+  const int64_t base = (int64_t)b * 1024;
+  bool keep[4], in[4];
+  int64_t vi[4], vj[4], vk[4];
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    const int64_t e = base + u * 256 + t;
+    in[u] = e < E;
+    vi[u] = in[u] ? A.ii[e] : 0; vj[u] = in[u] ? A.jj[e] : 0; vk[u] = in[u] ? A.kk[e] : 0;
+    keep[u] = in[u] && !remove_pred(A, drop, n, vi[u], vj[u], vk[u], kf);
+    const int wc = __popcll(__ballot(keep[u]));
+    if (lane == 0) s_pre[u][wave] = wc;
+  }
+  __syncthreads();
+  const int kbase = A.counts[b];
+  const int64_t rbase = base - kbase;
+  int kept_before_tile = 0;
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    int pre = kept_before_tile;
+    for (int w = 0; w < wave; w++) pre += s_pre[u][w];
+    const unsigned long long bal = __ballot(keep[u]);
+    const int rank_in_wave = __popcll(bal & ((1ull << lane) - 1ull));
+    const int64_t e = base + u * 256 + t;
+    if (keep[u]) {
+      const int64_t d = (int64_t)kbase + pre + rank_in_wave;
+      int64_t i = vi[u], j = vj[u], k = vk[u];
+      if (drop) {   // frame kf left: patches and frames above it move down (slam.py:425-427)
+        if (i > kf) { k -= A.M; i -= 1; }
+        if (j > kf) j -= 1;
+      }
+      A.ii_o[d] = i; A.jj_o[d] = j; A.kk_o[d] = k;
+      *reinterpret_cast<float2*>(A.target_o + 2 * d) = *reinterpret_cast<const float2*>(A.target + 2 * e);
+      *reinterpret_cast<float2*>(A.weight_o + 2 * d) = *reinterpret_cast<const float2*>(A.weight + 2 * e);
+    } else if (in[u] && store) {
+      const int before_in_tile = u * 256 + t;
+      const int64_t d = r0 + rbase + (before_in_tile - (pre + rank_in_wave));
+      A.ii_r[d] = vi[u]; A.jj_r[d] = vj[u]; A.kk_r[d] = vk[u];
+      *reinterpret_cast<float2*>(A.target_r + 2 * d) = *reinterpret_cast<const float2*>(A.target + 2 * e);
+      *reinterpret_cast<float2*>(A.weight_r + 2 * d) = *reinterpret_cast<const float2*>(A.weight + 2 * e);
+    }
+    kept_before_tile += s_pre[u][0] + s_pre[u][1] + s_pre[u][2] + s_pre[u][3];
+  }
+}
+
+// keyframe(): every per-frame buffer moves frames k + 1 .. n - 1 down by one (slam.py:431-441) -- if the test dropped k
+struct ShiftBufs {
+  cdv_frame_buf b[CDV_MAX_FRAME_BUFS];
+  int64_t first[CDV_MAX_FRAME_BUFS + 1];
+  int32_t gran[CDV_MAX_FRAME_BUFS];
+  int n_bufs;
+};
+
+__global__ __launch_bounds__(256) void stream_shift_kernel(const ShiftBufs F, const int32_t* __restrict__ dyn_before,
+                                                           const int32_t* __restrict__ dyn_after, int ki) {
+  if (!dyn_after[CDV_DYN_DROP]) return;
+  const int n = dyn_before[CDV_DYN_N], k = n - ki;
+  const int64_t total = F.first[F.n_bufs];
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    int bi = 0;
+    while (bi + 1 < F.n_bufs && t >= F.first[bi + 1]) bi++;
+    const int64_t piece = t - F.first[bi];
+    char* base = reinterpret_cast<char*>(F.b[bi].base);
+    const int64_t sb = F.b[bi].slot_bytes;
+    const int m = F.b[bi].modulus;
+    if (F.gran[bi] == 16) {
+      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+      for (int i = k; i < n - 1; i++) {
+        const int64_t d = m > 0 ? i % m : i, s2 = m > 0 ? (i + 1) % m : i + 1;
+        *reinterpret_cast<u32x4*>(base + d * sb + 16 * piece) = *reinterpret_cast<const u32x4*>(base + s2 * sb + 16 * piece);
+      }
+    } else {
+      for (int i = k; i < n - 1; i++) {
+        const int64_t d = m > 0 ? i % m : i, s2 = m > 0 ? (i + 1) % m : i + 1;
+        *reinterpret_cast<uint32_t*>(base + d * sb + 4 * piece) = *reinterpret_cast<const uint32_t*>(base + s2 * sb + 4 * piece);
+      }
+    }
+  }
+}
+
+inline int grid_of(int64_t n, int per, int cap) {
+  const int64_t b = (n + per - 1) / per;
+  return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+}  // namespace
+
+extern "C" size_t cdv_stream_workspace_bytes(int64_t edge_capacity, int M) {
+  // [16] meta words | per-workgroup counts | flow_buf [4][M] | motion [2]
+  return sizeof(int32_t) * (size_t)(16 + (edge_capacity + 1023) / 1024 + 16) + sizeof(float) * (size_t)(4 * M + 8) + 256;
+}
+
+namespace {
+struct StreamWs {
+  int32_t *meta, *counts;
+  float *flow_buf, *motion;
+};
+inline StreamWs stream_ws(void* ws, int64_t cap, int M) {
+  StreamWs w;
+  w.meta = (int32_t*)ws;
+  w.counts = w.meta + 16;
+  const size_t nc = (size_t)((cap + 1023) / 1024 + 16);
+  w.flow_buf = reinterpret_cast<float*>(w.counts + nc);
+  w.motion = w.flow_buf + 4 * (size_t)M;
+  return w;
+}
+}  // namespace
+
+// A frame arrives (slam.py:676-709 without the networks): reads dyn_in, writes dyn_out (n + 1, E + the frame's forward and
+// backward edges, the window of the coming update); appends the edges; with cx != NULL also writes the frame's patches,
+// pose guess and patch tiles (the stubbed network outputs).  ws: cdv_stream_workspace_bytes, zero-initialised once.
+extern "C" int cdv_stream_frame_begin(const int32_t* dyn_in, int32_t* dyn_out, int64_t* ii, int64_t* jj, int64_t* kk, float* target,
+                                      float* weight, const int64_t* ix, int64_t edge_capacity, int M, int patch_lifetime,
+                                      int opt_window, int frames_capacity, const float* cx, const float* cy, const float* d,
+                                      const void* fmap_chw, void* gmap_planar, float* poses, float* patches, int C, int H, int W,
+                                      int pmem, float pose_step, void* ws, void* stream) {
+  CDV_REQUIRE(dyn_in && dyn_out && dyn_in != dyn_out && ii && jj && kk && target && weight && ix && ws, CDV_ERR_ARG,
+              "cdv_stream_frame_begin: NULL buffer (or dyn_in == dyn_out)");
+  CDV_REQUIRE(M >= 1 && patch_lifetime >= 1 && opt_window >= 1 && frames_capacity >= 2, CDV_ERR_ARG, "cdv_stream_frame_begin: sizes");
+  CDV_REQUIRE(cx == nullptr || (cy && d && fmap_chw && gmap_planar && poses && patches && C >= 1 && pmem >= 1), CDV_ERR_ARG,
+              "cdv_stream_frame_begin: frame inputs");
+  const StreamWs w = stream_ws(ws, edge_capacity, M);
+  BeginArgs A;
+  A.dyn_in = dyn_in; A.dyn_out = dyn_out; A.ii = ii; A.jj = jj; A.kk = kk; A.target = target; A.weight = weight; A.ix = ix;
+  A.cap = edge_capacity; A.M = M; A.r = patch_lifetime; A.opt_window = opt_window; A.frames_cap = frames_capacity;
+  A.cx = cx; A.cy = cy; A.d = d; A.fmap = (const _Float16*)fmap_chw; A.gmap = (_Float16*)gmap_planar; A.poses = poses;
+  A.patches = patches; A.C = C; A.h = H; A.w = W; A.pmem = pmem; A.pose_step = pose_step; A.flow_buf = w.flow_buf;
+  A.n_edge_blocks = grid_of((int64_t)2 * patch_lifetime * M, 256, 1024);
+  A.n_tile_blocks = cx ? grid_of((int64_t)M * C * 9, 256, 1024) : 0;
+  hipLaunchKernelGGL(stream_begin_kernel, dim3(A.n_edge_blocks + 1 + A.n_tile_blocks), dim3(256), 0, (hipStream_t)stream, A);
+  CDV_LAUNCH_CHECK();
+  return CDV_OK;
+}
+
+extern "C" int cdv_stream_operator_stub(const int32_t* dyn, const float* coords, const void* corr, int corr_pitch, float* target,
+                                        float* weight, float gain, int64_t E_bound, void* stream) {
+  CDV_REQUIRE(dyn && coords && corr && target && weight && corr_pitch >= 4, CDV_ERR_ARG, "cdv_stream_operator_stub: arguments");
+  hipLaunchKernelGGL(stream_operator_stub_kernel, dim3(grid_of(E_bound, 256, 4096)), dim3(256), 0, (hipStream_t)stream, dyn, coords,
+                     (const _Float16*)corr, corr_pitch, target, weight, gain);
+  CDV_LAUNCH_CHECK();
+  return CDV_OK;
+}
+
+extern "C" int cdv_stream_points(const int32_t* dyn, const float* poses, const float* patches, const float* intrinsics,
+                                 const int64_t* ix, int M, int window_frames, float* points, void* stream) {
+  CDV_REQUIRE(dyn && poses && patches && intrinsics && ix && points && M >= 1 && window_frames >= 1, CDV_ERR_ARG,
+              "cdv_stream_points: arguments");
+  hipLaunchKernelGGL(stream_points_kernel, dim3(grid_of((int64_t)window_frames * M, 256, 1024)), dim3(256), 0, (hipStream_t)stream,
+                     dyn, poses, patches, intrinsics, ix, M, window_frames, points);
+  CDV_LAUNCH_CHECK();
+  return CDV_OK;
+}
+
+// The whole of SLAM.keyframe() (slam.py:408-458) for a 3 x 3 patch graph, six launches, no read-back:
+//   the flow statistic of the frames around k = n - KEYFRAME_INDEX, the decision (force: -1 the reference's test with
+//   `thresh`, 0 / 1 the caller's), removal of k's edges + index shift, shift of the frame buffers, removal-window pruning
+//   with the pruned edges stored as inactive ones.  dyn_in -> dyn_mid (after the keyframe removal) -> dyn_out.
+// Edge buffers: `a` holds the lists on entry and on return, `b` is the twin they pass through.
+extern "C" int cdv_stream_keyframe(const int32_t* dyn_in, int32_t* dyn_mid, int32_t* dyn_out, const float* poses,
+                                   const float* patches, const float* intrinsics, const int64_t* ix, int64_t* ii_a, int64_t* jj_a,
+                                   int64_t* kk_a, float* target_a, float* weight_a, int64_t* ii_b, int64_t* jj_b, int64_t* kk_b,
+                                   float* target_b, float* weight_b, int64_t* ii_inac, int64_t* jj_inac, int64_t* kk_inac,
+                                   float* target_inac, float* weight_inac, int64_t inactive_capacity, int64_t edge_capacity,
+                                   int64_t E_bound, int M, int keyframe_index, int removal_window, float keyframe_thresh,
+                                   int force, const cdv_frame_buf* bufs, int n_bufs, int64_t* mirror_host, void* ws,
+                                   void* stream) {
+  CDV_REQUIRE(dyn_in && dyn_mid && dyn_out && dyn_in != dyn_mid && dyn_mid != dyn_out && dyn_in != dyn_out, CDV_ERR_ARG,
+              "cdv_stream_keyframe: three distinct dynamic blocks");
+  CDV_REQUIRE(poses && patches && intrinsics && ix && ii_a && jj_a && kk_a && target_a && weight_a && ii_b && jj_b && kk_b &&
+                  target_b && weight_b && ws, CDV_ERR_ARG, "cdv_stream_keyframe: NULL buffer");
+  CDV_REQUIRE(n_bufs >= 0 && n_bufs <= CDV_MAX_FRAME_BUFS && (n_bufs == 0 || bufs), CDV_ERR_ARG, "cdv_stream_keyframe: frame buffers");
+  CDV_REQUIRE(E_bound >= 1 && E_bound <= edge_capacity, CDV_ERR_ARG, "cdv_stream_keyframe: E_bound");
+  hipStream_t s = (hipStream_t)stream;
+  const StreamWs w = stream_ws(ws, edge_capacity, M);
+  hipLaunchKernelGGL(stream_motion_kernel, dim3(grid_of(E_bound, 256, 4096)), dim3(256), 0, s, dyn_in, poses, patches, intrinsics,
+                     ii_a, jj_a, kk_a, M, keyframe_index, 0.5f, w.flow_buf);
+  RemoveArgs A;
+  A.dyn_in = dyn_in; A.dyn_out = dyn_mid; A.pass = 0; A.M = M; A.ki = keyframe_index; A.removal_window = removal_window;
+  A.thresh = keyframe_thresh; A.force = force; A.flow_buf = w.flow_buf; A.motion_out = w.motion; A.ix = ix;
+  A.ii = ii_a; A.jj = jj_a; A.kk = kk_a; A.target = target_a; A.weight = weight_a;
+  A.ii_o = ii_b; A.jj_o = jj_b; A.kk_o = kk_b; A.target_o = target_b; A.weight_o = weight_b;
+  A.ii_r = nullptr; A.jj_r = nullptr; A.kk_r = nullptr; A.target_r = nullptr; A.weight_r = nullptr; A.inac_cap = inactive_capacity;
+  A.counts = w.counts; A.meta = w.meta; A.mirror = nullptr;
+  const int nb = grid_of(E_bound, 1024, 1 << 22);
+  hipLaunchKernelGGL(stream_count_kernel, dim3(nb), dim3(256), 0, s, A);
+  hipLaunchKernelGGL(stream_compact_kernel, dim3(nb), dim3(256), 0, s, A);
+  if (n_bufs > 0) {
+    ShiftBufs F;
+    F.n_bufs = n_bufs;
+    F.first[0] = 0;
+    for (int i = 0; i < n_bufs; i++) {
+      const cdv_frame_buf& b = bufs[i];
+      CDV_REQUIRE(b.base != nullptr && b.slot_bytes > 0 && b.slot_bytes % 4 == 0 && b.modulus >= 0 && ((uintptr_t)b.base & 3) == 0,
+                  CDV_ERR_ARG, "cdv_stream_keyframe: a buffer needs a 4-byte aligned base, slot_bytes % 4 == 0, modulus >= 0");
+      F.b[i] = b;
+      F.gran[i] = (b.slot_bytes % 16 == 0 && ((uintptr_t)b.base & 15) == 0) ? 16 : 4;
+      F.first[i + 1] = F.first[i] + b.slot_bytes / F.gran[i];
+    }
+    hipLaunchKernelGGL(stream_shift_kernel, dim3(grid_of(F.first[n_bufs], 256, 4096)), dim3(256), 0, s, F, dyn_in, dyn_mid,
+                       keyframe_index);
+  }
+  RemoveArgs B = A;
+  B.dyn_in = dyn_mid; B.dyn_out = dyn_out; B.pass = 1;
+  B.ii = ii_b; B.jj = jj_b; B.kk = kk_b; B.target = target_b; B.weight = weight_b;
+  B.ii_o = ii_a; B.jj_o = jj_a; B.kk_o = kk_a; B.target_o = target_a; B.weight_o = weight_a;
+  B.ii_r = ii_inac; B.jj_r = jj_inac; B.kk_r = kk_inac; B.target_r = target_inac; B.weight_r = weight_inac;
+  B.mirror = mirror_host;
+  hipLaunchKernelGGL(stream_count_kernel, dim3(nb), dim3(256), 0, s, B);
+  hipLaunchKernelGGL(stream_compact_kernel, dim3(nb), dim3(256), 0, s, B);
+  CDV_LAUNCH_CHECK();
+  return CDV_OK;
+}
+
+// (motion, decision) of the last cdv_stream_keyframe on this workspace: two floats on the device (tests read them back)
+extern "C" const float* cdv_stream_motion(void* ws, int64_t edge_capacity, int M) {
+  return ws ? stream_ws(ws, edge_capacity, M).motion : nullptr;
+}

@@ -962,6 +962,20 @@ def _ba_workspace(dev, E, U_max, N):
     return ws
 
 
+def ba_private_workspace(dev, E, U_max, N):
+    """a bundle-adjustment workspace of the caller's own (the per-device one above is re-allocated when somebody asks for
+    more): initialised, bound to the device's event counters"""
+    lib = _lib.load()
+    ws = torch.empty(int(lib.cdv_ba_workspace_bytes(E, U_max, max(N, 1))) + 4096, dtype=torch.uint8, device=dev)
+    _lib.check(lib.cdv_ba_workspace_init(_p(ws), _stream()), "cdv_ba_workspace_init")
+    cnt = _ba_counters.get(dev)
+    if cnt is None:
+        cnt = _ba_counters[dev] = torch.zeros(4, dtype=torch.int32).pin_memory()
+        _ba_seen[dev] = [0, 0, 0, 0]
+    _lib.check(lib.cdv_ba_bind_status_counters(_p(ws), ctypes.c_void_p(cnt.data_ptr())), "cdv_ba_bind_status_counters")
+    return ws
+
+
 def ba_event_counts(device=None):
     """Failure events the BA kernels have counted on `device` since start-up, WITHOUT synchronising: a list of four
     ints in the order of BA_EVENTS.  (The counters live in pinned host memory the kernels write to.)"""

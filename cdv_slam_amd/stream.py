@@ -200,3 +200,201 @@ class StreamRunner:
             ops.fmap_ingest(fmap, self.fmap1, self.fmap2, (self.n - 1) % self.mem, gmap=self.gmap, gmap_pm=self.gmap_pm,
                             gmap_first=tile0, gmap_count=self.M)
         return self.n, self.edges.E
+
+    def counts(self):
+        """(n, E): host integers here (DeviceStreamRunner has to ask the device)"""
+        return self.n, self.edges.E
+
+
+class _EdgeViews:
+    """the live part of the device-resident edge lists, reference names (after a synchronisation: the owner asked for it)"""
+
+    def __init__(self, owner, E):
+        o = owner
+        self.E = E
+        self.ii, self.jj, self.kk = o._ii[0, :E], o._jj[0, :E], o._kk[0, :E]
+        self.target, self.weight = o._target[0, :E][None], o._weight[0, :E][None]
+
+
+class DeviceStreamRunner:
+    """StreamRunner with every size on the device (include/cdvslam_hip.h "a frame stream whose sizes live on the DEVICE").
+
+    The reference reads its keyframe decision back to the host (two .item() calls, cdvslam/slam.py:399-413) and from there on
+    n and the number of edges are host integers; StreamRunner above does the same (one read-back per removal).  Here a frame
+    is a fixed sequence of 17 launches and NO synchronisation:
+
+        cdv_stream_frame_begin        n + 1, the frame's edges, patches_, pose guess, patch tiles          slam.py:676-709
+        cdv_update_prologue_table_dyn ring ingest | table fill, then sort + neighbors + reprojection + packed stream
+        cdv_corr_fused_stream_dyn     two-level correlation                                              slam.py:316-323
+        cdv_stream_operator_stub      (stands where the Update operator runs)
+        cdv_ba_forward_dyn            BA(iterations=2) over [max(1, n - OPTIMIZATION_WINDOW), n)            slam.py:512-515
+        cdv_stream_points             point cloud of the patches inside the removal window                 slam.py:524-526
+        cdv_stream_keyframe           flow statistic -> decision ON THE DEVICE -> removal + shifts -> window pruning
+                                                                                                           slam.py:399-458
+    n, E, the decision live in a ring of "dynamic blocks"; the host only keeps an upper bound of E (from a pinned word the
+    last launch of a frame writes) to dimension the launches.  Anything the host wants to KNOW (counts(), n, edges, poses of
+    the keyframes) synchronises -- tests and the end of a run do, the frame loop does not.  Configurations: 3 x 3 patches,
+    OPTIMIZATION_WINDOW <= 10 (the window solver), no loop closure (StreamRunner serves those)."""
+
+    def __init__(self, device, M=96, ht=384, wd=512, C=24, mem=36, pmem=36, buffer_size=512, patch_lifetime=13,
+                 removal_window=22, opt_window=10, keyframe_index=4, seed=1234, keyframe_thresh=12.5, gain=0.01):
+        import ctypes
+        from . import _lib
+        if opt_window > 10:
+            raise NotImplementedError("DeviceStreamRunner: OPTIMIZATION_WINDOW <= 10 (cdv_ba_forward_dyn)")
+        self.lib = lib = _lib.load()
+        self.dev = device
+        self.M, self.C, self.mem, self.pmem, self.N = M, C, mem, pmem, buffer_size
+        self.h, self.w = ht // 4, wd // 4
+        self.r, self.rw, self.ow, self.ki = patch_lifetime, removal_window, opt_window, keyframe_index
+        self.kthresh, self.gain = keyframe_thresh, gain
+        f32 = dict(dtype=torch.float32, device=device)
+        self.poses = torch.zeros((self.N, 7), **f32); self.poses[:, 6] = 1.0
+        self.patches = torch.zeros((self.N * M, 3, 3, 3), **f32)
+        intr = torch.tensor([wd / 2.0, wd / 2.0, wd / 2.0, ht / 2.0]) / 4.0
+        self.intrinsics = intr.to(device).repeat(self.N, 1).contiguous()
+        self.ix = torch.arange(self.N, device=device).repeat_interleave(M)
+        self.points = torch.zeros((self.N * M, 3), **f32)
+        self.fmap1 = ops.alloc_fmap_ring(mem, C, self.h, self.w, device)
+        self.fmap2 = ops.alloc_fmap_ring(mem, C, self.h // 4, self.w // 4, device)
+        self.gmap = torch.zeros((pmem * M, C, 3, 3), dtype=torch.float16, device=device)
+        self.gmap_pm = torch.zeros((pmem * M, 9, C), dtype=torch.float16, device=device)
+        self.ecap = ecap = M * (removal_window + 6) * 2 * patch_lifetime
+        self.icap = icap = ecap + buffer_size * M * 2 * patch_lifetime
+        z = lambda *s, dt=torch.int64: torch.zeros(s, dtype=dt, device=device)
+        self._ii, self._jj, self._kk = z(2, ecap), z(2, ecap), z(2, ecap)                  # [0]: the lists, [1]: their twin
+        self._target, self._weight = z(2, ecap, 2, dt=torch.float32), z(2, ecap, 2, dt=torch.float32)
+        self.ii_inac, self.jj_inac, self.kk_inac = z(icap), z(icap), z(icap)
+        self.target_inac, self.weight_inac = z(icap, 2, dt=torch.float32), z(icap, 2, dt=torch.float32)
+        self.dyn = torch.zeros((8, 16), dtype=torch.int32, device=device)                  # ring of dynamic blocks
+        self.slot = 0
+        self.mirror = torch.zeros(1, dtype=torch.int64).pin_memory()                       # (frames << 32 | edges), written by the device
+        self.ws = torch.zeros(lib.cdv_stream_workspace_bytes(ecap, M), dtype=torch.uint8, device=device)
+        self.tcap = (removal_window + 8) * M
+        self.graph = ops.GraphIndex(device, E_cap=ecap, k_range=(removal_window + 8) * M + M * pmem, table_capacity=self.tcap)
+        self.coords_buf = torch.empty((1, ecap, 2, 3, 3), **f32)
+        self.graph.bind_corr_stream(None, M * pmem, mem, pmem * M, mem)
+        self.corr_out = torch.empty((1, ecap, 882), dtype=torch.float16, device=device)
+        self.lmbda = torch.tensor([1e-4], **f32)
+        self.ba_ws = ops.ba_private_workspace(device, ecap, self.tcap, opt_window)
+        self.frames = 0
+        # the stubbed feature network: a pool of feature maps and, drawn ON THE DEVICE once, every frame's patch centres / depths
+        g = torch.Generator(device=device).manual_seed(seed)
+        self.pool = [(torch.randn((C, self.h, self.w), generator=g, device=device) / 4).half() for _ in range(4)]
+        u = torch.rand((self.N, 3, M), generator=g, device=device)
+        self._draws = torch.stack([u[:, 0] * (self.w - 16) + 8, u[:, 1] * (self.h - 16) + 8, u[:, 2] * 0.75 + 0.25], 1).contiguous()
+        # the frame buffers keyframe() shifts (slam.py:431-441), as one descriptor list
+        bufs = [(self.poses, 0), (self.intrinsics, 0), (self.patches.view(self.N, -1), 0), (self.gmap.view(pmem, -1), pmem),
+                (self.gmap_pm.view(pmem, -1), pmem), (self.fmap1, mem), (self.fmap2, mem)]
+        self._bufs = (_lib.FrameBuf * len(bufs))()
+        for a, (t, m) in zip(self._bufs, bufs):
+            a.base, a.slot_bytes, a.modulus, a.reserved = t.data_ptr(), t[0].numel() * t.element_size(), int(m), 0
+        self._nbufs = len(bufs)
+        self._p = lambda t: ctypes.c_void_p(t.data_ptr())
+        self._cast = ctypes.cast
+
+    # ---- what the host may look at (synchronises) --------------------------------------------------------------
+    def counts(self):
+        """(n, E) after everything enqueued so far; raises if a capacity was exceeded on the device"""
+        blk = self.dyn[self.slot].cpu()
+        if int(blk[7]):
+            raise RuntimeError("DeviceStreamRunner: capacity exceeded on the device (code %d): edges %d / %d, inactive %d / %d, "
+                               "frames %d / %d" % (int(blk[7]), int(blk[1]), self.ecap, int(blk[2]), self.icap, int(blk[0]), self.N))
+        return int(blk[0]), int(blk[1])
+
+    n = property(lambda s: s.counts()[0])
+    edges = property(lambda s: _EdgeViews(s, s.counts()[1]))
+    E_inac = property(lambda s: int(s.dyn[s.slot, 2].item()))
+
+    @property
+    def last_motion(self):
+        """the flow statistic of the last keyframe test (slam.py:409-413), None before the first one"""
+        if self.frames < 8:
+            return None
+        p = self.lib.cdv_stream_motion(self._p(self.ws), self.ecap, self.M)
+        off = (p - self.ws.data_ptr()) // 4
+        return float(self.ws.view(torch.float32)[off].item())
+
+    def _edge_bound(self):
+        """an upper bound of the number of edges once the frame about to begin has arrived, without asking the device: what
+        the last finished keyframe() left (pinned word) plus 2 r M per frame begun since"""
+        v = int(self.mirror[0])
+        seen_frame, seen_E = v >> 32, v & 0xFFFFFFFF
+        return min(self.ecap, seen_E + (self.frames + 1 - seen_frame) * 2 * self.r * self.M)
+
+    def _pointers(self):
+        """every buffer address of a frame's launches, once (they never change): a frame then costs 17 ctypes calls and no
+        tensor indexing"""
+        import ctypes
+        V = ctypes.c_void_p
+        q = lambda t: V(t.data_ptr())
+        eb8, eb4 = self.ecap * 8, self.ecap * 2 * 4
+        self._c = dict(
+            ii=(V(self._ii.data_ptr()), V(self._ii.data_ptr() + eb8)), jj=(V(self._jj.data_ptr()), V(self._jj.data_ptr() + eb8)),
+            kk=(V(self._kk.data_ptr()), V(self._kk.data_ptr() + eb8)),
+            tg=(V(self._target.data_ptr()), V(self._target.data_ptr() + eb4)),
+            wt=(V(self._weight.data_ptr()), V(self._weight.data_ptr() + eb4)),
+            ix=q(self.ix), gmap=q(self.gmap), gmap_pm=q(self.gmap_pm), poses=q(self.poses), patches=q(self.patches),
+            intr=q(self.intrinsics), ws=q(self.ws), fmap1=q(self.fmap1), fmap2=q(self.fmap2), coords=q(self.coords_buf),
+            corr=q(self.corr_out), lmbda=q(self.lmbda), gws=q(self.graph.ws), ba_ws=q(self.ba_ws), points=q(self.points),
+            inac=(q(self.ii_inac), q(self.jj_inac), q(self.kk_inac), q(self.target_inac), q(self.weight_inac)),
+            bufs=ctypes.cast(self._bufs, V), mirror=V(self.mirror.data_ptr()),
+            dyn=[V(self.dyn.data_ptr() + 64 * i) for i in range(8)],
+            draws=[tuple(V(self._draws.data_ptr() + 4 * self.M * (3 * f + k)) for k in range(3)) for f in range(self.N)],
+            pool=[q(t) for t in self.pool])
+
+    def frame(self, drop=False, inputs=None):
+        """one incoming frame, enqueued; nothing is read back.  drop: None = the reference's keyframe test on the device,
+        True / False = the caller decides; inputs: (fmap [C,h,w] f16, cx, cy, d [M]) on the device, default: the stub's own"""
+        if self.frames + 2 >= self.N:
+            raise RuntimeError("DeviceStreamRunner: frame buffer full")
+        if not hasattr(self, "_c"):
+            self._pointers()
+        lib, c, s, check = self.lib, self._c, ops._stream(), ops._lib.check
+        M, f = self.M, self.frames
+        if inputs is None:
+            fmap_t = self.pool[f % len(self.pool)]
+            fmap = c["pool"][f % len(self.pool)]
+            cx, cy, d = c["draws"][f]
+        else:
+            fmap_t, cx, cy, d = inputs
+            fmap_t, cx, cy, d = fmap_t.contiguous(), cx.contiguous(), cy.contiguous(), d.contiguous()
+            self._hold = (fmap_t, cx, cy, d)           # alive until the launches that read them are enqueued again
+            fmap, cx, cy, d = (self._p(t) for t in self._hold)
+        dyn = c["dyn"]
+        a, b, m, e = self.slot, (self.slot + 1) & 7, (self.slot + 2) & 7, (self.slot + 3) & 7
+        Eb = self._edge_bound()
+        ii, jj, kk, tg, wt = c["ii"], c["jj"], c["kk"], c["tg"], c["wt"]
+        check(lib.cdv_stream_frame_begin(dyn[a], dyn[b], ii[0], jj[0], kk[0], tg[0], wt[0], c["ix"], self.ecap, M, self.r, self.ow,
+                                         self.N, cx, cy, d, fmap, c["gmap"], c["poses"], c["patches"], self.C, self.h, self.w,
+                                         self.pmem, 0.05, c["ws"], s), "cdv_stream_frame_begin")
+        self.frames += 1
+        if self.frames < 8:      # before initialisation only the rings are filled (n == frames: no keyframe has been tested yet)
+            ops.fmap_ingest(fmap_t, self.fmap1, self.fmap2, (self.frames - 1) % self.mem, gmap=self.gmap, gmap_pm=self.gmap_pm,
+                            gmap_first=((self.frames - 1) % self.pmem) * M, gmap_count=M)
+            self.slot = b
+            return
+        g = self.graph
+        check(lib.cdv_update_prologue_table_dyn(fmap, c["fmap1"], c["fmap2"], self.mem, self.pmem, self.C, self.h, self.w, c["gmap"],
+                                                c["gmap_pm"], self.pmem * M, M, c["poses"], c["patches"], c["intr"], ii[0], jj[0],
+                                                kk[0], Eb, dyn[b], c["coords"], c["gws"], g.ws_bytes, g.E_cap, g.k_range,
+                                                g.table_capacity, s), "cdv_update_prologue_table_dyn")
+        g.is_table, g._key, g._nbr = True, None, None
+        if not hasattr(self, "_rec"):
+            self._rec = g.corr_records_ptr()
+        check(lib.cdv_corr_fused_stream_dyn(c["gmap_pm"], c["fmap1"], c["fmap2"], self._rec, c["corr"], Eb, dyn[b], self.pmem * M,
+                                            self.mem, self.C, self.h, self.w, self.h // 4, self.w // 4, 1.0, 4.0, 1, s),
+              "cdv_corr_fused_stream_dyn")
+        check(lib.cdv_stream_operator_stub(dyn[b], c["coords"], c["corr"], 882, tg[0], wt[0], self.gain, Eb, s),
+              "cdv_stream_operator_stub")
+        check(lib.cdv_ba_forward_dyn(c["poses"], c["patches"], c["intr"], tg[0], wt[0], c["lmbda"], ii[0], jj[0], kk[0], Eb, 3,
+                                     self.ow, dyn[b], 2, c["gws"], c["ba_ws"], self.ba_ws.numel(), self.tcap, s), "cdv_ba_forward_dyn")
+        check(lib.cdv_stream_points(dyn[b], c["poses"], c["patches"], c["intr"], c["ix"], M, self.rw + 2, c["points"], s),
+              "cdv_stream_points")
+        force = -1 if drop is None else (1 if drop else 0)
+        ia = c["inac"]
+        check(lib.cdv_stream_keyframe(dyn[b], dyn[m], dyn[e], c["poses"], c["patches"], c["intr"], c["ix"], ii[0], jj[0], kk[0], tg[0],
+                                      wt[0], ii[1], jj[1], kk[1], tg[1], wt[1], ia[0], ia[1], ia[2], ia[3], ia[4], self.icap, self.ecap,
+                                      Eb, M, self.ki, self.rw, self.kthresh, force, c["bufs"], self._nbufs, c["mirror"], c["ws"], s),
+              "cdv_stream_keyframe")
+        self.slot = e

@@ -375,6 +375,7 @@ int cdv_ba_bind_status_counters(void* ba_ws, int32_t* counters);
  */
 int cdv_ba_test_handoff(int mode);
 
+
 /* altcorr.patchify(net, coords, radius, mode) -- correlation.py:51-71 -- in one launch: the gather of
  * patchify_forward plus the blend the reference composes from four slice products.
  *   mode 1 'bilinear': out [B][M][C][2r+1][2r+1] FLOAT32 (the reference multiplies float32 offsets into the tile);
@@ -494,6 +495,96 @@ typedef struct {
   int32_t reserved;
 } cdv_frame_buf;
 int cdv_frames_keyframe_shift(const cdv_frame_buf* bufs, int n_bufs, int k, int n, void* stream);
+
+/*
+ * ---- a frame stream whose sizes live on the DEVICE ------------------------------------------------------------------
+ * The reference decides per frame, on the host, whether frame n - KEYFRAME_INDEX leaves the graph (two .item() read-backs,
+ * cdvslam/slam.py:399-413), and every size that follows -- the number of keyframes n, the number of edges E after the
+ * mask-indexing of remove_factors (slam.py:339-354) -- is a host integer again.  Here the decision and the sizes can stay
+ * on the device: a "dynamic block" of CDV_DYN_WORDS int32 words holds them, the *_dyn entry points read their sizes from
+ * it (their size ARGUMENTS are then upper bounds that only dimension the launches), and the three entry points that
+ * change a size -- cdv_stream_frame_begin, and the two compactions inside cdv_stream_keyframe -- read one block and write
+ * the next (the caller hands in a small ring of blocks: nothing is updated in place under a running launch).  No host
+ * synchronisation anywhere in a frame; the whole frame is a fixed sequence of launches (hipGraph-capturable).
+ */
+#define CDV_DYN_WORDS 16
+enum {
+  CDV_DYN_N = 0,      /* keyframes in the graph (slam.py: self.n) */
+  CDV_DYN_E = 1,      /* active edges */
+  CDV_DYN_EINAC = 2,  /* inactive (stored) edges */
+  CDV_DYN_DROP = 3,   /* outcome of the last keyframe test: 1 = frame n - KEYFRAME_INDEX was dropped */
+  CDV_DYN_T0 = 4,     /* first free pose of the update: max(1, n - OPTIMIZATION_WINDOW) (slam.py:512-513) */
+  CDV_DYN_NFREE = 5,  /* n - t0 */
+  CDV_DYN_FRAME = 6,  /* frames seen so far */
+  CDV_DYN_ERR = 7     /* != 0: a capacity was exceeded (edges / inactive edges / frame buffer); the stream stops changing */
+};
+
+/* cdv_update_prologue_table (above) with the sizes on the device: dyn[CDV_DYN_E] edges (E_bound dimensions the launches), the
+ * new frame goes to ring slot (n - 1) % mem and tiles [((n - 1) % pmem) * tiles_per_frame, + tiles_per_frame), n = dyn[CDV_DYN_N].
+ * No neighbor lists are written (cdv_neighbors serves them from the index). */
+int cdv_update_prologue_table_dyn(const void* fmap_chw, void* fmap1_nhwc, void* fmap2_nhwc, int mem, int pmem, int C, int H, int W,
+                                  const void* gmap_planar, void* gmap_pm, int64_t Ng, int64_t tiles_per_frame, const float* poses,
+                                  const float* patches, const float* intrinsics, const int64_t* ii, const int64_t* jj,
+                                  const int64_t* kk, int64_t E_bound, const int32_t* dyn, float* coords, void* graph_ws,
+                                  size_t graph_ws_bytes, int64_t E_max, int64_t k_range, int64_t table_capacity, void* stream);
+
+/* cdv_corr_fused_stream with dyn[CDV_DYN_E] edges; out must hold E_bound rows. */
+int cdv_corr_fused_stream_dyn(const void* gmap, const void* fmap0_nhwc, const void* fmap1_nhwc, const void* records, void* out,
+                              int64_t E_bound, const int32_t* dyn, int64_t Ng, int64_t slots, int C, int H0, int W0, int H1, int W1,
+                              float scale0, float scale1, int gmap_pixel_major, void* stream);
+
+/* cdv_ba_forward over the window [dyn[CDV_DYN_T0], + dyn[CDV_DYN_NFREE]) (slam.py:512-513), NFREE <= N_max <= 10; graph_ws must
+ * hold a patch table; E_bound / U_max size the workspace (cdv_ba_workspace_bytes(E_bound, U_max, N_max)). */
+int cdv_ba_forward_dyn(float* poses, float* patches, const float* intrinsics, const float* target, const float* weight,
+                       const float* lmbda, const int64_t* ii, const int64_t* jj, const int64_t* kk, int64_t E_bound, int P,
+                       int N_max, const int32_t* dyn, int iterations, const void* graph_ws, void* ba_ws, size_t ba_ws_bytes,
+                       int64_t U_max, void* stream);
+
+/* Workspace of the stream entry points below (zero-initialise once). */
+size_t cdv_stream_workspace_bytes(int64_t edge_capacity, int M);
+
+/*
+ * A frame arrives (slam.py:697-709; the state write of :676-696 when the frame's patch centres are given): dyn_out <- dyn_in
+ * with n + 1, E + the frame's forward / backward edges (slam.py:528-541), the window of the coming update; the edges are
+ * appended at E (ii = ix[kk], their target / weight rows zeroed, slam.py:331-337).  cx / cy / d [M] (optional): the new
+ * frame's patch centres and inverse depths -> patches_[n] (3 x 3 grids), the pose guess poses_[n] = poses_[n - 1] moved by
+ * pose_step along x, and the frame's patch tiles gmap_[n % pmem] = altcorr.patchify(fmap, centres, 1, 'bilinear') in half.
+ */
+int cdv_stream_frame_begin(const int32_t* dyn_in, int32_t* dyn_out, int64_t* ii, int64_t* jj, int64_t* kk, float* target,
+                           float* weight, const int64_t* ix, int64_t edge_capacity, int M, int patch_lifetime, int opt_window,
+                           int frames_capacity, const float* cx, const float* cy, const float* d, const void* fmap_chw,
+                           void* gmap_planar, float* poses, float* patches, int C, int H, int W, int pmem, float pose_step,
+                           void* ws, void* stream);
+
+/* Stand-in for the update operator in a stream without networks: target = reprojected patch centre + gain * tanh(corr[:, 0:2]),
+ * weight = sigmoid(corr[:, 2:4]) for the dyn[CDV_DYN_E] edges (coords [E][2][3][3] f32, corr rows of corr_pitch halves). */
+int cdv_stream_operator_stub(const int32_t* dyn, const float* coords, const void* corr, int corr_pitch, float* target,
+                             float* weight, float gain, int64_t E_bound, void* stream);
+
+/* slam.py:524-526 restricted to what can have moved: points [*][3] <- world point of the centre pixel of every patch of the
+ * last window_frames keyframes. */
+int cdv_stream_points(const int32_t* dyn, const float* poses, const float* patches, const float* intrinsics, const int64_t* ix,
+                      int M, int window_frames, float* points, void* stream);
+
+/*
+ * SLAM.keyframe() (slam.py:408-458), 3 x 3 patches, no read-back: mean flow_mag of the edges between the frames either side
+ * of k = n - keyframe_index (slam.py:399-413, beta 0.5) -> decision on the device (force -1: drop k when the mean is under
+ * keyframe_thresh and n > keyframe_index + 2; 0 / 1: the caller decides) -> k's edges removed and the indices above it
+ * shifted (:423-427), the frame buffers `bufs` shifted (:431-441, as cdv_frames_keyframe_shift), n - 1; then the edges whose
+ * source frame left the removal window are removed and stored as inactive edges (:453-458).  dyn_in -> dyn_mid -> dyn_out
+ * (three distinct blocks).  The `a` buffers hold the edge lists on entry and on return; `b` is their twin.  mirror_host
+ * (optional, pinned): receives (frames << 32 | edges) so that the host can size the next launches without synchronising.
+ */
+int cdv_stream_keyframe(const int32_t* dyn_in, int32_t* dyn_mid, int32_t* dyn_out, const float* poses, const float* patches,
+                        const float* intrinsics, const int64_t* ix, int64_t* ii_a, int64_t* jj_a, int64_t* kk_a, float* target_a,
+                        float* weight_a, int64_t* ii_b, int64_t* jj_b, int64_t* kk_b, float* target_b, float* weight_b,
+                        int64_t* ii_inac, int64_t* jj_inac, int64_t* kk_inac, float* target_inac, float* weight_inac,
+                        int64_t inactive_capacity, int64_t edge_capacity, int64_t E_bound, int M, int keyframe_index,
+                        int removal_window, float keyframe_thresh, int force, const cdv_frame_buf* bufs, int n_bufs,
+                        int64_t* mirror_host, void* ws, void* stream);
+
+/* device pointer to {flow statistic, decision} of the last cdv_stream_keyframe on the workspace (tests). */
+const float* cdv_stream_motion(void* ws, int64_t edge_capacity, int M);
 
 /* ------------------------------------------------------------------------------------------------
  * lietorch forward ops  (replaces lietorch_backends.{expm,logm,inv,mul,adj,adjT,act,act4,as_matrix})

@@ -179,7 +179,8 @@ def closed_loop(run, so, frames, seed=1234, drop="pattern", check_edges=True, pr
         want = (f % 3 == 2) if drop == "pattern" else None
         n0 = so.n
         n_o, E_o = so.frame(pool[f % 4], cx, cy, d, drop=want)
-        n_g, E_g = run.frame(drop=want, inputs=(pool_dev[f % 4], T(cx), T(cy), T(d)))
+        run.frame(drop=want, inputs=(pool_dev[f % 4], T(cx), T(cy), T(d)))
+        n_g, E_g = run.counts()
         res["dropped"] += int(n_o == n0)
         if drop == "flow" and so.last_motion is not None:
             res["motion_maxdiff"] = max(res["motion_maxdiff"], abs(so.last_motion - run.last_motion))

@@ -369,7 +369,7 @@ def test_dropin_table_gives_way_to_the_ranked_index_when_the_ids_do_not_fit():
             jj2, kk2 = jj.clone(), kk.clone()
             ix, jx = cuda_ba.neighbors(kk2, jj2)
             assert np.array_equal(ix.cpu().numpy(), ix_o) and np.array_equal(jx.cpu().numpy(), jx_o)
-            cuda_ba.forward(poses, patches, *args(None, None)[2:8], jj2, kk2, *args(None, None)[10:])
+            cuda_ba.forward(poses, patches, *args(None, None)[2:7], jj2, kk2, *args(None, None)[9:])
             torch.cuda.synchronize()
         assert any("falling back to the ranked index" in str(x.message) for x in w)
         assert not ops._device_graph(dev).is_table

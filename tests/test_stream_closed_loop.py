@@ -61,3 +61,78 @@ def test_closed_loop_stream_with_the_reference_keyframe_test():
     _log("closed_loop_flow", "gain0.01", {"ate": ate, "frames": res["frames"], "keyframes": res["keyframes"],
                                           "dropped": res["dropped"], "motion_maxdiff": res["motion_maxdiff"]}, {"ate": ATE_TOL})
     assert ate <= ATE_TOL
+
+
+# ---- the same three runs with every size on the device (DeviceStreamRunner: no read-back inside a frame) ----------------------
+
+def _pair_dev(gain, **kw):
+    from cdv_slam_amd.stream import DeviceStreamRunner
+    return DeviceStreamRunner(torch.device(DEV), gain=gain, **CFG, **kw), StreamOracle(gain=gain, **CFG, **kw)
+
+
+@pytest.mark.parametrize("gain", [0.01, 0.25])
+def test_device_stream_with_dropped_keyframes(gain):
+    run, so = _pair_dev(gain)
+    res = closed_loop(run, so, frames=132, drop="pattern")
+    assert res["edges_identical"], res.get("first_mismatch")
+    assert res["frames"] == 132 and res["dropped"] >= 35 and res["keyframes"] >= 60
+    ate = metrics.ate_rmse(res["poses_oracle"], res["poses_gpu"])
+    _log("device_stream_pattern", "gain%g" % gain, {"ate": ate, "frames": res["frames"], "keyframes": res["keyframes"],
+                                                   "dropped": res["dropped"]}, {"ate": ATE_TOL})
+    assert ate <= ATE_TOL
+    rel = np.abs(res["patches_gpu"] - res["patches_oracle"]) / np.abs(res["patches_oracle"])
+    assert np.median(rel) <= 1e-4
+    # the inactive edges (removal-window pruning, slam.py:453-458) are the oracle's, in its order
+    a = run.E_inac
+    assert a == len(so.edges.ii_inac) and a > 0
+    assert np.array_equal(run.ii_inac[:a].cpu().numpy(), so.edges.ii_inac) and np.array_equal(run.kk_inac[:a].cpu().numpy(), so.edges.kk_inac)
+    assert np.array_equal(run.jj_inac[:a].cpu().numpy(), so.edges.jj_inac)
+    # the point cloud of the patches inside the removal window (slam.py:524-526)
+    n, M = res["keyframes"], so.M
+    lo = max(n - so.rw, 0) * M
+    got, want = run.points[lo:n * M].cpu().numpy(), so.points[lo:n * M]
+    assert np.abs(got - want).max() <= 1e-3 * max(1.0, np.abs(want).max())
+
+
+def test_device_stream_with_the_reference_keyframe_test():
+    """the decision never leaves the device (slam.py:409-413 reads it back twice per frame): flow statistic -> compare ->
+    conditional removal, index shift and buffer shift, all in the launches of cdv_stream_keyframe"""
+    run, so = _pair_dev(0.01, keyframe_thresh=2.5)
+    res = closed_loop(run, so, frames=126, drop="flow")
+    assert not res["decisions_differ"], res["decisions_differ"]
+    assert res["motion_maxdiff"] <= 1e-3
+    assert res["edges_identical"], res.get("first_mismatch")
+    assert 10 <= res["dropped"] <= 110
+    ate = metrics.ate_rmse(res["poses_oracle"], res["poses_gpu"])
+    _log("device_stream_flow", "gain0.01", {"ate": ate, "frames": res["frames"], "keyframes": res["keyframes"],
+                                            "dropped": res["dropped"], "motion_maxdiff": res["motion_maxdiff"]}, {"ate": ATE_TOL})
+    assert ate <= ATE_TOL
+
+
+def test_device_stream_equals_the_host_sized_stream_and_does_not_synchronise():
+    """DeviceStreamRunner against StreamRunner (one read-back per removal) on the benchmark frame size, same frames, same
+    forced drops: edge lists and keyframe count identical, poses equal to rounding (the tiles' blend and the operator stub are
+    other instantiations of the same arithmetic); and a frame of the device runner really enqueues without waiting: 40
+    frames are issued in less host time than the device needs to run them"""
+    import time
+    from cdv_slam_amd.stream import DeviceStreamRunner, StreamRunner
+    dev = torch.device(DEV)
+    a, b = DeviceStreamRunner(dev, buffer_size=128), StreamRunner(dev, buffer_size=128)
+    for f in range(70):
+        inp = (a.pool[f % 4], a._draws[f, 0], a._draws[f, 1], a._draws[f, 2])
+        a.frame(drop=(f % 3 == 2), inputs=inp)
+        b.frame(drop=(f % 3 == 2), inputs=inp)
+    n, E = a.counts()
+    assert (n, E) == b.counts() and E > 30000
+    ea, eb = a.edges, b.edges
+    assert torch.equal(ea.ii, eb.ii) and torch.equal(ea.jj, eb.jj) and torch.equal(ea.kk, eb.kk)
+    assert float((a.poses[:n] - b.poses[:n]).abs().max()) < 1e-5
+    assert float((a.patches[:n * a.M] - b.patches[:n * a.M]).abs().max()) < 1e-4
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for f in range(70, 110):
+        a.frame(drop=(f % 3 == 2))
+    t_enq = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    t_all = time.perf_counter() - t0
+    assert t_enq < t_all and a.counts()[0] > n
