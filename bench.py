@@ -378,7 +378,7 @@ def main():
             extra["stress"] = {"error": repr(ex)}
         try:
             from cdv_slam_amd.stream import DeviceStreamRunner
-            run = DeviceStreamRunner(dev, buffer_size=1024, keyframe_thresh=15.0)
+            run = DeviceStreamRunner(dev, buffer_size=1024, keyframe_thresh=12.5, pose_step=0.1)   # KEYFRAME_THRESH of config.py:20
             for _ in range(45):       # reach the steady state (E = 47,712 at the default window)
                 run.frame(drop=False)
             for f in range(30):       # ... and the reference's keyframe test deciding on the device

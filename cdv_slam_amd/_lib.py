@@ -89,6 +89,7 @@ SIGNATURES = {
     "cdv_stream_keyframe": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                    _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _f32, _i32, _vp, _i32, _vp, _vp, _vp]),
     "cdv_stream_motion": (_vp, [_vp, _i64, _i32]),
+    "cdv_stream_frame": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp]),
 }
 
 class FrameBuf(ctypes.Structure):
@@ -98,6 +99,26 @@ class FrameBuf(ctypes.Structure):
 
 
 MAX_FRAME_BUFS = 16
+
+
+def _stream_desc_fields():
+    P, I, L, F = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+    return ([(n, I) for n in ("M", "C", "H", "W", "mem", "pmem", "frames_capacity", "patch_lifetime", "removal_window",
+                              "opt_window", "keyframe_index", "n_bufs")]
+            + [(n, F) for n in ("keyframe_thresh", "gain", "pose_step")]
+            + [("slot", I), ("frames", I)]
+            + [(n, L) for n in ("edge_capacity", "inactive_capacity", "table_capacity", "graph_E_max", "graph_k_range")]
+            + [("graph_ws_bytes", ctypes.c_size_t), ("ba_ws_bytes", ctypes.c_size_t)]
+            + [(n, P) for n in ("poses", "patches", "intrinsics", "points", "ix", "fmap1_nhwc", "fmap2_nhwc", "gmap_planar", "gmap_pm")]
+            + [(n, P * 2) for n in ("ii", "jj", "kk", "target", "weight")]
+            + [(n, P) for n in ("ii_inac", "jj_inac", "kk_inac", "target_inac", "weight_inac", "coords", "corr_out", "lmbda", "dyn",
+                                "ws", "graph_ws", "ba_ws", "mirror_host")]
+            + [("bufs", FrameBuf * 16)])
+
+
+class StreamDesc(ctypes.Structure):
+    """cdv_stream_desc (include/cdvslam_hip.h): the buffers and sizes of a device-resident frame stream, field for field"""
+    _fields_ = _stream_desc_fields()
 
 
 class PatchifyJob(ctypes.Structure):

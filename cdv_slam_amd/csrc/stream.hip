@@ -586,3 +586,56 @@ extern "C" int cdv_stream_keyframe(const int32_t* dyn_in, int32_t* dyn_mid, int3
 extern "C" const float* cdv_stream_motion(void* ws, int64_t edge_capacity, int M) {
   return ws ? stream_ws(ws, edge_capacity, M).motion : nullptr;
 }
+
+extern "C" int cdv_frame_ingest(const void* fmap_chw, void* fmap1_nhwc, void* fmap2_nhwc, void* fmap1_nchw, void* fmap2_nchw, int slot,
+                                int C, int H, int W, const void* gmap_planar, void* gmap_pm, int64_t Ng, int64_t gmap_first,
+                                int64_t gmap_count, void* stream);
+
+extern "C" int cdv_stream_frame(cdv_stream_desc* D, const void* fmap_chw, const float* cx, const float* cy, const float* depth,
+                                int force, void* stream) {
+  CDV_REQUIRE(D != nullptr && fmap_chw && cx && cy && depth, CDV_ERR_ARG, "cdv_stream_frame: NULL argument");
+  CDV_REQUIRE(D->frames + 2 < D->frames_capacity, CDV_ERR_WORKSPACE, "cdv_stream_frame: frame buffer full");
+  CDV_REQUIRE(D->opt_window >= 1 && D->opt_window <= 10, CDV_ERR_UNSUPPORTED, "cdv_stream_frame: OPTIMIZATION_WINDOW 1 .. 10");
+  const int M = D->M;
+  auto blk = [&](int i) { return D->dyn + CDV_DYN_WORDS * (i & 7); };
+  const int a = D->slot, b = a + 1, m = a + 2, e = a + 3;
+  // an upper bound of the number of edges once this frame has arrived, without asking the device: what the last finished
+  // keyframe() left (pinned word: frames << 32 | edges) plus 2 r M per frame begun since
+  const int64_t seen = D->mirror_host ? *reinterpret_cast<volatile int64_t*>(D->mirror_host) : 0;
+  int64_t Eb = (seen & 0xFFFFFFFFll) + ((int64_t)D->frames + 1 - (seen >> 32)) * 2 * D->patch_lifetime * M;
+  if (Eb > D->edge_capacity) Eb = D->edge_capacity;
+  if (Eb < 1) Eb = 1;
+  int rc = cdv_stream_frame_begin(blk(a), blk(b), D->ii[0], D->jj[0], D->kk[0], D->target[0], D->weight[0], D->ix, D->edge_capacity, M,
+                                  D->patch_lifetime, D->opt_window, D->frames_capacity, cx, cy, depth, fmap_chw, D->gmap_planar,
+                                  D->poses, D->patches, D->C, D->H, D->W, D->pmem, D->pose_step, D->ws, stream);
+  if (rc != CDV_OK) return rc;
+  D->frames += 1;
+  if (D->frames < 8) {   // before initialisation only the rings are filled (n == frames: no keyframe test has run yet)
+    D->slot = b & 7;
+    return cdv_frame_ingest(fmap_chw, D->fmap1_nhwc, D->fmap2_nhwc, nullptr, nullptr, (D->frames - 1) % D->mem, D->C, D->H, D->W,
+                            D->gmap_planar, D->gmap_pm, (int64_t)D->pmem * M, (int64_t)((D->frames - 1) % D->pmem) * M, M, stream);
+  }
+  rc = cdv_update_prologue_table_dyn(fmap_chw, D->fmap1_nhwc, D->fmap2_nhwc, D->mem, D->pmem, D->C, D->H, D->W, D->gmap_planar,
+                                     D->gmap_pm, (int64_t)D->pmem * M, M, D->poses, D->patches, D->intrinsics, D->ii[0], D->jj[0],
+                                     D->kk[0], Eb, blk(b), D->coords, D->graph_ws, D->graph_ws_bytes, D->graph_E_max,
+                                     D->graph_k_range, D->table_capacity, stream);
+  if (rc != CDV_OK) return rc;
+  rc = cdv_corr_fused_stream_dyn(D->gmap_pm, D->fmap1_nhwc, D->fmap2_nhwc, cdv_graph_corr_records(D->graph_ws), D->corr_out, Eb,
+                                 blk(b), (int64_t)D->pmem * M, D->mem, D->C, D->H, D->W, D->H / 4, D->W / 4, 1.0f, 4.0f, 1, stream);
+  if (rc != CDV_OK) return rc;
+  rc = cdv_stream_operator_stub(blk(b), D->coords, D->corr_out, 882, D->target[0], D->weight[0], D->gain, Eb, stream);
+  if (rc != CDV_OK) return rc;
+  rc = cdv_ba_forward_dyn(D->poses, D->patches, D->intrinsics, D->target[0], D->weight[0], D->lmbda, D->ii[0], D->jj[0], D->kk[0], Eb,
+                          3, D->opt_window, blk(b), 2, D->graph_ws, D->ba_ws, D->ba_ws_bytes, D->table_capacity, stream);
+  if (rc != CDV_OK) return rc;
+  rc = cdv_stream_points(blk(b), D->poses, D->patches, D->intrinsics, D->ix, M, D->removal_window + 2, D->points, stream);
+  if (rc != CDV_OK) return rc;
+  rc = cdv_stream_keyframe(blk(b), blk(m), blk(e), D->poses, D->patches, D->intrinsics, D->ix, D->ii[0], D->jj[0], D->kk[0],
+                           D->target[0], D->weight[0], D->ii[1], D->jj[1], D->kk[1], D->target[1], D->weight[1], D->ii_inac,
+                           D->jj_inac, D->kk_inac, D->target_inac, D->weight_inac, D->inactive_capacity, D->edge_capacity, Eb, M,
+                           D->keyframe_index, D->removal_window, D->keyframe_thresh, force, D->bufs, D->n_bufs, D->mirror_host,
+                           D->ws, stream);
+  if (rc != CDV_OK) return rc;
+  D->slot = e & 7;
+  return CDV_OK;
+}

@@ -17,7 +17,8 @@ from .edges import EdgeStore, frames_keyframe_shift
 class StreamRunner:
     def __init__(self, device, M=96, ht=384, wd=512, C=24, mem=36, pmem=36, buffer_size=512, patch_lifetime=13,
                  removal_window=22, opt_window=10, keyframe_index=4, seed=1234, loop_closure=False, max_edge_age=1000,
-                 global_opt_freq=15, backend_thresh=64.0, pose_init=None, record_global=False, keyframe_thresh=12.5, gain=0.01):
+                 global_opt_freq=15, backend_thresh=64.0, pose_init=None, record_global=False, keyframe_thresh=12.5, gain=0.01,
+                 pose_step=0.05):
         """loop_closure: the LOOP_CLOSURE configuration of the reference (default_cdvslam.yaml): the patch ring holds
         MAX_EDGE_AGE frames (slam.py:66-68), proximity loop edges are added every GLOBAL_OPT_FREQ frames
         (slam.py:699-705, patchgraph.py:71-97), edges that close loops survive the removal window (slam.py:453-457) and an
@@ -37,6 +38,7 @@ class StreamRunner:
         self.r, self.rw, self.ow, self.ki = patch_lifetime, removal_window, opt_window, keyframe_index
         self.N = buffer_size
         self.kthresh, self.gain = keyframe_thresh, gain      # KEYFRAME_THRESH (config.py:20); the operator stub's step
+        self.pose_step = pose_step
         self.last_motion = None
         g = torch.Generator(device="cpu").manual_seed(seed)
         self.g = g
@@ -94,7 +96,7 @@ class StreamRunner:
             self.poses[n] = torch.as_tensor(self.pose_init(n), dtype=torch.float32, device=self.dev)
         elif n > 0:   # constant-position initialisation plus a small forward motion
             self.poses[n] = self.poses[n - 1]
-            self.poses[n, 0] += 0.05
+            self.poses[n, 0] += self.pose_step
         return fmap, t0
 
     def _update(self, fmap, tile0):
@@ -237,9 +239,10 @@ class DeviceStreamRunner:
     OPTIMIZATION_WINDOW <= 10 (the window solver), no loop closure (StreamRunner serves those)."""
 
     def __init__(self, device, M=96, ht=384, wd=512, C=24, mem=36, pmem=36, buffer_size=512, patch_lifetime=13,
-                 removal_window=22, opt_window=10, keyframe_index=4, seed=1234, keyframe_thresh=12.5, gain=0.01):
+                 removal_window=22, opt_window=10, keyframe_index=4, seed=1234, keyframe_thresh=12.5, gain=0.01, pose_step=0.05):
         import ctypes
         from . import _lib
+        self.pose_step = pose_step
         if opt_window > 10:
             raise NotImplementedError("DeviceStreamRunner: OPTIMIZATION_WINDOW <= 10 (cdv_ba_forward_dyn)")
         self.lib = lib = _lib.load()
@@ -322,79 +325,52 @@ class DeviceStreamRunner:
         seen_frame, seen_E = v >> 32, v & 0xFFFFFFFF
         return min(self.ecap, seen_E + (self.frames + 1 - seen_frame) * 2 * self.r * self.M)
 
-    def _pointers(self):
-        """every buffer address of a frame's launches, once (they never change): a frame then costs 17 ctypes calls and no
-        tensor indexing"""
-        import ctypes
-        V = ctypes.c_void_p
-        q = lambda t: V(t.data_ptr())
-        eb8, eb4 = self.ecap * 8, self.ecap * 2 * 4
-        self._c = dict(
-            ii=(V(self._ii.data_ptr()), V(self._ii.data_ptr() + eb8)), jj=(V(self._jj.data_ptr()), V(self._jj.data_ptr() + eb8)),
-            kk=(V(self._kk.data_ptr()), V(self._kk.data_ptr() + eb8)),
-            tg=(V(self._target.data_ptr()), V(self._target.data_ptr() + eb4)),
-            wt=(V(self._weight.data_ptr()), V(self._weight.data_ptr() + eb4)),
-            ix=q(self.ix), gmap=q(self.gmap), gmap_pm=q(self.gmap_pm), poses=q(self.poses), patches=q(self.patches),
-            intr=q(self.intrinsics), ws=q(self.ws), fmap1=q(self.fmap1), fmap2=q(self.fmap2), coords=q(self.coords_buf),
-            corr=q(self.corr_out), lmbda=q(self.lmbda), gws=q(self.graph.ws), ba_ws=q(self.ba_ws), points=q(self.points),
-            inac=(q(self.ii_inac), q(self.jj_inac), q(self.kk_inac), q(self.target_inac), q(self.weight_inac)),
-            bufs=ctypes.cast(self._bufs, V), mirror=V(self.mirror.data_ptr()),
-            dyn=[V(self.dyn.data_ptr() + 64 * i) for i in range(8)],
-            draws=[tuple(V(self._draws.data_ptr() + 4 * self.M * (3 * f + k)) for k in range(3)) for f in range(self.N)],
-            pool=[q(t) for t in self.pool])
+    def _descriptor(self):
+        """cdv_stream_desc: every buffer and size of the stream, once; a frame is then ONE ctypes call"""
+        from . import _lib
+        D = _lib.StreamDesc()
+        D.M, D.C, D.H, D.W, D.mem, D.pmem, D.frames_capacity = self.M, self.C, self.h, self.w, self.mem, self.pmem, self.N
+        D.patch_lifetime, D.removal_window, D.opt_window, D.keyframe_index = self.r, self.rw, self.ow, self.ki
+        D.keyframe_thresh, D.gain, D.pose_step = self.kthresh, self.gain, self.pose_step
+        D.slot, D.frames = self.slot, self.frames
+        g = self.graph
+        D.edge_capacity, D.inactive_capacity, D.table_capacity = self.ecap, self.icap, g.table_capacity
+        D.graph_E_max, D.graph_k_range, D.graph_ws_bytes, D.ba_ws_bytes = g.E_cap, g.k_range, g.ws_bytes, self.ba_ws.numel()
+        for name, t in (("poses", self.poses), ("patches", self.patches), ("intrinsics", self.intrinsics), ("points", self.points),
+                        ("ix", self.ix), ("fmap1_nhwc", self.fmap1), ("fmap2_nhwc", self.fmap2), ("gmap_planar", self.gmap),
+                        ("gmap_pm", self.gmap_pm), ("ii_inac", self.ii_inac), ("jj_inac", self.jj_inac), ("kk_inac", self.kk_inac),
+                        ("target_inac", self.target_inac), ("weight_inac", self.weight_inac), ("coords", self.coords_buf),
+                        ("corr_out", self.corr_out), ("lmbda", self.lmbda), ("dyn", self.dyn), ("ws", self.ws), ("graph_ws", g.ws),
+                        ("ba_ws", self.ba_ws)):
+            setattr(D, name, t.data_ptr())
+        D.mirror_host = self.mirror.data_ptr()
+        for name, t in (("ii", self._ii), ("jj", self._jj), ("kk", self._kk), ("target", self._target), ("weight", self._weight)):
+            arr = getattr(D, name)
+            arr[0], arr[1] = t[0].data_ptr(), t[1].data_ptr()
+        D.n_bufs = self._nbufs
+        for i in range(self._nbufs):
+            D.bufs[i] = self._bufs[i]
+        self._desc = D
+        self._desc_ref = self._cast(ops.ctypes.pointer(D), ops.ctypes.c_void_p)
+        V = ops.ctypes.c_void_p
+        self._draw_ptrs = [tuple(V(self._draws.data_ptr() + 4 * self.M * (3 * f + k)) for k in range(3)) for f in range(self.N)]
+        self._pool_ptrs = [V(t.data_ptr()) for t in self.pool]
 
     def frame(self, drop=False, inputs=None):
-        """one incoming frame, enqueued; nothing is read back.  drop: None = the reference's keyframe test on the device,
-        True / False = the caller decides; inputs: (fmap [C,h,w] f16, cx, cy, d [M]) on the device, default: the stub's own"""
-        if self.frames + 2 >= self.N:
-            raise RuntimeError("DeviceStreamRunner: frame buffer full")
-        if not hasattr(self, "_c"):
-            self._pointers()
-        lib, c, s, check = self.lib, self._c, ops._stream(), ops._lib.check
-        M, f = self.M, self.frames
+        """one incoming frame, enqueued (cdv_stream_frame: 17 launches behind ONE call); nothing is read back.  drop: None =
+        the reference's keyframe test on the device, True / False = the caller decides; inputs: (fmap [C,h,w] f16, cx, cy,
+        d [M]) on the device, default: the stub's own"""
+        if not hasattr(self, "_desc"):
+            self._descriptor()
+        f = self.frames
         if inputs is None:
-            fmap_t = self.pool[f % len(self.pool)]
-            fmap = c["pool"][f % len(self.pool)]
-            cx, cy, d = c["draws"][f]
+            fmap = self._pool_ptrs[f % len(self._pool_ptrs)]
+            cx, cy, d = self._draw_ptrs[f]
         else:
-            fmap_t, cx, cy, d = inputs
-            fmap_t, cx, cy, d = fmap_t.contiguous(), cx.contiguous(), cy.contiguous(), d.contiguous()
-            self._hold = (fmap_t, cx, cy, d)           # alive until the launches that read them are enqueued again
+            self._hold = tuple(t.contiguous() for t in inputs)           # alive until the launches that read them are enqueued
             fmap, cx, cy, d = (self._p(t) for t in self._hold)
-        dyn = c["dyn"]
-        a, b, m, e = self.slot, (self.slot + 1) & 7, (self.slot + 2) & 7, (self.slot + 3) & 7
-        Eb = self._edge_bound()
-        ii, jj, kk, tg, wt = c["ii"], c["jj"], c["kk"], c["tg"], c["wt"]
-        check(lib.cdv_stream_frame_begin(dyn[a], dyn[b], ii[0], jj[0], kk[0], tg[0], wt[0], c["ix"], self.ecap, M, self.r, self.ow,
-                                         self.N, cx, cy, d, fmap, c["gmap"], c["poses"], c["patches"], self.C, self.h, self.w,
-                                         self.pmem, 0.05, c["ws"], s), "cdv_stream_frame_begin")
-        self.frames += 1
-        if self.frames < 8:      # before initialisation only the rings are filled (n == frames: no keyframe has been tested yet)
-            ops.fmap_ingest(fmap_t, self.fmap1, self.fmap2, (self.frames - 1) % self.mem, gmap=self.gmap, gmap_pm=self.gmap_pm,
-                            gmap_first=((self.frames - 1) % self.pmem) * M, gmap_count=M)
-            self.slot = b
-            return
-        g = self.graph
-        check(lib.cdv_update_prologue_table_dyn(fmap, c["fmap1"], c["fmap2"], self.mem, self.pmem, self.C, self.h, self.w, c["gmap"],
-                                                c["gmap_pm"], self.pmem * M, M, c["poses"], c["patches"], c["intr"], ii[0], jj[0],
-                                                kk[0], Eb, dyn[b], c["coords"], c["gws"], g.ws_bytes, g.E_cap, g.k_range,
-                                                g.table_capacity, s), "cdv_update_prologue_table_dyn")
-        g.is_table, g._key, g._nbr = True, None, None
-        if not hasattr(self, "_rec"):
-            self._rec = g.corr_records_ptr()
-        check(lib.cdv_corr_fused_stream_dyn(c["gmap_pm"], c["fmap1"], c["fmap2"], self._rec, c["corr"], Eb, dyn[b], self.pmem * M,
-                                            self.mem, self.C, self.h, self.w, self.h // 4, self.w // 4, 1.0, 4.0, 1, s),
-              "cdv_corr_fused_stream_dyn")
-        check(lib.cdv_stream_operator_stub(dyn[b], c["coords"], c["corr"], 882, tg[0], wt[0], self.gain, Eb, s),
-              "cdv_stream_operator_stub")
-        check(lib.cdv_ba_forward_dyn(c["poses"], c["patches"], c["intr"], tg[0], wt[0], c["lmbda"], ii[0], jj[0], kk[0], Eb, 3,
-                                     self.ow, dyn[b], 2, c["gws"], c["ba_ws"], self.ba_ws.numel(), self.tcap, s), "cdv_ba_forward_dyn")
-        check(lib.cdv_stream_points(dyn[b], c["poses"], c["patches"], c["intr"], c["ix"], M, self.rw + 2, c["points"], s),
-              "cdv_stream_points")
         force = -1 if drop is None else (1 if drop else 0)
-        ia = c["inac"]
-        check(lib.cdv_stream_keyframe(dyn[b], dyn[m], dyn[e], c["poses"], c["patches"], c["intr"], c["ix"], ii[0], jj[0], kk[0], tg[0],
-                                      wt[0], ii[1], jj[1], kk[1], tg[1], wt[1], ia[0], ia[1], ia[2], ia[3], ia[4], self.icap, self.ecap,
-                                      Eb, M, self.ki, self.rw, self.kthresh, force, c["bufs"], self._nbufs, c["mirror"], c["ws"], s),
-              "cdv_stream_keyframe")
-        self.slot = e
+        ops._lib.check(self.lib.cdv_stream_frame(self._desc_ref, fmap, cx, cy, d, force, ops._stream()), "cdv_stream_frame")
+        self.frames, self.slot = self._desc.frames, self._desc.slot
+        g = self.graph
+        g.is_table, g._key, g._nbr = True, None, None

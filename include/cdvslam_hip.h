@@ -586,6 +586,38 @@ int cdv_stream_keyframe(const int32_t* dyn_in, int32_t* dyn_mid, int32_t* dyn_ou
 /* device pointer to {flow statistic, decision} of the last cdv_stream_keyframe on the workspace (tests). */
 const float* cdv_stream_motion(void* ws, int64_t edge_capacity, int M);
 
+/*
+ * One frame of the stream as ONE call: everything SLAM.__call__ does for an initialised system around the (stubbed) networks
+ * -- cdv_stream_frame_begin, cdv_update_prologue_table_dyn, cdv_corr_fused_stream_dyn, cdv_stream_operator_stub,
+ * cdv_ba_forward_dyn (2 iterations), cdv_stream_points, cdv_stream_keyframe; for the first 7 frames only the state write
+ * and the ring ingest, as slam.py:711 waits for 8 frames -- enqueued on `stream`, 17 launches, no synchronisation.  The
+ * descriptor names the buffers once; `slot` and `frames` are host state the call advances; the launches are sized from
+ * the pinned word `mirror_host` (cdv_stream_keyframe).  force: -1 the reference's keyframe test, 0 / 1 the caller's decision.
+ */
+typedef struct {
+  int32_t M, C, H, W, mem, pmem, frames_capacity, patch_lifetime, removal_window, opt_window, keyframe_index, n_bufs;
+  float keyframe_thresh, gain, pose_step;
+  int32_t slot, frames;              /* host state: current dynamic block, frames begun */
+  int64_t edge_capacity, inactive_capacity, table_capacity, graph_E_max, graph_k_range;
+  size_t graph_ws_bytes, ba_ws_bytes;
+  float *poses, *patches, *intrinsics, *points;
+  const int64_t* ix;
+  void *fmap1_nhwc, *fmap2_nhwc, *gmap_planar, *gmap_pm;
+  int64_t *ii[2], *jj[2], *kk[2];    /* [0]: the edge lists, [1]: their twin */
+  float *target[2], *weight[2];
+  int64_t *ii_inac, *jj_inac, *kk_inac;
+  float *target_inac, *weight_inac;
+  float* coords;                     /* [edge_capacity][2][3][3] */
+  void* corr_out;                    /* [edge_capacity][882] f16 */
+  const float* lmbda;
+  int32_t* dyn;                      /* ring of 8 dynamic blocks (8 x CDV_DYN_WORDS int32, zero-initialised) */
+  void *ws, *graph_ws, *ba_ws;
+  int64_t* mirror_host;              /* pinned, zero-initialised */
+  cdv_frame_buf bufs[CDV_MAX_FRAME_BUFS];
+} cdv_stream_desc;
+int cdv_stream_frame(cdv_stream_desc* desc, const void* fmap_chw, const float* cx, const float* cy, const float* depth, int force,
+                     void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * lietorch forward ops  (replaces lietorch_backends.{expm,logm,inv,mul,adj,adjT,act,act4,as_matrix})
  * group ids as the reference: SO3 = 1, SE3 = 3 (lietorch.cpp:286-316, groups.py:236-290).

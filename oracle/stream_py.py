@@ -46,7 +46,8 @@ def flow_mag(poses, patches, intrinsics, ii, jj, kk, beta, dtype=np.float32):
 
 class StreamOracle:
     def __init__(self, M=96, ht=384, wd=512, C=24, mem=36, pmem=36, buffer_size=512, patch_lifetime=13, removal_window=22,
-                 opt_window=10, keyframe_index=4, keyframe_thresh=12.5, corr_mode="ref", dtype=np.float32, gain=0.01):
+                 opt_window=10, keyframe_index=4, keyframe_thresh=12.5, corr_mode="ref", dtype=np.float32, gain=0.01, pose_step=0.05):
+        self.pose_step = pose_step
         self.M, self.C, self.mem, self.pmem, self.N = M, C, mem, pmem, buffer_size
         self.h, self.w = ht // 4, wd // 4
         self.r, self.rw, self.ow, self.ki, self.kthresh = patch_lifetime, removal_window, opt_window, keyframe_index, keyframe_thresh
@@ -78,7 +79,7 @@ class StreamOracle:
         self.gmap[t0:t0 + M] = tiles
         if n > 0:
             self.poses[n] = self.poses[n - 1]
-            self.poses[n, 0] += np.float32(0.05)
+            self.poses[n, 0] += np.float32(self.pose_step)
 
     def _update(self, fmap):
         M, n, e = self.M, self.n, self.edges

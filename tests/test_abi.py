@@ -114,3 +114,20 @@ def test_ba_workspace_accounts_for_the_pair_index():
     # ~250 bytes per edge of index workspace + 8 of keys, and at most (N + 1)(N + 2) / 2 pair slots of 384 bytes
     per_edge = (big[2] - big[1]) / 900000.0
     assert 100.0 < per_edge < 600.0
+
+
+def test_stream_descriptor_layout_matches_the_header(tmp_path):
+    """cdv_stream_desc is handed over by address: the ctypes mirror must have the C compiler's layout"""
+    import ctypes
+    import subprocess
+    from cdv_slam_amd import _lib
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "%s"\nint main(void){printf("%%zu %%zu %%zu %%zu %%zu %%zu\\n", '
+                   'sizeof(cdv_stream_desc), offsetof(cdv_stream_desc, slot), offsetof(cdv_stream_desc, edge_capacity), '
+                   'offsetof(cdv_stream_desc, ii), offsetof(cdv_stream_desc, mirror_host), offsetof(cdv_stream_desc, bufs));return 0;}\n'
+                   % os.path.join(ROOT, "include", "cdvslam_hip.h"))
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-o", str(exe), str(src)])
+    got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    D = _lib.StreamDesc
+    assert got == [ctypes.sizeof(D), D.slot.offset, D.edge_capacity.offset, D.ii.offset, D.mirror_host.offset, D.bufs.offset]
