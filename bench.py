@@ -397,7 +397,7 @@ def main():
                                    "host_enqueue_ms_per_frame": 1e3 * t_enq / nf, "edges": int(E_s), "keyframes": int(n_kf),
                                    "keyframes_dropped_in_the_timed_frames": int(nf - (n_kf - n_a)),
                                    "what": "SURVEY 8(d)(iii): synthetic 512x384 stream end to end with every size on the device "
-                                           "(cdv_slam_amd.stream.DeviceStreamRunner), 17 launches per frame and no read-back: state "
+                                           "(cdv_slam_amd.stream.DeviceStreamRunner), 12 launches per frame and no read-back: state "
                                            "write + patch tiles + edge append, ring ingest + index + reprojection, two-level "
                                            "correlation, operator stub, BA(2), point cloud of the removal window (slam.py:524-526), "
                                            "keyframe test from flow_mag decided ON THE DEVICE (slam.py:399-413) with the removal, index "

@@ -87,7 +87,7 @@ SIGNATURES = {
     "cdv_stream_operator_stub": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _f32, _i64, _vp]),
     "cdv_stream_points": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
     "cdv_stream_keyframe": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                                   _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _f32, _i32, _vp, _i32, _vp, _vp, _vp]),
+                                   _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _f32, _i32, _vp, _i32, _vp, _vp, _vp, _vp]),
     "cdv_stream_motion": (_vp, [_vp, _i64, _i32]),
     "cdv_stream_frame": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _vp]),
 }
@@ -106,7 +106,7 @@ def _stream_desc_fields():
     return ([(n, I) for n in ("M", "C", "H", "W", "mem", "pmem", "frames_capacity", "patch_lifetime", "removal_window",
                               "opt_window", "keyframe_index", "n_bufs")]
             + [(n, F) for n in ("keyframe_thresh", "gain", "pose_step")]
-            + [("slot", I), ("frames", I)]
+            + [("slot", I), ("frames", I), ("cur", I)]
             + [(n, L) for n in ("edge_capacity", "inactive_capacity", "table_capacity", "graph_E_max", "graph_k_range")]
             + [("graph_ws_bytes", ctypes.c_size_t), ("ba_ws_bytes", ctypes.c_size_t)]
             + [(n, P) for n in ("poses", "patches", "intrinsics", "points", "ix", "fmap1_nhwc", "fmap2_nhwc", "gmap_planar", "gmap_pm")]

@@ -149,93 +149,126 @@ __global__ __launch_bounds__(256) void stream_operator_stub_kernel(const int32_t
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// 3. the world points of the patches the update touched (slam.py:524-526 computes ALL m patches every frame; only those of
-//    the frames inside the removal window can have moved): points_[m] = (P^-1 iproj(centre))[:3] / [3]
+// 3. after the bundle adjustment, one launch, two independent jobs:
+//    (a) the world points of the patches the update touched (slam.py:524-526 computes ALL m patches every frame; only those
+//        of the frames inside the removal window can have moved): points_[m] = (P^-1 iproj(centre))[:3] / [3];
+//    (b) the keyframe test's statistic (slam.py:399-413): mean flow_mag (projective_ops.py:120-130, beta = 0.5) over the
+//        edges i -> j and j -> i with i = n - KI - 1, j = n - KI + 1.  A workgroup scans its share of the edge list, collects
+//        the (few) matching edges in LDS and works them off lane-dense; every matching edge puts the sum over its nine
+//        pixels into the slot of ITS patch (kk - M ii: one edge per patch and direction in a patch graph), so the total is
+//        summed later in a fixed order -- the decision does not depend on which workgroup got where first.
 // ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void stream_points_kernel(const int32_t* __restrict__ dyn, const float* __restrict__ poses,
-                                                            const float* __restrict__ patches, const float* __restrict__ intr,
-                                                            const int64_t* __restrict__ ix, int M, int window_frames,
-                                                            float* __restrict__ points) {
-  const int n = dyn[CDV_DYN_N];
-  const int64_t m0 = (int64_t)imax(n - window_frames, 0) * M, m1 = (int64_t)n * M;
-  for (int64_t m = m0 + (int64_t)blockIdx.x * 256 + threadIdx.x; m < m1; m += (int64_t)gridDim.x * 256) {
-    const int64_t f = ix[m];
-    float Pi[7], Pinv[7], t[3], q[4];
+struct AfterArgs {
+  const int32_t* dyn;
+  const float *poses, *patches, *intr;
+  const int64_t* ix;
+  const int64_t *ii, *jj, *kk;
+  int M, window_frames, ki;
+  float beta;
+  float* points;
+  float* flow_buf;
+  int n_motion_blocks, n_point_blocks;
+};
+
+__device__ __forceinline__ void motion_edge(const AfterArgs& A, int e, int dir) {
+  const float* __restrict__ poses = A.poses;
+  const float* __restrict__ intr = A.intr;
+  const int64_t ix = A.ii[e], jx = A.jj[e], kx = A.kk[e];
+  float Pi[7], Pj[7], Pinv[7], G[3][7];
 #pragma unroll
-    for (int a = 0; a < 7; a++) Pi[a] = poses[7 * f + a];
-    cdv::lt_se3_inv(Pi, Pinv);
-    cdv::lt_se3_load(Pinv, t, q);
-    const float* pk = patches + m * 27;
-    float X0[4], X1[4];
-    X0[0] = (pk[4] - intr[4 * f + 2]) / intr[4 * f + 0];
-    X0[1] = (pk[13] - intr[4 * f + 3]) / intr[4 * f + 1];
+  for (int a = 0; a < 7; a++) { Pi[a] = poses[7 * ix + a]; Pj[a] = poses[7 * jx + a]; }
+  cdv::lt_se3_inv(Pi, Pinv);
+  cdv::lt_se3_mul(Pi, Pinv, G[0]);
+  cdv::lt_se3_mul(Pj, Pinv, G[1]);
+#pragma unroll
+  for (int a = 0; a < 3; a++) G[2][a] = G[1][a];
+  G[2][3] = 0.f; G[2][4] = 0.f; G[2][5] = 0.f; G[2][6] = 1.f;   // tonly (projective_ops.py:62)
+  float t[3][3], q[3][4];
+#pragma unroll
+  for (int v = 0; v < 3; v++) cdv::lt_se3_load(G[v], t[v], q[v]);
+  const float fxi = intr[4 * ix + 0], fyi = intr[4 * ix + 1], cxi = intr[4 * ix + 2], cyi = intr[4 * ix + 3];
+  const float fxj = intr[4 * jx + 0], fyj = intr[4 * jx + 1], cxj = intr[4 * jx + 2], cyj = intr[4 * jx + 3];
+  const float* pk = A.patches + kx * 27;
+  float tot = 0.f;
+#pragma unroll
+  for (int a = 0; a < 9; a++) {
+    float X0[4], X1[4], xy[3][2];
+    X0[0] = (pk[a] - cxi) / fxi;
+    X0[1] = (pk[9 + a] - cyi) / fyi;
     X0[2] = 1.f;
-    X0[3] = pk[22];
-    cdv::lt_act4_loaded(t, q, X0, X1);
-    points[3 * m] = X1[0] / X1[3];
-    points[3 * m + 1] = X1[1] / X1[3];
-    points[3 * m + 2] = X1[2] / X1[3];
+    X0[3] = pk[18 + a];
+#pragma unroll
+    for (int v = 0; v < 3; v++) {
+      cdv::lt_act4_loaded(t[v], q[v], X0, X1);
+      const float d = 1.0f / fmaxf(X1[2], 0.1f);
+      const float fx = v == 0 ? fxi : fxj, fy = v == 0 ? fyi : fyj, cx = v == 0 ? cxi : cxj, cy = v == 0 ? cyi : cyj;
+      xy[v][0] = fx * (d * X1[0]) + cx;
+      xy[v][1] = fy * (d * X1[1]) + cy;
+    }
+    const float ax = xy[1][0] - xy[0][0], ay = xy[1][1] - xy[0][1];
+    const float bx = xy[2][0] - xy[0][0], by = xy[2][1] - xy[0][1];
+    tot += A.beta * sqrtf(ax * ax + ay * ay) + (1.0f - A.beta) * sqrtf(bx * bx + by * by);
+  }
+  const int slot = (int)(kx - (int64_t)A.M * ix);
+  if (slot >= 0 && slot < A.M) {
+    A.flow_buf[dir * A.M + slot] = tot;          // one edge per (direction, patch): a plain store
+    A.flow_buf[(2 + dir) * A.M + slot] = 9.0f;   // pixels counted
   }
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// 4. the keyframe test's statistic (slam.py:399-413): mean flow_mag (projective_ops.py:120-130, beta = 0.5) over the edges
-//    i -> j and j -> i with i = n - KI - 1, j = n - KI + 1.  Every matching edge puts the sum over its nine pixels into the
-//    slot of ITS patch (kk - M ii: one edge per patch and direction in a patch graph), so the total is summed later in a
-//    fixed order -- the decision does not depend on which workgroup got where first.
-// ------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void stream_motion_kernel(const int32_t* __restrict__ dyn, const float* __restrict__ poses,
-                                                            const float* __restrict__ patches, const float* __restrict__ intr,
-                                                            const int64_t* __restrict__ ii, const int64_t* __restrict__ jj,
-                                                            const int64_t* __restrict__ kk, int M, int ki, float beta,
-                                                            float* __restrict__ flow_buf) {
-  const int n = dyn[CDV_DYN_N], E = dyn[CDV_DYN_E];
-  const int64_t fi = n - ki - 1, fj = n - ki + 1;
-  for (int e = (int)blockIdx.x * 256 + threadIdx.x; e < E; e += (int)gridDim.x * 256) {
-    const int64_t ix = ii[e], jx = jj[e];
-    const int dir = (ix == fi && jx == fj) ? 0 : ((ix == fj && jx == fi) ? 1 : -1);
-    if (dir < 0) continue;
-    const int64_t kx = kk[e];
-    float Pi[7], Pj[7], Pinv[7], G[3][7];
+__global__ __launch_bounds__(256) void stream_after_kernel(const AfterArgs A) {
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const int n = A.dyn[CDV_DYN_N];
+  if (b >= A.n_motion_blocks) {
+    // ---- (a) point cloud of the removal window ----
+    const int M = A.M;
+    const int64_t m0 = (int64_t)imax(n - A.window_frames, 0) * M, m1 = (int64_t)n * M;
+    for (int64_t m = m0 + (int64_t)(b - A.n_motion_blocks) * 256 + tid; m < m1; m += (int64_t)A.n_point_blocks * 256) {
+      const int64_t f = A.ix[m];
+      float Pi[7], Pinv[7], t[3], q[4];
 #pragma unroll
-    for (int a = 0; a < 7; a++) { Pi[a] = poses[7 * ix + a]; Pj[a] = poses[7 * jx + a]; }
-    cdv::lt_se3_inv(Pi, Pinv);
-    cdv::lt_se3_mul(Pi, Pinv, G[0]);
-    cdv::lt_se3_mul(Pj, Pinv, G[1]);
-#pragma unroll
-    for (int a = 0; a < 3; a++) G[2][a] = G[1][a];
-    G[2][3] = 0.f; G[2][4] = 0.f; G[2][5] = 0.f; G[2][6] = 1.f;   // tonly (projective_ops.py:62)
-    float t[3][3], q[3][4];
-#pragma unroll
-    for (int v = 0; v < 3; v++) cdv::lt_se3_load(G[v], t[v], q[v]);
-    const float fxi = intr[4 * ix + 0], fyi = intr[4 * ix + 1], cxi = intr[4 * ix + 2], cyi = intr[4 * ix + 3];
-    const float fxj = intr[4 * jx + 0], fyj = intr[4 * jx + 1], cxj = intr[4 * jx + 2], cyj = intr[4 * jx + 3];
-    const float* pk = patches + kx * 27;
-    float tot = 0.f;
-#pragma unroll
-    for (int a = 0; a < 9; a++) {
-      float X0[4], X1[4], xy[3][2];
-      X0[0] = (pk[a] - cxi) / fxi;
-      X0[1] = (pk[9 + a] - cyi) / fyi;
+      for (int a = 0; a < 7; a++) Pi[a] = A.poses[7 * f + a];
+      cdv::lt_se3_inv(Pi, Pinv);
+      cdv::lt_se3_load(Pinv, t, q);
+      const float* pk = A.patches + m * 27;
+      float X0[4], X1[4];
+      X0[0] = (pk[4] - A.intr[4 * f + 2]) / A.intr[4 * f + 0];
+      X0[1] = (pk[13] - A.intr[4 * f + 3]) / A.intr[4 * f + 1];
       X0[2] = 1.f;
-      X0[3] = pk[18 + a];
+      X0[3] = pk[22];
+      cdv::lt_act4_loaded(t, q, X0, X1);
+      A.points[3 * m] = X1[0] / X1[3];
+      A.points[3 * m + 1] = X1[1] / X1[3];
+      A.points[3 * m + 2] = X1[2] / X1[3];
+    }
+    return;
+  }
+  // ---- (b) the flow statistic: scan, collect, then work the matches off with dense lanes ----
+  __shared__ int s_n;
+  __shared__ int s_list[1024];   // (edge << 1 | direction) of this workgroup's matches
+  if (tid == 0) s_n = 0;
+  __syncthreads();
+  const int E = A.dyn[CDV_DYN_E];
+  const int64_t fi = n - A.ki - 1, fj = n - A.ki + 1;
+  for (int e0 = b * 1024; e0 < E; e0 += A.n_motion_blocks * 1024) {   // workgroup-uniform trips
 #pragma unroll
-      for (int v = 0; v < 3; v++) {
-        cdv::lt_act4_loaded(t[v], q[v], X0, X1);
-        const float d = 1.0f / fmaxf(X1[2], 0.1f);
-        const float fx = v == 0 ? fxi : fxj, fy = v == 0 ? fyi : fyj, cx = v == 0 ? cxi : cxj, cy = v == 0 ? cyi : cyj;
-        xy[v][0] = fx * (d * X1[0]) + cx;
-        xy[v][1] = fy * (d * X1[1]) + cy;
+    for (int u = 0; u < 4; u++) {
+      const int e = e0 + u * 256 + tid;
+      if (e < E) {
+        const int64_t ix = A.ii[e], jx = A.jj[e];
+        const int dir = (ix == fi && jx == fj) ? 0 : ((ix == fj && jx == fi) ? 1 : -1);
+        if (dir >= 0) {
+          const int at = atomicAdd(&s_n, 1);
+          if (at < 1024) s_list[at] = (e << 1) | dir;
+        }
       }
-      const float ax = xy[1][0] - xy[0][0], ay = xy[1][1] - xy[0][1];
-      const float bx = xy[2][0] - xy[0][0], by = xy[2][1] - xy[0][1];
-      tot += beta * sqrtf(ax * ax + ay * ay) + (1.0f - beta) * sqrtf(bx * bx + by * by);
     }
-    const int slot = (int)(kx - (int64_t)M * ix);
-    if (slot >= 0 && slot < M) {
-      flow_buf[dir * M + slot] = tot;          // one edge per (direction, patch): a plain store
-      flow_buf[(2 + dir) * M + slot] = 9.0f;   // pixels counted
-    }
+    __syncthreads();
+    const int cnt = min(s_n, 1024);
+    for (int i = tid; i < cnt; i += 256) motion_edge(A, s_list[i] >> 1, s_list[i] & 1);
+    __syncthreads();
+    if (tid == 0) s_n = 0;
+    __syncthreads();
   }
 }
 
@@ -259,12 +292,16 @@ __device__ __forceinline__ int keyframe_decision(const float* __restrict__ flow_
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// 5. removals as stable compactions with the predicate inside (slam.py:339-354 with the masks of :423, :453)
+// 4. keyframe()'s two removals (slam.py:415-427 and :453-458) as ONE stable compaction.  The reference removes the edges of
+//    the dropped frame k (not stored), shifts the indices above k, then removes -- and stores as inactive edges -- those
+//    whose source frame left the removal window, judged on the SHIFTED indices with n already decremented.  Per edge that is
+//       gone   = drop and (ii == k or jj == k)
+//       (i', j', k') = drop ? shifted : as they are;     pruned = not gone and ix[k'] < (n - drop) - REMOVAL_WINDOW
+//    kept edges go to the twin buffer, pruned ones to the inactive lists, both in list order: two ranks from one pass.
 // ------------------------------------------------------------------------------------------------------------------
 struct RemoveArgs {
   const int32_t* dyn_in;
   int32_t* dyn_out;
-  int pass;                       // 0: frame k = n - KI leaves if the keyframe test says so (slam.py:415-427), 1: removal window (:453-458)
   int M, ki, removal_window;
   float thresh;
   int force;
@@ -275,51 +312,59 @@ struct RemoveArgs {
   const float *target, *weight;
   int64_t *ii_o, *jj_o, *kk_o;    // kept edges, compacted (the twin buffers)
   float *target_o, *weight_o;
-  int64_t *ii_r, *jj_r, *kk_r;    // pass 1: removed edges are stored as inactive edges at dyn[EINAC]
+  int64_t *ii_r, *jj_r, *kk_r;    // pruned edges, appended at dyn[EINAC]
   float *target_r, *weight_r;
   int64_t inac_cap;
-  int32_t *counts, *meta;         // per-workgroup keep counts -> exclusive offsets; meta[0] kept, [1] removed, [2] arrival
-  int64_t* mirror;                // pinned host word: (frames << 32 | edges) after pass 1 (no synchronisation needed to size launches)
+  int32_t *counts, *meta;         // [2 nb] per-workgroup (kept, pruned) counts -> exclusive offsets; meta[2]: arrival counter
+  int nb;
+  int64_t* mirror;                // pinned host word: (frames << 32 | edges) afterwards (sizes the next launches without a sync)
+  int n_compact_blocks;           // compact launch: workgroups beyond these shift the frame buffers
 };
 
-__device__ __forceinline__ bool remove_pred(const RemoveArgs& A, int drop, int n_after, int64_t i, int64_t j, int64_t k,
-                                            int kf) {
-  if (A.pass == 0) return drop && (i == kf || j == kf);
-  return A.ix[k] < n_after - A.removal_window;
+// 0: kept, 1: pruned (stored), 2: gone; i, j, k come back shifted
+__device__ __forceinline__ int edge_fate(const RemoveArgs& A, int drop, int n_after, int kf, int64_t& i, int64_t& j, int64_t& k) {
+  if (drop) {
+    if (i == kf || j == kf) return 2;
+    if (i > kf) { k -= A.M; i -= 1; }
+    if (j > kf) j -= 1;
+  }
+  return (A.ix[k] < n_after - A.removal_window) ? 1 : 0;
 }
 
 __global__ __launch_bounds__(256) void stream_count_kernel(const RemoveArgs A) {
-  __shared__ int s_w[4];
+  __shared__ int s_w[2][4];
   __shared__ int s_last, s_drop;
   const int t = threadIdx.x, b = blockIdx.x;
   const int n = A.dyn_in[CDV_DYN_N], E = A.dyn_in[CDV_DYN_E];
   const int kf = n - A.ki;
-  if (A.pass == 0) {
-    if (t < 64) {
-      float motion;
-      const int d = keyframe_decision(A.flow_buf, A.M, n, A.ki, A.thresh, A.force, t, &motion);
-      if (t == 0) {
-        s_drop = d;
-        if (b == 0 && A.motion_out) { A.motion_out[0] = motion; A.motion_out[1] = (float)d; }
-      }
+  if (t < 64) {
+    float motion;
+    const int d = keyframe_decision(A.flow_buf, A.M, n, A.ki, A.thresh, A.force, t, &motion);
+    if (t == 0) {
+      s_drop = d;
+      if (b == 0 && A.motion_out) { A.motion_out[0] = motion; A.motion_out[1] = (float)d; }
     }
-    __syncthreads();
   }
-  const int drop = A.pass == 0 ? s_drop : 0;
+  __syncthreads();
+  const int drop = s_drop;
   const int64_t base = (int64_t)b * 1024;
-  int c = 0;
+  int c0 = 0, c1 = 0;
 #pragma unroll
   for (int u = 0; u < 4; u++) {
     const int64_t e = base + u * 256 + t;
-    if (e < E) c += remove_pred(A, drop, n, A.ii[e], A.jj[e], A.kk[e], kf) ? 0 : 1;
+    if (e < E) {
+      int64_t i = A.ii[e], j = A.jj[e], k = A.kk[e];
+      const int fate = edge_fate(A, drop, n - drop, kf, i, j, k);
+      c0 += fate == 0; c1 += fate == 1;
+    }
   }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-  if ((t & 63) == 0) s_w[t >> 6] = c;
+  for (int o = 32; o > 0; o >>= 1) { c0 += __shfl_xor(c0, o); c1 += __shfl_xor(c1, o); }
+  if ((t & 63) == 0) { s_w[0][t >> 6] = c0; s_w[1][t >> 6] = c1; }
   __syncthreads();
   if (t == 0) {
-    const int tot = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-    __hip_atomic_store(&A.counts[b], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&A.counts[2 * b], s_w[0][0] + s_w[0][1] + s_w[0][2] + s_w[0][3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&A.counts[2 * b + 1], s_w[1][0] + s_w[1][1] + s_w[1][2] + s_w[1][3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int prev = __hip_atomic_fetch_add(&A.meta[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last = prev == (int)gridDim.x - 1;
@@ -327,90 +372,35 @@ __global__ __launch_bounds__(256) void stream_count_kernel(const RemoveArgs A) {
   }
   __syncthreads();
   if (!s_last) return;
-  if (t < 64) {   // the last workgroup to arrive: exclusive scan of the keep counts, the sizes after this removal
+  if (t < 64) {   // the last workgroup to arrive: exclusive scans of both counts, the sizes after keyframe()
     const int nb = (int)gridDim.x;
-    int run = 0;
-    for (int c0 = 0; c0 < nb; c0 += 64) {
-      const int i = c0 + t;
-      const int v = (i < nb) ? __hip_atomic_load(&A.counts[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-      int inc = v;
+    int run0 = 0, run1 = 0;
+    for (int q0 = 0; q0 < nb; q0 += 64) {
+      const int i = q0 + t;
+      const int v0 = (i < nb) ? __hip_atomic_load(&A.counts[2 * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+      const int v1 = (i < nb) ? __hip_atomic_load(&A.counts[2 * i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+      int inc0 = v0, inc1 = v1;
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) {
-        const int a1 = __shfl_up(inc, o);
-        if (t >= o) inc += a1;
+        const int a0 = __shfl_up(inc0, o), a1 = __shfl_up(inc1, o);
+        if (t >= o) { inc0 += a0; inc1 += a1; }
       }
-      if (i < nb) A.counts[i] = run + inc - v;
-      run += __shfl(inc, 63);
+      if (i < nb) { A.counts[2 * i] = run0 + inc0 - v0; A.counts[2 * i + 1] = run1 + inc1 - v1; }
+      run0 += __shfl(inc0, 63);
+      run1 += __shfl(inc1, 63);
     }
     if (t == 0) {
-      const int removed = E - run;
-      A.meta[0] = run; A.meta[1] = removed;
       for (int i = 0; i < CDV_DYN_WORDS; i++) A.dyn_out[i] = A.dyn_in[i];
-      A.dyn_out[CDV_DYN_E] = run;
-      if (A.pass == 0) {
-        A.dyn_out[CDV_DYN_DROP] = drop;
-        A.dyn_out[CDV_DYN_N] = n - drop;
-      } else {
-        const int inac = A.dyn_in[CDV_DYN_EINAC];
-        if ((int64_t)inac + removed > A.inac_cap) A.dyn_out[CDV_DYN_ERR] = 2;   // inactive edges beyond their capacity: not stored
-        else A.dyn_out[CDV_DYN_EINAC] = inac + removed;
-        if (A.mirror)
-          __hip_atomic_store(A.mirror, ((int64_t)A.dyn_in[CDV_DYN_FRAME] << 32) | (int64_t)(uint32_t)run, __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_SYSTEM);
-      }
+      A.dyn_out[CDV_DYN_E] = run0;
+      A.dyn_out[CDV_DYN_DROP] = drop;
+      A.dyn_out[CDV_DYN_N] = n - drop;
+      const int inac = A.dyn_in[CDV_DYN_EINAC];
+      if ((int64_t)inac + run1 > A.inac_cap) A.dyn_out[CDV_DYN_ERR] = 2;   // inactive edges beyond their capacity: not stored
+      else A.dyn_out[CDV_DYN_EINAC] = inac + run1;
+      if (A.mirror)
+        __hip_atomic_store(A.mirror, ((int64_t)A.dyn_in[CDV_DYN_FRAME] << 32) | (int64_t)(uint32_t)run0, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
     }
-  }
-}
-
-__global__ __launch_bounds__(256) void stream_compact_kernel(const RemoveArgs A) {
-  __shared__ int s_pre[4][4];
-  const int t = threadIdx.x, b = blockIdx.x, lane = t & 63, wave = t >> 6;
-  const int n = A.dyn_in[CDV_DYN_N], E = A.dyn_in[CDV_DYN_E];
-  const int drop = A.pass == 0 ? A.dyn_out[CDV_DYN_DROP] : 0;      // written by the count launch in front
-  const int kf = n - A.ki;
-  const int64_t r0 = A.dyn_in[CDV_DYN_EINAC];
-  const bool store = A.pass == 1 && A.ii_r != nullptr && A.dyn_out[CDV_DYN_ERR] == 0;
-  const int64_t base = (int64_t)b * 1024;
-  bool keep[4], in[4];
-  int64_t vi[4], vj[4], vk[4];
-#pragma unroll
-  for (int u = 0; u < 4; u++) {
-    const int64_t e = base + u * 256 + t;
-    in[u] = e < E;
-    vi[u] = in[u] ? A.ii[e] : 0; vj[u] = in[u] ? A.jj[e] : 0; vk[u] = in[u] ? A.kk[e] : 0;
-    keep[u] = in[u] && !remove_pred(A, drop, n, vi[u], vj[u], vk[u], kf);
-    const int wc = __popcll(__ballot(keep[u]));
-    if (lane == 0) s_pre[u][wave] = wc;
-  }
-  __syncthreads();
-  const int kbase = A.counts[b];
-  const int64_t rbase = base - kbase;
-  int kept_before_tile = 0;
-#pragma unroll
-  for (int u = 0; u < 4; u++) {
-    int pre = kept_before_tile;
-    for (int w = 0; w < wave; w++) pre += s_pre[u][w];
-    const unsigned long long bal = __ballot(keep[u]);
-    const int rank_in_wave = __popcll(bal & ((1ull << lane) - 1ull));
-    const int64_t e = base + u * 256 + t;
-    if (keep[u]) {
-      const int64_t d = (int64_t)kbase + pre + rank_in_wave;
-      int64_t i = vi[u], j = vj[u], k = vk[u];
-      if (drop) {   // frame kf left: patches and frames above it move down (slam.py:425-427)
-        if (i > kf) { k -= A.M; i -= 1; }
-        if (j > kf) j -= 1;
-      }
-      A.ii_o[d] = i; A.jj_o[d] = j; A.kk_o[d] = k;
-      *reinterpret_cast<float2*>(A.target_o + 2 * d) = *reinterpret_cast<const float2*>(A.target + 2 * e);
-      *reinterpret_cast<float2*>(A.weight_o + 2 * d) = *reinterpret_cast<const float2*>(A.weight + 2 * e);
-    } else if (in[u] && store) {
-      const int before_in_tile = u * 256 + t;
-      const int64_t d = r0 + rbase + (before_in_tile - (pre + rank_in_wave));
-      A.ii_r[d] = vi[u]; A.jj_r[d] = vj[u]; A.kk_r[d] = vk[u];
-      *reinterpret_cast<float2*>(A.target_r + 2 * d) = *reinterpret_cast<const float2*>(A.target + 2 * e);
-      *reinterpret_cast<float2*>(A.weight_r + 2 * d) = *reinterpret_cast<const float2*>(A.weight + 2 * e);
-    }
-    kept_before_tile += s_pre[u][0] + s_pre[u][1] + s_pre[u][2] + s_pre[u][3];
   }
 }
 
@@ -420,14 +410,12 @@ struct ShiftBufs {
   int64_t first[CDV_MAX_FRAME_BUFS + 1];
   int32_t gran[CDV_MAX_FRAME_BUFS];
   int n_bufs;
+  int n_blocks;
 };
 
-__global__ __launch_bounds__(256) void stream_shift_kernel(const ShiftBufs F, const int32_t* __restrict__ dyn_before,
-                                                           const int32_t* __restrict__ dyn_after, int ki) {
-  if (!dyn_after[CDV_DYN_DROP]) return;
-  const int n = dyn_before[CDV_DYN_N], k = n - ki;
+__device__ __forceinline__ void shift_buffers(const ShiftBufs& F, int bid, int tid, int k, int n) {
   const int64_t total = F.first[F.n_bufs];
-  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+  for (int64_t t = (int64_t)bid * 256 + tid; t < total; t += (int64_t)F.n_blocks * 256) {
     int bi = 0;
     while (bi + 1 < F.n_bufs && t >= F.first[bi + 1]) bi++;
     const int64_t piece = t - F.first[bi];
@@ -449,6 +437,63 @@ __global__ __launch_bounds__(256) void stream_shift_kernel(const ShiftBufs F, co
   }
 }
 
+__global__ __launch_bounds__(256) void stream_compact_kernel(const RemoveArgs A, const ShiftBufs F) {
+  __shared__ int s_pre[2][4][4];
+  const int t = threadIdx.x, b = blockIdx.x, lane = t & 63, wave = t >> 6;
+  const int n = A.dyn_in[CDV_DYN_N], E = A.dyn_in[CDV_DYN_E];
+  const int drop = A.dyn_out[CDV_DYN_DROP];      // written by the count launch in front
+  const int kf = n - A.ki;
+  if (b >= A.n_compact_blocks) {                 // the frame buffers: independent of the edge lists
+    if (drop) shift_buffers(F, b - A.n_compact_blocks, t, kf, n);
+    return;
+  }
+  const int64_t r0 = A.dyn_in[CDV_DYN_EINAC];
+  const bool store = A.ii_r != nullptr && A.dyn_out[CDV_DYN_ERR] == 0;
+  const int64_t base = (int64_t)b * 1024;
+  int fate[4];
+  int64_t vi[4], vj[4], vk[4];
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    const int64_t e = base + u * 256 + t;
+    fate[u] = 2;
+    vi[u] = vj[u] = vk[u] = 0;
+    if (e < E) {
+      vi[u] = A.ii[e]; vj[u] = A.jj[e]; vk[u] = A.kk[e];
+      fate[u] = edge_fate(A, drop, n - drop, kf, vi[u], vj[u], vk[u]);
+    }
+    const int w0 = __popcll(__ballot(fate[u] == 0)), w1 = __popcll(__ballot(fate[u] == 1));
+    if (lane == 0) { s_pre[0][u][wave] = w0; s_pre[1][u][wave] = w1; }
+  }
+  __syncthreads();
+  const int kbase = A.counts[2 * b], pbase = A.counts[2 * b + 1];
+  int before0 = 0, before1 = 0;
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    int pre0 = before0, pre1 = before1;
+    for (int w = 0; w < wave; w++) { pre0 += s_pre[0][u][w]; pre1 += s_pre[1][u][w]; }
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int64_t e = base + u * 256 + t;
+    const unsigned long long bal0 = __ballot(fate[u] == 0);
+    if (fate[u] == 0) {
+      const int64_t d = (int64_t)kbase + pre0 + __popcll(bal0 & below);
+      A.ii_o[d] = vi[u]; A.jj_o[d] = vj[u]; A.kk_o[d] = vk[u];
+      *reinterpret_cast<float2*>(A.target_o + 2 * d) = *reinterpret_cast<const float2*>(A.target + 2 * e);
+      *reinterpret_cast<float2*>(A.weight_o + 2 * d) = *reinterpret_cast<const float2*>(A.weight + 2 * e);
+    }
+    {
+      const unsigned long long bal1 = __ballot(fate[u] == 1);
+      if (fate[u] == 1 && store) {
+        const int64_t d = r0 + pbase + pre1 + __popcll(bal1 & below);
+        A.ii_r[d] = vi[u]; A.jj_r[d] = vj[u]; A.kk_r[d] = vk[u];
+        *reinterpret_cast<float2*>(A.target_r + 2 * d) = *reinterpret_cast<const float2*>(A.target + 2 * e);
+        *reinterpret_cast<float2*>(A.weight_r + 2 * d) = *reinterpret_cast<const float2*>(A.weight + 2 * e);
+      }
+    }
+    before0 += s_pre[0][u][0] + s_pre[0][u][1] + s_pre[0][u][2] + s_pre[0][u][3];
+    before1 += s_pre[1][u][0] + s_pre[1][u][1] + s_pre[1][u][2] + s_pre[1][u][3];
+  }
+}
+
 inline int grid_of(int64_t n, int per, int cap) {
   const int64_t b = (n + per - 1) / per;
   return (int)(b < 1 ? 1 : (b > cap ? cap : b));
@@ -457,8 +502,8 @@ inline int grid_of(int64_t n, int per, int cap) {
 }  // namespace
 
 extern "C" size_t cdv_stream_workspace_bytes(int64_t edge_capacity, int M) {
-  // [16] meta words | per-workgroup counts | flow_buf [4][M] | motion [2]
-  return sizeof(int32_t) * (size_t)(16 + (edge_capacity + 1023) / 1024 + 16) + sizeof(float) * (size_t)(4 * M + 8) + 256;
+  // [16] meta words | per-workgroup (kept, pruned) counts | flow_buf [4][M] | motion [2]
+  return sizeof(int32_t) * (size_t)(16 + 2 * ((edge_capacity + 1023) / 1024 + 16)) + sizeof(float) * (size_t)(4 * M + 8) + 256;
 }
 
 namespace {
@@ -470,7 +515,7 @@ inline StreamWs stream_ws(void* ws, int64_t cap, int M) {
   StreamWs w;
   w.meta = (int32_t*)ws;
   w.counts = w.meta + 16;
-  const size_t nc = (size_t)((cap + 1023) / 1024 + 16);
+  const size_t nc = 2 * (size_t)((cap + 1023) / 1024 + 16);
   w.flow_buf = reinterpret_cast<float*>(w.counts + nc);
   w.motion = w.flow_buf + 4 * (size_t)M;
   return w;
@@ -512,72 +557,73 @@ extern "C" int cdv_stream_operator_stub(const int32_t* dyn, const float* coords,
   return CDV_OK;
 }
 
-extern "C" int cdv_stream_points(const int32_t* dyn, const float* poses, const float* patches, const float* intrinsics,
-                                 const int64_t* ix, int M, int window_frames, float* points, void* stream) {
-  CDV_REQUIRE(dyn && poses && patches && intrinsics && ix && points && M >= 1 && window_frames >= 1, CDV_ERR_ARG,
-              "cdv_stream_points: arguments");
-  hipLaunchKernelGGL(stream_points_kernel, dim3(grid_of((int64_t)window_frames * M, 256, 1024)), dim3(256), 0, (hipStream_t)stream,
-                     dyn, poses, patches, intrinsics, ix, M, window_frames, points);
-  CDV_LAUNCH_CHECK();
-  return CDV_OK;
-}
-
-// The whole of SLAM.keyframe() (slam.py:408-458) for a 3 x 3 patch graph, six launches, no read-back:
-//   the flow statistic of the frames around k = n - KEYFRAME_INDEX, the decision (force: -1 the reference's test with
-//   `thresh`, 0 / 1 the caller's), removal of k's edges + index shift, shift of the frame buffers, removal-window pruning
-//   with the pruned edges stored as inactive ones.  dyn_in -> dyn_mid (after the keyframe removal) -> dyn_out.
-// Edge buffers: `a` holds the lists on entry and on return, `b` is the twin they pass through.
-extern "C" int cdv_stream_keyframe(const int32_t* dyn_in, int32_t* dyn_mid, int32_t* dyn_out, const float* poses,
-                                   const float* patches, const float* intrinsics, const int64_t* ix, int64_t* ii_a, int64_t* jj_a,
-                                   int64_t* kk_a, float* target_a, float* weight_a, int64_t* ii_b, int64_t* jj_b, int64_t* kk_b,
-                                   float* target_b, float* weight_b, int64_t* ii_inac, int64_t* jj_inac, int64_t* kk_inac,
-                                   float* target_inac, float* weight_inac, int64_t inactive_capacity, int64_t edge_capacity,
-                                   int64_t E_bound, int M, int keyframe_index, int removal_window, float keyframe_thresh,
-                                   int force, const cdv_frame_buf* bufs, int n_bufs, int64_t* mirror_host, void* ws,
-                                   void* stream) {
-  CDV_REQUIRE(dyn_in && dyn_mid && dyn_out && dyn_in != dyn_mid && dyn_mid != dyn_out && dyn_in != dyn_out, CDV_ERR_ARG,
-              "cdv_stream_keyframe: three distinct dynamic blocks");
-  CDV_REQUIRE(poses && patches && intrinsics && ix && ii_a && jj_a && kk_a && target_a && weight_a && ii_b && jj_b && kk_b &&
-                  target_b && weight_b && ws, CDV_ERR_ARG, "cdv_stream_keyframe: NULL buffer");
+// SLAM.keyframe() (slam.py:408-458) and the point cloud of slam.py:524-526 for a 3 x 3 patch graph, three launches, no read-back:
+//   1. point cloud of the removal window | flow statistic of the frames around k = n - KEYFRAME_INDEX
+//   2. the decision (force: -1 the reference's test with `thresh`, 0 / 1 the caller's) and the counts of ONE compaction that
+//      does both removals of keyframe(); the sizes after it -> dyn_out
+//   3. the compaction (kept edges -> the twin buffers `dst`, pruned ones -> the inactive lists, indices shifted when k was
+//      dropped) | the shift of the frame buffers
+// points may be NULL (no point cloud).
+extern "C" int cdv_stream_keyframe(const int32_t* dyn_in, int32_t* dyn_out, const float* poses, const float* patches,
+                                   const float* intrinsics, const int64_t* ix, const int64_t* ii_src, const int64_t* jj_src,
+                                   const int64_t* kk_src, const float* target_src, const float* weight_src, int64_t* ii_dst,
+                                   int64_t* jj_dst, int64_t* kk_dst, float* target_dst, float* weight_dst, int64_t* ii_inac,
+                                   int64_t* jj_inac, int64_t* kk_inac, float* target_inac, float* weight_inac,
+                                   int64_t inactive_capacity, int64_t edge_capacity, int64_t E_bound, int M, int keyframe_index,
+                                   int removal_window, float keyframe_thresh, int force, const cdv_frame_buf* bufs, int n_bufs,
+                                   float* points, int64_t* mirror_host, void* ws, void* stream) {
+  CDV_REQUIRE(dyn_in && dyn_out && dyn_in != dyn_out, CDV_ERR_ARG, "cdv_stream_keyframe: two distinct dynamic blocks");
+  CDV_REQUIRE(poses && patches && intrinsics && ix && ii_src && jj_src && kk_src && target_src && weight_src && ii_dst && jj_dst &&
+                  kk_dst && target_dst && weight_dst && ws, CDV_ERR_ARG, "cdv_stream_keyframe: NULL buffer");
+  CDV_REQUIRE(ii_src != ii_dst, CDV_ERR_ARG, "cdv_stream_keyframe: the compaction is not in place (src == dst)");
   CDV_REQUIRE(n_bufs >= 0 && n_bufs <= CDV_MAX_FRAME_BUFS && (n_bufs == 0 || bufs), CDV_ERR_ARG, "cdv_stream_keyframe: frame buffers");
   CDV_REQUIRE(E_bound >= 1 && E_bound <= edge_capacity, CDV_ERR_ARG, "cdv_stream_keyframe: E_bound");
   hipStream_t s = (hipStream_t)stream;
   const StreamWs w = stream_ws(ws, edge_capacity, M);
-  hipLaunchKernelGGL(stream_motion_kernel, dim3(grid_of(E_bound, 256, 4096)), dim3(256), 0, s, dyn_in, poses, patches, intrinsics,
-                     ii_a, jj_a, kk_a, M, keyframe_index, 0.5f, w.flow_buf);
+  AfterArgs P;
+  P.dyn = dyn_in; P.poses = poses; P.patches = patches; P.intr = intrinsics; P.ix = ix; P.ii = ii_src; P.jj = jj_src; P.kk = kk_src;
+  P.M = M; P.window_frames = removal_window + 2; P.ki = keyframe_index; P.beta = 0.5f; P.points = points; P.flow_buf = w.flow_buf;
+  P.n_motion_blocks = grid_of(E_bound, 1024, 256);
+  P.n_point_blocks = points ? grid_of((int64_t)(removal_window + 2) * M, 256, 256) : 0;
+  hipLaunchKernelGGL(stream_after_kernel, dim3(P.n_motion_blocks + P.n_point_blocks), dim3(256), 0, s, P);
   RemoveArgs A;
-  A.dyn_in = dyn_in; A.dyn_out = dyn_mid; A.pass = 0; A.M = M; A.ki = keyframe_index; A.removal_window = removal_window;
+  A.dyn_in = dyn_in; A.dyn_out = dyn_out; A.M = M; A.ki = keyframe_index; A.removal_window = removal_window;
   A.thresh = keyframe_thresh; A.force = force; A.flow_buf = w.flow_buf; A.motion_out = w.motion; A.ix = ix;
-  A.ii = ii_a; A.jj = jj_a; A.kk = kk_a; A.target = target_a; A.weight = weight_a;
-  A.ii_o = ii_b; A.jj_o = jj_b; A.kk_o = kk_b; A.target_o = target_b; A.weight_o = weight_b;
-  A.ii_r = nullptr; A.jj_r = nullptr; A.kk_r = nullptr; A.target_r = nullptr; A.weight_r = nullptr; A.inac_cap = inactive_capacity;
-  A.counts = w.counts; A.meta = w.meta; A.mirror = nullptr;
+  A.ii = ii_src; A.jj = jj_src; A.kk = kk_src; A.target = target_src; A.weight = weight_src;
+  A.ii_o = ii_dst; A.jj_o = jj_dst; A.kk_o = kk_dst; A.target_o = target_dst; A.weight_o = weight_dst;
+  A.ii_r = ii_inac; A.jj_r = jj_inac; A.kk_r = kk_inac; A.target_r = target_inac; A.weight_r = weight_inac;
+  A.inac_cap = inactive_capacity; A.counts = w.counts; A.meta = w.meta; A.mirror = mirror_host;
   const int nb = grid_of(E_bound, 1024, 1 << 22);
+  A.nb = nb; A.n_compact_blocks = nb;
   hipLaunchKernelGGL(stream_count_kernel, dim3(nb), dim3(256), 0, s, A);
-  hipLaunchKernelGGL(stream_compact_kernel, dim3(nb), dim3(256), 0, s, A);
-  if (n_bufs > 0) {
-    ShiftBufs F;
-    F.n_bufs = n_bufs;
-    F.first[0] = 0;
-    for (int i = 0; i < n_bufs; i++) {
-      const cdv_frame_buf& b = bufs[i];
-      CDV_REQUIRE(b.base != nullptr && b.slot_bytes > 0 && b.slot_bytes % 4 == 0 && b.modulus >= 0 && ((uintptr_t)b.base & 3) == 0,
-                  CDV_ERR_ARG, "cdv_stream_keyframe: a buffer needs a 4-byte aligned base, slot_bytes % 4 == 0, modulus >= 0");
-      F.b[i] = b;
-      F.gran[i] = (b.slot_bytes % 16 == 0 && ((uintptr_t)b.base & 15) == 0) ? 16 : 4;
-      F.first[i + 1] = F.first[i] + b.slot_bytes / F.gran[i];
-    }
-    hipLaunchKernelGGL(stream_shift_kernel, dim3(grid_of(F.first[n_bufs], 256, 4096)), dim3(256), 0, s, F, dyn_in, dyn_mid,
-                       keyframe_index);
+  ShiftBufs F;
+  F.n_bufs = n_bufs;
+  F.first[0] = 0;
+  for (int i = 0; i < n_bufs; i++) {
+    const cdv_frame_buf& b = bufs[i];
+    CDV_REQUIRE(b.base != nullptr && b.slot_bytes > 0 && b.slot_bytes % 4 == 0 && b.modulus >= 0 && ((uintptr_t)b.base & 3) == 0,
+                CDV_ERR_ARG, "cdv_stream_keyframe: a buffer needs a 4-byte aligned base, slot_bytes % 4 == 0, modulus >= 0");
+    F.b[i] = b;
+    F.gran[i] = (b.slot_bytes % 16 == 0 && ((uintptr_t)b.base & 15) == 0) ? 16 : 4;
+    F.first[i + 1] = F.first[i] + b.slot_bytes / F.gran[i];
   }
-  RemoveArgs B = A;
-  B.dyn_in = dyn_mid; B.dyn_out = dyn_out; B.pass = 1;
-  B.ii = ii_b; B.jj = jj_b; B.kk = kk_b; B.target = target_b; B.weight = weight_b;
-  B.ii_o = ii_a; B.jj_o = jj_a; B.kk_o = kk_a; B.target_o = target_a; B.weight_o = weight_a;
-  B.ii_r = ii_inac; B.jj_r = jj_inac; B.kk_r = kk_inac; B.target_r = target_inac; B.weight_r = weight_inac;
-  B.mirror = mirror_host;
-  hipLaunchKernelGGL(stream_count_kernel, dim3(nb), dim3(256), 0, s, B);
-  hipLaunchKernelGGL(stream_compact_kernel, dim3(nb), dim3(256), 0, s, B);
+  F.n_blocks = n_bufs > 0 ? grid_of(F.first[n_bufs], 256, 2048) : 0;
+  hipLaunchKernelGGL(stream_compact_kernel, dim3(nb + F.n_blocks), dim3(256), 0, s, A, F);
+  CDV_LAUNCH_CHECK();
+  return CDV_OK;
+}
+
+// slam.py:524-526 on its own (cdv_stream_keyframe does it next to the flow statistic)
+extern "C" int cdv_stream_points(const int32_t* dyn, const float* poses, const float* patches, const float* intrinsics,
+                                 const int64_t* ix, int M, int window_frames, float* points, void* stream) {
+  CDV_REQUIRE(dyn && poses && patches && intrinsics && ix && points && M >= 1 && window_frames >= 1, CDV_ERR_ARG,
+              "cdv_stream_points: arguments");
+  AfterArgs P;
+  P.dyn = dyn; P.poses = poses; P.patches = patches; P.intr = intrinsics; P.ix = ix; P.ii = nullptr; P.jj = nullptr; P.kk = nullptr;
+  P.M = M; P.window_frames = window_frames; P.ki = 0; P.beta = 0.5f; P.points = points; P.flow_buf = nullptr;
+  P.n_motion_blocks = 0;
+  P.n_point_blocks = grid_of((int64_t)window_frames * M, 256, 256);
+  hipLaunchKernelGGL(stream_after_kernel, dim3(P.n_point_blocks), dim3(256), 0, (hipStream_t)stream, P);
   CDV_LAUNCH_CHECK();
   return CDV_OK;
 }
@@ -598,14 +644,15 @@ extern "C" int cdv_stream_frame(cdv_stream_desc* D, const void* fmap_chw, const 
   CDV_REQUIRE(D->opt_window >= 1 && D->opt_window <= 10, CDV_ERR_UNSUPPORTED, "cdv_stream_frame: OPTIMIZATION_WINDOW 1 .. 10");
   const int M = D->M;
   auto blk = [&](int i) { return D->dyn + CDV_DYN_WORDS * (i & 7); };
-  const int a = D->slot, b = a + 1, m = a + 2, e = a + 3;
+  const int a = D->slot, b = a + 1, e = a + 2;
+  const int cur = D->cur & 1, oth = cur ^ 1;
   // an upper bound of the number of edges once this frame has arrived, without asking the device: what the last finished
   // keyframe() left (pinned word: frames << 32 | edges) plus 2 r M per frame begun since
   const int64_t seen = D->mirror_host ? *reinterpret_cast<volatile int64_t*>(D->mirror_host) : 0;
   int64_t Eb = (seen & 0xFFFFFFFFll) + ((int64_t)D->frames + 1 - (seen >> 32)) * 2 * D->patch_lifetime * M;
   if (Eb > D->edge_capacity) Eb = D->edge_capacity;
   if (Eb < 1) Eb = 1;
-  int rc = cdv_stream_frame_begin(blk(a), blk(b), D->ii[0], D->jj[0], D->kk[0], D->target[0], D->weight[0], D->ix, D->edge_capacity, M,
+  int rc = cdv_stream_frame_begin(blk(a), blk(b), D->ii[cur], D->jj[cur], D->kk[cur], D->target[cur], D->weight[cur], D->ix, D->edge_capacity, M,
                                   D->patch_lifetime, D->opt_window, D->frames_capacity, cx, cy, depth, fmap_chw, D->gmap_planar,
                                   D->poses, D->patches, D->C, D->H, D->W, D->pmem, D->pose_step, D->ws, stream);
   if (rc != CDV_OK) return rc;
@@ -616,26 +663,25 @@ extern "C" int cdv_stream_frame(cdv_stream_desc* D, const void* fmap_chw, const 
                             D->gmap_planar, D->gmap_pm, (int64_t)D->pmem * M, (int64_t)((D->frames - 1) % D->pmem) * M, M, stream);
   }
   rc = cdv_update_prologue_table_dyn(fmap_chw, D->fmap1_nhwc, D->fmap2_nhwc, D->mem, D->pmem, D->C, D->H, D->W, D->gmap_planar,
-                                     D->gmap_pm, (int64_t)D->pmem * M, M, D->poses, D->patches, D->intrinsics, D->ii[0], D->jj[0],
-                                     D->kk[0], Eb, blk(b), D->coords, D->graph_ws, D->graph_ws_bytes, D->graph_E_max,
+                                     D->gmap_pm, (int64_t)D->pmem * M, M, D->poses, D->patches, D->intrinsics, D->ii[cur], D->jj[cur],
+                                     D->kk[cur], Eb, blk(b), D->coords, D->graph_ws, D->graph_ws_bytes, D->graph_E_max,
                                      D->graph_k_range, D->table_capacity, stream);
   if (rc != CDV_OK) return rc;
   rc = cdv_corr_fused_stream_dyn(D->gmap_pm, D->fmap1_nhwc, D->fmap2_nhwc, cdv_graph_corr_records(D->graph_ws), D->corr_out, Eb,
                                  blk(b), (int64_t)D->pmem * M, D->mem, D->C, D->H, D->W, D->H / 4, D->W / 4, 1.0f, 4.0f, 1, stream);
   if (rc != CDV_OK) return rc;
-  rc = cdv_stream_operator_stub(blk(b), D->coords, D->corr_out, 882, D->target[0], D->weight[0], D->gain, Eb, stream);
+  rc = cdv_stream_operator_stub(blk(b), D->coords, D->corr_out, 882, D->target[cur], D->weight[cur], D->gain, Eb, stream);
   if (rc != CDV_OK) return rc;
-  rc = cdv_ba_forward_dyn(D->poses, D->patches, D->intrinsics, D->target[0], D->weight[0], D->lmbda, D->ii[0], D->jj[0], D->kk[0], Eb,
+  rc = cdv_ba_forward_dyn(D->poses, D->patches, D->intrinsics, D->target[cur], D->weight[cur], D->lmbda, D->ii[cur], D->jj[cur], D->kk[cur], Eb,
                           3, D->opt_window, blk(b), 2, D->graph_ws, D->ba_ws, D->ba_ws_bytes, D->table_capacity, stream);
   if (rc != CDV_OK) return rc;
-  rc = cdv_stream_points(blk(b), D->poses, D->patches, D->intrinsics, D->ix, M, D->removal_window + 2, D->points, stream);
-  if (rc != CDV_OK) return rc;
-  rc = cdv_stream_keyframe(blk(b), blk(m), blk(e), D->poses, D->patches, D->intrinsics, D->ix, D->ii[0], D->jj[0], D->kk[0],
-                           D->target[0], D->weight[0], D->ii[1], D->jj[1], D->kk[1], D->target[1], D->weight[1], D->ii_inac,
+  rc = cdv_stream_keyframe(blk(b), blk(e), D->poses, D->patches, D->intrinsics, D->ix, D->ii[cur], D->jj[cur], D->kk[cur],
+                           D->target[cur], D->weight[cur], D->ii[oth], D->jj[oth], D->kk[oth], D->target[oth], D->weight[oth], D->ii_inac,
                            D->jj_inac, D->kk_inac, D->target_inac, D->weight_inac, D->inactive_capacity, D->edge_capacity, Eb, M,
-                           D->keyframe_index, D->removal_window, D->keyframe_thresh, force, D->bufs, D->n_bufs, D->mirror_host,
-                           D->ws, stream);
+                           D->keyframe_index, D->removal_window, D->keyframe_thresh, force, D->bufs, D->n_bufs, D->points,
+                           D->mirror_host, D->ws, stream);
   if (rc != CDV_OK) return rc;
+  D->cur = oth;
   D->slot = e & 7;
   return CDV_OK;
 }

@@ -214,8 +214,9 @@ class _EdgeViews:
     def __init__(self, owner, E):
         o = owner
         self.E = E
-        self.ii, self.jj, self.kk = o._ii[0, :E], o._jj[0, :E], o._kk[0, :E]
-        self.target, self.weight = o._target[0, :E][None], o._weight[0, :E][None]
+        c = o.cur
+        self.ii, self.jj, self.kk = o._ii[c, :E], o._jj[c, :E], o._kk[c, :E]
+        self.target, self.weight = o._target[c, :E][None], o._weight[c, :E][None]
 
 
 class DeviceStreamRunner:
@@ -223,16 +224,15 @@ class DeviceStreamRunner:
 
     The reference reads its keyframe decision back to the host (two .item() calls, cdvslam/slam.py:399-413) and from there on
     n and the number of edges are host integers; StreamRunner above does the same (one read-back per removal).  Here a frame
-    is a fixed sequence of 17 launches and NO synchronisation:
+    is a fixed sequence of 12 launches and NO synchronisation:
 
         cdv_stream_frame_begin        n + 1, the frame's edges, patches_, pose guess, patch tiles          slam.py:676-709
         cdv_update_prologue_table_dyn ring ingest | table fill, then sort + neighbors + reprojection + packed stream
         cdv_corr_fused_stream_dyn     two-level correlation                                              slam.py:316-323
         cdv_stream_operator_stub      (stands where the Update operator runs)
         cdv_ba_forward_dyn            BA(iterations=2) over [max(1, n - OPTIMIZATION_WINDOW), n)            slam.py:512-515
-        cdv_stream_points             point cloud of the patches inside the removal window                 slam.py:524-526
-        cdv_stream_keyframe           flow statistic -> decision ON THE DEVICE -> removal + shifts -> window pruning
-                                                                                                           slam.py:399-458
+        cdv_stream_keyframe           point cloud of the removal window | flow statistic -> decision ON THE DEVICE -> ONE
+                                      compaction for both removals + index shift | frame-buffer shift  slam.py:399-458,524-526
     n, E, the decision live in a ring of "dynamic blocks"; the host only keeps an upper bound of E (from a pinned word the
     last launch of a frame writes) to dimension the launches.  Anything the host wants to KNOW (counts(), n, edges, poses of
     the keyframes) synchronises -- tests and the end of a run do, the frame loop does not.  Configurations: 3 x 3 patches,
@@ -270,7 +270,7 @@ class DeviceStreamRunner:
         self.ii_inac, self.jj_inac, self.kk_inac = z(icap), z(icap), z(icap)
         self.target_inac, self.weight_inac = z(icap, 2, dt=torch.float32), z(icap, 2, dt=torch.float32)
         self.dyn = torch.zeros((8, 16), dtype=torch.int32, device=device)                  # ring of dynamic blocks
-        self.slot = 0
+        self.slot, self.cur = 0, 0
         self.mirror = torch.zeros(1, dtype=torch.int64).pin_memory()                       # (frames << 32 | edges), written by the device
         self.ws = torch.zeros(lib.cdv_stream_workspace_bytes(ecap, M), dtype=torch.uint8, device=device)
         self.tcap = (removal_window + 8) * M
@@ -332,7 +332,7 @@ class DeviceStreamRunner:
         D.M, D.C, D.H, D.W, D.mem, D.pmem, D.frames_capacity = self.M, self.C, self.h, self.w, self.mem, self.pmem, self.N
         D.patch_lifetime, D.removal_window, D.opt_window, D.keyframe_index = self.r, self.rw, self.ow, self.ki
         D.keyframe_thresh, D.gain, D.pose_step = self.kthresh, self.gain, self.pose_step
-        D.slot, D.frames = self.slot, self.frames
+        D.slot, D.frames, D.cur = self.slot, self.frames, self.cur
         g = self.graph
         D.edge_capacity, D.inactive_capacity, D.table_capacity = self.ecap, self.icap, g.table_capacity
         D.graph_E_max, D.graph_k_range, D.graph_ws_bytes, D.ba_ws_bytes = g.E_cap, g.k_range, g.ws_bytes, self.ba_ws.numel()
@@ -357,7 +357,7 @@ class DeviceStreamRunner:
         self._pool_ptrs = [V(t.data_ptr()) for t in self.pool]
 
     def frame(self, drop=False, inputs=None):
-        """one incoming frame, enqueued (cdv_stream_frame: 17 launches behind ONE call); nothing is read back.  drop: None =
+        """one incoming frame, enqueued (cdv_stream_frame: 12 launches behind ONE call); nothing is read back.  drop: None =
         the reference's keyframe test on the device, True / False = the caller decides; inputs: (fmap [C,h,w] f16, cx, cy,
         d [M]) on the device, default: the stub's own"""
         if not hasattr(self, "_desc"):
@@ -371,6 +371,6 @@ class DeviceStreamRunner:
             fmap, cx, cy, d = (self._p(t) for t in self._hold)
         force = -1 if drop is None else (1 if drop else 0)
         ops._lib.check(self.lib.cdv_stream_frame(self._desc_ref, fmap, cx, cy, d, force, ops._stream()), "cdv_stream_frame")
-        self.frames, self.slot = self._desc.frames, self._desc.slot
+        self.frames, self.slot, self.cur = self._desc.frames, self._desc.slot, self._desc.cur
         g = self.graph
         g.is_table, g._key, g._nbr = True, None, None

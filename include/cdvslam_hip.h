@@ -567,21 +567,23 @@ int cdv_stream_points(const int32_t* dyn, const float* poses, const float* patch
                       int M, int window_frames, float* points, void* stream);
 
 /*
- * SLAM.keyframe() (slam.py:408-458), 3 x 3 patches, no read-back: mean flow_mag of the edges between the frames either side
- * of k = n - keyframe_index (slam.py:399-413, beta 0.5) -> decision on the device (force -1: drop k when the mean is under
- * keyframe_thresh and n > keyframe_index + 2; 0 / 1: the caller decides) -> k's edges removed and the indices above it
- * shifted (:423-427), the frame buffers `bufs` shifted (:431-441, as cdv_frames_keyframe_shift), n - 1; then the edges whose
- * source frame left the removal window are removed and stored as inactive edges (:453-458).  dyn_in -> dyn_mid -> dyn_out
- * (three distinct blocks).  The `a` buffers hold the edge lists on entry and on return; `b` is their twin.  mirror_host
- * (optional, pinned): receives (frames << 32 | edges) so that the host can size the next launches without synchronising.
+ * SLAM.keyframe() (slam.py:408-458) and the point cloud of slam.py:524-526, 3 x 3 patches, three launches, no read-back: mean
+ * flow_mag of the edges between the frames either side of k = n - keyframe_index (slam.py:399-413, beta 0.5) -> decision on the
+ * device (force -1: drop k when the mean is under keyframe_thresh and n > keyframe_index + 2; 0 / 1: the caller decides) -> ONE
+ * stable compaction src -> dst that does both removals of keyframe(): k's edges go (:423), the indices above k are shifted
+ * (:425-427), the edges whose source frame left the removal window (judged on the shifted indices, n - 1) are stored as
+ * inactive edges (:453-458); next to it the frame buffers `bufs` are shifted (:431-441, as cdv_frames_keyframe_shift).
+ * dyn_in -> dyn_out (n - drop, the edges left, the inactive edges).  points (optional): as cdv_stream_points, same launch as the
+ * flow statistic.  mirror_host (optional, pinned): receives (frames << 32 | edges) so that the host can size the next launches
+ * without synchronising.
  */
-int cdv_stream_keyframe(const int32_t* dyn_in, int32_t* dyn_mid, int32_t* dyn_out, const float* poses, const float* patches,
-                        const float* intrinsics, const int64_t* ix, int64_t* ii_a, int64_t* jj_a, int64_t* kk_a, float* target_a,
-                        float* weight_a, int64_t* ii_b, int64_t* jj_b, int64_t* kk_b, float* target_b, float* weight_b,
-                        int64_t* ii_inac, int64_t* jj_inac, int64_t* kk_inac, float* target_inac, float* weight_inac,
-                        int64_t inactive_capacity, int64_t edge_capacity, int64_t E_bound, int M, int keyframe_index,
-                        int removal_window, float keyframe_thresh, int force, const cdv_frame_buf* bufs, int n_bufs,
-                        int64_t* mirror_host, void* ws, void* stream);
+int cdv_stream_keyframe(const int32_t* dyn_in, int32_t* dyn_out, const float* poses, const float* patches, const float* intrinsics,
+                        const int64_t* ix, const int64_t* ii_src, const int64_t* jj_src, const int64_t* kk_src,
+                        const float* target_src, const float* weight_src, int64_t* ii_dst, int64_t* jj_dst, int64_t* kk_dst,
+                        float* target_dst, float* weight_dst, int64_t* ii_inac, int64_t* jj_inac, int64_t* kk_inac,
+                        float* target_inac, float* weight_inac, int64_t inactive_capacity, int64_t edge_capacity, int64_t E_bound,
+                        int M, int keyframe_index, int removal_window, float keyframe_thresh, int force, const cdv_frame_buf* bufs,
+                        int n_bufs, float* points, int64_t* mirror_host, void* ws, void* stream);
 
 /* device pointer to {flow statistic, decision} of the last cdv_stream_keyframe on the workspace (tests). */
 const float* cdv_stream_motion(void* ws, int64_t edge_capacity, int M);
@@ -589,21 +591,21 @@ const float* cdv_stream_motion(void* ws, int64_t edge_capacity, int M);
 /*
  * One frame of the stream as ONE call: everything SLAM.__call__ does for an initialised system around the (stubbed) networks
  * -- cdv_stream_frame_begin, cdv_update_prologue_table_dyn, cdv_corr_fused_stream_dyn, cdv_stream_operator_stub,
- * cdv_ba_forward_dyn (2 iterations), cdv_stream_points, cdv_stream_keyframe; for the first 7 frames only the state write
- * and the ring ingest, as slam.py:711 waits for 8 frames -- enqueued on `stream`, 17 launches, no synchronisation.  The
+ * cdv_ba_forward_dyn (2 iterations), cdv_stream_keyframe (with the point cloud); for the first 7 frames only the state write
+ * and the ring ingest, as slam.py:711 waits for 8 frames -- enqueued on `stream`, 12 launches, no synchronisation.  The
  * descriptor names the buffers once; `slot` and `frames` are host state the call advances; the launches are sized from
  * the pinned word `mirror_host` (cdv_stream_keyframe).  force: -1 the reference's keyframe test, 0 / 1 the caller's decision.
  */
 typedef struct {
   int32_t M, C, H, W, mem, pmem, frames_capacity, patch_lifetime, removal_window, opt_window, keyframe_index, n_bufs;
   float keyframe_thresh, gain, pose_step;
-  int32_t slot, frames;              /* host state: current dynamic block, frames begun */
+  int32_t slot, frames, cur;         /* host state: current dynamic block, frames begun, which twin holds the edge lists */
   int64_t edge_capacity, inactive_capacity, table_capacity, graph_E_max, graph_k_range;
   size_t graph_ws_bytes, ba_ws_bytes;
   float *poses, *patches, *intrinsics, *points;
   const int64_t* ix;
   void *fmap1_nhwc, *fmap2_nhwc, *gmap_planar, *gmap_pm;
-  int64_t *ii[2], *jj[2], *kk[2];    /* [0]: the edge lists, [1]: their twin */
+  int64_t *ii[2], *jj[2], *kk[2];    /* the edge lists and their twin: [cur] is current, every keyframe() compacts into the other */
   float *target[2], *weight[2];
   int64_t *ii_inac, *jj_inac, *kk_inac;
   float *target_inac, *weight_inac;
