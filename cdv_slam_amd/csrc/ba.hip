@@ -37,6 +37,7 @@ struct WsState {
 std::mutex g_ws_mutex;
 std::unordered_map<const void*, WsState> g_ws_state;
 std::unordered_map<const void*, int32_t*> g_ws_counters;   // cdv_ba_bind_status_counters
+std::unordered_map<const void*, int> g_ws_ppf;              // cdv_ba_set_patches_per_frame
 std::atomic<int> g_handoff_test{0};                        // cdv_ba_test_handoff: fault injection for the in-launch hand-offs
 
 typedef EdgeFactor EdgeJ;   // residual, weights and Jacobian rows of one edge (cdv_se3.h: fastba_factor)
@@ -1154,6 +1155,7 @@ extern "C" void cdv_workspace_forget(const void* ws) {
     std::lock_guard<std::mutex> lk(g_ws_mutex);
     g_ws_state.erase(ws);
     g_ws_counters.erase(ws);
+    g_ws_ppf.erase(ws);
   }
   cdv_graph_forget(ws);
 }
@@ -1243,6 +1245,7 @@ static int ba_forward_impl(float* poses, float* patches, const float* intrinsics
   bool fresh;
   int32_t token_base = 0;
   int32_t* counters = nullptr;
+  int ppf_hint = 0;
   {
     std::lock_guard<std::mutex> lk(g_ws_mutex);
     WsState& st = g_ws_state[ba_ws];
@@ -1252,6 +1255,8 @@ static int ba_forward_impl(float* poses, float* patches, const float* intrinsics
     st = WsState{true, U_max, N, ba_ws_bytes, tok0 + (iterations > 0 ? iterations : 1)};
     auto it = g_ws_counters.find(ba_ws);
     if (it != g_ws_counters.end()) counters = it->second;
+    auto ip = g_ws_ppf.find(ba_ws);
+    if (ip != g_ws_ppf.end()) ppf_hint = ip->second;
   }
   // the slab paths: two launches per iteration, no float atomics (ba_win.hip up to 10 free poses, ba_mid.hip up to 32)
   const bool window = N >= 1 && N <= MID_N;
@@ -1288,6 +1293,8 @@ static int ba_forward_impl(float* poses, float* patches, const float* intrinsics
     wa.info = info; wa.counters = counters;
     wa.test = g_handoff_test.load();
     wa.dyn = dyn;
+    // wide chunks cut per frame (ba_mid.hip): only when a frame's patches really are ppf consecutive table slots
+    wa.ppf = (table && N > WIN_N && ppf_hint >= 4 && ppf_hint % 4 == 0 && wa.tab_cap % ppf_hint == 0) ? ppf_hint : 0;
     wa.dbg = nullptr;
     wa.token = token_base + 1;
     for (int itr = 0; itr < iterations; itr++) {
@@ -1376,6 +1383,17 @@ static int ba_forward_impl(float* poses, float* patches, const float* intrinsics
 extern "C" int cdv_ba_test_handoff(int mode) {
   CDV_REQUIRE(mode >= 0 && mode <= 2, CDV_ERR_ARG, "cdv_ba_test_handoff: mode 0, 1 or 2");
   g_handoff_test.store(mode);
+  return CDV_OK;
+}
+
+// PPF of cuda_ba.forward (fastba/ba.cpp:31-45 passes the patches per frame; the reference's kernels only use it in the
+// block-sparse E of eff_impl): a hint that lets the 10 < N <= 32 path cut its workgroups' patch ranges per frame when the
+// patch table's capacity is a multiple of it.  0 forgets the hint.  Results do not depend on it beyond summation order.
+extern "C" int cdv_ba_set_patches_per_frame(void* ba_ws, int patches_per_frame) {
+  CDV_REQUIRE(ba_ws != nullptr && patches_per_frame >= 0, CDV_ERR_ARG, "cdv_ba_set_patches_per_frame: arguments");
+  std::lock_guard<std::mutex> lk(g_ws_mutex);
+  if (patches_per_frame > 0) g_ws_ppf[ba_ws] = patches_per_frame;
+  else g_ws_ppf.erase(ba_ws);
   return CDV_OK;
 }
 

@@ -33,7 +33,13 @@ CDV_STAMP_TU(bam)
 namespace {
 
 constexpr int CK = WIN_CK;
-constexpr int EDL = CK + 1;                // row stride of the chunk's [E; u] block in LDS
+// A workgroup takes SC consecutive chunks of 16 patches (a "wide chunk"): what it does AFTER the edges -- summing the wave
+// copies of the footprint, folding, the Schur tiles, the scatter and the slab copy-out, half of its time at N = 22 -- is
+// the same work for 16 patches as for 32, and the stress configuration's 294 chunks needed a second round of workgroups
+// on the 256 CUs (one 8-wave workgroup per CU: registers): 147 wide chunks are one round, and half the slabs.
+constexpr int SC = 2;
+constexpr int CKS = SC * CK;               // patches per workgroup
+constexpr int EDL = CKS + 1;               // row stride of the wide chunk's [E; u] block in LDS
 constexpr int FT = 512;                    // threads of a finish workgroup
 
 // ---- footprint of a chunk in B and v, per wave --------------------------------------------------------------------
@@ -50,7 +56,7 @@ __host__ __device__ inline int fp_stride(int N, int waves) {
   return fp_floats(N) > need ? fp_floats(N) : need;
 }
 inline size_t chunk_lds_bytes(int N, int waves) {
-  return sizeof(float) * ((size_t)waves * fp_stride(N, waves) + (size_t)ed_rows(N) * EDL + (size_t)waves * 8 * CK + 2 * CK + 8);
+  return sizeof(float) * ((size_t)waves * fp_stride(N, waves) + (size_t)ed_rows(N) * EDL + (size_t)SC * waves * 8 * CK + 2 * CKS + 8);
 }
 
 // where value `code` of a frame pair goes inside a footprint: base + ms * (source slot) + mj * (target frame); need: bit 0
@@ -81,6 +87,28 @@ __device__ __forceinline__ int nth_bit(uint32_t m, int k) {
 #else
 #define CDV_MID_OCC
 #endif
+// Rows of wide chunk wc: plainly [CKS wc, + CKS); with A.ppf > 0 (a patch table whose capacity is a multiple of the patches per
+// frame: a frame's patches then sit in ppf consecutive slots) the wide chunks are cut PER FRAME -- pieces of CKS rows, the
+// last one shorter -- so that no workgroup holds patches of two source frames: a row of 16 lanes whose patches belong to two
+// frames takes two passes of the pair products instead of one, and the workgroup that had such rows was the launch's long
+// pole (stress configuration, 196 patches per frame: one wide chunk in six).
+__host__ __device__ inline int wide_per_frame(int ppf) { return (ppf + CKS - 1) / CKS; }
+__device__ __forceinline__ void wide_rows(const BaWinArgs& A, int wc, int& r0w, int& cnt) {
+  if (A.ppf > 0) {
+    const int per = wide_per_frame(A.ppf);
+    const int b = wc / per, piece = wc - b * per;
+    r0w = b * A.ppf + CKS * piece;
+    cnt = min(CKS, A.ppf - CKS * piece);
+  } else {
+    r0w = wc * CKS;
+    cnt = CKS;
+  }
+}
+__device__ __forceinline__ int wide_count(const BaWinArgs& A, int U) {
+  if (A.ppf > 0) return (U / A.ppf) * wide_per_frame(A.ppf);
+  return ((U + CK - 1) / CK + SC - 1) / SC;
+}
+
 template <bool HAS_II, int MKW, bool TABLE>
 __global__ __launch_bounds__(64 * MKW) CDV_MID_OCC void ba_mid_chunk_kernel(BaWinArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -91,10 +119,10 @@ __global__ __launch_bounds__(64 * MKW) CDV_MID_OCC void ba_mid_chunk_kernel(BaWi
   const int slabf = (TRI_N + n6 + 7) / 8 * 8;
   float* Fw = smem;                            // [MKW][FP] per-wave footprints
   float* Ed = Fw + MKW * FP;                   // [ER][EDL]  rows 0..6N-1 E, row 6N u, the rest zero
-  float* part = Ed + ER * EDL;                 // [MKW][8][CK] per-wave partial sums: 6 rows of E_i, C, u
-  float* qs = part + MKW * 8 * CK;             // [CK]
-  int* ixp = reinterpret_cast<int*>(qs + CK);  // [CK] free-pose index of the patch's source frame (-1: fixed / none)
-  uint32_t* smask = reinterpret_cast<uint32_t*>(ixp + CK);   // [2] free source frames of the chunk's edges (ping-pong)
+  float* part = Ed + ER * EDL;                 // [SC][MKW][8][CK] per-wave partial sums: 6 rows of E_i, C, u
+  float* qs = part + SC * MKW * 8 * CK;        // [CKS]
+  int* ixp = reinterpret_cast<int*>(qs + CKS); // [CKS] free-pose index of the patch's source frame (-1: fixed / none)
+  uint32_t* smask = reinterpret_cast<uint32_t*>(ixp + CKS);   // [2] free source frames of the chunk's edges (ping-pong)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: loops over a wave's share are uniform
@@ -127,7 +155,7 @@ __global__ __launch_bounds__(64 * MKW) CDV_MID_OCC void ba_mid_chunk_kernel(BaWi
 #pragma unroll
     for (int g = 0; g < 6; g++) ea[g] = emit_addr(pair_code_rt(g, br), N);
   }
-  const int n_chunks = (U + CK - 1) / CK;
+  const int n_wide = wide_count(A, U);
   if (tid < 2) smask[tid] = 0u;
   __syncthreads();
 
@@ -135,22 +163,12 @@ __global__ __launch_bounds__(64 * MKW) CDV_MID_OCC void ba_mid_chunk_kernel(BaWi
   CDV_STAMP(bam, sslot, 0);
   CDV_STAMP_RT(bam, sslot, 14);
   int par = 0;   // which mask word this pass fills
-  for (int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+  for (int wc = blockIdx.x; wc < n_wide; wc += gridDim.x) {
     int pass = 0, npass = 1;
     do {
-      const int r0 = chunk * CK;
-      const int r = r0 + p;
-      const bool live = r < U;
-      // ---- level 1 (see ba_win.hip): records of this lane's first-round slot and of the patch's first edge from the
-      // chunk-slot copy, the patch's CSR offsets and id; everything unconditional on clamped indices
+      int r0w, cntw;                             // first patch row of the wide chunk, its rows
+      wide_rows(A, wc, r0w, cntw);
       const int step = 4 * MKW;
-      int tb = 4 * wave;
-      const bool use_ell = TABLE || chunk < A.ell_chunks;
-      const int rs = live ? r : 0;
-      const int4* cell = use_ell ? reinterpret_cast<const int4*>(A.pell) : reinterpret_cast<const int4*>(A.prec);
-      int4 raw = cell[(use_ell && tb + so < ELL_SLOTS) ? cell_index(rs, tb + so) : 0];
-      int4 raw0 = cell[use_ell ? cell_index(rs, 0) : 0];
-      const PatchRow row = patch_row<TABLE>(A, rs);
       const float fx = A.intr[0], fy = A.intr[1], cx = A.intr[2], cy = A.intr[3];
       const float lm = A.lmbda[0];
       const EdgeRec safe = {A.prec[0], A.prec[1], A.prec[2]};   // stands in for slots that do not exist
@@ -162,6 +180,53 @@ __global__ __launch_bounds__(64 * MKW) CDV_MID_OCC void ba_mid_chunk_kernel(BaWi
         for (int i = tid; i < ER * EDL; i += 64 * MKW) Ed[i] = 0.f;
         if (tid == 0) smask[par ^ 1] = 0u;      // the word of the NEXT pass
       }
+      // ---- the free source frames of the wide chunk's edges: every edge's (of all its SC chunks), so that an edge list
+      // which gives one patch two source frames (never built by slam.py) is still summed where it belongs.  Records only:
+      // this pre-pass requests the first-round record of every sub-chunk at once ----
+      {
+        uint32_t mbits = 0u;
+#pragma unroll
+        for (int sc = 0; sc < SC; sc++) {
+          const int r = r0w + sc * CK + p;
+          const bool live = r < U && sc * CK + p < cntw;
+          const bool use_ell = TABLE || (r >> 4) < A.ell_chunks;
+          const int rs = live ? r : 0;
+          const int tb = 4 * wave;
+          const int4* cell = use_ell ? reinterpret_cast<const int4*>(A.pell) : reinterpret_cast<const int4*>(A.prec);
+          int4 raw = cell[(use_ell && tb + so < ELL_SLOTS) ? cell_index(rs, tb + so) : 0];
+          const PatchRow row = patch_row<TABLE>(A, rs);
+          const int plo = live ? row.plo : 0, deg = live ? row.deg : 0;
+          if (!use_ell || tb + so >= ELL_SLOTS) raw = reinterpret_cast<const int4*>(A.prec)[(tb + so < deg) ? plo + tb + so : 0];
+          for (int t = tb + so; t < deg; t += step) {   // the first trip uses the record in hand
+            const int4 rk = (t == tb + so) ? raw
+                                           : ((use_ell && t < ELL_SLOTS) ? cell[cell_index(rs, t)] : reinterpret_cast<const int4*>(A.prec)[plo + t]);
+            const int a = (HAS_II ? rk.y : (int)A.ii[rk.x]) - t0;
+            if (a >= 0 && a < N) mbits |= 1u << a;
+          }
+        }
+        if (mbits) atomicOr(&smask[par], mbits);
+      }
+      CDV_STAMP(bam, sslot, 13);
+      lds_barrier();   // accumulators are zero, the mask is complete (LDS only: loads stay in flight)
+      const uint32_t mask = smask[par];
+      if (pass == 0) npass = max(1, (__popc(mask) + 1) >> 1);
+      const int isrc0 = nth_bit(mask, 2 * pass), isrc1 = nth_bit(mask, 2 * pass + 1);   // free-pose indices or -1
+      CDV_STAMP(bam, sslot, 1);
+
+#pragma unroll 1
+      for (int sc = 0; sc < SC; sc++) {
+      const int r0 = r0w + sc * CK;
+      const int r = r0 + p;
+      const bool live = r < U && sc * CK + p < cntw;
+      // ---- level 1 (see ba_win.hip): records of this lane's first-round slot and of the patch's first edge from the
+      // chunk-slot copy, the patch's CSR offsets and id; everything unconditional on clamped indices
+      int tb = 4 * wave;
+      const bool use_ell = TABLE || (r0 >> 4) < A.ell_chunks;
+      const int rs = live ? r : 0;
+      const int4* cell = use_ell ? reinterpret_cast<const int4*>(A.pell) : reinterpret_cast<const int4*>(A.prec);
+      int4 raw = cell[(use_ell && tb + so < ELL_SLOTS) ? cell_index(rs, tb + so) : 0];
+      int4 raw0 = cell[use_ell ? cell_index(rs, 0) : 0];
+      const PatchRow row = patch_row<TABLE>(A, rs);
       const int plo = live ? row.plo : 0;
       const int deg = live ? row.deg : 0;
       const int64_t kxr = live ? row.id : 0;
@@ -181,32 +246,9 @@ __global__ __launch_bounds__(64 * MKW) CDV_MID_OCC void ba_mid_chunk_kernel(BaWi
 #pragma unroll
       for (int o = 8; o > 0; o >>= 1) maxdeg = max(maxdeg, __shfl_xor(maxdeg, o));
       maxdeg = __builtin_amdgcn_readfirstlane(maxdeg);
-      CDV_STAMP(bam, sslot, 12);
       const int a0 = ix_patch - t0;
       const int ixf_patch = (deg > 0 && a0 >= 0 && a0 < N) ? a0 : -1;
-      // ---- the free source frames of the chunk's edges: every edge's, so that an edge list which gives one patch two
-      // source frames (never built by slam.py) is still summed where it belongs
-      {
-        uint32_t mbits = 0u;
-        if (tb + so < deg) {
-          const int a = rec.ix - t0;
-          if (a >= 0 && a < N) mbits |= 1u << a;
-        }
-        if (maxdeg > step) {   // wave-uniform, rare: the records of this lane's later rounds
-          for (int t = tb + so + step; t < deg; t += step) {
-            const int4 rk = (use_ell && t < ELL_SLOTS) ? cell[cell_index(rs, t)] : reinterpret_cast<const int4*>(A.prec)[plo + t];
-            const int a = (HAS_II ? rk.y : (int)A.ii[rk.x]) - t0;
-            if (a >= 0 && a < N) mbits |= 1u << a;
-          }
-        }
-        if (mbits) atomicOr(&smask[par], mbits);
-      }
-      CDV_STAMP(bam, sslot, 13);
-      lds_barrier();   // accumulators are zero, the mask is complete (LDS only: the loads above stay in flight)
-      const uint32_t mask = smask[par];
-      if (pass == 0) npass = max(1, (__popc(mask) + 1) >> 1);
-      const int isrc0 = nth_bit(mask, 2 * pass), isrc1 = nth_bit(mask, 2 * pass + 1);   // free-pose indices or -1
-      CDV_STAMP(bam, sslot, 1);
+      const int pc = sc * CK + p;                // this lane's patch column of the wide chunk
 
       float Cacc = 0.f, uacc = 0.f;
       float eiacc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -251,13 +293,13 @@ __global__ __launch_bounds__(64 * MKW) CDV_MID_OCC void ba_mid_chunk_kernel(BaWi
               for (int c = 0; c < 6; c++) eiacc[c] += ei[c];      // the patch's own frame: summed in registers, fixed order
             } else {
 #pragma unroll
-              for (int c = 0; c < 6; c++) atomicAdd(&Ed[(6 * ixf + c) * EDL + p], ei[c]);
+              for (int c = 0; c < 6; c++) atomicAdd(&Ed[(6 * ixf + c) * EDL + pc], ei[c]);
             }
           }
           if (jxf >= 0) {
             // (patch, target frame) is unique per edge in a patch graph: ONE add onto zero per address (exact, order-free)
 #pragma unroll
-            for (int c = 0; c < 6; c++) atomicAdd(&Ed[(6 * jxf + c) * EDL + p], ej[c]);
+            for (int c = 0; c < 6; c++) atomicAdd(&Ed[(6 * jxf + c) * EDL + pc], ej[c]);
           }
         }
         // ---- B and v: per DPP row (16 patches of one target slot) the pairs (i, j) present, one leader pass each; an
@@ -296,6 +338,7 @@ __global__ __launch_bounds__(64 * MKW) CDV_MID_OCC void ba_mid_chunk_kernel(BaWi
           todo &= ~__ballot(match);
         }
       }
+      if (sc == 0) { CDV_STAMP(bam, sslot, 12); }
       CDV_STAMP(bam, sslot, 2);
       // ---- the wave's partial E_i, C, u: over its four target slots in fixed order, then published ----
       {
@@ -304,10 +347,11 @@ __global__ __launch_bounds__(64 * MKW) CDV_MID_OCC void ba_mid_chunk_kernel(BaWi
         for (int c = 0; c < 8; c++) {
           v[c] += __shfl_xor(v[c], 16);
           v[c] += __shfl_xor(v[c], 32);
-          if (sub == 0) part[(wave * 8 + c) * CK + p] = v[c];
+          if (sub == 0) part[((sc * MKW + wave) * 8 + c) * CK + p] = v[c];
         }
-        if (wave == 0 && sub == 0) ixp[p] = ixf_patch;
+        if (wave == 0 && sub == 0) ixp[pc] = ixf_patch;
       }
+      }   // sub-chunks
       lds_barrier();
       CDV_STAMP(bam, sslot, 9);
       // the wave copies of the footprint summed in fixed order into copy 0 (each thread its own 16-byte columns)
@@ -322,23 +366,26 @@ __global__ __launch_bounds__(64 * MKW) CDV_MID_OCC void ba_mid_chunk_kernel(BaWi
         }
       }
       if (pass == 0) {
-        if (tid < 6 * CK) {          // E_i rows of every patch: the wave partials in fixed order, onto the E_j entries
-          const int c = tid / CK, pp = tid - c * CK;
+        if (tid < 6 * CKS) {         // E_i rows of every patch: the wave partials in fixed order, onto the E_j entries
+          const int c = tid / CKS, pp = tid - c * CKS;
+          const int sc = pp / CK, pl = pp - sc * CK;
           float tot = 0.f;
 #pragma unroll
-          for (int w = 0; w < MKW; w++) tot += part[(w * 8 + c) * CK + pp];
+          for (int w = 0; w < MKW; w++) tot += part[((sc * MKW + w) * 8 + c) * CK + pl];
           const int ib = ixp[pp];
           if (ib >= 0) Ed[(6 * ib + c) * EDL + pp] += tot;
-        } else if (tid < 7 * CK) {   // C, u, q of every patch
-          const int pp = tid - 6 * CK;
+        } else if (tid < 7 * CKS) {  // C, u, q of every patch
+          const int pp = tid - 6 * CKS;
+          const int sc = pp / CK, pl = pp - sc * CK;
           float Ct = 0.f, ut = 0.f;
 #pragma unroll
-          for (int w = 0; w < MKW; w++) { Ct += part[(w * 8 + 6) * CK + pp]; ut += part[(w * 8 + 7) * CK + pp]; }
-          const int rr = r0 + pp;
-          const float q = (rr < U) ? 1.0f / (Ct + lm) : 0.f;      // Q = 1 / (C + lambda)   (ba_cuda.cu:548 semantics)
+          for (int w = 0; w < MKW; w++) { Ct += part[((sc * MKW + w) * 8 + 6) * CK + pl]; ut += part[((sc * MKW + w) * 8 + 7) * CK + pl]; }
+          const int rr = r0w + pp;
+          const bool mine = rr < U && pp < cntw;
+          const float q = mine ? 1.0f / (Ct + lm) : 0.f;      // Q = 1 / (C + lambda)   (ba_cuda.cu:548 semantics)
           qs[pp] = q;
-          Ed[n6 * EDL + pp] = (rr < U) ? ut : 0.f;
-          part[6 * CK + pp] = Ct;      // (wave 0's slot, consumed above) kept for the stores at the end of the pass
+          Ed[n6 * EDL + pp] = mine ? ut : 0.f;
+          Ed[(ER - 1) * EDL + pp] = Ct;  // (the last padding row of the block: nobody's tile reads beyond row 6N) kept for the debug dump
         }
       }
       CDV_STAMP(bam, sslot, 10);
@@ -380,9 +427,10 @@ __global__ __launch_bounds__(64 * MKW) CDV_MID_OCC void ba_mid_chunk_kernel(BaWi
       // three tiles of a wave in flight together (operand reads, the four dependent MFMA steps and the scattered writes of
       // one tile are ~1,500 cycles of latency when taken alone; 45 tiles at N = 22 are six per wave)
       constexpr int TU = 3;
-      float qk[4];
+      constexpr int KST = CKS / 4;       // k-steps of 4 patches
+      float qk[KST];
 #pragma unroll
-      for (int st = 0; st < 4; st++) qk[st] = qs[4 * st + g4];
+      for (int st = 0; st < KST; st++) qk[st] = qs[4 * st + g4];
       for (int p0 = wave; p0 < ntile; p0 += TU * MKW) {
         int ti[TU], tj[TU];
         bool on[TU];   // wave-uniform
@@ -401,19 +449,19 @@ __global__ __launch_bounds__(64 * MKW) CDV_MID_OCC void ba_mid_chunk_kernel(BaWi
 #pragma unroll
         for (int u = 0; u < TU; u++) acc[u] = cdv_float4{0.f, 0.f, 0.f, 0.f};
         if (pass == 0) {
-          float av[TU][4], bv[TU][4];
+          float av[TU][KST], bv[TU][KST];
 #pragma unroll
           for (int u = 0; u < TU; u++) {
             const float* pa = Ed + (16 * ti[u] + c16) * EDL;
             const float* pb = Ed + (16 * tj[u] + c16) * EDL;
 #pragma unroll
-            for (int st = 0; st < 4; st++) {
+            for (int st = 0; st < KST; st++) {
               av[u][st] = pa[4 * st + g4];
               bv[u][st] = pb[4 * st + g4];
             }
           }
 #pragma unroll
-          for (int st = 0; st < 4; st++) {
+          for (int st = 0; st < KST; st++) {
 #pragma unroll
             for (int u = 0; u < TU; u++)
               acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][st], qk[st] * bv[u][st], acc[u], 0, 0, 0);
@@ -469,27 +517,28 @@ __global__ __launch_bounds__(64 * MKW) CDV_MID_OCC void ba_mid_chunk_kernel(BaWi
         // ---- the chunk's E columns for the retraction (complete values; 16 bytes per lane: narrow stores are bound by
         // the CU's store issue, not by bandwidth).  Issued here, after the tile loop: the compiler makes whoever reuses a
         // store's data registers wait for the store (s_waitcnt vmcnt inside the tile loop: 2,000 cycles per tile) ----
-        if (tid < CK) {   // q, u (and C for the debug dump) of the chunk's patches
-          const int rr = r0 + tid;
+        if (tid < cntw && r0w + tid < A.U_stride) {   // q, u (and C for the debug dump) of the wide chunk's patches
+          const int rr = r0w + tid;
           A.qg[rr] = qs[tid];
           A.ug[rr] = Ed[n6 * EDL + tid];
           if (A.dbg) {
             float* dbgp = A.dbg + (size_t)n6 * n6 + 2 * n6;
-            dbgp[A.U_stride + rr] = part[6 * CK + tid];
+            dbgp[A.U_stride + rr] = Ed[(ER - 1) * EDL + tid];
             dbgp[2 * (size_t)A.U_stride + rr] = Ed[n6 * EDL + tid];
           }
         }
-        for (int i = tid; i < n6 * (CK / 4); i += 64 * MKW) {
-          const int row = i >> 2, p4 = (i & 3) * 4;
+        for (int i = tid; i < n6 * (CKS / 4); i += 64 * MKW) {
+          const int row = i / (CKS / 4), p4 = (i % (CKS / 4)) * 4;
+          if (r0w + p4 >= A.U_stride || p4 >= cntw) continue;   // beyond the rows / beyond this piece of the frame (a multiple of 4 rows)
           const float* e = Ed + row * EDL + p4;
           const cdv_float4 v = {e[0], e[1], e[2], e[3]};
-          *reinterpret_cast<cdv_float4*>(A.Edg + (size_t)row * A.U_stride + r0 + p4) = v;
+          *reinterpret_cast<cdv_float4*>(A.Edg + (size_t)row * A.U_stride + r0w + p4) = v;
           if (A.dbg)
-            *reinterpret_cast<cdv_float4*>(A.dbg + (size_t)n6 * n6 + 2 * n6 + 3 * (size_t)A.U_stride + (size_t)row * A.U_stride + r0 + p4) = v;
+            *reinterpret_cast<cdv_float4*>(A.dbg + (size_t)n6 * n6 + 2 * n6 + 3 * (size_t)A.U_stride + (size_t)row * A.U_stride + r0w + p4) = v;
         }
       }
       {
-        cdv_float4* dst = reinterpret_cast<cdv_float4*>(A.slabs + (size_t)chunk * slabf);
+        cdv_float4* dst = reinterpret_cast<cdv_float4*>(A.slabs + (size_t)wc * slabf);
         const cdv_float4* src = reinterpret_cast<const cdv_float4*>(Sd);
         if (pass == 0) {
           for (int i = tid; i < slabf / 4; i += 64 * MKW) dst[i] = src[i];
@@ -902,7 +951,7 @@ __global__ __launch_bounds__(256) void ba_mid_reduce_kernel(BaWinArgs A) {
   const int slabf = (TRI_N + n6 + 7) / 8 * 8;
   const int LD = solve_ld(n6);
   const int S4 = slabf / 4;
-  const int nsl = (U + CK - 1) / CK;
+  const int nsl = wide_count(A, U);      // one slab per wide chunk
   const int W = nsl <= 128 ? 1 : (nsl <= 256 ? 2 : 4);
   const int cols_per_wg = 16 / W;
   const int tid = threadIdx.x, g = tid & 15, slot = tid >> 4;
@@ -1146,7 +1195,8 @@ int cdv::cdv_ba_mid_iteration(const BaWinArgs& a, hipStream_t s) {
   // whatever the split.  Workgroups of 4 waves, two per CU -- so that the stress configuration's 294 chunks are resident at
   // once instead of taking a second round of 38 workgroups -- were measured: 49.1 against 41.7 us; the kernel is written
   // for either, CDV_MID_WAVES=4 selects them.)
-  const int n_ck = a.n_ck_cap < WIN_MAX_GRID ? a.n_ck_cap : WIN_MAX_GRID;
+  const int n_wide = a.ppf > 0 ? (a.tab_cap / a.ppf) * wide_per_frame(a.ppf) : cdv_div_up(a.n_ck_cap, SC);
+  const int n_ck = n_wide < WIN_MAX_GRID ? n_wide : WIN_MAX_GRID;
   const bool table = a.tab_cap > 0;
   static const int mkw_env = getenv("CDV_MID_WAVES") ? atoi(getenv("CDV_MID_WAVES")) : 8;
   const int mkw = mkw_env == 4 ? 4 : (mkw_env == 7 ? 7 : 8);

@@ -145,6 +145,8 @@ struct BaWinArgs {
   float* dbg;                        // iteration-0 dump (see cdv_ba_forward), may be NULL
   int token;                         // tag of this launch's in-launch hand-offs (arrival flags, dX granules): never 0, new per launch
   int test;                          // HO_TEST_*: hand-off fault injection (tests only), 0 in production
+  int ppf;                           // > 0: patches per frame, with a patch table whose capacity is a multiple of it and ppf % 4 == 0:
+                                     // the 10 < N <= 32 path cuts its wide chunks per frame (ba_mid.hip wide_rows); 0: plain
   const int32_t* dyn;                // != NULL: t0 and N are dyn[CDV_DYN_T0], dyn[CDV_DYN_NFREE] (sizes on the device; N <= the N above)
   int first;                         // first iteration of a call: clears the sticky status words
   int has_ii;                        // the graph's records carry the source frames (it was built with ii)

@@ -941,6 +941,7 @@ def point_cloud(poses, patches, intrinsics, ix):
 # ---------------------------------------------------------------------------------------------------
 
 _ba_ws = {}
+_ba_ppf = {}          # device -> the PPF hint its workspace currently carries
 _ba_counters = {}     # device -> pinned int32[4] event counters the kernels bump (cdv_ba_bind_status_counters)
 _ba_seen = {}         # device -> counts already reported
 BA_EVENTS = ("reduced system not positive definite", "more unique patches than U_max (update skipped)",
@@ -1048,6 +1049,10 @@ def ba_forward(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, PP
     if g.is_table:
         U_max = max(U_max, g.table_capacity)      # the slab kernels work through every slot of the table
     ws = _ba_workspace(dev, E, U_max, N)
+    ppf = int(PPF) if (PPF is not None and int(PPF) > 0) else 0      # cuda_ba.forward's PPF: a hint for the 10 < N <= 32 path
+    if _ba_ppf.get((dev, ws.data_ptr())) != ppf:
+        _lib.check(lib.cdv_ba_set_patches_per_frame(_p(ws), ppf), "cdv_ba_set_patches_per_frame")
+        _ba_ppf[(dev, ws.data_ptr())] = ppf
     dbg = None
     if debug:
         n6, Us = 6 * N, (U_max + 63) // 64 * 64

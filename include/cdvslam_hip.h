@@ -367,6 +367,14 @@ int cdv_ba_status(const void* ba_ws, int32_t* info_host, void* stream);
 int cdv_ba_bind_status_counters(void* ba_ws, int32_t* counters);
 
 /*
+ * The PPF argument of cuda_ba.forward (fastba/ba.cpp:31-45: patches per frame) as a hint on a workspace: when graph_ws holds a
+ * patch table whose capacity is a multiple of it (a frame's patches are then consecutive slots) and it is a multiple of 4, the
+ * 10 < N <= 32 path cuts its workgroups' patch ranges per frame -- no workgroup then mixes two source frames (+9 % on
+ * BASELINE configs[4]).  Affects summation order only.  0 forgets the hint.
+ */
+int cdv_ba_set_patches_per_frame(void* ba_ws, int patches_per_frame);
+
+/*
  * Fault injection for the in-launch hand-offs (tests only; process-wide, read by the following cdv_ba_forward calls; no
  * counterpart in the reference, whose kernels hand nothing over inside a launch):  0 off;  1 the solver of the N <= 32
  * paths stalls before it commits / the global path's back substitution withholds one block -- the waiting workgroups

@@ -35,8 +35,8 @@ for (i0, i1), nme in zip(((0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (5, 6)),
                           "E store + schur tiles -> LDS", "slab copy-out", "tail (last barrier)"]):
     d = ck[:, i1] - ck[:, i0]
     print("  %-36s median %7.0f  p90 %7.0f  max %7.0f cycles" % (nme, np.median(d), np.percentile(d, 90), d.max()))
-for (i0, i1), nme in zip(((0, 12), (12, 13), (13, 1), (2, 9), (9, 10), (10, 11), (11, 3), (3, 7), (7, 8), (8, 4)),
-                         ["first loads -> degrees known", "LDS zero + mask", "barrier", "partials -> barrier",
+for (i0, i1), nme in zip(((0, 13), (13, 1), (1, 12), (12, 2), (2, 9), (9, 10), (10, 11), (11, 3), (3, 7), (7, 8), (8, 4)),
+                         ["zero + records of both chunks + mask", "barrier", "chunk 0: loads + rounds", "chunk 1: loads + rounds", "partials -> barrier",
                           "copies summed + E_i, C, u", "barrier", "fold + barrier", "tile loop", "barrier", "B part scatter"]):
     d = ck[:, i1] - ck[:, i0]
     print("    %-34s median %7.0f  p90 %7.0f  max %7.0f cycles" % (nme, np.median(d), np.percentile(d, 90), d.max()))
