@@ -41,23 +41,31 @@ def corr_algorithmic_bytes(st):
     return E * 882 * 2 + E * 72 + E * 16 + U * C * 9 * 2 + maps
 
 
+CORR_LAUNCHES_PER_PAIR = 4
+
+
 def corr_event_ms(up, reps):
-    """median launch time of the fused correlation: HIP event pairs on the launching stream, recorded back to back inside a
-    stream of full steps and read after ONE synchronisation at the end"""
+    """average launch duration of the fused correlation: HIP event pairs on the launching stream around
+    CORR_LAUNCHES_PER_PAIR back-to-back launches, recorded inside a stream of full steps (two queued in front of every
+    pair, so that the device, not the host, sets the pace) and read after ONE synchronisation at the end; median over the
+    pairs, divided by the launches per pair.  (One launch per pair carries the pair's own packet handling -- 2.5 us on most
+    boxes of the pool, 6 us on some: 35.0 against 38.3 us for the same kernel, whose own duration rocprofv3 puts at 32.3 --
+    32.9 us on either; four launches per pair leave a quarter of that in the figure.)"""
     import numpy as np
     import torch
     pairs = []
     for _ in range(reps):
-        up.step()      # two steps in front of every pair: the GPU is still busy with them while the host enqueues the pair, so
-        up.step()      # the interval is the device's, not the host's hurry (a host-bound loop reads 3 us longer)
+        up.step()
+        up.step()
         coords = up.last_coords
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        up.corr_only(coords)
+        for _ in range(CORR_LAUNCHES_PER_PAIR):
+            up.corr_only(coords)
         e1.record()
         pairs.append((e0, e1))
     torch.cuda.synchronize()
-    return float(np.median([a.elapsed_time(b) for a, b in pairs]))
+    return float(np.median([a.elapsed_time(b) for a, b in pairs])) / CORR_LAUNCHES_PER_PAIR
 
 
 def closed_loop_ate(dev, frames=126, progress=None):
@@ -297,6 +305,9 @@ def main():
             for _ in range(50):
                 run_step()
             torch.cuda.synchronize()
+    dbg = os.environ.get("CDV_BENCH_DEBUG") == "1"
+    if dbg:
+        print("debug: corr event ms after settle: %.5f" % corr_event_ms(up, 50), file=sys.stderr, flush=True)
     for _ in range(args.warmup):
         run_step()
     # `--windows` timed windows of EXACTLY K steps each, every one bracketed by barrier + synchronise on both sides and
@@ -318,6 +329,8 @@ def main():
     # stream the metric is about.  The pair still includes ~2 us of packet handling around the kernel: rocprofv3's average
     # over the same command, profiles/r2_kernel_stats_default.txt, is the kernel's own duration)
     corr_ms = corr_event_ms(up, max(10, min(args.steps, 50)))
+    if dbg:
+        print("debug: corr event ms after the windows: %.5f, again %.5f" % (corr_ms, corr_event_ms(up, 50)), file=sys.stderr, flush=True)
     corr_bytes = corr_algorithmic_bytes(st)
     achieved = corr_bytes / (corr_ms * 1e-3) / 1e9
 
@@ -467,6 +480,7 @@ def main():
                                    "launch from separate rocprofv3 --pmc passes of the same workload, profiles/corr_traffic.json (%s)"
                                    % pmc.get("round", "r2")),
                 "kernel": "corr_fused2_kernel<24, 2, stream>", "avg_launch_ms": corr_ms, "algorithmic_bytes": corr_bytes,
+                "launches_per_event_pair": CORR_LAUNCHES_PER_PAIR,
             },
             "roofline_valu": roofline_valu,
             "stages_us": stages,
