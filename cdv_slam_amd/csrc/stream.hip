@@ -170,6 +170,10 @@ struct AfterArgs {
   int n_motion_blocks, n_point_blocks;
 };
 
+// one matching edge per lane: the three reprojections of flow_mag for its nine pixels.  (A group of 16 lanes per edge, one
+// pixel per lane, was measured: 27 against 10.6 us for the launch -- the matches are neighbours in the edge list (the
+// forward edges of a frame are appended together, slam.py:528-534), so ONE workgroup holds ~M of them and then needs six
+// trips of the pose algebra and its three dependent load levels instead of one.)
 __device__ __forceinline__ void motion_edge(const AfterArgs& A, int e, int dir) {
   const float* __restrict__ poses = A.poses;
   const float* __restrict__ intr = A.intr;
@@ -250,17 +254,25 @@ __global__ __launch_bounds__(256) void stream_after_kernel(const AfterArgs A) {
   __syncthreads();
   const int E = A.dyn[CDV_DYN_E];
   const int64_t fi = n - A.ki - 1, fj = n - A.ki + 1;
-  for (int e0 = b * 1024; e0 < E; e0 += A.n_motion_blocks * 1024) {   // workgroup-uniform trips
+  // (edges dealt to the workgroups in pieces of 64 -- wave w of workgroup b takes piece p0 + w nb + b --: the ~M matching
+  // forward edges are neighbours in the list and would otherwise all be one workgroup's)
+  const int nbk = A.n_motion_blocks;
+  for (int p0 = 0; p0 * 64 < E; p0 += 16 * nbk) {   // workgroup-uniform trips: ONE when the launch was sized for E (1024 edges per workgroup)
+    int64_t vi[4], vj[4];
+    int ve[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {     // four pieces per thread, their loads in flight together
+      ve[u] = (p0 + (4 * u + (tid >> 6)) * nbk + b) * 64 + (tid & 63);
+      const bool in = ve[u] < E;
+      vi[u] = in ? A.ii[ve[u]] : -1;
+      vj[u] = in ? A.jj[ve[u]] : -1;
+    }
 #pragma unroll
     for (int u = 0; u < 4; u++) {
-      const int e = e0 + u * 256 + tid;
-      if (e < E) {
-        const int64_t ix = A.ii[e], jx = A.jj[e];
-        const int dir = (ix == fi && jx == fj) ? 0 : ((ix == fj && jx == fi) ? 1 : -1);
-        if (dir >= 0) {
-          const int at = atomicAdd(&s_n, 1);
-          if (at < 1024) s_list[at] = (e << 1) | dir;
-        }
+      const int dir = (vi[u] == fi && vj[u] == fj) ? 0 : ((vi[u] == fj && vj[u] == fi) ? 1 : -1);
+      if (dir >= 0 && vi[u] >= 0) {
+        const int at = atomicAdd(&s_n, 1);
+        if (at < 1024) s_list[at] = (ve[u] << 1) | dir;
       }
     }
     __syncthreads();
@@ -321,22 +333,36 @@ struct RemoveArgs {
   int n_compact_blocks;           // compact launch: workgroups beyond these shift the frame buffers
 };
 
-// 0: kept, 1: pruned (stored), 2: gone; i, j, k come back shifted
-__device__ __forceinline__ int edge_fate(const RemoveArgs& A, int drop, int n_after, int kf, int64_t& i, int64_t& j, int64_t& k) {
+// 0: kept, 1: pruned (stored), 2: gone; i, j, k come back shifted.  f_same / f_down: ix[k] and ix[k - M] (the patch's frame if
+// it stays / if it moves down), requested by the caller before the decision is known
+__device__ __forceinline__ int edge_fate(const RemoveArgs& A, int drop, int n_after, int kf, int64_t& i, int64_t& j, int64_t& k,
+                                         int64_t f_same, int64_t f_down) {
+  bool moved = false;
   if (drop) {
     if (i == kf || j == kf) return 2;
-    if (i > kf) { k -= A.M; i -= 1; }
+    if (i > kf) { k -= A.M; i -= 1; moved = true; }
     if (j > kf) j -= 1;
   }
-  return (A.ix[k] < n_after - A.removal_window) ? 1 : 0;
+  return ((moved ? f_down : f_same) < n_after - A.removal_window) ? 1 : 0;
 }
 
 __global__ __launch_bounds__(256) void stream_count_kernel(const RemoveArgs A) {
   __shared__ int s_w[2][4];
-  __shared__ int s_last, s_drop;
+  __shared__ int s_drop;
   const int t = threadIdx.x, b = blockIdx.x;
   const int n = A.dyn_in[CDV_DYN_N], E = A.dyn_in[CDV_DYN_E];
   const int kf = n - A.ki;
+  // the edges first (their loads do not depend on the decision), then the decision, then their fates
+  const int64_t base = (int64_t)b * 1024;
+  int64_t vi[4], vj[4], vk[4], fs[4], fd[4];
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    const int64_t e = base + u * 256 + t;
+    const bool in = e < E;
+    vi[u] = in ? A.ii[e] : -1; vj[u] = in ? A.jj[e] : -1; vk[u] = in ? A.kk[e] : 0;
+  }
+#pragma unroll
+  for (int u = 0; u < 4; u++) { fs[u] = A.ix[vk[u]]; fd[u] = A.ix[vk[u] >= A.M ? vk[u] - A.M : 0]; }
   if (t < 64) {
     float motion;
     const int d = keyframe_decision(A.flow_buf, A.M, n, A.ki, A.thresh, A.force, t, &motion);
@@ -347,14 +373,11 @@ __global__ __launch_bounds__(256) void stream_count_kernel(const RemoveArgs A) {
   }
   __syncthreads();
   const int drop = s_drop;
-  const int64_t base = (int64_t)b * 1024;
   int c0 = 0, c1 = 0;
 #pragma unroll
   for (int u = 0; u < 4; u++) {
-    const int64_t e = base + u * 256 + t;
-    if (e < E) {
-      int64_t i = A.ii[e], j = A.jj[e], k = A.kk[e];
-      const int fate = edge_fate(A, drop, n - drop, kf, i, j, k);
+    if (vi[u] >= 0) {
+      const int fate = edge_fate(A, drop, n - drop, kf, vi[u], vj[u], vk[u], fs[u], fd[u]);
       c0 += fate == 0; c1 += fate == 1;
     }
   }
@@ -362,45 +385,11 @@ __global__ __launch_bounds__(256) void stream_count_kernel(const RemoveArgs A) {
   for (int o = 32; o > 0; o >>= 1) { c0 += __shfl_xor(c0, o); c1 += __shfl_xor(c1, o); }
   if ((t & 63) == 0) { s_w[0][t >> 6] = c0; s_w[1][t >> 6] = c1; }
   __syncthreads();
+  // plain stores, read by the compact LAUNCH that follows (every workgroup of it sums the counts in front of its own: a
+  // shared arrival counter here serialised the workgroups' atomics, ~90 ns each, and one workgroup then scanned for all)
   if (t == 0) {
-    __hip_atomic_store(&A.counts[2 * b], s_w[0][0] + s_w[0][1] + s_w[0][2] + s_w[0][3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&A.counts[2 * b + 1], s_w[1][0] + s_w[1][1] + s_w[1][2] + s_w[1][3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const int prev = __hip_atomic_fetch_add(&A.meta[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = prev == (int)gridDim.x - 1;
-    if (s_last) __hip_atomic_store(&A.meta[2], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __syncthreads();
-  if (!s_last) return;
-  if (t < 64) {   // the last workgroup to arrive: exclusive scans of both counts, the sizes after keyframe()
-    const int nb = (int)gridDim.x;
-    int run0 = 0, run1 = 0;
-    for (int q0 = 0; q0 < nb; q0 += 64) {
-      const int i = q0 + t;
-      const int v0 = (i < nb) ? __hip_atomic_load(&A.counts[2 * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-      const int v1 = (i < nb) ? __hip_atomic_load(&A.counts[2 * i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-      int inc0 = v0, inc1 = v1;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const int a0 = __shfl_up(inc0, o), a1 = __shfl_up(inc1, o);
-        if (t >= o) { inc0 += a0; inc1 += a1; }
-      }
-      if (i < nb) { A.counts[2 * i] = run0 + inc0 - v0; A.counts[2 * i + 1] = run1 + inc1 - v1; }
-      run0 += __shfl(inc0, 63);
-      run1 += __shfl(inc1, 63);
-    }
-    if (t == 0) {
-      for (int i = 0; i < CDV_DYN_WORDS; i++) A.dyn_out[i] = A.dyn_in[i];
-      A.dyn_out[CDV_DYN_E] = run0;
-      A.dyn_out[CDV_DYN_DROP] = drop;
-      A.dyn_out[CDV_DYN_N] = n - drop;
-      const int inac = A.dyn_in[CDV_DYN_EINAC];
-      if ((int64_t)inac + run1 > A.inac_cap) A.dyn_out[CDV_DYN_ERR] = 2;   // inactive edges beyond their capacity: not stored
-      else A.dyn_out[CDV_DYN_EINAC] = inac + run1;
-      if (A.mirror)
-        __hip_atomic_store(A.mirror, ((int64_t)A.dyn_in[CDV_DYN_FRAME] << 32) | (int64_t)(uint32_t)run0, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    A.counts[2 * b] = s_w[0][0] + s_w[0][1] + s_w[0][2] + s_w[0][3];
+    A.counts[2 * b + 1] = s_w[1][0] + s_w[1][1] + s_w[1][2] + s_w[1][3];
   }
 }
 
@@ -439,33 +428,72 @@ __device__ __forceinline__ void shift_buffers(const ShiftBufs& F, int bid, int t
 
 __global__ __launch_bounds__(256) void stream_compact_kernel(const RemoveArgs A, const ShiftBufs F) {
   __shared__ int s_pre[2][4][4];
+  __shared__ int s_drop, s_base[4];
   const int t = threadIdx.x, b = blockIdx.x, lane = t & 63, wave = t >> 6;
   const int n = A.dyn_in[CDV_DYN_N], E = A.dyn_in[CDV_DYN_E];
-  const int drop = A.dyn_out[CDV_DYN_DROP];      // written by the count launch in front
   const int kf = n - A.ki;
+  // this thread's edges and their patches' candidate frames first: nothing of it depends on the decision
+  int64_t vi[4], vj[4], vk[4], fs[4], fd[4];
+  const bool edge_wg = b < A.n_compact_blocks;
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    const int64_t e = (int64_t)b * 1024 + u * 256 + t;
+    const bool in = edge_wg && e < E;
+    vi[u] = in ? A.ii[e] : -1; vj[u] = in ? A.jj[e] : -1; vk[u] = in ? A.kk[e] : 0;
+  }
+#pragma unroll
+  for (int u = 0; u < 4; u++) { fs[u] = A.ix[vk[u]]; fd[u] = A.ix[vk[u] >= A.M ? vk[u] - A.M : 0]; }
+  // the decision again (the same 4 M words summed in the same order: the same answer in every workgroup of both launches),
+  // and -- by wave 1 -- the counts of the workgroups in front of this one and of all of them
+  if (t < 64) {
+    const int d = keyframe_decision(A.flow_buf, A.M, n, A.ki, A.thresh, A.force, t, nullptr);
+    if (t == 0) s_drop = d;
+  } else if (t < 128) {
+    int k0 = 0, p0 = 0, kt = 0, pt = 0;
+    for (int i = t - 64; i < A.nb; i += 64) {
+      const int c0 = A.counts[2 * i], c1 = A.counts[2 * i + 1];
+      kt += c0; pt += c1;
+      if (i < b) { k0 += c0; p0 += c1; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      k0 += __shfl_xor(k0, o); p0 += __shfl_xor(p0, o); kt += __shfl_xor(kt, o); pt += __shfl_xor(pt, o);
+    }
+    if (t == 64) { s_base[0] = k0; s_base[1] = p0; s_base[2] = kt; s_base[3] = pt; }
+  }
+  __syncthreads();
+  const int drop = s_drop;
+  const int kept_total = s_base[2], pruned_total = s_base[3];
+  const int inac = A.dyn_in[CDV_DYN_EINAC];
+  const bool inac_fits = (int64_t)inac + pruned_total <= A.inac_cap;
+  if (b == 0 && t == 0) {   // the sizes after keyframe()
+    for (int i = 0; i < CDV_DYN_WORDS; i++) A.dyn_out[i] = A.dyn_in[i];
+    A.dyn_out[CDV_DYN_E] = kept_total;
+    A.dyn_out[CDV_DYN_DROP] = drop;
+    A.dyn_out[CDV_DYN_N] = n - drop;
+    if (!inac_fits) A.dyn_out[CDV_DYN_ERR] = 2;   // inactive edges beyond their capacity: not stored
+    else A.dyn_out[CDV_DYN_EINAC] = inac + pruned_total;
+    if (A.mirror)
+      __hip_atomic_store(A.mirror, ((int64_t)A.dyn_in[CDV_DYN_FRAME] << 32) | (int64_t)(uint32_t)kept_total, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   if (b >= A.n_compact_blocks) {                 // the frame buffers: independent of the edge lists
     if (drop) shift_buffers(F, b - A.n_compact_blocks, t, kf, n);
     return;
   }
-  const int64_t r0 = A.dyn_in[CDV_DYN_EINAC];
-  const bool store = A.ii_r != nullptr && A.dyn_out[CDV_DYN_ERR] == 0;
+  const int64_t r0 = inac;
+  const bool store = A.ii_r != nullptr && inac_fits && A.dyn_in[CDV_DYN_ERR] == 0;
   const int64_t base = (int64_t)b * 1024;
   int fate[4];
-  int64_t vi[4], vj[4], vk[4];
 #pragma unroll
   for (int u = 0; u < 4; u++) {
-    const int64_t e = base + u * 256 + t;
     fate[u] = 2;
-    vi[u] = vj[u] = vk[u] = 0;
-    if (e < E) {
-      vi[u] = A.ii[e]; vj[u] = A.jj[e]; vk[u] = A.kk[e];
-      fate[u] = edge_fate(A, drop, n - drop, kf, vi[u], vj[u], vk[u]);
-    }
+    if (vi[u] >= 0) fate[u] = edge_fate(A, drop, n - drop, kf, vi[u], vj[u], vk[u], fs[u], fd[u]);
     const int w0 = __popcll(__ballot(fate[u] == 0)), w1 = __popcll(__ballot(fate[u] == 1));
     if (lane == 0) { s_pre[0][u][wave] = w0; s_pre[1][u][wave] = w1; }
   }
   __syncthreads();
-  const int kbase = A.counts[2 * b], pbase = A.counts[2 * b + 1];
+  const int kbase = s_base[0], pbase = s_base[1];
   int before0 = 0, before1 = 0;
 #pragma unroll
   for (int u = 0; u < 4; u++) {
