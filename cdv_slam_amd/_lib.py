@@ -107,7 +107,7 @@ def _stream_desc_fields():
     return ([(n, I) for n in ("M", "C", "H", "W", "mem", "pmem", "frames_capacity", "patch_lifetime", "removal_window",
                               "opt_window", "keyframe_index", "n_bufs")]
             + [(n, F) for n in ("keyframe_thresh", "gain", "pose_step")]
-            + [("slot", I), ("frames", I), ("cur", I)]
+            + [("slot", I), ("frames", I), ("cur", I), ("ring_blocks", I), ("fixed_bound", I)]
             + [(n, L) for n in ("edge_capacity", "inactive_capacity", "table_capacity", "graph_E_max", "graph_k_range")]
             + [("graph_ws_bytes", ctypes.c_size_t), ("ba_ws_bytes", ctypes.c_size_t)]
             + [(n, P) for n in ("poses", "patches", "intrinsics", "points", "ix", "fmap1_nhwc", "fmap2_nhwc", "gmap_planar", "gmap_pm")]

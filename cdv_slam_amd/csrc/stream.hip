@@ -671,14 +671,16 @@ extern "C" int cdv_stream_frame(cdv_stream_desc* D, const void* fmap_chw, const 
   CDV_REQUIRE(D->frames + 2 < D->frames_capacity, CDV_ERR_WORKSPACE, "cdv_stream_frame: frame buffer full");
   CDV_REQUIRE(D->opt_window >= 1 && D->opt_window <= 10, CDV_ERR_UNSUPPORTED, "cdv_stream_frame: OPTIMIZATION_WINDOW 1 .. 10");
   const int M = D->M;
-  auto blk = [&](int i) { return D->dyn + CDV_DYN_WORDS * (i & 7); };
+  const int ring = D->ring_blocks > 0 ? D->ring_blocks : 8;
+  CDV_REQUIRE(ring == 2 || ring == 4 || ring == 8, CDV_ERR_ARG, "cdv_stream_frame: ring_blocks must be 0 (8), 2, 4 or 8");
+  auto blk = [&](int i) { return D->dyn + CDV_DYN_WORDS * (i % ring); };
   const int a = D->slot, b = a + 1, e = a + 2;
   const int cur = D->cur & 1, oth = cur ^ 1;
   // an upper bound of the number of edges once this frame has arrived, without asking the device: what the last finished
   // keyframe() left (pinned word: frames << 32 | edges) plus 2 r M per frame begun since
   const int64_t seen = D->mirror_host ? *reinterpret_cast<volatile int64_t*>(D->mirror_host) : 0;
   int64_t Eb = (seen & 0xFFFFFFFFll) + ((int64_t)D->frames + 1 - (seen >> 32)) * 2 * D->patch_lifetime * M;
-  if (Eb > D->edge_capacity) Eb = D->edge_capacity;
+  if (Eb > D->edge_capacity || D->fixed_bound) Eb = D->edge_capacity;
   if (Eb < 1) Eb = 1;
   int rc = cdv_stream_frame_begin(blk(a), blk(b), D->ii[cur], D->jj[cur], D->kk[cur], D->target[cur], D->weight[cur], D->ix, D->edge_capacity, M,
                                   D->patch_lifetime, D->opt_window, D->frames_capacity, cx, cy, depth, fmap_chw, D->gmap_planar,
@@ -686,7 +688,7 @@ extern "C" int cdv_stream_frame(cdv_stream_desc* D, const void* fmap_chw, const 
   if (rc != CDV_OK) return rc;
   D->frames += 1;
   if (D->frames < 8) {   // before initialisation only the rings are filled (n == frames: no keyframe test has run yet)
-    D->slot = b & 7;
+    D->slot = b % ring;
     return cdv_frame_ingest(fmap_chw, D->fmap1_nhwc, D->fmap2_nhwc, nullptr, nullptr, (D->frames - 1) % D->mem, D->C, D->H, D->W,
                             D->gmap_planar, D->gmap_pm, (int64_t)D->pmem * M, (int64_t)((D->frames - 1) % D->pmem) * M, M, stream);
   }
@@ -710,6 +712,6 @@ extern "C" int cdv_stream_frame(cdv_stream_desc* D, const void* fmap_chw, const 
                            D->mirror_host, D->ws, stream);
   if (rc != CDV_OK) return rc;
   D->cur = oth;
-  D->slot = e & 7;
+  D->slot = e % ring;
   return CDV_OK;
 }

@@ -356,6 +356,54 @@ class DeviceStreamRunner:
         self._draw_ptrs = [tuple(V(self._draws.data_ptr() + 4 * self.M * (3 * f + k)) for k in range(3)) for f in range(self.N)]
         self._pool_ptrs = [V(t.data_ptr()) for t in self.pool]
 
+    # ---- two frames as one hipGraph ------------------------------------------------------------------------------
+    def capture_pair(self):
+        """Capture TWO frames (24 launches) as one hipGraph and return replay(): with every size on the device nothing in a
+        frame's launches depends on the host any more -- the dynamic blocks form a ring of two (a frame ends in the block it
+        started from), the edge lists are back in their first twin after two frames, the launches are sized for the edge
+        capacity.  The frames' inputs are read from fixed staging buffers (`stage_inputs(k, fmap, cx, cy, d)`, k = 0, 1) and
+        the keyframe test is the reference's own (decided on the device).  Call after initialisation (>= 8 frames) with an
+        even number of frames begun; the runner goes on in graph mode (frame() keeps working: same descriptor)."""
+        if self.frames < 8 or self.cur != 0:
+            raise RuntimeError("capture_pair: after initialisation, with the edge lists in their first twin (an even number of "
+                               "frames since frame 8)")
+        if not hasattr(self, "_desc"):
+            self._descriptor()
+        torch.cuda.synchronize()
+        D = self._desc
+        # continue from the current block in a ring of two: copy it to block 0
+        self.dyn[0].copy_(self.dyn[self.slot].clone())
+        D.slot, D.ring_blocks, D.fixed_bound = 0, 2, 1
+        self.slot = 0
+        M = self.M
+        self._stage = [(torch.empty_like(self.pool[0]), torch.empty(3, M, dtype=torch.float32, device=self.dev)) for _ in range(2)]
+        for k in range(2):
+            self.stage_inputs(k, self.pool[k], *self._draws[self.frames + k])
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        frames0 = self.frames
+        with torch.cuda.graph(g):
+            for k in range(2):
+                fm, dr = self._stage[k]
+                self.frame(drop=None, inputs=(fm, dr[0], dr[1], dr[2]))
+        torch.cuda.synchronize()
+        # the capture enqueued nothing: the host counters it advanced are taken back, replay() advances them
+        D.frames, D.slot, D.cur = frames0, 0, 0
+        self.frames, self.slot, self.cur = frames0, 0, 0
+        self._graph = g
+
+        def replay():
+            g.replay()
+            self.frames += 2
+            D.frames = self.frames
+        return replay
+
+    def stage_inputs(self, k, fmap, cx, cy, d):
+        """the (stubbed) network outputs of frame k (0 or 1) of the next replayed pair"""
+        fm, dr = self._stage[k]
+        fm.copy_(fmap)
+        dr[0].copy_(cx); dr[1].copy_(cy); dr[2].copy_(d)
+
     def frame(self, drop=False, inputs=None):
         """one incoming frame, enqueued (cdv_stream_frame: 12 launches behind ONE call); nothing is read back.  drop: None =
         the reference's keyframe test on the device, True / False = the caller decides; inputs: (fmap [C,h,w] f16, cx, cy,

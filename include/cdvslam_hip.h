@@ -608,6 +608,10 @@ typedef struct {
   int32_t M, C, H, W, mem, pmem, frames_capacity, patch_lifetime, removal_window, opt_window, keyframe_index, n_bufs;
   float keyframe_thresh, gain, pose_step;
   int32_t slot, frames, cur;         /* host state: current dynamic block, frames begun, which twin holds the edge lists */
+  int32_t ring_blocks;               /* dynamic blocks in `dyn`: 0 = 8.  2: a frame ends in the block it started from, so TWO frames
+                                        (the edge lists are back in their first twin then) are a closed sequence of launches */
+  int32_t fixed_bound;               /* != 0: every launch is sized for edge_capacity instead of the bound read from mirror_host --
+                                        together with ring_blocks = 2 a pair of frames can be captured as a hipGraph and replayed */
   int64_t edge_capacity, inactive_capacity, table_capacity, graph_E_max, graph_k_range;
   size_t graph_ws_bytes, ba_ws_bytes;
   float *poses, *patches, *intrinsics, *points;

@@ -136,3 +136,33 @@ def test_device_stream_equals_the_host_sized_stream_and_does_not_synchronise():
     torch.cuda.synchronize()
     t_all = time.perf_counter() - t0
     assert t_enq < t_all and a.counts()[0] > n
+
+
+def test_device_stream_two_frames_as_a_hipgraph():
+    """With every size on the device a frame's launches do not depend on the host: two frames (24 launches: the edge lists are
+    back in their first twin after two) captured as ONE hipGraph and replayed give the eager runner's bits -- edge lists,
+    keyframe count, poses, depths -- over 40 frames with the reference's keyframe test deciding on the device"""
+    from cdv_slam_amd.stream import DeviceStreamRunner
+    dev = torch.device(DEV)
+    kw = dict(buffer_size=160, pose_step=0.1)
+    a, b = DeviceStreamRunner(dev, **kw), DeviceStreamRunner(dev, **kw)
+    for f in range(20):
+        a.frame(drop=None)
+        b.frame(drop=None)
+    while a.cur != 0:          # capture needs the lists in their first twin
+        a.frame(drop=None)
+        b.frame(drop=None)
+    replay = a.capture_pair()
+    for pair in range(20):
+        f = a.frames
+        for k in range(2):
+            dr = a._draws[f + k]
+            a.stage_inputs(k, a.pool[(f + k) % 4], dr[0], dr[1], dr[2])
+            b.frame(drop=None, inputs=(b.pool[(f + k) % 4], dr[0], dr[1], dr[2]))
+        replay()
+    n, E = a.counts()
+    assert (n, E) == b.counts() and a.frames == b.frames and n < a.frames          # keyframes were dropped on the way
+    ea, eb = a.edges, b.edges
+    assert torch.equal(ea.ii, eb.ii) and torch.equal(ea.jj, eb.jj) and torch.equal(ea.kk, eb.kk)
+    assert torch.equal(a.poses[:n], b.poses[:n]) and torch.equal(a.patches[:n * a.M], b.patches[:n * a.M])
+    assert a.E_inac == b.E_inac
