@@ -166,3 +166,22 @@ def test_device_stream_two_frames_as_a_hipgraph():
     assert torch.equal(ea.ii, eb.ii) and torch.equal(ea.jj, eb.jj) and torch.equal(ea.kk, eb.kk)
     assert torch.equal(a.poses[:n], b.poses[:n]) and torch.equal(a.patches[:n * a.M], b.patches[:n * a.M])
     assert a.E_inac == b.E_inac
+
+
+def test_device_stream_reports_a_capacity_error_instead_of_writing_past_it():
+    """the device cannot raise: when a frame's edges would not fit the edge buffers the begin launch sets the error word of
+    the dynamic block and appends nothing; every later frame leaves the stream as it is; counts() raises on the host"""
+    from cdv_slam_amd.stream import DeviceStreamRunner
+    run = DeviceStreamRunner(torch.device(DEV), M=24, ht=192, wd=256, buffer_size=64)
+    for f in range(6):
+        run.frame(drop=False)
+    n0, E0 = run.counts()
+    run._desc.edge_capacity = E0 + 100          # the next frame's 2 r M edges do not fit any more
+    guard = run._ii[run.cur, E0:E0 + 2000].clone()
+    for f in range(3):
+        run.frame(drop=False)
+    with pytest.raises(RuntimeError, match="capacity exceeded"):
+        run.counts()
+    blk = run.dyn[run.slot].cpu()
+    assert (int(blk[0]), int(blk[1])) == (n0, E0) and int(blk[7]) == 1
+    assert torch.equal(run._ii[run.cur, E0:E0 + 2000], guard)      # nothing was appended
