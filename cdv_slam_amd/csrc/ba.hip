@@ -573,11 +573,12 @@ __global__ __launch_bounds__(256) void ba_schur_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void ba_big_fold_kernel(float* __restrict__ sy, int sy_stride, int n, int npad,
                                                           float* __restrict__ A, const int32_t* __restrict__ gmeta,
                                                           float* __restrict__ dbg, const int32_t* __restrict__ info,
-                                                          uint64_t* __restrict__ xg) {
+                                                          uint64_t* __restrict__ xg, int32_t* __restrict__ fctl, int n_fctl) {
   if (gmeta[GM_ERROR] || info[1]) return;
   // the granules of the back-substitution launch lose their tags (per-launch tokens from host state at enqueue time: a
-  // captured hipGraph replays the same ones)
+  // captured hipGraph replays the same ones); the factorisation launch's ticket counter, abort word and block flags go down
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npad; i += gridDim.x * blockDim.x) xg[i] = 0ull;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_fctl; i += gridDim.x * blockDim.x) fctl[i] = 0;
   const int64_t total = (int64_t)(npad + 1) * npad;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     const int a = (int)(idx / npad), b = (int)(idx - (int64_t)a * npad);
@@ -953,6 +954,7 @@ __global__ __launch_bounds__(256) void ba_big_backsolve_kernel(float* __restrict
                                                                const int32_t* __restrict__ gmeta, float* __restrict__ dbg,
                                                                int32_t* __restrict__ info, int test) {
   if (gmeta[GM_ERROR] || info[1]) return;
+  if (info[BI_HANDOFF]) return;   // the factorisation in front gave up on a hand-off: nothing of this iteration is applied
   __shared__ __attribute__((aligned(16))) float Lb[CNB * CLD];
   __shared__ float xs[CNB];
   __shared__ int s_ok;
@@ -1310,6 +1312,7 @@ static int ba_forward_impl(float* poses, float* patches, const float* intrinsics
   const int n_chunks = cdv_div_up(L.U_max, BA_CHUNK);
   const int rb = cdv_div_up(L.U_max > N ? L.U_max : N, 64);
   const int npad = (int)L.npad, nbk = npad / CNB;
+  static const bool block_steps = []() { const char* e = getenv("CDV_BA_BLOCK_STEPS"); return e && e[0] == '1'; }();
   if (big) {
     // the frame-pair index of this call's edges (both iterations use it): keys, an ordinary index build over them, the
     // (a, b) -> pair table
@@ -1345,13 +1348,20 @@ static int ba_forward_impl(float* poses, float* patches, const float* intrinsics
       hipLaunchKernelGGL(ba_schur_kernel, dim3(npan * (npan + 1) / 2), dim3(256), 0, s, lmbda, N, gv.meta, sy, Cg, ug, Edg,
                          (int)L.U_stride, cmask, n_chunks, info);
       hipLaunchKernelGGL(ba_big_fold_kernel, dim3(1024), dim3(256), 0, s, sy, (int)L.sy_stride, n6i, npad, Abig, gv.meta,
-                         d, info, (uint64_t*)(b + L.xgran));
-      // block step 0: the panel alone; block step kb >= 1: the panel together with what step kb - 1 owes the matrix
-      hipLaunchKernelGGL(ba_big_panel_kernel, dim3(nbk + 1), dim3(64), 0, s, Abig, npad, 0, gv.meta, info);
-      for (int kb = 1; kb < nbk; kb++) {
-        const int T = nbk - kb - 1;
-        hipLaunchKernelGGL(ba_big_step_kernel, dim3(nbk - kb + 1 + T * (T + 1) / 2 + T), dim3(STEP_T), 0, s, Abig, npad, kb, gv.meta,
-                           info);
+                         d, info, (uint64_t*)(b + L.xgran), (int32_t*)(b + L.fctl), fac_ctl_words(nbk));
+      if (!block_steps) {
+        // the factorisation as one launch of block work items (ba_factor.hip)
+        const int rcf = cdv_ba_big_factor(Abig, npad, (int32_t*)(b + L.fctl), gv.meta, info, g_handoff_test.load(), s);
+        if (rcf != CDV_OK) return rcf;
+      } else {
+        // (rounds 1-3, kept for comparison: CDV_BA_BLOCK_STEPS=1) one launch per block column.  Block step 0: the panel alone;
+        // block step kb >= 1: the panel together with what step kb - 1 owes the matrix
+        hipLaunchKernelGGL(ba_big_panel_kernel, dim3(nbk + 1), dim3(64), 0, s, Abig, npad, 0, gv.meta, info);
+        for (int kb = 1; kb < nbk; kb++) {
+          const int T = nbk - kb - 1;
+          hipLaunchKernelGGL(ba_big_step_kernel, dim3(nbk - kb + 1 + T * (T + 1) / 2 + T), dim3(STEP_T), 0, s, Abig, npad, kb, gv.meta,
+                             info);
+        }
       }
       hipLaunchKernelGGL(ba_big_backsolve_kernel, dim3(cdv_div_up(npad, 256)), dim3(256), 0, s, Abig, npad, n6i, dXg,
                          (uint64_t*)(b + L.xgran), token_base + 1 + itr, gv.meta, d, info, g_handoff_test.load());
@@ -1379,9 +1389,11 @@ static int ba_forward_impl(float* poses, float* patches, const float* intrinsics
 //   0 off; 1 the solver of the N <= 32 paths stalls BEFORE its commit (the retract workgroups abandon: nothing is applied) --
 //   on the global path the back substitution withholds one block's solution (its readers time out: nothing is applied);
 //   2 the solver stalls AFTER its commit (the retract workgroups lose their patience, learn that the solution is coming and
-//   wait on: the update is applied as usual).  The waits are shortened so that a test takes milliseconds.
+//   wait on: the update is applied as usual);  3 (global path) a diagonal block of the factorisation launch never raises its flag
+//   (everybody who needs it times out, the launch drains, nothing is applied).  The waits are shortened so that a test takes
+//   milliseconds.
 extern "C" int cdv_ba_test_handoff(int mode) {
-  CDV_REQUIRE(mode >= 0 && mode <= 2, CDV_ERR_ARG, "cdv_ba_test_handoff: mode 0, 1 or 2");
+  CDV_REQUIRE(mode >= 0 && mode <= 3, CDV_ERR_ARG, "cdv_ba_test_handoff: mode 0 .. 3");
   g_handoff_test.store(mode);
   return CDV_OK;
 }

@@ -38,7 +38,8 @@ constexpr int HAND_WORDS = 16 + WIN_MAX_RW;      // hand-off words: [HO_VERDICT]
 constexpr int HO_VERDICT = 2;                    // index into the hand-off words
 enum { HO_UNDECIDED = 0, HO_COMMITTED = 1, HO_ABANDONED = 2 };
 // test switch (cdv_ba_test_handoff): the solver stalls before / after its commit, the retract workgroups' patience is short
-enum { HO_TEST_OFF = 0, HO_TEST_STALL_BEFORE = 1, HO_TEST_STALL_AFTER = 2 };
+enum { HO_TEST_OFF = 0, HO_TEST_STALL_BEFORE = 1, HO_TEST_STALL_AFTER = 2,
+       HO_TEST_FACTOR = 3 };   // global path: a block of the factorisation launch never raises its flag
 
 // ---- the same design for 10 < N <= BA_NMAX free poses (ba_mid.hip): the slab is the packed triangle of a 6N x 6N system
 constexpr int MID_N = BA_NMAX;
@@ -53,8 +54,12 @@ __host__ __device__ inline int solve_ld(int n) { return (n + 27) / 32 * 32 + 4; 
 // status words of a workspace (int32 info[16] on the device; cdv_ba_status reads the first four)
 enum { BI_CHOL = 0, BI_OVERFLOW = 1, BI_HANDOFF = 2, BI_GRAPH = 3 };
 
+// control words of the factorisation launch (ba_factor.hip): 16 + one flag per block of the lower triangle and of the
+// right-hand-side row, rounded to 16 bytes
+inline int fac_ctl_words(int nb) { return (16 + (nb + 1) * nb + 3) / 4 * 4; }
+
 struct BaLayout {
-  size_t sy, C, u, Ed, cmask, zero_bytes, q, dX, info, Abig, xgran, slabs, ared, hand, pnext, ptab, pdiag, pkeys, pgraph, pgraph_bytes, total;
+  size_t sy, C, u, Ed, cmask, zero_bytes, q, dX, info, Abig, xgran, fctl, slabs, ared, hand, pnext, ptab, pdiag, pkeys, pgraph, pgraph_bytes, total;
   int64_t E_max, pair_cap, pair_range;  // global path: edges the pair index is sized for, frame pairs it can hold, key range
   int64_t npad;                         // global-BA path: 6 N rounded up to the Cholesky block (0: not used)
   int64_t U_max, U_stride, sy_stride;   // sy_stride: floats between two copies of [S | y]
@@ -79,12 +84,14 @@ inline BaLayout ba_layout(int64_t U_max, int N_max, int64_t E_max = 1) {
   L.q = o;    o = align256(o + sizeof(float) * (size_t)L.U_stride);
   L.dX = o;   o = align256(o + sizeof(float) * (n6 + 8));
   L.info = o; o = align256(o + sizeof(int32_t) * 16 + sizeof(uint64_t) * MID_GRAN);   // 16 words + the dX granules of the solve -> retract hand-off
-  L.npad = 0; L.Abig = o; L.xgran = o;
+  L.npad = 0; L.Abig = o; L.xgran = o; L.fctl = o;
   if (N_max > BA_NMAX) {   // working copy of [S ; y^T] for the blocked Cholesky, padded with identity to 64-blocks
     L.npad = (int64_t)((n6 + CNB - 1) / CNB * CNB);
     o = align256(o + sizeof(float) * (size_t)(L.npad + 1) * (size_t)L.npad);
     // the solution as {launch token, value} granules: the hand-off between the workgroups of the back-substitution launch
     L.xgran = o; o = align256(o + sizeof(uint64_t) * (size_t)L.npad);
+    // the factorisation launch's ticket counter, abort word and one flag per 64 x 64 block (ba_factor.hip)
+    L.fctl = o; o = align256(o + sizeof(int32_t) * (size_t)fac_ctl_words((int)(L.npad / CNB)));
   }
   // window path: one partial system per chunk of 16 patches, the reduced system, the arrival counter
   L.n_ck = 0; L.slabs = o; L.ared = o; L.hand = o; L.pnext = o;
@@ -151,6 +158,11 @@ struct BaWinArgs {
   int first;                         // first iteration of a call: clears the sticky status words
   int has_ii;                        // the graph's records carry the source frames (it was built with ii)
 };
+
+// the blocked Cholesky factorisation of the global path as one launch (ba_factor.hip): A [(npad + 1)][npad] in place; ctl
+// (fac_ctl_words(npad / CNB) words) must be zero when the launch starts
+int cdv_ba_big_factor(float* A, int npad, int32_t* ctl, const int32_t* gmeta, int32_t* info, int test, hipStream_t s);
+int cdv_ba_big_factor_items(int nb);
 
 // one Gauss-Newton iteration of the window path: two launches on `s`
 int cdv_ba_window_iteration(const BaWinArgs& a, hipStream_t s);

@@ -379,7 +379,8 @@ int cdv_ba_set_patches_per_frame(void* ba_ws, int patches_per_frame);
  * counterpart in the reference, whose kernels hand nothing over inside a launch):  0 off;  1 the solver of the N <= 32
  * paths stalls before it commits / the global path's back substitution withholds one block -- the waiting workgroups
  * give up, the status word `hand-off` is set and NOTHING of the iteration is applied;  2 the solver stalls after its
- * commit -- the waiting workgroups lose patience, learn that the solution is coming, wait on, and the update is applied.
+ * commit -- the waiting workgroups lose patience, learn that the solution is coming, wait on, and the update is applied;
+ * 3 (global path) a diagonal block of the one-launch factorisation never raises its flag -- as 1: nothing is applied.
  */
 int cdv_ba_test_handoff(int mode);
 

@@ -1360,14 +1360,16 @@ def test_ba_window_irregular_graph(variant):
     ba_checks.check_end_state("small", st, poses, patches, p64, x64)
 
 
-@pytest.mark.parametrize("name,mode", [("default", 1), ("default", 2), ("stress", 1), ("stress", 2), ("global", 1)])
+@pytest.mark.parametrize("name,mode", [("default", 1), ("default", 2), ("stress", 1), ("stress", 2), ("global", 1), ("global", 3)])
 def test_ba_handoff_is_all_or_nothing(name, mode):
     """The solve -> retract hand-off inside a finish launch, with faults injected (cdv_ba_test_handoff): mode 1 -- the solver
     stalls before its commit (N <= 32: the retract workgroups run out of patience, decide ABANDONED, the solver publishes
     nothing) / the global back substitution withholds a block: the hand-off word is set, the event is counted, and poses
     and patches are BIT-IDENTICAL to the input -- in every workgroup, not in some.  mode 2 -- the solver stalls after its
     commit: the retract workgroups lose patience, learn that the solution is coming, wait on; the result is the undisturbed
-    one bit for bit.  Afterwards the workspace works as if nothing had happened."""
+    one bit for bit.  mode 3 (global path) -- a diagonal block of the one-launch factorisation never raises its flag: every
+    workgroup that needs it gives up, the launch drains, nothing is applied.  Afterwards the workspace works as if nothing
+    had happened."""
     from cdv_slam_amd import _lib
     lib = _lib.load()
     st = synth.make_state(name, features=False)
@@ -1387,7 +1389,7 @@ def test_ba_handoff_is_all_or_nothing(name, mode):
         call(poses, patches)
         torch.cuda.synchronize()
         info = ops.ba_status(dev, raise_on_error=False)
-        if mode == 1:
+        if mode in (1, 3):
             assert info[2] == 1, info
             assert torch.equal(poses, T(st.poses)) and torch.equal(patches, T(st.patches))       # nothing applied, anywhere
             assert ops.ba_event_counts(dev)[2] > before[2]
