@@ -4,24 +4,37 @@
 // The matrix A [(npad + 1)][npad] (ba.hip ba_big_fold_kernel: S with the damping of ba_cuda.cu:589, identity on the padded
 // diagonal, row npad = y^T) is cut into 64 x 64 blocks; the result -- L in the lower blocks, z = L^-1 y in the last row --
 // is what ba_big_backsolve_kernel reads.  Rounds 1-3 ran one launch per block column (28 x 26 us at N = 299: a one-wave
-// panel chain behind a launch boundary each).  Here a block is a WORK ITEM that is computed left-looking by one workgroup,
+// panel chain behind a launch boundary each).  Here a block is computed LEFT-LOOKING,
 //
 //     block (r, c) = ( A(r, c) - sum_{k < c} L(r, k) L(c, k)^T ) L(c, c)^-T         (the right-hand side: r = nb, one row)
 //
-// with the sum kept in the matrix cores' accumulators for the whole life of the item, the inputs taken from the workgroups
-// that produced them as soon as their flags are up (the hand-off of the programming guide: write-through stores, one flag
-// per block, every load of a handed-off byte past the L1), and nothing written but the finished block.  Items are dealt by
-// a ticket counter in an order in which every item only needs items with smaller tickets: the lowest unfinished ticket is
-// always held by a running workgroup whose inputs are complete, so the launch finishes whatever the number of resident
-// workgroups and whatever order they start in.
+// with the sum kept in the matrix cores' accumulators, the inputs taken from whoever produced them as soon as their flags
+// are up (the hand-off of the programming guide: write-through stores, one flag per block, every load of a handed-off byte
+// past the L1), and nothing written but finished blocks.
 //
-// What is on the critical path is the chain of diagonal blocks.  The work item D(c) owns the diagonal block (c, c) AND its
-// left neighbour (c, c - 1): when L(c - 1, c - 1) arrives it solves the neighbour (one wave, forward substitution along the
-// rows), takes the neighbour's product off the diagonal block on the matrix cores and factors it (one wave, the register
-// scheme of ba_win.hip's solver) -- one hand-off per block column instead of two, and no launch boundary.
+// Two kinds of workgroup share the launch:
+//  * ONE chain workgroup (whoever draws ticket 0) walks down the diagonal and never hands the critical path to anybody:
+//    stage c = factor the diagonal block (c, c) (wave 0, the register scheme of ba_win.hip's solver), solve its lower
+//    neighbour (c + 1, c) against it (wave 0, forward substitution along the rows), take the neighbour's product off the
+//    next diagonal block (matrix cores) -- L(c, c) and L(c + 1, c) never leave the LDS on their way to the next stage.  Four
+//    helper waves prepare the next stage's two blocks underneath (fetch what item workgroups pre-accumulated, apply the one
+//    product that was still missing), two publisher waves write L(c, c) and L(c + 1, c) out for everybody else.  The waves of
+//    this workgroup meet through counters in LDS, not through s_barrier: a publisher that waits for its stores to drain holds
+//    nobody up.
+//  * item workgroups draw the other tickets: O items -- a block (r, c), r >= c + 2, or the right-hand side's block of column
+//    c: all its products, then the solve against L(c, c); P items -- the two blocks of block row c that the chain will take
+//    over (its neighbour block (c, c - 1) and the diagonal block), with the products of the columns k <= c - 3.
+//    Tickets are dealt in an order in which an item only needs items with smaller tickets and chain stages that, in turn,
+//    only need such items: the lowest unfinished ticket is always held by a running workgroup whose inputs will arrive, so the
+//    launch finishes whatever the number of resident workgroups and the order they start in.
 #include <hip/hip_runtime.h>
 
 #include "cdv_ba.h"
+
+CDV_STAMP_TU(baf)
+// (only the waves with a slot stamp: hundreds of waves storing to one dummy slot queue up behind each other for ~100 us)
+#define FSTAMP(id) do { CDV_IF_STAMPS(if (sslot >= 0) { CDV_STAMP(baf, sslot, id); }) } while (0)
+#define FSTAMP_RT(id) do { CDV_IF_STAMPS(if (sslot >= 0) { CDV_STAMP_RT(baf, sslot, id); }) } while (0)
 
 namespace cdv {
 namespace {
@@ -29,8 +42,6 @@ namespace {
 constexpr int FT = 512;                 // threads of a workgroup: 8 waves, two 16 x 16 tiles of a block each
 constexpr int FLD = CNB + 4;            // LDS row stride of a block (16-byte aligned rows, 8 rows cover the banks once)
 constexpr int FBUF = CNB * FLD;         // floats of a block in LDS
-constexpr int FAC_PAD = 16 * 1024;      // bytes of dynamic LDS asked for on top of the 70 KB used: more than half a CU's together, so
-                                        // that ONE workgroup runs per CU (the form of the hand-off used here was measured that way)
 constexpr int AUX_SC1 = 16;             // buffer load / store past the L1, write-through
 
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -38,33 +49,30 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 struct FacArgs {
   float* A;
-  int npad, nb, total;
-  int32_t* ctl;            // [0] ticket counter, [1] abort word, [FAC_CTL + r * nb + c] flag of block (r, c), r = nb: right-hand side
+  int npad, nb, total;     // total: tickets (1 + items)
+  int32_t* ctl;            // [0] ticket counter, [1] abort word, [16 + r * nb + c] flag of block (r, c) (r = nb: right-hand side),
+                           // [16 + (nb + 1) * nb + c] flag of the P item of block row c
   const int32_t* gmeta;
   int32_t* info;
   int test;
 };
 
-// ticket -> work item.  Order: D(0); then for g = 1 .. nb: D(g) (g < nb) followed by O(g - 1) = the blocks (r, g - 1),
-// r = g + 1 .. nb - 1, and the right-hand side's block of column g - 1.
-//   D(c) needs L(c, k), L(c - 1, k), k <= c - 2 (items of O(k), or D(c - 1) for (c - 1, c - 2)) and L(c - 1, c - 1) (D(c - 1));
-//   (r, c) of O(c) needs L(r, k) (O(k), k < c), L(c, k) (O(k) for k < c - 1, D(c) for k = c - 1) and L(c, c) (D(c)):
-// all with smaller tickets.
+// ticket (>= 1) -> item.  Order: for g = 0 .. nb - 1: O(g) = the blocks (r, g), r = g + 2 .. nb - 1, and the right-hand side's
+// block of column g; then P(g + 3).  What an item needs:
+//   (r, c) of O(c): L(r, k), k < c (items of O(k)); L(c, k), k <= c - 2 (O(k)); L(c, c - 1) and L(c, c) (chain stages c - 1, c);
+//   P(c):           L(c, k), L(c - 1, k), k <= c - 3 (items of O(k), k <= c - 3);
+//   chain stage c (factor (c, c), solve (c + 1, c)): P(c + 1), the block (c + 1, c - 1) of O(c - 1), chain stage c - 1:
+// smaller tickets, or chain stages that need nothing but smaller tickets.
 __device__ __forceinline__ bool fac_decode(int t, int nb, int& kind, int& c, int& r) {
-  if (t == 0) { kind = 0; c = 0; r = 0; return true; }
   t -= 1;
-  for (int g = 1; g <= nb; g++) {
-    const int nd = g < nb ? 1 : 0;
-    const int co = g - 1;
-    const int nrows = nb - co - 2 > 0 ? nb - co - 2 : 0;
-    const int sz = nd + nrows + 1;
-    if (t < sz) {
-      if (t < nd) { kind = 0; c = g; r = g; return true; }
-      t -= nd;
-      kind = 1; c = co; r = t < nrows ? co + 2 + t : nb;
-      return true;
+  for (int g = 0; g < nb; g++) {
+    const int nrows = nb - g - 2 > 0 ? nb - g - 2 : 0;
+    if (t < nrows + 1) { kind = 1; c = g; r = t < nrows ? g + 2 + t : nb; return true; }
+    t -= nrows + 1;
+    if (g + 3 < nb) {
+      if (t == 0) { kind = 2; c = g + 3; r = g + 3; return true; }
+      t -= 1;
     }
-    t -= sz;
   }
   return false;
 }
@@ -73,7 +81,7 @@ __device__ __forceinline__ int ld_flag(const int32_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// wave 0: wait until both flags are up (f1 may equal f0).  false: gave up (the abort word is set: by us on a timeout, or by
+// one wave: wait until both flags are up (f1 may equal f0).  false: gave up (the abort word is set: by us on a timeout, or by
 // another workgroup) -- uniform over the wave.
 __device__ __forceinline__ bool fac_wait(const int32_t* f0, const int32_t* f1, int32_t* ctl, int32_t* info, int lane, int test) {
   const int limit = test == HO_TEST_FACTOR ? (1 << 11) : (1 << 21);
@@ -96,6 +104,34 @@ __device__ __forceinline__ bool fac_wait(const int32_t* f0, const int32_t* f1, i
   return false;
 }
 
+// ---- the waves of the chain workgroup meet through words in LDS.  The LDS unit executes a wave's instructions in order and
+// holds the only copy of the data: a wave that has read a word's new value reads everything its writer wrote before it.
+// Only the compiler has to be kept from moving accesses across.
+enum { SY_L = 0, SY_X = 1, SY_S = 2, SY_U = 3, SY_PUB1 = 4, SY_PUB2 = 5, SY_ABORT = 6 };
+__device__ __forceinline__ int lds_get(int* sy, int word) {
+  return __hip_atomic_load(&sy[word], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_set(int* sy, int word, int value) {
+  __hip_atomic_store(&sy[word], value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ bool lds_wait(int* sy, int word, int target) {
+  for (int spins = 0; spins < (1 << 24); spins++) {
+    if (lds_get(sy, word) >= target) { asm volatile("" ::: "memory"); return true; }
+    if (lds_get(sy, SY_ABORT)) return false;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  lds_set(sy, SY_ABORT, 1);
+  return false;
+}
+__device__ __forceinline__ void lds_post(int* sy, int word, int value) {   // one writer per word
+  asm volatile("" ::: "memory");
+  lds_set(sy, word, value);
+}
+__device__ __forceinline__ void lds_arrive(int* sy, int word, int lane) {           // several writers: a counter
+  asm volatile("" ::: "memory");
+  if (lane == 0) __hip_atomic_fetch_add(&sy[word], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 __device__ __forceinline__ cdv_float4 ld4(__amdgpu_buffer_rsrc_t rs, size_t elem) {
   return __builtin_bit_cast(cdv_float4, (i32x4)__builtin_amdgcn_raw_buffer_load_b128(rs, (int)(unsigned)(elem * 4u), 0, AUX_SC1));
 }
@@ -104,6 +140,24 @@ __device__ __forceinline__ float ld1(__amdgpu_buffer_rsrc_t rs, size_t elem) {
 }
 __device__ __forceinline__ void st4(__amdgpu_buffer_rsrc_t rs, size_t elem, cdv_float4 v) {
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), rs, (int)(unsigned)(elem * 4u), 0, AUX_SC1);
+}
+
+// the tiles (ti, 0 .. NT - 1) of X Y^T for two blocks in LDS, K = 64, added to acc: lane (c16, g4) holds rows 16 ti + 4 g4 + q,
+// column 16 tj + c16
+template <int NT>
+__device__ __forceinline__ void tiles_row(const float* X, const float* Y, int ti, int c16, int g4, cdv_float4 (&acc)[NT]) {
+  const float* pa = X + (size_t)(16 * ti + c16) * FLD + 16 * g4;
+  const float* pb = Y + (size_t)c16 * FLD + 16 * g4;
+#pragma unroll
+  for (int s4 = 0; s4 < 4; s4++) {
+    const cdv_float4 av = *reinterpret_cast<const cdv_float4*>(pa + 4 * s4);
+#pragma unroll
+    for (int tj = 0; tj < NT; tj++) {
+      const cdv_float4 bv = *reinterpret_cast<const cdv_float4*>(pb + (size_t)16 * tj * FLD + 4 * s4);
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc[tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j], acc[tj], 0, 0, 0);
+    }
+  }
 }
 
 // the two tiles (ti, tj0), (ti, tj0 + 1) of X Y^T for two blocks in LDS, K = 64, added to acc[0], acc[1]: lane (c16, g4) holds
@@ -125,51 +179,69 @@ __device__ __forceinline__ void tiles_xyt(const float* X, const float* Y, int ti
   }
 }
 
-// one wave, lane = row: X L^T = S by forward substitution along the row; S rows in Sb, L (lower triangle + diagonal) in Lb,
-// both row-major with stride FLD; rinvb: scratch of 64 floats.  Returns the row in x.
-__device__ __forceinline__ void solve_rows(const float* Sb, const float* Lb, float* rinvb, int lane, float (&x)[CNB]) {
+// 16 rows of X L^T = S by forward substitution along the rows, FOUR LANES PER ROW (lane = 4 r + g): lane g of a row holds its
+// columns 16 m + 4 g .. + 3, m = 0 .. 3, takes its share of every dot product sum_{j < c} x_j L[c][j] and the four shares meet by
+// two quad permutes; the owner of column c keeps the new x_c.  L0: L row-major with the DIAGONAL ZEROED (so that every lane
+// multiplies whole 16-byte pieces: what is not left of column c meets a zero), rinv_v: lane j holds 1 / L[j][j].  A row's pieces
+// of L are requested one row ahead.  (One lane per row, 64 rows in one wave, was 544 broadcast reads with the LDS latency
+// exposed at every row: ~20,000 cycles; this is four waves of ~5,000 side by side.)
+__device__ __forceinline__ float quad_sum(float s) {
+  s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0xB1, 0xf, 0xf, false));   // quad_perm:[1,0,3,2]
+  s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x4E, 0xf, 0xf, false));   // quad_perm:[2,3,0,1]
+  return s;
+}
+__device__ __forceinline__ void solve_rows4(const float* Sb, const float* L0, float rinv_v, float* Xb, int R0, int lane) {
+  const int r = lane >> 2, g = lane & 3;
+  cdv_float4 xs[4];
 #pragma unroll
-  for (int c4 = 0; c4 < CNB / 4; c4++) {
-    const cdv_float4 q = *reinterpret_cast<const cdv_float4*>(&Sb[lane * FLD + 4 * c4]);
-    x[4 * c4] = q[0]; x[4 * c4 + 1] = q[1]; x[4 * c4 + 2] = q[2]; x[4 * c4 + 3] = q[3];
-  }
-  rinvb[lane] = 1.0f / Lb[lane * FLD + lane];
-  wave_lds_sync();
+  for (int m = 0; m < 4; m++) xs[m] = *reinterpret_cast<const cdv_float4*>(&Sb[(R0 + r) * FLD + 16 * m + 4 * g]);
+  const float* Lg = L0 + 4 * g;
+  cdv_float4 cur[4], nxt[4];
+  cur[0] = *reinterpret_cast<const cdv_float4*>(&Lg[0]);
 #pragma unroll
   for (int c = 0; c < CNB; c++) {
-    // sum_{j < c} x_j L[c][j]: two chains over the whole quads (packed FMAs), the quad that holds the diagonal by itself
-    f2 sa = {0.f, 0.f}, sb = {0.f, 0.f};
+    const int mc = c >> 4, gc = (c >> 2) & 3, ec = c & 3;
+    if (c + 1 < CNB) {
 #pragma unroll
-    for (int j4 = 0; j4 < c / 4; j4++) {
-      const cdv_float4 l = *reinterpret_cast<const cdv_float4*>(&Lb[c * FLD + 4 * j4]);
-      sa = __builtin_elementwise_fma(f2{x[4 * j4], x[4 * j4 + 1]}, f2{l[0], l[1]}, sa);
-      sb = __builtin_elementwise_fma(f2{x[4 * j4 + 2], x[4 * j4 + 3]}, f2{l[2], l[3]}, sb);
+      for (int m = 0; m <= ((c + 1) >> 4); m++) nxt[m] = *reinterpret_cast<const cdv_float4*>(&Lg[(c + 1) * FLD + 16 * m]);
     }
-    float s = (sa[0] + sa[1]) + (sb[0] + sb[1]);
-    if (c & 3) {
-      const cdv_float4 l = *reinterpret_cast<const cdv_float4*>(&Lb[c * FLD + (c & ~3)]);
+    // the 16-column groups left of column c's (old x) and column c's own group (the newest x) in separate chains
+    f2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
 #pragma unroll
-      for (int j = 0; j < (c & 3); j++) s = fmaf(x[(c & ~3) + j], l[j], s);
+    for (int m = 0; m < mc; m++) {
+      a0 = __builtin_elementwise_fma(f2{xs[m][0], xs[m][1]}, f2{cur[m][0], cur[m][1]}, a0);
+      a0 = __builtin_elementwise_fma(f2{xs[m][2], xs[m][3]}, f2{cur[m][2], cur[m][3]}, a0);
     }
-    x[c] = (x[c] - s) * rinvb[c];
+    a1 = __builtin_elementwise_fma(f2{xs[mc][0], xs[mc][1]}, f2{cur[mc][0], cur[mc][1]}, a1);
+    a1 = __builtin_elementwise_fma(f2{xs[mc][2], xs[mc][3]}, f2{cur[mc][2], cur[mc][3]}, a1);
+    const float s = quad_sum((a0[0] + a0[1]) + (a1[0] + a1[1]));
+    const float xc = (xs[mc][ec] - s) * readlane_f(rinv_v, c);
+    xs[mc][ec] = (g == gc) ? xc : xs[mc][ec];
+#pragma unroll
+    for (int m = 0; m < 4; m++) cur[m] = nxt[m];
   }
+#pragma unroll
+  for (int m = 0; m < 4; m++) *reinterpret_cast<cdv_float4*>(&Xb[(R0 + r) * FLD + 16 * m + 4 * g]) = xs[m];
 }
 
 // one wave, lane = row: the 64 x 64 block in Db (row-major, stride FLD; only its lower triangle matters) -> its Cholesky
 // factor, row `lane` returned in a2 (pairs of columns; entries right of the diagonal are not part of it).  Right-looking in
-// the wave's registers, column k + 1 broadcast through LDS while column k's rank-1 update runs (ba_win.hip's solver).
-__device__ __forceinline__ bool factor_rows(const float* Db, float* colb, int lane, f2 (&a2)[CNB / 2]) {
+// the wave's registers, column k + 1 broadcast through LDS while column k's rank-1 update runs (ba_win.hip's solver).  A pivot
+// that is not positive leaves a NaN or an infinity on the diagonal below it: the caller looks there.
+// (Measured and dropped: the same by four waves, 16 columns each, the waves behind the panel wave taking every finished column
+// off their own columns as it appears in LDS: 23,800 cycles against 16,500 -- a column costs ~260 cycles here and ~280 there, both
+// times the chain pivot -> v_readlane -> scale -> v_readlane -> FMA, not the rank-1 FMAs that the other waves take over; updating
+// two or four columns ahead through v_readlane and applying the LDS read-backs three steps late changed nothing either.)
+__device__ __forceinline__ void factor_rows(const float* Db, float* colb, int lane, f2 (&a2)[CNB / 2]) {
 #pragma unroll
   for (int c4 = 0; c4 < CNB / 4; c4++) {
     const cdv_float4 q = *reinterpret_cast<const cdv_float4*>(&Db[lane * FLD + 4 * c4]);
     a2[2 * c4] = f2{q[0], q[1]};
     a2[2 * c4 + 1] = f2{q[2], q[3]};
   }
-  bool bad = false;
   float Lk;
   {
     const float piv = readlane_f(a2[0][0], 0);
-    bad = !(piv > 0.f);
     Lk = a2[0][0] * __builtin_amdgcn_rsqf(piv);
     a2[0][0] = Lk;
     colb[lane] = Lk;
@@ -187,7 +259,6 @@ __device__ __forceinline__ bool factor_rows(const float* Db, float* colb, int la
     if (k + 1 < CNB) {
       const float an = fmaf(-Lk, readlane_f(Lk, k + 1), a2[(k + 1) >> 1][(k + 1) & 1]);
       const float piv = readlane_f(an, k + 1);
-      bad = bad || !(piv > 0.f);                          // wave-uniform
       Ln = an * __builtin_amdgcn_rsqf(piv);
       a2[(k + 1) >> 1][(k + 1) & 1] = Ln;
       colb[lane] = Ln;      // in-order LDS: the reads of column k were issued before this write
@@ -207,47 +278,246 @@ __device__ __forceinline__ bool factor_rows(const float* Db, float* colb, int la
 #pragma unroll
     for (int pp = (k + 2) >> 1; pp < CNB / 2; pp++) bcur[pp] = bnxt[pp];
   }
-  return bad;
 }
+
+constexpr int NSOLVE = 4;              // waves 0 .. 3 of the chain workgroup: wave 0 factors, all four solve (16 rows each)
+constexpr int NHELP = 4;               // its helper waves 4 .. 7: helper h prepares the tile row h of the next stage's blocks
 
 __global__ __launch_bounds__(FT) void ba_big_factor_kernel(FacArgs P) {
   if (P.gmeta[GM_ERROR] || P.info[BI_OVERFLOW]) return;
-  // (static: the addresses are instruction offsets; the launch asks for FAC_PAD more bytes of dynamic LDS on top)
-  __shared__ __attribute__((aligned(16))) float B0[FBUF];
-  __shared__ __attribute__((aligned(16))) float B1[FBUF];
-  __shared__ __attribute__((aligned(16))) float B2[FBUF];
-  __shared__ __attribute__((aligned(16))) float B3[FBUF];
+  // seven block buffers: 119 KB of the CU's 160 -- ONE workgroup per CU (the form of the hand-off used here was measured that way)
+  __shared__ __attribute__((aligned(16))) float BB[7 * FBUF];
   __shared__ __attribute__((aligned(16))) float colb[CNB];
+  float* const B0 = BB;
+  float* const B1 = BB + FBUF;
+  float* const B2 = BB + 2 * FBUF;
+  float* const B3 = BB + 3 * FBUF;
   __shared__ __attribute__((aligned(16))) float rinvb[CNB];
-  __shared__ int sh[8];   // [0] kind, [1] c, [2] r, [3] go on, [4], [5] wait verdicts of even / odd k, [6] of the diagonal block
+  __shared__ int sh[8];    // [0] kind, [1] c, [2] r, [3] go on, [4], [5] wait verdicts of even / odd k, [6] of the diagonal block
+  __shared__ int sy[8];    // chain workgroup: SY_* words
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, c16 = lane & 15, g4 = lane >> 4;
   const int nb = P.nb, npad = P.npad;
   const size_t lda = (size_t)npad;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
       P.A, (short)0, (int)(unsigned)((size_t)(npad + 1) * lda * sizeof(float)), 0x00020000);
   int32_t* const flags = P.ctl + 16;
-  const int ti = wave >> 1, tj0 = 2 * (wave & 1);   // this wave's two tiles of a block: (ti, tj0), (ti, tj0 + 1)
+  int32_t* const pflags = flags + (nb + 1) * nb;
+  const int ti = wave >> 1, tj0 = 2 * (wave & 1);   // item workgroups: this wave's two tiles of a block: (ti, tj0), (ti, tj0 + 1)
+  // first element of row `row` of block row blk / of the right-hand side (one row: the others read as zero)
+  auto row_base = [&](int blk, int row) -> size_t {
+    return blk == nb ? (size_t)npad * lda : (size_t)(CNB * blk + row) * lda;
+  };
 
   for (;;) {
     if (t == 0) {
       const int ticket = atomicAdd(P.ctl, 1);
       int kind = 0, c = 0, r = 0;
-      const bool have = ticket < P.total && fac_decode(ticket, nb, kind, c, r);
+      const bool have = ticket < P.total && (ticket == 0 || fac_decode(ticket, nb, kind, c, r));
       sh[0] = kind; sh[1] = c; sh[2] = r; sh[3] = have ? 1 : 0;
+      for (int i = 0; i < 8; i++) sy[i] = 0;
     }
     __syncthreads();
     const int kind = sh[0], c = sh[1], r = sh[2];
     if (!sh[3]) return;
-    const bool diag = kind == 0;
+
+    if (kind == 0) {
+      // =====================================================================================================
+      // the chain workgroup.  Waves 0 .. 3: wave 0 factors, all four solve the neighbour (16 rows each); waves 4 .. 7: helpers
+      // (helper 0 also writes L(c, c) out, helper 1 L(c + 1, c))
+      // =====================================================================================================
+      float* const Db = BB;                // the diagonal block to factor
+      float* const Lb = BB + FBUF;         // L(c, c), row-major, zeros right of the diagonal
+      float* const Sb = BB + 2 * FBUF;     // the neighbour (c + 1, c), all products of the columns left of it applied
+      float* const Xs = BB + 3 * FBUF;     // L(c + 1, c)
+      float* const Y01 = BB + 4 * FBUF;    // L(c + 1, c - 1) as fetched by the helpers, two buffers: stages alternate
+      float* const L0b = BB + 6 * FBUF;    // L(c, c) with the diagonal zeroed: what the solve multiplies by
+      int* const vy = sy;
+      auto give_up = [&]() {   // an LDS wait ran out (cannot happen unless a wave of this workgroup died): everybody leaves
+        if (lane == 0) {
+          __hip_atomic_store(P.ctl + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (P.info[BI_HANDOFF] == 0) ba_flag(P.info, BI_HANDOFF, 1);
+        }
+      };
+      if (wave < NSOLVE) {
+        if (wave == 0) {   // the first diagonal block straight from the matrix
+          cdv_float4 pl[CNB / 4];
+#pragma unroll
+          for (int u = 0; u < CNB / 4; u++) pl[u] = ld4(rs, (size_t)(4 * u + g4) * lda + 4 * c16);
+#pragma unroll
+          for (int u = 0; u < CNB / 4; u++) *reinterpret_cast<cdv_float4*>(&Db[(4 * u + g4) * FLD + 4 * c16]) = pl[u];
+          wave_lds_sync();
+        }
+        for (int cs = 0; cs < nb; cs++) {
+          CDV_IF_STAMPS(const int sslot = wave == 0 ? cs : wave == NSOLVE - 1 ? 32 + cs : -1;)
+          if (wave == 0) {
+            if (cs > 0 && !lds_wait(vy, SY_U, NHELP * cs)) break;          // the diagonal block is complete
+            FSTAMP(0);
+            FSTAMP_RT(14);
+            f2 a2[CNB / 2];
+            factor_rows(Db, colb, lane, a2);
+            FSTAMP(1);
+            if (cs > 0 && !lds_wait(vy, SY_PUB1, cs)) break;               // the previous L(c, c) has been taken
+            // L(c, c) into LDS: the rows as they are (Lb: the publisher cuts off what lies right of the diagonal) and strictly lower
+            // (L0b: what the solve multiplies by).  (The lane index behind an empty asm: what is compared with it is not hoisted out
+            // of the stage loop as 64 lane masks that then live in spilled SGPRs -- that made this step 9,000 cycles.)
+            int lane_o = lane;
+            asm volatile("" : "+v"(lane_o));
+#pragma unroll
+            for (int c4 = 0; c4 < CNB / 4; c4++) {
+              cdv_float4 q, q0;
+#pragma unroll
+              for (int j = 0; j < 4; j++) {
+                const int cc = 4 * c4 + j;
+                q[j] = a2[cc >> 1][cc & 1];
+                q0[j] = (cc < lane_o) ? q[j] : 0.f;
+              }
+              *reinterpret_cast<cdv_float4*>(&Lb[lane * FLD + 4 * c4]) = q;
+              *reinterpret_cast<cdv_float4*>(&L0b[lane * FLD + 4 * c4]) = q0;
+            }
+            lds_post(vy, SY_L, cs + 1);
+            FSTAMP(2);
+          } else if (!lds_wait(vy, SY_L, cs + 1)) break;
+          const float dg = Lb[lane * FLD + lane];
+          if (wave == 0) {   // a pivot that was not positive has left a NaN (or an infinity) on the diagonal below it
+            const bool bad = !(dg > 0.f && dg < 3.0e38f);
+            if (__any(bad) && lane == 0 && P.info[BI_CHOL] == 0) ba_flag(P.info, BI_CHOL, cs + 1);
+          }
+          if (cs + 1 == nb) break;
+          const float rinv_v = 1.0f / dg;
+          if (!lds_wait(vy, SY_S, NHELP * (cs + 1))) break;                // the neighbour is complete (and the helpers are done with Xs)
+          if (cs > 0 && !lds_wait(vy, SY_PUB2, cs)) break;                 // the previous L(c + 1, c) has been taken
+          FSTAMP(3);
+          solve_rows4(Sb, L0b, rinv_v, Xs, 16 * wave, lane);
+          lds_arrive(sy, SY_X, lane);
+          FSTAMP(4);
+        }
+        if (wave == 0 && lds_get(vy, SY_ABORT)) give_up();
+        return;
+      }
+      // ---- the helpers: helper h owns the tile row h (rows 16 h .. 16 h + 15) of the two blocks of the next stage ----
+      const int h = wave - NSOLVE;
+      // publishing: a block in LDS (row-major) -> the matrix, whole lines per store instruction; the stores are left in flight,
+      // the flag goes up later (publish_flag), after the wave has had other things to do
+      cdv_float4 pubv[CNB / 4];
+      auto publish_issue = [&](const float* src, bool lower) {   // lower: zeros right of the diagonal
+        int g4o = g4, c16o = c16;
+        asm volatile("" : "+v"(g4o), "+v"(c16o));   // (see lane_o above)
+#pragma unroll
+        for (int u = 0; u < CNB / 4; u++) {
+          pubv[u] = *reinterpret_cast<const cdv_float4*>(&src[(4 * u + g4) * FLD + 4 * c16]);
+          if (lower) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) pubv[u][j] = (4 * c16o + j <= 4 * u + g4o) ? pubv[u][j] : 0.f;
+          }
+        }
+        wave_lds_sync();
+      };
+      auto publish_store = [&](int br, int bcn) {
+#pragma unroll
+        for (int u = 0; u < CNB / 4; u++) st4(rs, (size_t)(CNB * br + 4 * u + g4) * lda + CNB * bcn + 4 * c16, pubv[u]);
+      };
+      auto publish_flag = [&](int br, int bcn, bool withhold) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0 && !withhold) __hip_atomic_store(&flags[br * nb + bcn], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      };
+      for (int cs = 0; cs + 1 < nb; cs++) {
+        CDV_IF_STAMPS(const int sslot = h == NHELP - 1 ? 64 + cs : -1;)
+        FSTAMP(0);
+        const int rn = cs + 1;
+        if (rn >= 3 && !fac_wait(&pflags[rn], &pflags[rn], P.ctl, P.info, lane, P.test)) { lds_set(vy, SY_ABORT, 1); return; }
+        float sT[4][4], dT[4][4];
+#pragma unroll
+        for (int tj = 0; tj < 4; tj++)
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const size_t rowp = (size_t)(CNB * rn + 16 * h + 4 * g4 + q) * lda;
+            sT[tj][q] = ld1(rs, rowp + CNB * cs + 16 * tj + c16);
+            dT[tj][q] = ld1(rs, rowp + CNB * rn + 16 * tj + c16);
+          }
+        FSTAMP(1);
+        float* const Yb = Y01 + (cs & 1) * FBUF;
+        if (cs >= 1) {
+          // the one product the neighbour still lacks: L(c + 1, c - 1) L(c, c - 1)^T -- this helper's 16 rows of the first, fetched
+          // by itself; the second is what the solve left in Xs a stage ago
+          if (!fac_wait(&flags[rn * nb + cs - 1], &flags[rn * nb + cs - 1], P.ctl, P.info, lane, P.test)) { lds_set(vy, SY_ABORT, 1); return; }
+          FSTAMP(2);
+          cdv_float4 py[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) py[u] = ld4(rs, (size_t)(CNB * rn + 16 * h + 4 * u + g4) * lda + CNB * (cs - 1) + 4 * c16);
+#pragma unroll
+          for (int u = 0; u < 4; u++) *reinterpret_cast<cdv_float4*>(&Yb[(16 * h + 4 * u + g4) * FLD + 4 * c16]) = py[u];
+          wave_lds_sync();
+          FSTAMP(3);
+          if (!lds_wait(vy, SY_X, NSOLVE * cs)) return;
+          cdv_float4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+          tiles_row<4>(Yb, Xs, h, c16, g4, acc);
+#pragma unroll
+          for (int tj = 0; tj < 4; tj++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) sT[tj][q] -= acc[tj][q];
+        }
+#pragma unroll
+        for (int tj = 0; tj < 4; tj++)
+#pragma unroll
+          for (int q = 0; q < 4; q++) Sb[(16 * h + 4 * g4 + q) * FLD + 16 * tj + c16] = sT[tj][q];
+        lds_arrive(sy, SY_S, lane);
+        FSTAMP(4);
+        if (cs >= 1) {
+          if (!lds_wait(vy, SY_S, NHELP * (cs + 1))) return;   // every helper's rows of L(c + 1, c - 1) are in
+          cdv_float4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+          tiles_row<4>(Yb, Yb, h, c16, g4, acc);
+#pragma unroll
+          for (int tj = 0; tj < 4; tj++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) dT[tj][q] -= acc[tj][q];
+        }
+        FSTAMP(5);
+        if (h == 0) {                                            // L(c, c) on its way out while the neighbour is solved
+          if (!lds_wait(vy, SY_L, cs + 1)) return;
+          publish_issue(Lb, true);
+          lds_post(vy, SY_PUB1, cs + 1);
+          publish_store(cs, cs);
+        }
+        if (!lds_wait(vy, SY_X, NSOLVE * (cs + 1))) return;     // L(c + 1, c) is in Xs
+        FSTAMP(6);
+        // fault injection (tests): the second diagonal block never becomes visible
+        if (h == 0) publish_flag(cs, cs, P.test == HO_TEST_FACTOR && cs == 1);
+        if (h == 1) {
+          publish_issue(Xs, false);
+          lds_post(vy, SY_PUB2, cs + 1);
+          publish_store(cs + 1, cs);
+        }
+        {
+          cdv_float4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+          tiles_row<4>(Xs, Xs, h, c16, g4, acc);
+#pragma unroll
+          for (int tj = 0; tj < 4; tj++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) Db[(16 * h + 4 * g4 + q) * FLD + 16 * tj + c16] = dT[tj][q] - acc[tj][q];
+        }
+        lds_arrive(sy, SY_U, lane);
+        FSTAMP(7);
+        if (h == 1) publish_flag(cs + 1, cs, false);
+      }
+      if (h == 0) {   // the last diagonal block
+        if (!lds_wait(vy, SY_L, nb)) return;
+        publish_issue(Lb, true);
+        publish_store(nb - 1, nb - 1);
+        publish_flag(nb - 1, nb - 1, false);
+      }
+      return;
+    }
+
+    // =======================================================================================================
+    // item workgroups
+    // =======================================================================================================
+    const bool pitem = kind == 2;
     const bool rhs = r == nb;
-    // the block that is accumulated as a product of two different rows: (rowblk, bc); D(c): its left neighbour (c, c - 1)
-    const int bc = diag ? c - 1 : c;
-    const bool has_s = bc >= 0;
-    const int nk = has_s ? bc : 0;
-    // first element of row `row` of block row r / the right-hand side (one row: the others read as zero)
-    auto row_base = [&](int blk, int row) -> size_t {
-      return blk == nb ? (size_t)npad * lda : (size_t)(CNB * blk + row) * lda;
-    };
+    CDV_IF_STAMPS(const int sslot = wave != 0 ? -1 : (!pitem && r == c + 2 ? 192 + c : -1);)
+    FSTAMP(0);
+    // the block that is accumulated as a product of two different block rows: (r, bc); a P item: the neighbour (c, c - 1)
+    const int bc = pitem ? c - 1 : c;
+    const int nk = pitem ? c - 2 : c;   // products to apply: the columns k < nk
     // ---- the blocks as the fold launch left them: this wave's tiles, requested now ----
     float s0[2][4], d0[2][4];
 #pragma unroll
@@ -255,12 +525,12 @@ __global__ __launch_bounds__(FT) void ba_big_factor_kernel(FacArgs P) {
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         const int row = 16 * ti + 4 * g4 + q, col = 16 * (tj0 + u) + c16;
-        s0[u][q] = (has_s && (!rhs || row == 0)) ? ld1(rs, row_base(r, row) + CNB * bc + col) : 0.f;
-        d0[u][q] = diag ? ld1(rs, row_base(c, row) + CNB * c + col) : 0.f;
+        s0[u][q] = (!rhs || row == 0) ? ld1(rs, row_base(r, row) + CNB * bc + col) : 0.f;
+        d0[u][q] = pitem ? ld1(rs, row_base(c, row) + CNB * c + col) : 0.f;
       }
     cdv_float4 accS[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     cdv_float4 accD[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    // ---- sum over k < bc of L(r, k) L(bc, k)^T (and, D(c): of L(c, k) L(c, k)^T), the next k's blocks in flight under the products ----
+    // ---- sum over k < nk of L(r, k) L(bc, k)^T (a P item: and of L(c, k) L(c, k)^T), the next k's blocks in flight under the products ----
     // thread -> two 16-byte pieces of each operand block: piece i = t + 512 u: row i >> 4, columns 4 (i & 15) ..
     cdv_float4 px[2], py[2];
     auto request = [&](int k) {
@@ -282,8 +552,8 @@ __global__ __launch_bounds__(FT) void ba_big_factor_kernel(FacArgs P) {
       if (ok) request(0);
     }
     for (int k = 0; ok && k < nk; k++) {
-      float* const X = (k & 1) ? B2 : B0;
-      float* const Y = (k & 1) ? B3 : B1;
+      float* const X = BB + 2 * (k & 1) * FBUF;
+      float* const Y = X + FBUF;
 #pragma unroll
       for (int u = 0; u < 2; u++) {
         const int i = t + FT * u, row = i >> 4, c4 = i & 15;
@@ -300,103 +570,79 @@ __global__ __launch_bounds__(FT) void ba_big_factor_kernel(FacArgs P) {
         if (ok) request(k + 1);
       }
       tiles_xyt(X, Y, ti, tj0, c16, g4, accS);
-      if (diag) tiles_xyt(X, X, ti, tj0, c16, g4, accD);
+      if (pitem) tiles_xyt(X, X, ti, tj0, c16, g4, accD);
     }
     if (!ok) return;   // uniform: the abort word is up, everybody leaves as they find out
-    __syncthreads();   // the last products have read their operands: B0 .. B3 are free
+    __syncthreads();   // the last products have read their operands: the buffers are free
+    FSTAMP(1);
     float* const Sb = B0;
     float* const Db = B1;
     float* const Lb = B2;
     float* const Xs = B3;
-    if (has_s) {
 #pragma unroll
-      for (int u = 0; u < 2; u++)
+    for (int u = 0; u < 2; u++)
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const int row = 16 * ti + 4 * g4 + q, col = 16 * (tj0 + u) + c16;
-          Sb[row * FLD + col] = s0[u][q] - accS[u][q];
-        }
+      for (int q = 0; q < 4; q++) {
+        const int row = 16 * ti + 4 * g4 + q, col = 16 * (tj0 + u) + c16;
+        Sb[row * FLD + col] = s0[u][q] - accS[u][q];
+        if (pitem) Db[row * FLD + col] = d0[u][q] - accD[u][q];
+      }
+    if (pitem) {
+      // the two blocks go back where they came from, for the chain workgroup to take over (whole lines per store instruction)
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const int i = t + FT * u, row = i >> 4, c4 = i & 15;
+        st4(rs, (size_t)(CNB * c + row) * lda + CNB * bc + 4 * c4, *reinterpret_cast<const cdv_float4*>(&Sb[row * FLD + 4 * c4]));
+        st4(rs, (size_t)(CNB * c + row) * lda + CNB * c + 4 * c4, *reinterpret_cast<const cdv_float4*>(&Db[row * FLD + 4 * c4]));
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (t == 0) __hip_atomic_store(&pflags[c], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
       if (wave == 0) {
-        // L(bc, bc): this wave waits for it and fetches it by itself (16 pieces per lane), no barrier between the flag and the solve
+        FSTAMP(2);
+        // L(c, c): this wave waits for it and fetches it by itself (16 pieces per lane); into LDS with its diagonal zeroed, the
+        // reciprocals of the diagonal beside it (solve_rows4)
         const bool w = fac_wait(&flags[bc * nb + bc], &flags[bc * nb + bc], P.ctl, P.info, lane, P.test);
         if (lane == 0) sh[6] = w ? 1 : 0;
+        FSTAMP(3);
         if (w) {
           cdv_float4 pl[CNB / 4];
 #pragma unroll
-          for (int u = 0; u < CNB / 4; u++) {
-            const int row = 4 * u + g4;
-            pl[u] = ld4(rs, (size_t)(CNB * bc + row) * lda + CNB * bc + 4 * c16);
-          }
+          for (int u = 0; u < CNB / 4; u++) pl[u] = ld4(rs, (size_t)(CNB * bc + 4 * u + g4) * lda + CNB * bc + 4 * c16);
 #pragma unroll
           for (int u = 0; u < CNB / 4; u++) {
             const int row = 4 * u + g4;
+            if (c16 == (row >> 2)) {
+              float dg = pl[u][0];
+#pragma unroll
+              for (int j = 1; j < 4; j++) dg = (row & 3) == j ? pl[u][j] : dg;
+              rinvb[row] = 1.0f / dg;
+#pragma unroll
+              for (int j = 0; j < 4; j++) pl[u][j] = (row & 3) == j ? 0.f : pl[u][j];
+            }
             *reinterpret_cast<cdv_float4*>(&Lb[row * FLD + 4 * c16]) = pl[u];
           }
         }
+        FSTAMP(4);
       }
-      __syncthreads();   // the neighbour's rows are in Sb; the verdict
+      __syncthreads();   // the block's rows are in Sb, L(c, c) in Lb; the verdict
       if (!sh[6]) return;
-      if (wave == 0) {
-        float x[CNB];
-        solve_rows(Sb, Lb, rinvb, lane, x);
-        if (!diag) {
-          // an item of O(c): the finished block goes out from this wave's registers (the right-hand side: one row)
-          if (!rhs || lane == 0) {
-#pragma unroll
-            for (int c4 = 0; c4 < CNB / 4; c4++)
-              st4(rs, row_base(r, lane) + CNB * bc + 4 * c4, cdv_float4{x[4 * c4], x[4 * c4 + 1], x[4 * c4 + 2], x[4 * c4 + 3]});
-          }
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          if (lane == 0) __hip_atomic_store(&flags[r * nb + bc], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-#pragma unroll
-          for (int c4 = 0; c4 < CNB / 4; c4++)
-            *reinterpret_cast<cdv_float4*>(&Xs[lane * FLD + 4 * c4]) = cdv_float4{x[4 * c4], x[4 * c4 + 1], x[4 * c4 + 2], x[4 * c4 + 3]};
-        }
-      }
-    }
-    if (diag) {
-      if (has_s) {
-        __syncthreads();   // L(c, c - 1) is in Xs
-        tiles_xyt(Xs, Xs, ti, tj0, c16, g4, accD);
-      }
-#pragma unroll
-      for (int u = 0; u < 2; u++)
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const int row = 16 * ti + 4 * g4 + q, col = 16 * (tj0 + u) + c16;
-          Db[row * FLD + col] = d0[u][q] - accD[u][q];
-        }
+      FSTAMP(5);
+      if (wave < NSOLVE) solve_rows4(Sb, Lb, rinvb[lane], Xs, 16 * wave, lane);
+      FSTAMP(6);
+      // the finished block goes out through LDS: whole lines per store instruction, every wave stores (the right-hand side: one row)
       __syncthreads();
-      if (has_s && wave == FT / 64 - 1) {
-        // L(c, c - 1) goes out from the last wave while wave 0 factors (the blocks right of it need it a whole factorisation later)
-        cdv_float4 xr[CNB / 4];
 #pragma unroll
-        for (int c4 = 0; c4 < CNB / 4; c4++) xr[c4] = *reinterpret_cast<const cdv_float4*>(&Xs[lane * FLD + 4 * c4]);
-#pragma unroll
-        for (int c4 = 0; c4 < CNB / 4; c4++) st4(rs, (size_t)(CNB * c + lane) * lda + CNB * bc + 4 * c4, xr[c4]);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_store(&flags[c * nb + bc], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int u = 0; u < 2; u++) {
+        const int i = t + FT * u, row = i >> 4, c4 = i & 15;
+        if (!rhs || row == 0) st4(rs, row_base(r, row) + CNB * bc + 4 * c4, *reinterpret_cast<const cdv_float4*>(&Xs[row * FLD + 4 * c4]));
       }
-      if (wave == 0) {
-        f2 a2[CNB / 2];
-        const bool bad = factor_rows(Db, colb, lane, a2);
-#pragma unroll
-        for (int c4 = 0; c4 < CNB / 4; c4++) {
-          cdv_float4 q;
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            const int cc = 4 * c4 + j;
-            q[j] = (cc <= lane) ? a2[cc >> 1][cc & 1] : 0.f;
-          }
-          st4(rs, (size_t)(CNB * c + lane) * lda + CNB * c + 4 * c4, q);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // fault injection (tests): the second diagonal block never becomes visible
-        if (lane == 0 && !(P.test == HO_TEST_FACTOR && c == 1))
-          __hip_atomic_store(&flags[c * nb + c], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (lane == 0 && bad && P.info[BI_CHOL] == 0) ba_flag(P.info, BI_CHOL, c + 1);
-      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (t == 0) __hip_atomic_store(&flags[r * nb + bc], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      FSTAMP(10);
     }
     __syncthreads();   // sh and the buffers are rewritten by the next item
   }
@@ -406,9 +652,10 @@ int g_fac_cus = 0;
 
 }  // namespace
 
+// tickets of a launch: the chain workgroup's + one per item (fac_decode)
 int cdv_ba_big_factor_items(int nb) {
   int total = 1;
-  for (int g = 1; g <= nb; g++) total += (g < nb ? 1 : 0) + (nb - g - 1 > 0 ? nb - g - 1 : 0) + 1;
+  for (int g = 0; g < nb; g++) total += (nb - g - 2 > 0 ? nb - g - 2 : 0) + 1 + (g + 3 < nb ? 1 : 0);
   return total;
 }
 
@@ -417,15 +664,13 @@ int cdv_ba_big_factor(float* A, int npad, int32_t* ctl, const int32_t* gmeta, in
     int dev = 0, cus = 0;
     CDV_HIP_CHECK(hipGetDevice(&dev));
     CDV_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    CDV_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(ba_big_factor_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      FAC_PAD));
     g_fac_cus = cus > 0 ? cus : 256;
   }
   FacArgs P;
   P.A = A; P.npad = npad; P.nb = npad / CNB; P.total = cdv_ba_big_factor_items(P.nb);
   P.ctl = ctl; P.gmeta = gmeta; P.info = info; P.test = test;
   const int grid = P.total < g_fac_cus ? P.total : g_fac_cus;
-  hipLaunchKernelGGL(ba_big_factor_kernel, dim3(grid), dim3(FT), FAC_PAD, s, P);
+  hipLaunchKernelGGL(ba_big_factor_kernel, dim3(grid), dim3(FT), 0, s, P);
   return CDV_OK;
 }
 

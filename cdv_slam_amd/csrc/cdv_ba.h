@@ -55,8 +55,8 @@ __host__ __device__ inline int solve_ld(int n) { return (n + 27) / 32 * 32 + 4; 
 enum { BI_CHOL = 0, BI_OVERFLOW = 1, BI_HANDOFF = 2, BI_GRAPH = 3 };
 
 // control words of the factorisation launch (ba_factor.hip): 16 + one flag per block of the lower triangle and of the
-// right-hand-side row, rounded to 16 bytes
-inline int fac_ctl_words(int nb) { return (16 + (nb + 1) * nb + 3) / 4 * 4; }
+// right-hand-side row + one per block row (its P item), rounded to 16 bytes
+inline int fac_ctl_words(int nb) { return (16 + (nb + 1) * nb + nb + 3) / 4 * 4; }
 
 struct BaLayout {
   size_t sy, C, u, Ed, cmask, zero_bytes, q, dX, info, Abig, xgran, fctl, slabs, ared, hand, pnext, ptab, pdiag, pkeys, pgraph, pgraph_bytes, total;
