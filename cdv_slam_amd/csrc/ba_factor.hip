@@ -107,7 +107,7 @@ __device__ __forceinline__ bool fac_wait(const int32_t* f0, const int32_t* f1, i
 // ---- the waves of the chain workgroup meet through words in LDS.  The LDS unit executes a wave's instructions in order and
 // holds the only copy of the data: a wave that has read a word's new value reads everything its writer wrote before it.
 // Only the compiler has to be kept from moving accesses across.
-enum { SY_L = 0, SY_X = 1, SY_S = 2, SY_U = 3, SY_PUB1 = 4, SY_PUB2 = 5, SY_ABORT = 6 };
+enum { SY_L = 0, SY_X = 1, SY_S = 2, SY_U = 3, SY_PUB1 = 4, SY_PUB2 = 5, SY_ABORT = 6, SY_F = 7 };
 __device__ __forceinline__ int lds_get(int* sy, int word) {
   return __hip_atomic_load(&sy[word], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
@@ -232,7 +232,7 @@ __device__ __forceinline__ void solve_rows4(const float* Sb, const float* L0, fl
 // off their own columns as it appears in LDS: 23,800 cycles against 16,500 -- a column costs ~260 cycles here and ~280 there, both
 // times the chain pivot -> v_readlane -> scale -> v_readlane -> FMA, not the rank-1 FMAs that the other waves take over; updating
 // two or four columns ahead through v_readlane and applying the LDS read-backs three steps late changed nothing either.)
-__device__ __forceinline__ void factor_rows(const float* Db, float* colb, int lane, f2 (&a2)[CNB / 2]) {
+__device__ __forceinline__ void factor_rows(const float* Db, float* colb, float* Lt, int* sy, int base, int lane, f2 (&a2)[CNB / 2]) {
 #pragma unroll
   for (int c4 = 0; c4 < CNB / 4; c4++) {
     const cdv_float4 q = *reinterpret_cast<const cdv_float4*>(&Db[lane * FLD + 4 * c4]);
@@ -245,6 +245,8 @@ __device__ __forceinline__ void factor_rows(const float* Db, float* colb, int la
     Lk = a2[0][0] * __builtin_amdgcn_rsqf(piv);
     a2[0][0] = Lk;
     colb[lane] = Lk;
+    Lt[lane] = Lk;             // every column also into the column store, the progress word behind it (solve_cols2 follows)
+    lds_set(sy, SY_F, base + 1);
   }
   f2 bcur[CNB / 2], bnxt[CNB / 2];
 #pragma unroll
@@ -262,6 +264,8 @@ __device__ __forceinline__ void factor_rows(const float* Db, float* colb, int la
       Ln = an * __builtin_amdgcn_rsqf(piv);
       a2[(k + 1) >> 1][(k + 1) & 1] = Ln;
       colb[lane] = Ln;      // in-order LDS: the reads of column k were issued before this write
+      Lt[(k + 1) * CNB + lane] = Ln;
+      lds_set(sy, SY_F, base + k + 2);
 #pragma unroll
       for (int c4 = (k + 2) / 4; c4 < CNB / 4; c4++) {
         const cdv_float4 v = *reinterpret_cast<const cdv_float4*>(&colb[4 * c4]);
@@ -280,13 +284,101 @@ __device__ __forceinline__ void factor_rows(const float* Db, float* colb, int la
   }
 }
 
-constexpr int NSOLVE = 4;              // waves 0 .. 3 of the chain workgroup: wave 0 factors, all four solve (16 rows each)
+
+// X L^T = S for 32 rows, COLUMN BY COLUMN behind the factorisation: step k needs column k of L -- what factor_rows has just put
+// into the column store -- so the solve of the neighbour block runs underneath the factorisation of the diagonal block and ends a
+// step after it.  Two lanes per row (lane = 2 r + g): lane g holds the row's columns 8 m + 4 g .. + 3, m = 0 .. 7; step k: the
+// owner's x_k (times 1 / L[k][k]) goes to its partner by a quad permute, both take x_k L[c][k] off their columns c > k.  What the
+// column store holds above the diagonal is never multiplied (compile-time masks per step, one lane test).  false: gave up.
+__device__ __forceinline__ bool solve_cols2(const float* Sb, const float* Lt, int* sy, int base, float* Xb, int R0, int lane) {
+  const int r = lane >> 1, g = lane & 1;
+  cdv_float4 xs[8];
+#pragma unroll
+  for (int m = 0; m < 8; m++) xs[m] = *reinterpret_cast<const cdv_float4*>(&Sb[(R0 + r) * FLD + 8 * m + 4 * g]);
+  const bool g0 = g == 0;
+  bool ok = true;
+  cdv_float4 cur[8], nxt[8];
+  // (the lane's offset into a column behind an empty asm: otherwise the addresses below are loop-invariant for the caller's stage
+  // loop, get hoisted out of it as ~100 registers, and the solve spills)
+  int go = 4 * g;
+  asm volatile("" : "+v"(go));
+  const float* Lg = Lt + go;
+  // (the progress word is looked at once per eight columns: a test per column leaves the unrolled code -- xs is indexed by k, so it
+  // has to be unrolled -- with 64 spin loops in its control flow and the register allocator with 470 spills.  A column's pieces are
+  // requested a step ahead; the scheduling barrier keeps the compiler from requesting all eight steps' at once, which spills too.)
+#pragma clang loop unroll(full)
+  for (int k = 0; k < CNB; k++) {
+    const int mk = k >> 3, gk = (k >> 2) & 1, ek = k & 3;
+    if ((k & 7) == 0) {
+      // (every x pinned to a register here: the compiler otherwise sinks the updates of the columns further right across the spin
+      // loops down to where those columns are next read, and keeps eight steps' pieces of L alive for each of them -- 430 spills)
+#pragma unroll
+      for (int m = 0; m < 8; m++) asm volatile("" : "+v"(xs[m][0]), "+v"(xs[m][1]), "+v"(xs[m][2]), "+v"(xs[m][3]));
+      if (ok) {
+        int spins = 0, have;
+        do {
+          have = lds_get(sy, SY_F) - base;
+        } while (have < k + 8 && !lds_get(sy, SY_ABORT) && ++spins < (1 << 22));
+        ok = have >= k + 8;
+      }
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int m = mk; m < 8; m++) cur[m] = *reinterpret_cast<const cdv_float4*>(&Lg[k * CNB + 8 * m]);
+    }
+    if (((k + 1) & 7) != 0) {
+#pragma unroll
+      for (int m = (k + 1) >> 3; m < 8; m++) nxt[m] = *reinterpret_cast<const cdv_float4*>(&Lg[(k + 1) * CNB + 8 * m]);
+    }
+    // x_k and the diagonal L[k][k] sit in the owner's pieces: both to its partner by the same quad permute
+    const float xraw = xs[mk][ek], draw = cur[mk][ek];
+    float xb, db;
+    if (gk) {
+      xb = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(xraw), 0xF5, 0xf, 0xf, false));   // quad_perm:[1,1,3,3]
+      db = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(draw), 0xF5, 0xf, 0xf, false));
+    } else {
+      xb = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(xraw), 0xA0, 0xf, 0xf, false));   // quad_perm:[0,0,2,2]
+      db = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(draw), 0xA0, 0xf, 0xf, false));
+    }
+    const float xk = __builtin_amdgcn_rcpf(db) * xb;
+#pragma unroll
+    for (int m = mk; m < 8; m++) {
+      const cdv_float4 l = cur[m];
+      if (m > mk) {
+        const f2 nx = {-xk, -xk};
+        const f2 lo = __builtin_elementwise_fma(nx, f2{l[0], l[1]}, f2{xs[m][0], xs[m][1]});
+        const f2 hi = __builtin_elementwise_fma(nx, f2{l[2], l[3]}, f2{xs[m][2], xs[m][3]});
+        xs[m] = cdv_float4{lo[0], lo[1], hi[0], hi[1]};
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const bool c0 = 8 * mk + j > k, c1 = 8 * mk + 4 + j > k;   // lane g = 0 / g = 1: is this column right of k?
+          const float u = fmaf(-xk, l[j], xs[m][j]);
+          if (c0 && c1) xs[m][j] = u;
+          else if (c0) xs[m][j] = g0 ? u : xs[m][j];
+          else if (c1) xs[m][j] = g0 ? xs[m][j] : u;
+        }
+      }
+    }
+    xs[mk][ek] = ((gk == 0) == g0) ? xk : xs[mk][ek];
+#pragma unroll
+    for (int m = 0; m < 8; m++) cur[m] = nxt[m];
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int m = 0; m < 8; m++) *reinterpret_cast<cdv_float4*>(&Xb[(R0 + r) * FLD + 8 * m + 4 * g]) = xs[m];
+  if (!ok) lds_set(sy, SY_ABORT, 1);
+  return ok;
+}
+
+constexpr int NSOLVE = 4;              // item workgroups: waves 0 .. 3 solve (16 rows each, solve_rows4)
+constexpr int NTW = 2;                 // chain workgroup: waves 1, 2 solve the neighbour behind the factorisation (32 rows each, solve_cols2)
 constexpr int NHELP = 4;               // its helper waves 4 .. 7: helper h prepares the tile row h of the next stage's blocks
 
 __global__ __launch_bounds__(FT) void ba_big_factor_kernel(FacArgs P) {
   if (P.gmeta[GM_ERROR] || P.info[BI_OVERFLOW]) return;
-  // seven block buffers: 119 KB of the CU's 160 -- ONE workgroup per CU (the form of the hand-off used here was measured that way)
-  __shared__ __attribute__((aligned(16))) float BB[7 * FBUF];
+  // six block buffers and the column store: 118 KB of the CU's 160 -- ONE workgroup per CU (the form of the hand-off used here was measured that way)
+  __shared__ __attribute__((aligned(16))) float BB[6 * FBUF];
+  __shared__ __attribute__((aligned(16))) float Lt[CNB * CNB];   // chain workgroup: the column store (column k of L(c, c) at Lt[64 k + row])
   __shared__ __attribute__((aligned(16))) float colb[CNB];
   float* const B0 = BB;
   float* const B1 = BB + FBUF;
@@ -330,7 +422,6 @@ __global__ __launch_bounds__(FT) void ba_big_factor_kernel(FacArgs P) {
       float* const Sb = BB + 2 * FBUF;     // the neighbour (c + 1, c), all products of the columns left of it applied
       float* const Xs = BB + 3 * FBUF;     // L(c + 1, c)
       float* const Y01 = BB + 4 * FBUF;    // L(c + 1, c - 1) as fetched by the helpers, two buffers: stages alternate
-      float* const L0b = BB + 6 * FBUF;    // L(c, c) with the diagonal zeroed: what the solve multiplies by
       int* const vy = sy;
       auto give_up = [&]() {   // an LDS wait ran out (cannot happen unless a wave of this workgroup died): everybody leaves
         if (lane == 0) {
@@ -338,8 +429,9 @@ __global__ __launch_bounds__(FT) void ba_big_factor_kernel(FacArgs P) {
           if (P.info[BI_HANDOFF] == 0) ba_flag(P.info, BI_HANDOFF, 1);
         }
       };
-      if (wave < NSOLVE) {
-        if (wave == 0) {   // the first diagonal block straight from the matrix
+      if (wave == 0) {
+        // ---- the factoring wave ----
+        {   // the first diagonal block straight from the matrix
           cdv_float4 pl[CNB / 4];
 #pragma unroll
           for (int u = 0; u < CNB / 4; u++) pl[u] = ld4(rs, (size_t)(4 * u + g4) * lda + 4 * c16);
@@ -348,54 +440,46 @@ __global__ __launch_bounds__(FT) void ba_big_factor_kernel(FacArgs P) {
           wave_lds_sync();
         }
         for (int cs = 0; cs < nb; cs++) {
-          CDV_IF_STAMPS(const int sslot = wave == 0 ? cs : wave == NSOLVE - 1 ? 32 + cs : -1;)
-          if (wave == 0) {
-            if (cs > 0 && !lds_wait(vy, SY_U, NHELP * cs)) break;          // the diagonal block is complete
-            FSTAMP(0);
-            FSTAMP_RT(14);
-            f2 a2[CNB / 2];
-            factor_rows(Db, colb, lane, a2);
-            FSTAMP(1);
-            if (cs > 0 && !lds_wait(vy, SY_PUB1, cs)) break;               // the previous L(c, c) has been taken
-            // L(c, c) into LDS: the rows as they are (Lb: the publisher cuts off what lies right of the diagonal) and strictly lower
-            // (L0b: what the solve multiplies by).  (The lane index behind an empty asm: what is compared with it is not hoisted out
-            // of the stage loop as 64 lane masks that then live in spilled SGPRs -- that made this step 9,000 cycles.)
-            int lane_o = lane;
-            asm volatile("" : "+v"(lane_o));
+          CDV_IF_STAMPS(const int sslot = cs;)
+          if (cs > 0 && !lds_wait(vy, SY_U, NHELP * cs)) break;            // the diagonal block is complete
+          FSTAMP(0);
+          FSTAMP_RT(14);
+          f2 a2[CNB / 2];
+          factor_rows(Db, colb, Lt, sy, CNB * cs, lane, a2);
+          FSTAMP(1);
+          if (cs > 0 && !lds_wait(vy, SY_PUB1, cs)) break;                 // the previous L(c, c) has been taken
+          // L(c, c) row-major into LDS for the publisher (which cuts off what lies right of the diagonal): off the critical path,
+          // the solve took the columns as they came
 #pragma unroll
-            for (int c4 = 0; c4 < CNB / 4; c4++) {
-              cdv_float4 q, q0;
-#pragma unroll
-              for (int j = 0; j < 4; j++) {
-                const int cc = 4 * c4 + j;
-                q[j] = a2[cc >> 1][cc & 1];
-                q0[j] = (cc < lane_o) ? q[j] : 0.f;
-              }
-              *reinterpret_cast<cdv_float4*>(&Lb[lane * FLD + 4 * c4]) = q;
-              *reinterpret_cast<cdv_float4*>(&L0b[lane * FLD + 4 * c4]) = q0;
-            }
-            lds_post(vy, SY_L, cs + 1);
-            FSTAMP(2);
-          } else if (!lds_wait(vy, SY_L, cs + 1)) break;
-          const float dg = Lb[lane * FLD + lane];
-          if (wave == 0) {   // a pivot that was not positive has left a NaN (or an infinity) on the diagonal below it
-            const bool bad = !(dg > 0.f && dg < 3.0e38f);
-            if (__any(bad) && lane == 0 && P.info[BI_CHOL] == 0) ba_flag(P.info, BI_CHOL, cs + 1);
-          }
-          if (cs + 1 == nb) break;
-          const float rinv_v = 1.0f / dg;
+          for (int c4 = 0; c4 < CNB / 4; c4++)
+            *reinterpret_cast<cdv_float4*>(&Lb[lane * FLD + 4 * c4]) = cdv_float4{a2[2 * c4][0], a2[2 * c4][1], a2[2 * c4 + 1][0], a2[2 * c4 + 1][1]};
+          lds_post(vy, SY_L, cs + 1);
+          wave_lds_sync();
+          const float dg = Lb[lane * FLD + lane];   // a pivot that was not positive has left a NaN (or an infinity) on the diagonal below it
+          const bool bad = !(dg > 0.f && dg < 3.0e38f);
+          if (__any(bad) && lane == 0 && P.info[BI_CHOL] == 0) ba_flag(P.info, BI_CHOL, cs + 1);
+          FSTAMP(2);
+        }
+        if (lds_get(vy, SY_ABORT)) give_up();
+        return;
+      }
+      if (wave <= NTW) {
+        // ---- the solving waves: the neighbour (c + 1, c), 32 rows each, behind the factorisation of (c, c) ----
+        for (int cs = 0; cs + 1 < nb; cs++) {
+          CDV_IF_STAMPS(const int sslot = wave == 1 ? 32 + cs : -1;)
+          FSTAMP(0);
           if (!lds_wait(vy, SY_S, NHELP * (cs + 1))) break;                // the neighbour is complete (and the helpers are done with Xs)
           if (cs > 0 && !lds_wait(vy, SY_PUB2, cs)) break;                 // the previous L(c + 1, c) has been taken
           FSTAMP(3);
-          solve_rows4(Sb, L0b, rinv_v, Xs, 16 * wave, lane);
+          if (!solve_cols2(Sb, Lt, sy, CNB * cs, Xs, 32 * (wave - 1), lane)) break;
           lds_arrive(sy, SY_X, lane);
           FSTAMP(4);
         }
-        if (wave == 0 && lds_get(vy, SY_ABORT)) give_up();
         return;
       }
+      if (wave < 8 - NHELP) return;
       // ---- the helpers: helper h owns the tile row h (rows 16 h .. 16 h + 15) of the two blocks of the next stage ----
-      const int h = wave - NSOLVE;
+      const int h = wave - (8 - NHELP);
       // publishing: a block in LDS (row-major) -> the matrix, whole lines per store instruction; the stores are left in flight,
       // the flag goes up later (publish_flag), after the wave has had other things to do
       cdv_float4 pubv[CNB / 4];
@@ -448,7 +532,7 @@ __global__ __launch_bounds__(FT) void ba_big_factor_kernel(FacArgs P) {
           for (int u = 0; u < 4; u++) *reinterpret_cast<cdv_float4*>(&Yb[(16 * h + 4 * u + g4) * FLD + 4 * c16]) = py[u];
           wave_lds_sync();
           FSTAMP(3);
-          if (!lds_wait(vy, SY_X, NSOLVE * cs)) return;
+          if (!lds_wait(vy, SY_X, NTW * cs)) return;
           cdv_float4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
           tiles_row<4>(Yb, Xs, h, c16, g4, acc);
 #pragma unroll
@@ -477,11 +561,11 @@ __global__ __launch_bounds__(FT) void ba_big_factor_kernel(FacArgs P) {
           publish_issue(Lb, true);
           lds_post(vy, SY_PUB1, cs + 1);
           publish_store(cs, cs);
+          // fault injection (tests): the second diagonal block never becomes visible
+          publish_flag(cs, cs, P.test == HO_TEST_FACTOR && cs == 1);
         }
-        if (!lds_wait(vy, SY_X, NSOLVE * (cs + 1))) return;     // L(c + 1, c) is in Xs
+        if (!lds_wait(vy, SY_X, NTW * (cs + 1))) return;        // L(c + 1, c) is in Xs
         FSTAMP(6);
-        // fault injection (tests): the second diagonal block never becomes visible
-        if (h == 0) publish_flag(cs, cs, P.test == HO_TEST_FACTOR && cs == 1);
         if (h == 1) {
           publish_issue(Xs, false);
           lds_post(vy, SY_PUB2, cs + 1);

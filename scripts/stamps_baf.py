@@ -31,15 +31,20 @@ nb = (6 * (st.n - st.t0) + 63) // 64
 print("one-launch factorisation, N = %d free poses, %d block columns; cycles (medians over the stages)" % (st.n - st.t0, nb))
 d = b[1:nb - 1]
 print("wave 0 of the chain workgroup, stage c = 1 .. %d:" % (nb - 2))
-for i0, i1, nme in [(0, 1, "factor the diagonal block"), (1, 2, "-> LDS (as is + strictly lower), post"), (2, 3, "wait for the neighbour (helpers)"),
-                    (3, 4, "solve its 16 rows of the neighbour, arrive")]:
+for i0, i1, nme in [(0, 1, "factor the diagonal block (columns -> LDS as they come)"), (1, 2, "L(c, c) row-major -> LDS, post, pivot check")]:
     x = d[:, i1] - d[:, i0]
-    print("  %-44s median %7.0f  min %7.0f  max %7.0f" % (nme, np.median(x), x.min(), x.max()))
-nxt = b[2:nb, 0] - b[1:nb - 1, 4]
-print("  %-44s median %7.0f  min %7.0f  max %7.0f" % ("wait for the next diagonal block", np.median(nxt), nxt.min(), nxt.max()))
+    print("  %-56s median %7.0f  min %7.0f  max %7.0f" % (nme, np.median(x), x.min(), x.max()))
+nxt = b[2:nb, 0] - b[1:nb - 1, 1]
+print("  %-56s median %7.0f  min %7.0f  max %7.0f" % ("end of the factorisation -> next diagonal block complete", np.median(nxt), nxt.min(), nxt.max()))
 d3 = b[32 + 1:32 + nb - 1]
-x = d3[:, 4] - d3[:, 3]
-print("wave 3: solve its 16 rows of the neighbour, arrive: median %.0f" % np.median(x))
+print("wave 1 (solves 32 rows of the neighbour behind the factorisation):")
+for i0, i1, nme in [(0, 3, "wait for the neighbour (helpers)"), (3, 4, "solve, arrive")]:
+    x = d3[:, i1] - d3[:, i0]
+    print("  %-56s median %7.0f  min %7.0f  max %7.0f" % (nme, np.median(x), x.min(), x.max()))
+lag = d3[:, 4] - d[:, 1]
+print("  %-56s median %7.0f  min %7.0f  max %7.0f" % ("solve done after the factorisation's end", np.median(lag), lag.min(), lag.max()))
+late = d3[:, 3] - d[:, 0]
+print("  %-56s median %7.0f  min %7.0f  max %7.0f" % ("solve starts after the factorisation's start", np.median(late), late.min(), late.max()))
 rt = b[0:nb, 14] / 100.0
 step = np.diff(rt)
 print("  stage to stage: median %.2f us (min %.2f, max %.2f); %.1f us from stage 0 to stage %d" % (np.median(step), step.min(), step.max(), rt[-1] - rt[0], nb - 1))
