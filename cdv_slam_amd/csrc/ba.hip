@@ -1351,7 +1351,7 @@ static int ba_forward_impl(float* poses, float* patches, const float* intrinsics
                          d, info, (uint64_t*)(b + L.xgran), (int32_t*)(b + L.fctl), fac_ctl_words(nbk));
       if (!block_steps) {
         // the factorisation as one launch of block work items (ba_factor.hip)
-        const int rcf = cdv_ba_big_factor(Abig, npad, (int32_t*)(b + L.fctl), gv.meta, info, g_handoff_test.load(), s);
+        const int rcf = cdv_ba_big_factor(Abig, npad, (int32_t*)(b + L.fctl), (float*)(b + L.ltg), gv.meta, info, g_handoff_test.load(), s);
         if (rcf != CDV_OK) return rcf;
       } else {
         // (rounds 1-3, kept for comparison: CDV_BA_BLOCK_STEPS=1) one launch per block column.  Block step 0: the panel alone;

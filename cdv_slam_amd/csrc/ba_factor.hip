@@ -52,6 +52,8 @@ struct FacArgs {
   int npad, nb, total;     // total: tickets (1 + items)
   int32_t* ctl;            // [0] ticket counter, [1] abort word, [16 + r * nb + c] flag of block (r, c) (r = nb: right-hand side),
                            // [16 + (nb + 1) * nb + c] flag of the P item of block row c
+  float* Ltg;              // [nb][64][64]: L(c, c) as the chain workgroup's column store held it (column k at [64 k + row]): what the
+                           // item workgroups solve against
   const int32_t* gmeta;
   int32_t* info;
   int test;
@@ -177,51 +179,6 @@ __device__ __forceinline__ void tiles_xyt(const float* X, const float* Y, int ti
       acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], b1[j], acc[1], 0, 0, 0);
     }
   }
-}
-
-// 16 rows of X L^T = S by forward substitution along the rows, FOUR LANES PER ROW (lane = 4 r + g): lane g of a row holds its
-// columns 16 m + 4 g .. + 3, m = 0 .. 3, takes its share of every dot product sum_{j < c} x_j L[c][j] and the four shares meet by
-// two quad permutes; the owner of column c keeps the new x_c.  L0: L row-major with the DIAGONAL ZEROED (so that every lane
-// multiplies whole 16-byte pieces: what is not left of column c meets a zero), rinv_v: lane j holds 1 / L[j][j].  A row's pieces
-// of L are requested one row ahead.  (One lane per row, 64 rows in one wave, was 544 broadcast reads with the LDS latency
-// exposed at every row: ~20,000 cycles; this is four waves of ~5,000 side by side.)
-__device__ __forceinline__ float quad_sum(float s) {
-  s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0xB1, 0xf, 0xf, false));   // quad_perm:[1,0,3,2]
-  s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x4E, 0xf, 0xf, false));   // quad_perm:[2,3,0,1]
-  return s;
-}
-__device__ __forceinline__ void solve_rows4(const float* Sb, const float* L0, float rinv_v, float* Xb, int R0, int lane) {
-  const int r = lane >> 2, g = lane & 3;
-  cdv_float4 xs[4];
-#pragma unroll
-  for (int m = 0; m < 4; m++) xs[m] = *reinterpret_cast<const cdv_float4*>(&Sb[(R0 + r) * FLD + 16 * m + 4 * g]);
-  const float* Lg = L0 + 4 * g;
-  cdv_float4 cur[4], nxt[4];
-  cur[0] = *reinterpret_cast<const cdv_float4*>(&Lg[0]);
-#pragma unroll
-  for (int c = 0; c < CNB; c++) {
-    const int mc = c >> 4, gc = (c >> 2) & 3, ec = c & 3;
-    if (c + 1 < CNB) {
-#pragma unroll
-      for (int m = 0; m <= ((c + 1) >> 4); m++) nxt[m] = *reinterpret_cast<const cdv_float4*>(&Lg[(c + 1) * FLD + 16 * m]);
-    }
-    // the 16-column groups left of column c's (old x) and column c's own group (the newest x) in separate chains
-    f2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
-#pragma unroll
-    for (int m = 0; m < mc; m++) {
-      a0 = __builtin_elementwise_fma(f2{xs[m][0], xs[m][1]}, f2{cur[m][0], cur[m][1]}, a0);
-      a0 = __builtin_elementwise_fma(f2{xs[m][2], xs[m][3]}, f2{cur[m][2], cur[m][3]}, a0);
-    }
-    a1 = __builtin_elementwise_fma(f2{xs[mc][0], xs[mc][1]}, f2{cur[mc][0], cur[mc][1]}, a1);
-    a1 = __builtin_elementwise_fma(f2{xs[mc][2], xs[mc][3]}, f2{cur[mc][2], cur[mc][3]}, a1);
-    const float s = quad_sum((a0[0] + a0[1]) + (a1[0] + a1[1]));
-    const float xc = (xs[mc][ec] - s) * readlane_f(rinv_v, c);
-    xs[mc][ec] = (g == gc) ? xc : xs[mc][ec];
-#pragma unroll
-    for (int m = 0; m < 4; m++) cur[m] = nxt[m];
-  }
-#pragma unroll
-  for (int m = 0; m < 4; m++) *reinterpret_cast<cdv_float4*>(&Xb[(R0 + r) * FLD + 16 * m + 4 * g]) = xs[m];
 }
 
 // one wave, lane = row: the 64 x 64 block in Db (row-major, stride FLD; only its lower triangle matters) -> its Cholesky
@@ -370,7 +327,71 @@ __device__ __forceinline__ bool solve_cols2(const float* Sb, const float* Lt, in
   return ok;
 }
 
-constexpr int NSOLVE = 4;              // item workgroups: waves 0 .. 3 solve (16 rows each, solve_rows4)
+// The same column by column for an item workgroup (all of L(c, c) is there: no progress word): 16 rows per wave, FOUR lanes per row
+// (lane = 4 r + g): lane g holds the row's columns 16 m + 4 g .. + 3, m = 0 .. 3.  Lt: the column store as the chain workgroup
+// published it (column k at Lt[64 k + row]; what lies above the diagonal is never multiplied).
+__device__ __forceinline__ void solve_cols4(const float* Sb, const float* Lt, float* Xb, int R0, int lane) {
+  const int r = lane >> 2, g = lane & 3;
+  cdv_float4 xs[4];
+#pragma unroll
+  for (int m = 0; m < 4; m++) xs[m] = *reinterpret_cast<const cdv_float4*>(&Sb[(R0 + r) * FLD + 16 * m + 4 * g]);
+  int go = 4 * g;
+  asm volatile("" : "+v"(go));   // (see solve_cols2)
+  const float* Lg = Lt + go;
+  cdv_float4 cur[4], nxt[4];
+#pragma unroll
+  for (int m = 0; m < 4; m++) cur[m] = *reinterpret_cast<const cdv_float4*>(&Lg[16 * m]);
+#pragma clang loop unroll(full)
+  for (int k = 0; k < CNB; k++) {
+    const int mk = k >> 4, gk = (k >> 2) & 3, ek = k & 3;
+    if (k + 1 < CNB) {
+#pragma unroll
+      for (int m = (k + 1) >> 4; m < 4; m++) nxt[m] = *reinterpret_cast<const cdv_float4*>(&Lg[(k + 1) * CNB + 16 * m]);
+    }
+    const float xraw = xs[mk][ek], draw = cur[mk][ek];
+    float xb, db;   // x_k and L[k][k] from their owner to the four lanes of the row
+    if (gk == 0) {
+      xb = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(xraw), 0x00, 0xf, 0xf, false));
+      db = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(draw), 0x00, 0xf, 0xf, false));
+    } else if (gk == 1) {
+      xb = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(xraw), 0x55, 0xf, 0xf, false));
+      db = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(draw), 0x55, 0xf, 0xf, false));
+    } else if (gk == 2) {
+      xb = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(xraw), 0xAA, 0xf, 0xf, false));
+      db = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(draw), 0xAA, 0xf, 0xf, false));
+    } else {
+      xb = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(xraw), 0xFF, 0xf, 0xf, false));
+      db = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(draw), 0xFF, 0xf, 0xf, false));
+    }
+    const float xk = __builtin_amdgcn_rcpf(db) * xb;
+#pragma unroll
+    for (int m = mk; m < 4; m++) {
+      const cdv_float4 l = cur[m];
+      if (m > mk) {
+        const f2 nx = {-xk, -xk};
+        const f2 lo = __builtin_elementwise_fma(nx, f2{l[0], l[1]}, f2{xs[m][0], xs[m][1]});
+        const f2 hi = __builtin_elementwise_fma(nx, f2{l[2], l[3]}, f2{xs[m][2], xs[m][3]});
+        xs[m] = cdv_float4{lo[0], lo[1], hi[0], hi[1]};
+      } else {
+        // columns 16 mk + 4 g + j: right of k for the lanes g > gk, and for g == gk where j > ek
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const float u = fmaf(-xk, l[j], xs[m][j]);
+          const bool take = j > ek ? g >= gk : g > gk;
+          xs[m][j] = take ? u : xs[m][j];
+        }
+      }
+    }
+    xs[mk][ek] = (g == gk) ? xk : xs[mk][ek];
+#pragma unroll
+    for (int m = 0; m < 4; m++) cur[m] = nxt[m];
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int m = 0; m < 4; m++) *reinterpret_cast<cdv_float4*>(&Xb[(R0 + r) * FLD + 16 * m + 4 * g]) = xs[m];
+}
+
+constexpr int NSOLVE = 4;              // item workgroups: waves 0 .. 3 solve (16 rows each, solve_cols4)
 constexpr int NTW = 2;                 // chain workgroup: waves 1, 2 solve the neighbour behind the factorisation (32 rows each, solve_cols2)
 constexpr int NHELP = 4;               // its helper waves 4 .. 7: helper h prepares the tile row h of the next stage's blocks
 
@@ -384,7 +405,6 @@ __global__ __launch_bounds__(FT) void ba_big_factor_kernel(FacArgs P) {
   float* const B1 = BB + FBUF;
   float* const B2 = BB + 2 * FBUF;
   float* const B3 = BB + 3 * FBUF;
-  __shared__ __attribute__((aligned(16))) float rinvb[CNB];
   __shared__ int sh[8];    // [0] kind, [1] c, [2] r, [3] go on, [4], [5] wait verdicts of even / odd k, [6] of the diagonal block
   __shared__ int sy[8];    // chain workgroup: SY_* words
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, c16 = lane & 15, g4 = lane >> 4;
@@ -392,6 +412,8 @@ __global__ __launch_bounds__(FT) void ba_big_factor_kernel(FacArgs P) {
   const size_t lda = (size_t)npad;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
       P.A, (short)0, (int)(unsigned)((size_t)(npad + 1) * lda * sizeof(float)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs2 = __builtin_amdgcn_make_buffer_rsrc(
+      P.Ltg, (short)0, (int)(unsigned)((size_t)nb * CNB * CNB * sizeof(float)), 0x00020000);
   int32_t* const flags = P.ctl + 16;
   int32_t* const pflags = flags + (nb + 1) * nb;
   const int ti = wave >> 1, tj0 = 2 * (wave & 1);   // item workgroups: this wave's two tiles of a block: (ti, tj0), (ti, tj0 + 1)
@@ -556,13 +578,22 @@ __global__ __launch_bounds__(FT) void ba_big_factor_kernel(FacArgs P) {
             for (int q = 0; q < 4; q++) dT[tj][q] -= acc[tj][q];
         }
         FSTAMP(5);
-        if (h == 0) {                                            // L(c, c) on its way out while the neighbour is solved
+        if (h == 0) {
+          // L(c, c) out as soon as its last column is in the column store: the column store itself first (what the item workgroups
+          // solve against -- they are on the path to the next stage's neighbour block), the flag behind it; then row-major into the
+          // matrix (what the back substitution launch reads; nobody in this launch waits for it)
+          if (!lds_wait(vy, SY_F, CNB * (cs + 1))) return;
+#pragma unroll
+          for (int u = 0; u < CNB / 4; u++) pubv[u] = *reinterpret_cast<const cdv_float4*>(&Lt[(4 * u + g4) * CNB + 4 * c16]);
+          wave_lds_sync();
+#pragma unroll
+          for (int u = 0; u < CNB / 4; u++) st4(rs2, (size_t)cs * CNB * CNB + (4 * u + g4) * CNB + 4 * c16, pubv[u]);
+          // fault injection (tests): the second diagonal block never becomes visible
+          publish_flag(cs, cs, P.test == HO_TEST_FACTOR && cs == 1);
           if (!lds_wait(vy, SY_L, cs + 1)) return;
           publish_issue(Lb, true);
           lds_post(vy, SY_PUB1, cs + 1);
           publish_store(cs, cs);
-          // fault injection (tests): the second diagonal block never becomes visible
-          publish_flag(cs, cs, P.test == HO_TEST_FACTOR && cs == 1);
         }
         if (!lds_wait(vy, SY_X, NTW * (cs + 1))) return;        // L(c + 1, c) is in Xs
         FSTAMP(6);
@@ -583,11 +614,17 @@ __global__ __launch_bounds__(FT) void ba_big_factor_kernel(FacArgs P) {
         FSTAMP(7);
         if (h == 1) publish_flag(cs + 1, cs, false);
       }
-      if (h == 0) {   // the last diagonal block
+      if (h == 0) {   // the last diagonal block (the right-hand side's last block is solved against it)
+        if (!lds_wait(vy, SY_F, CNB * nb)) return;
+#pragma unroll
+        for (int u = 0; u < CNB / 4; u++) pubv[u] = *reinterpret_cast<const cdv_float4*>(&Lt[(4 * u + g4) * CNB + 4 * c16]);
+        wave_lds_sync();
+#pragma unroll
+        for (int u = 0; u < CNB / 4; u++) st4(rs2, (size_t)(nb - 1) * CNB * CNB + (4 * u + g4) * CNB + 4 * c16, pubv[u]);
+        publish_flag(nb - 1, nb - 1, false);
         if (!lds_wait(vy, SY_L, nb)) return;
         publish_issue(Lb, true);
         publish_store(nb - 1, nb - 1);
-        publish_flag(nb - 1, nb - 1, false);
       }
       return;
     }
@@ -686,35 +723,24 @@ __global__ __launch_bounds__(FT) void ba_big_factor_kernel(FacArgs P) {
     } else {
       if (wave == 0) {
         FSTAMP(2);
-        // L(c, c): this wave waits for it and fetches it by itself (16 pieces per lane); into LDS with its diagonal zeroed, the
-        // reciprocals of the diagonal beside it (solve_rows4)
         const bool w = fac_wait(&flags[bc * nb + bc], &flags[bc * nb + bc], P.ctl, P.info, lane, P.test);
         if (lane == 0) sh[6] = w ? 1 : 0;
         FSTAMP(3);
-        if (w) {
-          cdv_float4 pl[CNB / 4];
-#pragma unroll
-          for (int u = 0; u < CNB / 4; u++) pl[u] = ld4(rs, (size_t)(CNB * bc + 4 * u + g4) * lda + CNB * bc + 4 * c16);
-#pragma unroll
-          for (int u = 0; u < CNB / 4; u++) {
-            const int row = 4 * u + g4;
-            if (c16 == (row >> 2)) {
-              float dg = pl[u][0];
-#pragma unroll
-              for (int j = 1; j < 4; j++) dg = (row & 3) == j ? pl[u][j] : dg;
-              rinvb[row] = 1.0f / dg;
-#pragma unroll
-              for (int j = 0; j < 4; j++) pl[u][j] = (row & 3) == j ? 0.f : pl[u][j];
-            }
-            *reinterpret_cast<cdv_float4*>(&Lb[row * FLD + 4 * c16]) = pl[u];
-          }
-        }
-        FSTAMP(4);
       }
-      __syncthreads();   // the block's rows are in Sb, L(c, c) in Lb; the verdict
+      __syncthreads();   // the block's rows are in Sb; the verdict on L(c, c)
       if (!sh[6]) return;
+      {
+        // L(c, c) as the chain workgroup's column store held it: two 16-byte pieces per thread
+        cdv_float4 pl[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) pl[u] = ld4(rs2, (size_t)bc * CNB * CNB + 4 * (t + FT * u));
+#pragma unroll
+        for (int u = 0; u < 2; u++) *reinterpret_cast<cdv_float4*>(&Lb[4 * (t + FT * u)]) = pl[u];
+      }
+      FSTAMP(4);
+      __syncthreads();
       FSTAMP(5);
-      if (wave < NSOLVE) solve_rows4(Sb, Lb, rinvb[lane], Xs, 16 * wave, lane);
+      if (wave < NSOLVE) solve_cols4(Sb, Lb, Xs, 16 * wave, lane);
       FSTAMP(6);
       // the finished block goes out through LDS: whole lines per store instruction, every wave stores (the right-hand side: one row)
       __syncthreads();
@@ -743,7 +769,7 @@ int cdv_ba_big_factor_items(int nb) {
   return total;
 }
 
-int cdv_ba_big_factor(float* A, int npad, int32_t* ctl, const int32_t* gmeta, int32_t* info, int test, hipStream_t s) {
+int cdv_ba_big_factor(float* A, int npad, int32_t* ctl, float* ltg, const int32_t* gmeta, int32_t* info, int test, hipStream_t s) {
   if (g_fac_cus == 0) {
     int dev = 0, cus = 0;
     CDV_HIP_CHECK(hipGetDevice(&dev));
@@ -752,7 +778,7 @@ int cdv_ba_big_factor(float* A, int npad, int32_t* ctl, const int32_t* gmeta, in
   }
   FacArgs P;
   P.A = A; P.npad = npad; P.nb = npad / CNB; P.total = cdv_ba_big_factor_items(P.nb);
-  P.ctl = ctl; P.gmeta = gmeta; P.info = info; P.test = test;
+  P.ctl = ctl; P.Ltg = ltg; P.gmeta = gmeta; P.info = info; P.test = test;
   const int grid = P.total < g_fac_cus ? P.total : g_fac_cus;
   hipLaunchKernelGGL(ba_big_factor_kernel, dim3(grid), dim3(FT), 0, s, P);
   return CDV_OK;

@@ -59,7 +59,7 @@ enum { BI_CHOL = 0, BI_OVERFLOW = 1, BI_HANDOFF = 2, BI_GRAPH = 3 };
 inline int fac_ctl_words(int nb) { return (16 + (nb + 1) * nb + nb + 3) / 4 * 4; }
 
 struct BaLayout {
-  size_t sy, C, u, Ed, cmask, zero_bytes, q, dX, info, Abig, xgran, fctl, slabs, ared, hand, pnext, ptab, pdiag, pkeys, pgraph, pgraph_bytes, total;
+  size_t sy, C, u, Ed, cmask, zero_bytes, q, dX, info, Abig, xgran, fctl, ltg, slabs, ared, hand, pnext, ptab, pdiag, pkeys, pgraph, pgraph_bytes, total;
   int64_t E_max, pair_cap, pair_range;  // global path: edges the pair index is sized for, frame pairs it can hold, key range
   int64_t npad;                         // global-BA path: 6 N rounded up to the Cholesky block (0: not used)
   int64_t U_max, U_stride, sy_stride;   // sy_stride: floats between two copies of [S | y]
@@ -84,7 +84,7 @@ inline BaLayout ba_layout(int64_t U_max, int N_max, int64_t E_max = 1) {
   L.q = o;    o = align256(o + sizeof(float) * (size_t)L.U_stride);
   L.dX = o;   o = align256(o + sizeof(float) * (n6 + 8));
   L.info = o; o = align256(o + sizeof(int32_t) * 16 + sizeof(uint64_t) * MID_GRAN);   // 16 words + the dX granules of the solve -> retract hand-off
-  L.npad = 0; L.Abig = o; L.xgran = o; L.fctl = o;
+  L.npad = 0; L.Abig = o; L.xgran = o; L.fctl = o; L.ltg = o;
   if (N_max > BA_NMAX) {   // working copy of [S ; y^T] for the blocked Cholesky, padded with identity to 64-blocks
     L.npad = (int64_t)((n6 + CNB - 1) / CNB * CNB);
     o = align256(o + sizeof(float) * (size_t)(L.npad + 1) * (size_t)L.npad);
@@ -92,6 +92,7 @@ inline BaLayout ba_layout(int64_t U_max, int N_max, int64_t E_max = 1) {
     L.xgran = o; o = align256(o + sizeof(uint64_t) * (size_t)L.npad);
     // the factorisation launch's ticket counter, abort word and one flag per 64 x 64 block (ba_factor.hip)
     L.fctl = o; o = align256(o + sizeof(int32_t) * (size_t)fac_ctl_words((int)(L.npad / CNB)));
+    L.ltg = o;  o = align256(o + sizeof(float) * (size_t)L.npad * CNB);
   }
   // window path: one partial system per chunk of 16 patches, the reduced system, the arrival counter
   L.n_ck = 0; L.slabs = o; L.ared = o; L.hand = o; L.pnext = o;
@@ -160,8 +161,9 @@ struct BaWinArgs {
 };
 
 // the blocked Cholesky factorisation of the global path as one launch (ba_factor.hip): A [(npad + 1)][npad] in place; ctl
-// (fac_ctl_words(npad / CNB) words) must be zero when the launch starts
-int cdv_ba_big_factor(float* A, int npad, int32_t* ctl, const int32_t* gmeta, int32_t* info, int test, hipStream_t s);
+// (fac_ctl_words(npad / CNB) words) must be zero when the launch starts; ltg: npad * CNB floats of scratch (the diagonal blocks'
+// factors in the layout the item workgroups solve against)
+int cdv_ba_big_factor(float* A, int npad, int32_t* ctl, float* ltg, const int32_t* gmeta, int32_t* info, int test, hipStream_t s);
 int cdv_ba_big_factor_items(int nb);
 
 // one Gauss-Newton iteration of the window path: two launches on `s`
