@@ -873,6 +873,31 @@ def test_global_ba_at_the_reference_scale():
     assert ops.ba_status(torch.device(DEV)) == (0, 0, 0, 0)
 
 
+def test_global_ba_more_work_items_than_workgroups():
+    """the one-launch factorisation (ba_factor.hip) at 479 free poses: 45 block columns, ~1,000 block work items for the 256
+    workgroups of the launch -- items queue behind the ticket counter and wait on flags of items that other workgroups are
+    still holding.  Without an oracle run at this size: the solve's backward error || S dX - y || / || y || from the
+    iteration-0 dump (the same bound as everywhere), the factor flagged positive definite, and two calls bit for bit equal."""
+    st = synth.make_state("global", features=False, frames=480, M=24, buffer_size=496, ht=384, wd=512)
+    assert st.n - st.t0 == 479
+    _, _, dbg = _run_ba(st, iterations=1, debug=True)
+    S = np.tril(dbg["S"].cpu().numpy().astype(np.float64))
+    S = S + np.tril(S, -1).T
+    y = dbg["y"].cpu().numpy().astype(np.float64)
+    dX = dbg["dX"].cpu().numpy().astype(np.float64).reshape(-1)
+    # (the working copy carries the damping of ba_cuda.cu:589 on its diagonal: the dump is that copy)
+    res = np.linalg.norm(S @ dX - y) / np.linalg.norm(y)
+    print("solve residual at N = 479: %.2e (<= %.0e)" % (res, ba_checks.SOLVE_RESIDUAL_TOL))
+    assert res <= ba_checks.SOLVE_RESIDUAL_TOL, res
+    del dbg
+    assert ops.ba_status(torch.device(DEV)) == (0, 0, 0, 0)
+    p1, x1, _ = _run_ba(st, iterations=2)
+    p2, x2, _ = _run_ba(st, iterations=2)
+    assert np.isfinite(p1).all() and not np.array_equal(p1, st.poses)
+    assert np.array_equal(p1, p2) and np.array_equal(x1, x2)
+    assert ops.ba_status(torch.device(DEV)) == (0, 0, 0, 0)
+
+
 def _circle_pose(t, period=60.0, radius=0.5):
     """camera t of a closed path: world-to-camera pose (t, q) of a camera at radius * (cos a, sin a, 0) looking along +z"""
     a = 2 * np.pi * t / period
