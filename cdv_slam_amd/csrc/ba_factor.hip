@@ -14,16 +14,18 @@
 //
 // Two kinds of workgroup share the launch:
 //  * ONE chain workgroup (whoever draws ticket 0) walks down the diagonal and never hands the critical path to anybody:
-//    stage c = factor the diagonal block (c, c) (wave 0, the register scheme of ba_win.hip's solver), solve its lower
-//    neighbour (c + 1, c) against it (wave 0, forward substitution along the rows), take the neighbour's product off the
-//    next diagonal block (matrix cores) -- L(c, c) and L(c + 1, c) never leave the LDS on their way to the next stage.  Four
-//    helper waves prepare the next stage's two blocks underneath (fetch what item workgroups pre-accumulated, apply the one
-//    product that was still missing), two publisher waves write L(c, c) and L(c + 1, c) out for everybody else.  The waves of
-//    this workgroup meet through counters in LDS, not through s_barrier: a publisher that waits for its stores to drain holds
-//    nobody up.
+//    stage c = wave 0 factors the diagonal block (c, c) (the register scheme of ba_win.hip's solver) and leaves every finished
+//    column in a column store in LDS; waves 1, 2 solve the lower neighbour (c + 1, c) against it column by column BEHIND the
+//    factorisation (solve_cols2) and end a few columns after it; the helper waves 4 .. 7 take the neighbour's product off the
+//    next diagonal block (matrix cores) -- L(c, c) and L(c + 1, c) never leave the LDS on their way to the next stage.  Underneath
+//    the factorisation the helpers prepare the next stage's two blocks (fetch what an item workgroup pre-accumulated, apply the
+//    one product that was still missing); helper 0 writes L(c, c) out -- as the column store holds it, flag right behind --,
+//    helper 1 L(c + 1, c).  The waves of this workgroup meet through counters in LDS, not through s_barrier: a wave that waits
+//    for its stores to drain holds nobody up.
 //  * item workgroups draw the other tickets: O items -- a block (r, c), r >= c + 2, or the right-hand side's block of column
-//    c: all its products, then the solve against L(c, c); P items -- the two blocks of block row c that the chain will take
-//    over (its neighbour block (c, c - 1) and the diagonal block), with the products of the columns k <= c - 3.
+//    c: all its products, then the solve against L(c, c) (solve_cols4, against the published column store); P items -- the two
+//    blocks of block row c that the chain will take over (its neighbour block (c, c - 1) and the diagonal block), with the
+//    products of the columns k <= c - 3.
 //    Tickets are dealt in an order in which an item only needs items with smaller tickets and chain stages that, in turn,
 //    only need such items: the lowest unfinished ticket is always held by a running workgroup whose inputs will arrive, so the
 //    launch finishes whatever the number of resident workgroups and the order they start in.
