@@ -438,11 +438,11 @@ __global__ __launch_bounds__(FT) void ba_big_factor_kernel(FacArgs P) {
 
     if (kind == 0) {
       // =====================================================================================================
-      // the chain workgroup.  Waves 0 .. 3: wave 0 factors, all four solve the neighbour (16 rows each); waves 4 .. 7: helpers
-      // (helper 0 also writes L(c, c) out, helper 1 L(c + 1, c))
+      // the chain workgroup.  Wave 0 factors, waves 1 and 2 solve the neighbour behind it (32 rows each), wave 3 has nothing to do;
+      // waves 4 .. 7: helpers (helper 0 also writes L(c, c) out, helper 1 L(c + 1, c))
       // =====================================================================================================
       float* const Db = BB;                // the diagonal block to factor
-      float* const Lb = BB + FBUF;         // L(c, c), row-major, zeros right of the diagonal
+      float* const Lb = BB + FBUF;         // L(c, c), row-major as the factoring wave's registers held it (the publisher cuts off the upper part)
       float* const Sb = BB + 2 * FBUF;     // the neighbour (c + 1, c), all products of the columns left of it applied
       float* const Xs = BB + 3 * FBUF;     // L(c + 1, c)
       float* const Y01 = BB + 4 * FBUF;    // L(c + 1, c - 1) as fetched by the helpers, two buffers: stages alternate
@@ -508,8 +508,10 @@ __global__ __launch_bounds__(FT) void ba_big_factor_kernel(FacArgs P) {
       // the flag goes up later (publish_flag), after the wave has had other things to do
       cdv_float4 pubv[CNB / 4];
       auto publish_issue = [&](const float* src, bool lower) {   // lower: zeros right of the diagonal
+        // (the lane's coordinates behind an empty asm: what is compared with them is then not hoisted out of the stage loop as ~64
+        // lane masks that live in spilled scalar registers)
         int g4o = g4, c16o = c16;
-        asm volatile("" : "+v"(g4o), "+v"(c16o));   // (see lane_o above)
+        asm volatile("" : "+v"(g4o), "+v"(c16o));
 #pragma unroll
         for (int u = 0; u < CNB / 4; u++) {
           pubv[u] = *reinterpret_cast<const cdv_float4*>(&src[(4 * u + g4) * FLD + 4 * c16]);
