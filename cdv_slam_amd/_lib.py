@@ -73,6 +73,7 @@ SIGNATURES = {
     "cdv_ba_status": (_i32, [_vp, _vp, _vp]),
     "cdv_ba_bind_status_counters": (_i32, [_vp, _vp]),
     "cdv_ba_test_handoff": (_i32, [_i32]),
+    "cdv_ba_factor_ticket": (_i32, [_i32, _i32, _vp]),
     "cdv_ba_set_patches_per_frame": (_i32, [_vp, _i32]),
     "cdv_lie_op": (_i32, [_i32, _i32, _i32, _i64, _vp, _vp, _vp, _vp]),
     # ---- a frame stream whose sizes live on the device

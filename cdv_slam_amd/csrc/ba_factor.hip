@@ -67,7 +67,7 @@ struct FacArgs {
 //   P(c):           L(c, k), L(c - 1, k), k <= c - 3 (items of O(k), k <= c - 3);
 //   chain stage c (factor (c, c), solve (c + 1, c)): P(c + 1), the block (c + 1, c - 1) of O(c - 1), chain stage c - 1:
 // smaller tickets, or chain stages that need nothing but smaller tickets.
-__device__ __forceinline__ bool fac_decode(int t, int nb, int& kind, int& c, int& r) {
+__host__ __device__ __forceinline__ bool fac_decode(int t, int nb, int& kind, int& c, int& r) {
   t -= 1;
   for (int g = 0; g < nb; g++) {
     const int nrows = nb - g - 2 > 0 ? nb - g - 2 : 0;
@@ -772,6 +772,23 @@ int cdv_ba_big_factor_items(int nb) {
   for (int g = 0; g < nb; g++) total += (nb - g - 2 > 0 ? nb - g - 2 : 0) + 1 + (g + 3 < nb ? 1 : 0);
   return total;
 }
+
+}  // namespace cdv
+
+// The work item behind a ticket of the factorisation launch for a matrix of nb block columns (host copy of the kernel's own
+// decoding, for tests of the ticket order): out[0] = 0 chain workgroup / 1 block (r, c), solved against L(c, c) / 2 the two
+// pre-accumulated blocks of block row c; out[1] = c, out[2] = r (nb: the right-hand side).  Returns the number of tickets.
+extern "C" int cdv_ba_factor_ticket(int ticket, int nb, int32_t* out) {
+  const int total = cdv::cdv_ba_big_factor_items(nb);
+  if (out && ticket >= 0 && ticket < total) {
+    int kind = 0, c = 0, r = 0;
+    if (ticket > 0) cdv::fac_decode(ticket, nb, kind, c, r);
+    out[0] = kind; out[1] = c; out[2] = r;
+  }
+  return total;
+}
+
+namespace cdv {
 
 int cdv_ba_big_factor(float* A, int npad, int32_t* ctl, float* ltg, const int32_t* gmeta, int32_t* info, int test, hipStream_t s) {
   if (g_fac_cus == 0) {

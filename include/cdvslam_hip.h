@@ -384,6 +384,15 @@ int cdv_ba_set_patches_per_frame(void* ba_ws, int patches_per_frame);
  */
 int cdv_ba_test_handoff(int mode);
 
+/*
+ * Test hook, host only (no counterpart in the reference): the work item behind ticket `ticket` of the one-launch Cholesky
+ * factorisation of the global path (csrc/ba_factor.hip) for a reduced system of nb 64-column blocks.  out[0] = 0 the chain
+ * workgroup / 1 a block (r, c) that is solved against L(c, c) / 2 the two pre-accumulated blocks of block row c; out[1] = c;
+ * out[2] = r (nb: the right-hand side's block).  Returns the number of tickets.  tests/test_factor_order.py checks with it that
+ * every item only needs items with smaller tickets.
+ */
+int cdv_ba_factor_ticket(int ticket, int nb, int32_t* out);
+
 
 /* altcorr.patchify(net, coords, radius, mode) -- correlation.py:51-71 -- in one launch: the gather of
  * patchify_forward plus the blend the reference composes from four slice products.
