@@ -1322,6 +1322,7 @@ static int ba_forward_impl(float* poses, float* patches, const float* intrinsics
       const int rc0 = cdv_graph_workspace_init(pws, L.pgraph_bytes, L.E_max, L.pair_range, stream);
       if (rc0 != CDV_OK) return rc0;
     }
+    cdv_graph_no_corr_order(pws);   // (idempotent; the flag goes when the workspace is forgotten)
     hipLaunchKernelGGL(ba_pair_key_kernel, dim3(cdv_div_up(E, 256) < 2048 ? (int)cdv_div_up(E, 256) : 2048), dim3(256), 0, s, ii, jj,
                        (int32_t)E, t0, N, pkeys);
     const int rc1 = cdv_graph_build_edges(ii, jj, pkeys, E, pws, L.pgraph_bytes, L.E_max, L.pair_range, nullptr, nullptr, stream);

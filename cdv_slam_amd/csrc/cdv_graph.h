@@ -156,6 +156,9 @@ bool cdv_graph_lookup(const void* ws, cdv::GraphLayout* out);
 
 void cdv_graph_forget(const void* ws);
 
+// builds on this workspace skip the correlation's processing order (an index no correlation walks; forgotten with the workspace)
+void cdv_graph_no_corr_order(const void* ws);
+
 // was the last build on this workspace given the source frames ii (they are then part of the edge records)?
 bool cdv_graph_has_ii(const void* ws);
 

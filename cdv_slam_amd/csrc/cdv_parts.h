@@ -468,6 +468,30 @@ __device__ __forceinline__ int run_atomic_add(int32_t* counters, int bin, bool i
   return __shfl(base, in ? hl : lane) + (lane - hl);
 }
 
+// The same for ids WITHOUT runs (the frame-pair keys of a global bundle adjustment: consecutive edges go from one patch to a dozen
+// target frames, the same dozen for the next patch -- every key of a wave appears several times, never twice in a row): one atomic
+// per DISTINCT id of the wave.  First every lane finds its group (the lanes with its id: one ballot per distinct id), its rank in
+// it and the group's size; then the groups' first lanes add in ONE atomic instruction; then every lane picks up its group's base.
+// (705 k keys over 90 k bins: 64 us of atomics for the histogram launch, 80 for the fill launch, one atomic per edge.)
+__device__ __forceinline__ int group_atomic_add(int32_t* counters, int bin, bool in, int lane) {
+  unsigned long long todo = __ballot(in);
+  int leader = lane, rank = 0, size = 1;
+  while (todo) {   // wave-uniform
+    const int l = __ffsll((long long)todo) - 1;
+    const int b = __shfl(bin, l);
+    const unsigned long long same = __ballot(in && bin == b);
+    if (in && bin == b) {
+      leader = l;
+      rank = __popcll(same & ((1ull << lane) - 1ull));
+      size = __popcll(same);
+    }
+    todo &= ~same;
+  }
+  int base = 0;
+  if (in && leader == lane) base = atomicAdd(&counters[bin], size);
+  return __shfl(base, leader) + rank;
+}
+
 __device__ __forceinline__ void graph_hist_body(const HistArgs& a, int bid, int nblocks, int nthreads_per_block, int tid) {
   constexpr int IMAXV = 0x7fffffff, IMINV = (int)0x80000000;
   int kmin = IMAXV, kmax = IMINV, jmin = IMAXV, jmax = IMINV;
@@ -491,7 +515,8 @@ __device__ __forceinline__ void graph_hist_body(const HistArgs& a, int bid, int 
       m = (m < 0) ? m + R : m;
       m = (m >= R) ? m - R : m;
     }
-    run_atomic_add(a.khist, m, in && k >= 0, hl);
+    if (a.E > GRAPH_WIDE_EDGES) group_atomic_add(a.khist, m, in && k >= 0, hl);
+    else run_atomic_add(a.khist, m, in && k >= 0, hl);
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {

@@ -25,6 +25,7 @@
 //                predecessor / successor in time (fastba.neighbors); clears the fill cursors
 #include <mutex>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include "cdv_common.h"
@@ -46,6 +47,7 @@ struct RegEntry {
 };
 std::mutex g_reg_mutex;
 std::unordered_map<const void*, RegEntry> g_registry;
+std::unordered_set<const void*> g_no_order;   // workspaces whose builds skip the correlation's processing order (cdv_graph_no_corr_order)
 
 
 __global__ __launch_bounds__(256) void graph_init_kernel(int32_t* meta, int32_t* khist, int32_t* kcursor, int32_t* tcur,
@@ -75,6 +77,131 @@ __global__ __launch_bounds__(1024) void graph_scan_kernel(int32_t* meta, const i
                                                           int nstage, int32_t* khist, int32_t* kcount,
                                                           int32_t* krank, int32_t E, int64_t k_cap) {
   cdv::graph_scan_wide_body(meta, stage, nstage, khist, kcount, krank, E, k_cap, (int)blockDim.x, (int)threadIdx.x);
+}
+
+// The scan of a WIDE build (GRAPH_WIDE_EDGES) over several workgroups, two launches: (1) every workgroup sums its slice of the
+// histogram (edges, non-empty bins) into part[2 w], part[2 w + 1]; (2) every workgroup adds up the slices before its own, scans
+// its slice from there (CSR offsets by id - kmin, unique ranks), re-zeroes the histogram; workgroup 0 writes the meta words.  One
+// workgroup of 1024 threads walking the 90 k frame-pair keys of a global bundle adjustment was 69 us of dependent memory round trips.
+constexpr int SCAN_WG = 64, SCAN_T = 256;
+__device__ __forceinline__ void scan_wide_range(const int32_t* __restrict__ stage, int nstage, int32_t E, int64_t k_cap, int t,
+                                                int (&mm)[4], bool& bad, int& n) {
+  constexpr int IMAX = 0x7fffffff, IMIN = (int)0x80000000;
+  __shared__ int s_mm[SCAN_T / 64][4];
+  int kmin = IMAX, kmax = IMIN, jmin = IMAX, jmax = IMIN;
+  for (int i = t; i < nstage; i += SCAN_T) {
+    kmin = min(kmin, stage[4 * i]); kmax = max(kmax, stage[4 * i + 1]);
+    jmin = min(jmin, stage[4 * i + 2]); jmax = max(jmax, stage[4 * i + 3]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    kmin = min(kmin, __shfl_xor(kmin, o)); kmax = max(kmax, __shfl_xor(kmax, o));
+    jmin = min(jmin, __shfl_xor(jmin, o)); jmax = max(jmax, __shfl_xor(jmax, o));
+  }
+  if ((t & 63) == 0) { s_mm[t >> 6][0] = kmin; s_mm[t >> 6][1] = kmax; s_mm[t >> 6][2] = jmin; s_mm[t >> 6][3] = jmax; }
+  __syncthreads();
+  for (int w = 0; w < SCAN_T / 64; w++) {
+    kmin = min(kmin, s_mm[w][0]); kmax = max(kmax, s_mm[w][1]);
+    jmin = min(jmin, s_mm[w][2]); jmax = max(jmax, s_mm[w][3]);
+  }
+  mm[0] = kmin; mm[1] = kmax; mm[2] = jmin; mm[3] = jmax;
+  const int64_t krange = (E > 0) ? (int64_t)kmax - kmin + 1 : 0;
+  bad = E > 0 && (kmin < 0 || krange > k_cap);
+  n = (int)krange;
+}
+__device__ __forceinline__ int scan_wide_slice(int n) { return ((n + SCAN_WG - 1) / SCAN_WG + SCAN_T - 1) / SCAN_T * SCAN_T; }
+
+__global__ __launch_bounds__(SCAN_T) void graph_scan_part_kernel(const int32_t* __restrict__ stage, int nstage, const int32_t* __restrict__ khist,
+                                                                  int32_t* __restrict__ part, int32_t E, int64_t k_cap) {
+  const int t = threadIdx.x;
+  int mm[4], n; bool bad;
+  scan_wide_range(stage, nstage, E, k_cap, t, mm, bad, n);
+  __shared__ int s_sum[SCAN_T / 64], s_cnt[SCAN_T / 64];
+  int32_t sum = 0, cnt = 0;
+  if (!bad && E > 0) {
+    const int R = (int)k_cap, b0 = mm[0] % R, S = scan_wide_slice(n);
+    const int lo = min((int)blockIdx.x * S, n), hi = min(lo + S, n);
+    for (int i = lo + t; i < hi; i += SCAN_T) {
+      int bin = b0 + i; bin = (bin >= R) ? bin - R : bin;
+      const int32_t v = khist[bin];
+      sum += v; cnt += (v > 0);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o); cnt += __shfl_xor(cnt, o); }
+  if ((t & 63) == 0) { s_sum[t >> 6] = sum; s_cnt[t >> 6] = cnt; }
+  __syncthreads();
+  if (t == 0) {
+    int32_t a = 0, c = 0;
+    for (int w = 0; w < SCAN_T / 64; w++) { a += s_sum[w]; c += s_cnt[w]; }
+    part[2 * blockIdx.x] = a; part[2 * blockIdx.x + 1] = c;
+  }
+}
+
+__global__ __launch_bounds__(SCAN_T) void graph_scan_apply_kernel(int32_t* meta, const int32_t* __restrict__ stage, int nstage, int32_t* khist,
+                                                                   int32_t* kcount, int32_t* krank, const int32_t* __restrict__ part,
+                                                                   int32_t E, int64_t k_cap) {
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  int mm[4], n; bool bad;
+  scan_wide_range(stage, nstage, E, k_cap, t, mm, bad, n);
+  const int R = (int)k_cap;
+  if (blockIdx.x == 0 && t == 0) {
+    meta[GM_KMIN] = mm[0]; meta[GM_KMAX] = mm[1]; meta[GM_JMIN] = mm[2]; meta[GM_JMAX] = mm[3];
+    meta[GM_E] = E;
+    meta[GM_ERROR] = bad ? 1 : 0;
+    meta[GM_KRANGE] = bad ? 0 : n;
+    if (bad || E == 0) meta[GM_U] = 0;
+  }
+  if (bad || E == 0) {   // a failed build leaves a clean histogram too
+    for (int i = blockIdx.x * SCAN_T + t; i < R; i += gridDim.x * SCAN_T) khist[i] = 0;
+    return;
+  }
+  // what lies before this workgroup's slice, and the totals
+  __shared__ int s_a[SCAN_T / 64][4];
+  int32_t run = 0, rk = 0, tot = 0, totc = 0;
+  for (int w = t; w < SCAN_WG; w += SCAN_T) {
+    const int32_t a = part[2 * w], c = part[2 * w + 1];
+    tot += a; totc += c;
+    if (w < (int)blockIdx.x) { run += a; rk += c; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    run += __shfl_xor(run, o); rk += __shfl_xor(rk, o); tot += __shfl_xor(tot, o); totc += __shfl_xor(totc, o);
+  }
+  if (lane == 0) { s_a[wv][0] = run; s_a[wv][1] = rk; s_a[wv][2] = tot; s_a[wv][3] = totc; }
+  __syncthreads();
+  run = rk = tot = totc = 0;
+  for (int w = 0; w < SCAN_T / 64; w++) { run += s_a[w][0]; rk += s_a[w][1]; tot += s_a[w][2]; totc += s_a[w][3]; }
+  if (blockIdx.x == 0 && t == 0) { kcount[n] = tot; meta[GM_U] = totc; }
+  const int b0 = mm[0] % R, S = scan_wide_slice(n);
+  const int lo = min((int)blockIdx.x * S, n), hi = min(lo + S, n);
+  __shared__ int s_ws[SCAN_T / 64], s_wc[SCAN_T / 64];
+  for (int i0 = lo; i0 < hi; i0 += SCAN_T) {   // workgroup-uniform
+    const int i = i0 + t;
+    const bool in = i < hi;
+    int bin = b0 + min(i, hi - 1); bin = (bin >= R) ? bin - R : bin;
+    const int32_t v = in ? khist[bin] : 0;
+    int32_t is = v, ic = (v > 0);
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int32_t a1 = __shfl_up(is, o), c1 = __shfl_up(ic, o);
+      if (lane >= o) { is += a1; ic += c1; }
+    }
+    __syncthreads();   // (the slots below are read by the previous round until here)
+    if (lane == 63) { s_ws[wv] = is; s_wc[wv] = ic; }
+    __syncthreads();
+    int32_t wb = 0, wc = 0, rt = 0, rc = 0;
+    for (int w = 0; w < SCAN_T / 64; w++) {
+      if (w < wv) { wb += s_ws[w]; wc += s_wc[w]; }
+      rt += s_ws[w]; rc += s_wc[w];
+    }
+    if (in) {
+      khist[bin] = 0;
+      kcount[i] = run + wb + is - v;
+      krank[i] = rk + wc + ic - (v > 0);
+    }
+    run += rt; rk += rc;
+  }
 }
 
 // index % modulus with the host's reciprocal (as the correlation kernel reduces kk / jj itself when it reads them)
@@ -118,7 +245,8 @@ __global__ __launch_bounds__(256) void graph_fill_kernel(const int64_t* __restri
   const int flane = threadIdx.x & 63;
   if (!err) {   // (workgroup-uniform; one cursor atomic per run of equal ids among the wave's consecutive edges)
     d_first = t_first < E ? (int)kk_first - kmin : 0;
-    p_first = cdv::run_atomic_add(kcursor, d_first, t_first < E, flane);
+    p_first = (E > cdv::GRAPH_WIDE_EDGES) ? cdv::group_atomic_add(kcursor, d_first, t_first < E, flane)
+                                          : cdv::run_atomic_add(kcursor, d_first, t_first < E, flane);
     if (t_first < E) {
       kc_first = kcount[d_first];
       kr_first = krank[d_first];
@@ -203,7 +331,8 @@ __global__ __launch_bounds__(256) void graph_fill_kernel(const int64_t* __restri
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t - flane < n; t += gridDim.x * blockDim.x) {   // wave-uniform trip count
     const bool first = t == t_first;   // (the whole wave's first trip, or nobody's)
     int p_run = 0;
-    if (!first) p_run = cdv::run_atomic_add(kcursor, t < E ? (int)kk[t] - kmin : 0, t < E, flane);
+    if (!first) p_run = (E > cdv::GRAPH_WIDE_EDGES) ? cdv::group_atomic_add(kcursor, t < E ? (int)kk[t] - kmin : 0, t < E, flane)
+                                                    : cdv::run_atomic_add(kcursor, t < E ? (int)kk[t] - kmin : 0, t < E, flane);
     if (t <= krange) {  // dense bins -> unique ranks
       if (t == krange) {
         koff_u[meta[GM_U]] = kcount[krange];
@@ -257,15 +386,18 @@ __global__ __launch_bounds__(256) void graph_segsort_kernel(const int64_t* __res
     const uint64_t ke = ((uint64_t)(uint32_t)me.y << 32) | (uint32_t)e;
     int r = 0;
     uint64_t pk = 0, nk = ~(uint64_t)0;   // best predecessor / successor key so far (sentinels: none)
-    for (int s0 = lo; s0 < hi; s0 += 4) {
-      uint64_t ko[4];
+    // (sixteen entries of the list requested together: a frame pair of a global bundle adjustment has ~200 edges, and four at a
+    // time were 48 dependent memory round trips per thread -- 81 us for this launch at 705 k edges)
+    constexpr int SU = 16;
+    for (int s0 = lo; s0 < hi; s0 += SU) {
+      uint64_t ko[SU];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
+      for (int u = 0; u < SU; u++) {
         const int2 o = *reinterpret_cast<const int2*>(pcsr_tmp + 4 * (size_t)min(s0 + u, hi - 1));
         ko[u] = ((uint64_t)(uint32_t)o.y << 32) | (uint32_t)o.x;
       }
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
+      for (int u = 0; u < SU; u++) {
         const bool in = s0 + u < hi;
         const bool below = in && ko[u] < ke, above = in && ko[u] > ke;
         r += below;
@@ -644,6 +776,7 @@ bool cdv_graph_has_ii(const void* ws) {
 void cdv_graph_forget(const void* ws) {
   std::lock_guard<std::mutex> lk(g_reg_mutex);
   g_registry.erase(ws);
+  g_no_order.erase(ws);
 }
 
 // Explicit initialisation of an index workspace: zeroes what the builds keep zero between calls (histogram, cursors,
@@ -712,6 +845,7 @@ int cdv_graph_finish(const int64_t* ii, const int64_t* jj, const int64_t* kk, in
   const GraphLayout L = graph_layout(E_max, k_range);
   const GraphView v = graph_view(ws, L);
   CorrStream cs{nullptr, 0, 0, 0, 0, 0, 0, 1.0f};
+  bool want_order = true;
   {
     std::lock_guard<std::mutex> lk(g_reg_mutex);
     auto it = g_registry.find(ws);
@@ -719,22 +853,36 @@ int cdv_graph_finish(const int64_t* ii, const int64_t* jj, const int64_t* kk, in
       it->second.has_ii = ii != nullptr && E > 0;
       cs = it->second.cs;
     }
+    want_order = g_no_order.find(ws) == g_no_order.end();
   }
   hipStream_t s = (hipStream_t)stream;
   const int32_t En = (int32_t)E;
   const int tb = 256;
   const int fb = grid_for(E, tb, GRAPH_MAX_BLOCKS);
-  if (hist_blocks == 0 || E > cdv::GRAPH_WIDE_EDGES)   // otherwise the last workgroup of the histogram launch has done the scan
+  if (E > cdv::GRAPH_WIDE_EDGES) {   // the scan of a wide build: two launches over SCAN_WG workgroups (partial sums in ku, which the fill writes later)
+    hipLaunchKernelGGL(graph_scan_part_kernel, dim3(SCAN_WG), dim3(SCAN_T), 0, s, v.stage, hist_blocks, v.khist, v.ku, En, k_range);
+    hipLaunchKernelGGL(graph_scan_apply_kernel, dim3(SCAN_WG), dim3(SCAN_T), 0, s, v.meta, v.stage, hist_blocks, v.khist, v.kcount,
+                       v.krank, v.ku, En, k_range);
+  } else if (hist_blocks == 0) {     // otherwise the last workgroup of the histogram launch has done the scan
     hipLaunchKernelGGL(graph_scan_kernel, dim3(1), dim3(1024), 0, s, v.meta, v.stage, hist_blocks, v.khist, v.kcount,
                        v.krank, En, k_range);
+  }
   if (E > 0) {
     hipLaunchKernelGGL(graph_fill_kernel, dim3(fb), dim3(tb), 0, s, kk, En, v.meta, v.kcount, v.kcursor, v.krank,
-                       v.koff_u, v.kx, v.ku, v.pcsr_tmp, jj, v.ocnt, hist_blocks, v.order, cs, v.crec);
+                       v.koff_u, v.kx, v.ku, v.pcsr_tmp, jj, v.ocnt, hist_blocks, want_order ? v.order : nullptr, cs, v.crec);
     hipLaunchKernelGGL(graph_segsort_kernel, dim3(fb), dim3(tb), 0, s, ii, jj, kk, En, v.meta, v.kcount, v.pcsr_tmp,
                        v.pcsr, v.prec, v.pell, (int)L.ell_chunks, v.krank, v.nprev, v.nnext, v.kcursor, ix, jx);
   }
   CDV_LAUNCH_CHECK();
   return CDV_OK;
+}
+
+// An index that no correlation will ever walk (the frame-pair index of a global bundle adjustment: ba.hip): its builds skip the
+// correlation's processing order -- every workgroup of the fill launch sums the whole per-block count table for it, which is
+// nothing at the ~190 blocks of a frame-to-frame graph and 130 MB of reads at the 1024 blocks of a 700 k-edge one.
+void cdv_graph_no_corr_order(const void* ws) {
+  std::lock_guard<std::mutex> lk(g_reg_mutex);
+  g_no_order.insert(ws);
 }
 
 bool cdv_graph_is_table(const void* ws) {
