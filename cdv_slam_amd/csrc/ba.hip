@@ -974,6 +974,8 @@ __global__ __launch_bounds__(256) void ba_big_backsolve_kernel(float* __restrict
       }
   }
   for (int kb = nb - 1; kb >= 0; kb--) {
+    CDV_IF_STAMPS(const int sslot = 2000 + 64 * (int)blockIdx.x + kb;)
+    if (threadIdx.x < 64) { CDV_STAMP(ba, sslot, 0); }
     const int c0 = CNB * kb;
     if (c0 + CNB <= (int)blockIdx.x * 256) break;   // this block and all that follow lie left of my columns: nothing of
                                                      // them folds into mine (workgroup-uniform)
@@ -993,7 +995,9 @@ __global__ __launch_bounds__(256) void ba_big_backsolve_kernel(float* __restrict
       }
     }
     if (t == 0) s_ok = 1;
-    __syncthreads();   // Lb holds L_kk (written a step ago, or above)
+    lds_barrier();   // Lb holds L_kk (written a step ago, or above).  (LDS only, here and below: __syncthreads() would also wait for
+                     // the 64 row loads just requested -- their round trip then sat on the chain of every step: 130 us for the sweep)
+    if (threadIdx.x < 64) { CDV_STAMP(ba, sslot, 1); }
     if (owner) {
       if (wave == ((c0 & 255) >> 6)) {   // this wave's z IS block kb's: x_r = z_r / L[r][r] once every x_j, j > r, is folded in
         float col[CNB];
@@ -1030,7 +1034,9 @@ __global__ __launch_bounds__(256) void ba_big_backsolve_kernel(float* __restrict
       xs[lane] = xv;
       if (!ok) s_ok = 0;
     }
-    __syncthreads();
+    if (threadIdx.x < 64) { CDV_STAMP(ba, sslot, 2); }
+    lds_barrier();
+    if (threadIdx.x < 64) { CDV_STAMP(ba, sslot, 3); }
     if (!s_ok) {
       if (t == 0) ba_flag(info, BI_HANDOFF, 1);
       return;
@@ -1045,7 +1051,9 @@ __global__ __launch_bounds__(256) void ba_big_backsolve_kernel(float* __restrict
       }
       z -= (s0 + s1) + (s2 + s3);
     }
-    __syncthreads();   // xs and Lb are rewritten
+    if (threadIdx.x < 64) { CDV_STAMP(ba, sslot, 4); }
+    lds_barrier();   // xs and Lb are rewritten
+    if (threadIdx.x < 64) { CDV_STAMP(ba, sslot, 5); }
     if (owner_next) {
 #pragma unroll
       for (int u = 0; u < CNB * CNB / 256; u++) {

@@ -179,6 +179,12 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// workgroup barrier over LDS only: waits for this wave's LDS operations, NOT for its outstanding global loads (which
+// __syncthreads() would drain: the next level of a dependent load chain then starts a memory round trip late)
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // try to decide the launch's verdict; returns the verdict that holds afterwards (one lane calls it)
 __device__ __forceinline__ int ho_decide(int32_t* word, int want) {
   int expected = HO_UNDECIDED;

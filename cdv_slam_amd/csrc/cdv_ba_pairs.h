@@ -8,11 +8,6 @@
 
 namespace cdv {
 
-// workgroup barrier over LDS only: waits for this wave's LDS operations, NOT for its outstanding global loads (which
-// __syncthreads() would drain: the next level of a dependent load chain then starts a memory round trip late)
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
 
 constexpr int NV = 90;                     // distinct sums of one frame pair: 21 + 6 (B_ii, v_i) + 21 + 6 (B_jj, v_j) + 36 (B_ij)
 
