@@ -197,6 +197,12 @@ def test_graph_index_wrapping_ids_and_many_edges():
     kk = rng.integers(10 * R + 100, 10 * R + 100 + 5000, E).astype(np.int64)
     jj = rng.integers(0, 64, E).astype(np.int64)
     _check_graph(kk, jj, R)
+    # a WIDE build (more than 200 k edges: one atomic per distinct id of a wave, the histogram's scan on 64 workgroups) over an id
+    # range like a global bundle adjustment's frame-pair keys -- 90 k bins, ids without runs, the range wrapping around R
+    R2 = 100000
+    kk = rng.integers(3 * R2 - 40000, 3 * R2 + 50000, 250000).astype(np.int64)
+    jj = rng.integers(0, 300, 250000).astype(np.int64)
+    _check_graph(kk, jj, R2)
 
 
 def test_graph_range_overflow_is_reported():
