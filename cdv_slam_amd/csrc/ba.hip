@@ -1012,7 +1012,7 @@ __global__ __launch_bounds__(256) void ba_big_backsolve_kernel(float* __restrict
           zz = fmaf(-col[r], xr, zz);
         }
         xs[lane] = x;
-        if (!(test && kb == nb - 2))      // fault injection (tests): the second block's solution never leaves its owner
+        if (!(test == HO_TEST_STALL_BEFORE && kb == nb - 2))   // fault injection (tests, mode 1 only): the second block's solution never leaves its owner
           __hip_atomic_store(&xg[c0 + lane], ((uint64_t)(uint32_t)token << 32) | (uint64_t)(uint32_t)__float_as_int(x),
                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (c0 + lane < n) {
@@ -1023,7 +1023,7 @@ __global__ __launch_bounds__(256) void ba_big_backsolve_kernel(float* __restrict
     } else if (wave == 0) {
       float xv = 0.f;
       bool ok = false;
-      for (int spins = 0; spins < (test ? (1 << 10) : (1 << 20)); spins++) {
+      for (int spins = 0; spins < (test == HO_TEST_STALL_BEFORE ? (1 << 10) : (1 << 20)); spins++) {
         if (!ok) {
           const uint64_t g = __hip_atomic_load(&xg[c0 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if ((uint32_t)(g >> 32) == (uint32_t)token) { xv = __int_as_float((int)(uint32_t)g); ok = true; }
@@ -1304,7 +1304,12 @@ static int ba_forward_impl(float* poses, float* patches, const float* intrinsics
     wa.test = g_handoff_test.load();
     wa.dyn = dyn;
     // wide chunks cut per frame (ba_mid.hip): only when a frame's patches really are ppf consecutive table slots
-    wa.ppf = (table && N > WIN_N && ppf_hint >= 4 && ppf_hint % 4 == 0 && wa.tab_cap % ppf_hint == 0) ? ppf_hint : 0;
+    // ... and only when the per-frame cut does not need more slabs than the workspace holds (one per 16 rows of U_max): a
+    // frame of fewer than 16 patches would be a workgroup -- and a slab -- of its own (ppf 4, 8, 12: tab_cap / ppf > n_ck)
+    wa.ppf = 0;
+    if (table && N > WIN_N && ppf_hint >= 4 && ppf_hint % 4 == 0 && wa.tab_cap % ppf_hint == 0 &&
+        (int64_t)(wa.tab_cap / ppf_hint) * cdv_ba_mid_wide_per_frame(ppf_hint) <= L.n_ck)
+      wa.ppf = ppf_hint;
     wa.dbg = nullptr;
     wa.token = token_base + 1;
     for (int itr = 0; itr < iterations; itr++) {
@@ -1321,6 +1326,8 @@ static int ba_forward_impl(float* poses, float* patches, const float* intrinsics
   const int rb = cdv_div_up(L.U_max > N ? L.U_max : N, 64);
   const int npad = (int)L.npad, nbk = npad / CNB;
   static const bool block_steps = []() { const char* e = getenv("CDV_BA_BLOCK_STEPS"); return e && e[0] == '1'; }();
+  static const int diag_stop = []() { const char* e = getenv("CDV_BA_DIAG_STOP"); return e ? atoi(e) : 0; }();   // DIAG (temporary)
+#define CDV_DIAG(k) if (diag_stop == (k)) return CDV_OK;
   if (big) {
     // the frame-pair index of this call's edges (both iterations use it): keys, an ordinary index build over them, the
     // (a, b) -> pair table
@@ -1333,35 +1340,44 @@ static int ba_forward_impl(float* poses, float* patches, const float* intrinsics
     cdv_graph_no_corr_order(pws);   // (idempotent; the flag goes when the workspace is forgotten)
     hipLaunchKernelGGL(ba_pair_key_kernel, dim3(cdv_div_up(E, 256) < 2048 ? (int)cdv_div_up(E, 256) : 2048), dim3(256), 0, s, ii, jj,
                        (int32_t)E, t0, N, pkeys);
+    CDV_DIAG(1)
     const int rc1 = cdv_graph_build_edges(ii, jj, pkeys, E, pws, L.pgraph_bytes, L.E_max, L.pair_range, nullptr, nullptr, stream);
     if (rc1 != CDV_OK) return rc1;
+    CDV_DIAG(2)
     const GraphView pv = graph_view(pws, graph_layout(L.E_max, L.pair_range));
     int32_t* ptab = (int32_t*)(b + L.ptab);
     CDV_HIP_CHECK(hipMemsetAsync(ptab, 0, sizeof(int32_t) * (size_t)L.pair_range, s));
     hipLaunchKernelGGL(ba_pair_table_kernel, dim3(256), dim3(256), 0, s, pv.meta, pv.kx, ptab);
+    CDV_DIAG(3)
   }
   for (int itr = 0; itr < iterations; itr++) {
     float* d = (dbg && itr == 0) ? dbg : nullptr;
     const PatchArgs pa{poses, patches, intrinsics, target, weight, ii, P, t0, N, gv.meta, gv.prec, gv.koff_u, gv.kx, Cg, ug, Edg,
                        (int)L.U_stride, (int)L.U_max, info, cmask, counters, itr == 0 ? 1 : 0};
     hipLaunchKernelGGL(ba_patch_kernel, dim3(n_chunks), dim3(64), 0, s, pa);
+    CDV_DIAG(4)
     if (big) {
       const GraphView pv = graph_view(b + L.pgraph, graph_layout(L.E_max, L.pair_range));
       const PairArgs qa{poses, patches, intrinsics, target, weight, ii, kk, P, t0, N, gv.meta, pv.meta, pv.prec, pv.koff_u, pv.kx,
                         sy, (float*)(b + L.pdiag), (int32_t)L.pair_cap, info};
       const int pgrid = (int)(L.pair_cap < 16384 ? L.pair_cap : 16384);
       hipLaunchKernelGGL(ba_pair_kernel, dim3(pgrid), dim3(64), 0, s, qa);
+      CDV_DIAG(5)
       hipLaunchKernelGGL(ba_diag_kernel, dim3(N), dim3(64), 0, s, gv.meta, pv.meta, (const int32_t*)(b + L.ptab),
                          (const float*)(b + L.pdiag), N, sy, info);
+      CDV_DIAG(6)
       const int npan = cdv_div_up(N, BIG_PP);
       hipLaunchKernelGGL(ba_schur_kernel, dim3(npan * (npan + 1) / 2), dim3(256), 0, s, lmbda, N, gv.meta, sy, Cg, ug, Edg,
                          (int)L.U_stride, cmask, n_chunks, info);
+      CDV_DIAG(7)
       hipLaunchKernelGGL(ba_big_fold_kernel, dim3(1024), dim3(256), 0, s, sy, (int)L.sy_stride, n6i, npad, Abig, gv.meta,
                          d, info, (uint64_t*)(b + L.xgran), (int32_t*)(b + L.fctl), fac_ctl_words(nbk));
+      CDV_DIAG(8)
       if (!block_steps) {
         // the factorisation as one launch of block work items (ba_factor.hip)
         const int rcf = cdv_ba_big_factor(Abig, npad, (int32_t*)(b + L.fctl), (float*)(b + L.ltg), gv.meta, info, g_handoff_test.load(), s);
         if (rcf != CDV_OK) return rcf;
+        CDV_DIAG(9)
       } else {
         // (rounds 1-3, kept for comparison: CDV_BA_BLOCK_STEPS=1) one launch per block column.  Block step 0: the panel alone;
         // block step kb >= 1: the panel together with what step kb - 1 owes the matrix
@@ -1374,6 +1390,7 @@ static int ba_forward_impl(float* poses, float* patches, const float* intrinsics
       }
       hipLaunchKernelGGL(ba_big_backsolve_kernel, dim3(cdv_div_up(npad, 256)), dim3(256), 0, s, Abig, npad, n6i, dXg,
                          (uint64_t*)(b + L.xgran), token_base + 1 + itr, gv.meta, d, info, g_handoff_test.load());
+      CDV_DIAG(10)
     } else {
       // only N = 0 gets here (no free pose: depths alone are refined): q = 1 / (C + lambda)
       hipLaunchKernelGGL(ba_q_kernel, dim3(cdv_div_up(L.U_max, 256) < 1024 ? (int)cdv_div_up(L.U_max, 256) : 1024), dim3(256), 0, s,
@@ -1398,7 +1415,7 @@ static int ba_forward_impl(float* poses, float* patches, const float* intrinsics
 //   0 off; 1 the solver of the N <= 32 paths stalls BEFORE its commit (the retract workgroups abandon: nothing is applied) --
 //   on the global path the back substitution withholds one block's solution (its readers time out: nothing is applied);
 //   2 the solver stalls AFTER its commit (the retract workgroups lose their patience, learn that the solution is coming and
-//   wait on: the update is applied as usual);  3 (global path) a diagonal block of the factorisation launch never raises its flag
+//   wait on: the update is applied as usual; the global path has no such in-launch commit and runs undisturbed);  3 (global path) a diagonal block of the factorisation launch never raises its flag
 //   (everybody who needs it times out, the launch drains, nothing is applied).  The waits are shortened so that a test takes
 //   milliseconds.
 extern "C" int cdv_ba_test_handoff(int mode) {

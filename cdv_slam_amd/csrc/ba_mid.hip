@@ -1166,6 +1166,8 @@ void launch_finish(const BaWinArgs& a, int n, int RW, size_t lds_f, hipStream_t 
 
 }  // namespace
 
+int cdv::cdv_ba_mid_wide_per_frame(int ppf) { return wide_per_frame(ppf); }
+
 int cdv::cdv_ba_mid_iteration(const BaWinArgs& a, hipStream_t s) {
   static hipError_t attr_err = [] {
     hipError_t e = hipSuccess, x;
@@ -1196,6 +1198,7 @@ int cdv::cdv_ba_mid_iteration(const BaWinArgs& a, hipStream_t s) {
   // once instead of taking a second round of 38 workgroups -- were measured: 49.1 against 41.7 us; the kernel is written
   // for either, CDV_MID_WAVES=4 selects them.)
   const int n_wide = a.ppf > 0 ? (a.tab_cap / a.ppf) * wide_per_frame(a.ppf) : cdv_div_up(a.n_ck_cap, SC);
+  CDV_REQUIRE(n_wide <= a.n_ck_cap, CDV_ERR_WORKSPACE, "cdv_ba_forward: more wide chunks than slabs in the workspace");   // (ba.hip drops the hint before)
   const int n_ck = n_wide < WIN_MAX_GRID ? n_wide : WIN_MAX_GRID;
   const bool table = a.tab_cap > 0;
   static const int mkw_env = getenv("CDV_MID_WAVES") ? atoi(getenv("CDV_MID_WAVES")) : 8;

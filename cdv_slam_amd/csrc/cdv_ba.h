@@ -170,6 +170,8 @@ int cdv_ba_big_factor_items(int nb);
 int cdv_ba_window_iteration(const BaWinArgs& a, hipStream_t s);
 // the same for 10 < N <= MID_N (ba_mid.hip)
 int cdv_ba_mid_iteration(const BaWinArgs& a, hipStream_t s);
+// wide chunks (workgroups, slabs) one frame of ppf patches is cut into on that path
+int cdv_ba_mid_wide_per_frame(int ppf);
 
 // LDS hand-off between the lanes of ONE wave: the LDS unit executes a wave's DS instructions in order, so only the
 // compiler has to be kept from moving accesses across this point.  (A workgroup-scope release fence would also drain

@@ -19,12 +19,15 @@ enum {
   GM_STAGE = 16,   // arrival counter of the histogram launch (its last workgroup does the scan); zero between builds
   // ---- table build (cdv_graph_build_table / cdv_update_prologue_table; no scan, no ranks: a patch's slot is id mod R) ----
   GM_MODE = 20,    // 1: the index in the workspace is a patch TABLE, 0: the ranked CSR index above
-  GM_GEN = 21,     // generation (build counter) of the table build in the workspace
-  GM_TERR = 22,    // == GM_GEN: this build is in its error state (negative id, two live ids in one slot, a patch with more
-                   // than TAB_MAX_DEG edges) -- no reset needed: compared, not tested
+  GM_GEN = 21,     // generation (build counter) of the table build in the workspace.  The counter lives HERE, on the device:
+                   // a fill launch takes its generation from GM_GENNEXT and publishes it, the sort launch behind it advances
+                   // GM_GENNEXT -- no host value is frozen into a launch, so a captured hipGraph may be replayed for ever
   GM_TCAP = 23,    // capacity R (slots) of the table build in the workspace
+  GM_GENNEXT = 24, // generation the NEXT fill launch will take (written by the sort launch; only its parity matters)
   GM_PRECN = 26,   // records handed out of the overflow CSR (patches with more than ELL_SLOTS edges)
   GM_OVFN = 28,    // [2], by build parity: edges that did not fit their patch's ELL_SLOTS table slots
+  GM_TERR = 30,    // [2], by build parity: != 0: that build is in its error state (negative id, two live ids in one slot, a
+                   // patch with more than TAB_MAX_DEG edges).  The sort launch of build g clears the word of build g + 1.
   GM_WORDS = 64
 };
 
@@ -171,13 +174,14 @@ int64_t cdv_graph_table_capacity(const void* ws);
 // slot, a patch with more edges than the sort launch serves)
 namespace cdv {
 __device__ __forceinline__ int graph_error(const int32_t* __restrict__ meta) {
-  return meta[GM_MODE] ? (meta[GM_TERR] == meta[GM_GEN]) : meta[GM_ERROR];
+  const int e = meta[GM_ERROR], t0 = meta[GM_TERR], t1 = meta[GM_TERR + 1], g = meta[GM_GEN];
+  return meta[GM_MODE] ? ((g & 1) ? t1 : t0) : e;
 }
 // the same for a caller that knows which form the index has (a kernel argument): every word is read unconditionally, so
 // the answer costs ONE memory round trip, not two dependent ones, at the head of a latency-bound kernel
 __device__ __forceinline__ int graph_error_of(const int32_t* __restrict__ meta, bool table) {
-  const int e = meta[GM_ERROR], t = meta[GM_TERR], g = meta[GM_GEN];
-  return table ? (t == g) : e;
+  const int e = meta[GM_ERROR], t0 = meta[GM_TERR], t1 = meta[GM_TERR + 1], g = meta[GM_GEN];
+  return table ? ((g & 1) ? t1 : t0) : e;
 }
 }  // namespace cdv
 

@@ -571,21 +571,23 @@ struct TFillArgs {
   int32_t E, R;                  // R = capacity (slots) of this build
   int32_t* meta;
   int32_t* tcur;
-  unsigned long long* town;      // per slot (generation << 32 | id) of the patch that owns it
+  unsigned long long* town;      // per slot (1 << 32 | id) of the patch that owns it in the build in flight; zero between builds
   int32_t *ttab, *tovf, *tprec;
   int32_t* ocnt;                 // [blocks][ORD_BINS]
-  int32_t gen;                   // generation of this build (> 0)
   const int32_t* dyn = nullptr;  // != NULL: the number of edges is dyn[CDV_DYN_E]; E above is an upper bound (launch sizes)
 };
 
 __device__ __forceinline__ void graph_tfill_body(const TFillArgs& a_in, int bid, int nblocks, int nthreads_per_block, int tid) {
   TFillArgs a = a_in;
   if (a.dyn) a.E = min(a.dyn[CDV_DYN_E], a_in.E);
+  // this build's generation: a word the sort launch of the build before left on the device (nobody writes it during this
+  // launch).  Only its parity is used -- which of the two overflow counters / error words belongs to this build.
+  const int par = a.meta[GM_GENNEXT] & 1;
   __shared__ int s_obin[ORD_BINS];
   if (tid < ORD_BINS) s_obin[tid] = 0;
   if (bid == 0 && tid == 0) {     // words the sort launch accumulates into; nobody reads them between the two launches
     a.meta[GM_PRECN] = 1;
-    a.meta[GM_MODE] = 1; a.meta[GM_GEN] = a.gen; a.meta[GM_E] = a.E; a.meta[GM_HAS_II] = a.ii ? 1 : 0; a.meta[GM_TCAP] = a.R;
+    a.meta[GM_MODE] = 1; a.meta[GM_GEN] = a.meta[GM_GENNEXT]; a.meta[GM_E] = a.E; a.meta[GM_HAS_II] = a.ii ? 1 : 0; a.meta[GM_TCAP] = a.R;
   }
   __syncthreads();
   typedef int cdv_i4 __attribute__((ext_vector_type(4)));
@@ -602,7 +604,7 @@ __device__ __forceinline__ void graph_tfill_body(const TFillArgs& a_in, int bid,
     const cdv_i4 rec = {e, i, j, (int)k64};
     if (e == 0) *reinterpret_cast<cdv_i4*>(a.tprec) = rec;        // overflow-CSR record 0: the "always valid" record
     const bool ok = in && k64 >= 0 && k64 < ((int64_t)1 << 31);
-    if (in && !ok) a.meta[GM_TERR] = a.gen;                       // every writer stores the same value
+    if (in && !ok) a.meta[GM_TERR + par] = 1;                     // every writer stores the same value
     // id mod R without an integer division: float quotient estimate, then one correction step each way
     const int k = ok ? (int)k64 : -1 - lane;                      // invalid lanes: ids no neighbour shares
     int q = (int)((float)k * rinv);
@@ -621,21 +623,21 @@ __device__ __forceinline__ void graph_tfill_body(const TFillArgs& a_in, int bid,
     const int nexth = above ? __ffsll((long long)above) - 1 : 64;
     int base = 0;
     if (ok && head) {
-      // one patch per slot: the slot's owner word takes (generation, id) by an atomic max -- whoever finds another id of
-      // THIS generation there has met a second patch in the slot (stale generations are simply replaced: no reset pass)
-      const unsigned long long mine = ((unsigned long long)(uint32_t)a.gen << 32) | (uint32_t)k;
+      // one patch per slot: the slot's owner word takes (1, id) by an atomic max -- whoever finds another id there has met a
+      // second patch in the slot.  The sort launch zeroes the words of the slots it finds in use, next to their cursors.
+      const unsigned long long mine = (1ull << 32) | (uint32_t)k;
       const unsigned long long was = atomicMax(&a.town[slot], mine);
-      if ((uint32_t)(was >> 32) == (uint32_t)a.gen && (uint32_t)was != (uint32_t)k) a.meta[GM_TERR] = a.gen;
+      if (was != 0ull && (uint32_t)was != (uint32_t)k) a.meta[GM_TERR + par] = 1;
       base = atomicAdd(&a.tcur[slot], nexth - start);
     }
     base = __shfl(base, start);
     if (!ok) continue;
     const int t = base + (lane - start);
-    if (t >= TAB_MAX_DEG) a.meta[GM_TERR] = a.gen;               // more edges than the sort launch serves: known before it starts
+    if (t >= TAB_MAX_DEG) a.meta[GM_TERR + par] = 1;             // more edges than the sort launch serves: known before it starts
     if (t < ELL_SLOTS) {
       *reinterpret_cast<cdv_i4*>(a.ttab + 4 * ((size_t)((slot >> 4) * ELL_SLOTS + t) * 16 + (slot & 15))) = rec;
     } else {
-      const int p = atomicAdd(&a.meta[GM_OVFN + (a.gen & 1)], 1);
+      const int p = atomicAdd(&a.meta[GM_OVFN + par], 1);
       *reinterpret_cast<cdv_i4*>(a.tovf + 4 * (size_t)p) = rec;
     }
   }

@@ -41,7 +41,6 @@ struct RegEntry {
   bool initialised;
   bool has_ii;
   CorrStream cs;      // coords == nullptr: no packed correlation stream is written
-  int32_t gen;        // table builds on this workspace so far
   bool table;         // the index in the workspace is a patch table
   int32_t tab_cap;    // ... of this capacity (slots)
 };
@@ -455,8 +454,9 @@ __global__ __launch_bounds__(256) void graph_copy_unique_kernel(const int32_t* _
 // (projective_ops.py:53-113) computed right there when the caller asks for it (cdv_update_prologue_table) ------------
 struct TSortArgs {
   int32_t* meta;
-  int32_t R, E, gen;
+  int32_t R, E;
   int32_t *tcur, *tdeg, *tplo, *tkid, *tlive, *ttab, *tovf, *tprec;
+  unsigned long long* town;
   int32_t *nprev, *nnext;
   int64_t *ix, *jx;
   int n_patch_wg;                 // workgroups [0, n_patch_wg) take 8 slots each, the rest are edge workgroups
@@ -511,7 +511,10 @@ __global__ __launch_bounds__(256) void graph_tsort_kernel(const TSortArgs A_in) 
   TSortArgs A = A_in;
   if (A.dyn) A.E = min(A.dyn[CDV_DYN_E], A_in.E);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const bool terr = A.meta[GM_TERR] == A.gen;      // written by the fill launch
+  // this build's generation and its error word, as the fill launch left them (nothing in this launch depends on host state
+  // that a captured hipGraph would freeze)
+  const int gen = A.meta[GM_GEN], par = gen & 1;
+  const bool terr = A.meta[GM_TERR + par] != 0;
   if ((int)blockIdx.x >= A.n_patch_wg) {
     // =================================== edge workgroups ===================================
     const int bid = (int)blockIdx.x - A.n_patch_wg;
@@ -637,18 +640,22 @@ __global__ __launch_bounds__(256) void graph_tsort_kernel(const TSortArgs A_in) 
   __shared__ cdv_i4 s_orec[TS_OVF_MAX];
   __shared__ uint64_t s_okey[TS_OVF_MAX];
   __shared__ int s_osort[TS_OVF_MAX], s_ocnt;
-  if (blockIdx.x == 0 && tid == 0) A.meta[GM_OVFN + ((A.gen & 1) ^ 1)] = 0;   // the next build's overflow counter
+  if (blockIdx.x == 0 && tid == 0) {   // the next build's overflow counter, error word and generation
+    A.meta[GM_OVFN + (par ^ 1)] = 0;
+    A.meta[GM_TERR + (par ^ 1)] = 0;
+    A.meta[GM_GENNEXT] = (int)((unsigned)gen + 1u);
+  }
   const int deg = in_tab ? deg_raw : 0;
   const int d32 = min(deg, ELL_SLOTS);
   // two patch ids in one slot (the table's capacity is smaller than the live id range): error state
   const int k0 = __shfl(rec.w, lane & 32);                      // record 0 of this half-wave's slot
   const bool clash = hl < d32 && rec.w != k0;
-  if (__ballot(clash) != 0ull && lane == 0) A.meta[GM_TERR] = A.gen;
+  if (__ballot(clash) != 0ull && lane == 0) A.meta[GM_TERR + par] = 1;
   if (in_tab && hl == 0) {
     A.tdeg[slot] = min(deg, TS_OVF_MAX);
     A.tplo[slot] = 0;
     A.tkid[slot] = deg > 0 ? k0 : -1;
-    if (deg > 0) A.tcur[slot] = 0;                              // zero again for the next build
+    if (deg > 0) { A.tcur[slot] = 0; A.town[slot] = 0ull; }     // cursor and owner word: zero again for the next build
     s_flag[h] = deg > 0 ? 1 : 0;
   } else if (hl == 0) {
     s_flag[h] = 0;
@@ -689,12 +696,12 @@ __global__ __launch_bounds__(256) void graph_tsort_kernel(const TSortArgs A_in) 
 #pragma unroll
   for (int u = 0; u < 8; u++) any_ovf |= s_deg8[u] > ELL_SLOTS;
   if (!any_ovf) return;
-  const int n_ovf = A.meta[GM_OVFN + (A.gen & 1)];
+  const int n_ovf = A.meta[GM_OVFN + par];
   for (int hs = 0; hs < 8; hs++) {
     const int sdeg = s_deg8[hs], oslot = 8 * (int)blockIdx.x + hs;
     if (sdeg <= ELL_SLOTS) continue;
     if (sdeg > TS_OVF_MAX) {                                      // not served (flagged by the fill launch already)
-      if (lane == 0) A.meta[GM_TERR] = A.gen;
+      if (lane == 0) A.meta[GM_TERR + par] = 1;
       continue;
     }
     if (lane < ELL_SLOTS) s_orec[lane] = *reinterpret_cast<const cdv_i4*>(A.ttab + tab_index(oslot, lane));
@@ -710,7 +717,7 @@ __global__ __launch_bounds__(256) void graph_tsort_kernel(const TSortArgs A_in) 
       rs = (rs < 0) ? rs + A.R : rs;
       rs = (rs >= A.R) ? rs - A.R : rs;
       if (rs == oslot) {
-        if (r.w != okid) A.meta[GM_TERR] = A.gen;                 // another id in this slot
+        if (r.w != okid) A.meta[GM_TERR + par] = 1;               // another id in this slot
         const int idx = atomicAdd(&s_ocnt, 1);
         if (idx < TS_OVF_MAX) s_orec[idx] = r;
       }
@@ -793,7 +800,7 @@ extern "C" int cdv_graph_workspace_init(void* ws, size_t ws_bytes, int64_t E_max
                      v.meta, v.khist, v.kcursor, v.tcur, v.town, k_range);
   CDV_LAUNCH_CHECK();
   std::lock_guard<std::mutex> lk(g_reg_mutex);
-  g_registry[ws] = RegEntry{L, true, false, CorrStream{nullptr, 0, 0, 0, 0, 0, 0, 1.0f}, 0, false, 0};
+  g_registry[ws] = RegEntry{L, true, false, CorrStream{nullptr, 0, 0, 0, 0, 0, 0, 1.0f}, false, 0};
   return CDV_OK;
 }
 
@@ -828,8 +835,7 @@ int cdv_graph_prepare(const int64_t* jj, const int64_t* kk, int64_t E, void* ws,
     need_init = it == g_registry.end() || !it->second.initialised || it->second.L.E_max != E_max ||
                 it->second.L.k_range != k_range;
     const CorrStream keep = it != g_registry.end() ? it->second.cs : CorrStream{nullptr, 0, 0, 0, 0, 0, 0, 1.0f};
-    const int32_t gen = it != g_registry.end() ? it->second.gen : 0;
-    g_registry[ws] = RegEntry{L, true, false, keep, gen, false, 0};
+    g_registry[ws] = RegEntry{L, true, false, keep, false, 0};
   }
   const GraphView v = graph_view(ws, L);
   if (need_init)
@@ -913,23 +919,21 @@ int cdv_graph_table_prepare(const int64_t* ii, const int64_t* jj, const int64_t*
   const GraphLayout L = graph_layout(E_max, k_range);
   CDV_REQUIRE(L.total <= ws_bytes, CDV_ERR_WORKSPACE, "cdv_graph_build_table: workspace too small for (E_max, k_range)");
   bool need_init;
-  int32_t gen;
   {
     std::lock_guard<std::mutex> lk(g_reg_mutex);
     auto it = g_registry.find(ws);
     need_init = it == g_registry.end() || !it->second.initialised || it->second.L.E_max != E_max ||
                 it->second.L.k_range != k_range;
     const CorrStream keep = it != g_registry.end() ? it->second.cs : CorrStream{nullptr, 0, 0, 0, 0, 0, 0, 1.0f};
-    gen = (it != g_registry.end() && !need_init) ? it->second.gen : 0;
-    if (gen >= 0x7ffffff0) { gen = 0; need_init = true; }   // the owner words compare generations: start over from a clean table
-    gen += 1;
-    g_registry[ws] = RegEntry{L, true, ii != nullptr && E > 0, keep, gen, true, (int32_t)tab_cap};
+    g_registry[ws] = RegEntry{L, true, ii != nullptr && E > 0, keep, true, (int32_t)tab_cap};
   }
   const GraphView v = graph_view(ws, L);
   if (need_init)
     hipLaunchKernelGGL(graph_init_kernel, dim3(grid_for(k_range + 1 + GM_WORDS, 256, 2048)), dim3(256), 0,
                        (hipStream_t)stream, v.meta, v.khist, v.kcursor, v.tcur, v.town, k_range);
-  *fill = cdv::TFillArgs{ii, jj, kk, (int32_t)E, (int32_t)tab_cap, v.meta, v.tcur, v.town, v.ttab, v.tovf, v.tprec, v.ocnt, gen, dyn};
+  // (the build's generation is a device word, GM_GENNEXT: nothing of this call's host state reaches the launches by value
+  // except sizes and pointers, so the two launches may be captured into a hipGraph and replayed any number of times)
+  *fill = cdv::TFillArgs{ii, jj, kk, (int32_t)E, (int32_t)tab_cap, v.meta, v.tcur, v.town, v.ttab, v.tovf, v.tprec, v.ocnt, dyn};
   *fill_blocks = grid_for(E, 256, GRAPH_MAX_BLOCKS);   // >= 1: the first workgroup also resets the words of this build
   return CDV_OK;
 }
@@ -947,7 +951,7 @@ int cdv_graph_table_finish(const cdv::TFillArgs& fill, int fill_blocks, void* ws
   }
   const bool stream_ok = with_stream && (poses != nullptr || cs.coords != nullptr);
   TSortArgs A;
-  A.meta = v.meta; A.R = fill.R; A.E = fill.E; A.gen = fill.gen;
+  A.meta = v.meta; A.R = fill.R; A.E = fill.E; A.town = v.town;
   A.tcur = v.tcur; A.tdeg = v.tdeg; A.tplo = v.tplo; A.tkid = v.tkid; A.tlive = v.tlive; A.ttab = v.ttab; A.tovf = v.tovf;
   A.tprec = v.tprec;
   A.nprev = v.nprev; A.nnext = v.nnext; A.ix = ix; A.jx = jx;
@@ -1020,7 +1024,7 @@ extern "C" int cdv_graph_bind_corr_stream(void* ws, const float* coords, int64_t
   cs.jmagic = jmod > 1 ? (uint32_t)((((uint64_t)1 << 32) + (uint64_t)jmod - 1) / (uint64_t)jmod) : 0u;
   std::lock_guard<std::mutex> lk(g_reg_mutex);
   auto it = g_registry.find(ws);
-  if (it == g_registry.end()) g_registry[ws] = RegEntry{GraphLayout{}, false, false, cs, 0, false, 0};
+  if (it == g_registry.end()) g_registry[ws] = RegEntry{GraphLayout{}, false, false, cs, false, 0};
   else it->second.cs = cs;
   return CDV_OK;
 }
@@ -1038,7 +1042,7 @@ extern "C" int cdv_graph_read_meta_host(const void* ws, int64_t* meta_host, void
   CDV_HIP_CHECK(hipMemcpyAsync(m, (const char*)ws + L.meta, sizeof(m), hipMemcpyDeviceToHost, (hipStream_t)stream));
   CDV_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
   if (cdv_graph_is_table(ws)) {   // patch table: live patches and their id range from the per-slot ids; no frame range is kept
-    const int err = m[GM_TERR] == m[GM_GEN];
+    const int err = m[GM_TERR + (m[GM_GEN] & 1)] != 0;
     const int cap = (int)cdv_graph_table_capacity(ws);
     std::vector<int32_t> kid((size_t)(cap > 0 ? cap : 0));
     if (cap > 0) {

@@ -668,7 +668,9 @@ extern "C" int cdv_frame_ingest(const void* fmap_chw, void* fmap1_nhwc, void* fm
 extern "C" int cdv_stream_frame(cdv_stream_desc* D, const void* fmap_chw, const float* cx, const float* cy, const float* depth,
                                 int force, void* stream) {
   CDV_REQUIRE(D != nullptr && fmap_chw && cx && cy && depth, CDV_ERR_ARG, "cdv_stream_frame: NULL argument");
-  CDV_REQUIRE(D->frames + 2 < D->frames_capacity, CDV_ERR_WORKSPACE, "cdv_stream_frame: frame buffer full");
+  // (no host-side capacity check: what is bounded is the number of KEYFRAMES n, which only the device knows -- frames the
+  // keyframe test drops do not use up the buffers (slam.py bounds n the same way); the begin launch refuses a frame that does
+  // not fit and raises CDV_DYN_ERR, and a replayed hipGraph goes through exactly the same check)
   CDV_REQUIRE(D->opt_window >= 1 && D->opt_window <= 10, CDV_ERR_UNSUPPORTED, "cdv_stream_frame: OPTIMIZATION_WINDOW 1 .. 10");
   const int M = D->M;
   const int ring = D->ring_blocks > 0 ? D->ring_blocks : 8;

@@ -107,7 +107,17 @@ class GraphIndex:
         self.E = 0
         self.is_table = False
         self.n_builds = 0          # index builds enqueued on this workspace (diagnostics, tests)
+        self._events = None        # EventBlock of the bundle adjustments run over THIS index (created at the first one)
+        self._graph_events_seen = 0
         self._reserve(E_cap)
+
+    @property
+    def events(self):
+        """the failure events of the bundle adjustments that ran over this index (ops.EventBlock): counted per index, so that
+        what happens to one path's graph -- a stream runner's table overflowing -- is nobody else's business"""
+        if self._events is None:
+            self._events = EventBlock(self.device, "GraphIndex@%x" % id(self))
+        return self._events
 
     def _reserve(self, E):
         if self.ws is not None and E <= self.E_cap:
@@ -410,20 +420,21 @@ def _device_graph(dev, **kw):
     return g
 
 
-def _table_still_fits(g, dev):
+def _table_still_fits(g, dev=None):
     """The table form of the index assumes that the live patch ids fit its capacity (install_dropin(table_capacity=...)).
     When they do not -- loop-closure or long-range edges, slam.py:507-510 -- the build flags a collision, neighbors() of
     that update are -1 and its BA is skipped and COUNTED (pinned event counters, no synchronisation).  Seen here before the
     next build: the workspace then gives the table up for good and goes on with the ranked index, which assumes nothing
-    about the ids."""
-    cnt = _ba_counters.get(dev)
-    if cnt is None or not g.table_capacity:
+    about the ids.  Only the events of bundle adjustments that ran over THIS index count (GraphIndex.events): another
+    workspace's trouble on the same device does not cost this one its table."""
+    if not g.table_capacity or g._events is None:
         return
-    seen = _ba_seen[dev]
-    if int(cnt[3]) > seen[3]:
+    n = g._events.counts()[3]
+    if n > g._graph_events_seen:
+        g._graph_events_seen = n
         import warnings
         warnings.warn("cdv_slam_amd: the patch table (capacity %d) did not hold the live patch ids -- one update was skipped; "
-                      "falling back to the ranked index on %s from now on" % (g.table_capacity, dev), RuntimeWarning, stacklevel=3)
+                      "falling back to the ranked index on %s from now on" % (g.table_capacity, g.device), RuntimeWarning, stacklevel=3)
         g.table_capacity = 0
         g._key = None
 
@@ -431,7 +442,7 @@ def _table_still_fits(g, dev):
 def graph_for(jj, kk, ii=None, **kw):
     """Per-device shared GraphIndex, (re)built for (jj, kk) in the preferred form."""
     g = _device_graph(kk.device, **kw)
-    _table_still_fits(g, kk.device)
+    _table_still_fits(g)
     key = g._make_key(jj.contiguous(), kk.contiguous(), None if ii is None else ii.contiguous())
     if g._key is not None and g._same_key(key):
         return g
@@ -941,11 +952,52 @@ def point_cloud(poses, patches, intrinsics, ix):
 # ---------------------------------------------------------------------------------------------------
 
 _ba_ws = {}
-_ba_ppf = {}          # device -> the PPF hint its workspace currently carries
-_ba_counters = {}     # device -> pinned int32[4] event counters the kernels bump (cdv_ba_bind_status_counters)
-_ba_seen = {}         # device -> counts already reported
+_ba_ppf = {}          # (device, workspace address) -> the PPF hint the workspace currently carries
+_ba_bound = {}        # workspace address -> the EventBlock its kernels currently count into
 BA_EVENTS = ("reduced system not positive definite", "more unique patches than U_max (update skipped)",
              "in-launch hand-off timed out (update not applied)", "patch-graph index in its range-error state (update skipped)")
+
+
+class EventBlock:
+    """Four int32 event counters (order of BA_EVENTS) in pinned host memory that the BA kernels bump
+    (cdv_ba_bind_status_counters): readable without synchronising.  One block per patch-graph index (GraphIndex.events) and
+    one per private BA workspace (ba_private_workspace): an event belongs to the path it happened on.  The words come out of
+    pinned pools that are never handed back -- a kernel still in flight when its owner dies writes to memory that stays
+    what it was."""
+    _pools = []      # [(pinned tensor [256, 4], rows used)]
+    _all = []        # every block ever made: (device, row view) -- ba_event_counts(device) sums them
+
+    def __init__(self, device, label=""):
+        if not EventBlock._pools or EventBlock._pools[-1][1] >= 256:
+            EventBlock._pools.append([torch.zeros((256, 4), dtype=torch.int32).pin_memory(), 0])
+        pool = EventBlock._pools[-1]
+        self.cnt = pool[0][pool[1]]
+        pool[1] += 1
+        self.device, self.label = torch.device(device), label
+        self.seen = [0, 0, 0, 0]           # what has been warned about
+        EventBlock._all.append((self.device, self.cnt))
+
+    def ptr(self):
+        return ctypes.c_void_p(self.cnt.data_ptr())
+
+    def counts(self):
+        return [int(v) for v in self.cnt.tolist()]
+
+    def bind(self, ws):
+        """the BA launches on workspace `ws` count into this block from now on"""
+        if _ba_bound.get(ws.data_ptr()) is not self:
+            _lib.check(_lib.load().cdv_ba_bind_status_counters(_p(ws), self.ptr()), "cdv_ba_bind_status_counters")
+            _ba_bound[ws.data_ptr()] = self
+
+    def report(self):
+        """non-blocking: warn about failure events counted since the last look (the update they belong to is an earlier one)"""
+        now = self.cnt.tolist()
+        for i in range(4):
+            if now[i] > self.seen[i]:
+                import warnings
+                warnings.warn("cdv_slam_amd BA on %s (%s): %s -- %d new event(s); ops.ba_status() / CDV_CHECK=1 raise at the call"
+                              % (self.device, self.label, BA_EVENTS[i], now[i] - self.seen[i]), RuntimeWarning, stacklevel=4)
+                self.seen[i] = now[i]
 
 
 def _ba_workspace(dev, E, U_max, N):
@@ -953,36 +1005,36 @@ def _ba_workspace(dev, E, U_max, N):
     need = lib.cdv_ba_workspace_bytes(E, U_max, max(N, 1))
     ws = _ba_ws.get(dev)
     if ws is None or ws.numel() < need:
+        if ws is not None:
+            _ba_bound.pop(ws.data_ptr(), None)
         ws = _ba_ws[dev] = torch.empty(int(need * 1.25) + 4096, dtype=torch.uint8, device=dev)
         _lib.check(lib.cdv_ba_workspace_init(_p(ws), _stream()), "cdv_ba_workspace_init")   # whoever allocates initialises
-        cnt = _ba_counters.get(dev)
-        if cnt is None:
-            cnt = _ba_counters[dev] = torch.zeros(4, dtype=torch.int32).pin_memory()
-            _ba_seen[dev] = [0, 0, 0, 0]
-        _lib.check(lib.cdv_ba_bind_status_counters(_p(ws), ctypes.c_void_p(cnt.data_ptr())), "cdv_ba_bind_status_counters")
+        _ba_bound.pop(ws.data_ptr(), None)      # (an address the allocator hands out again carries no binding)
     return ws
 
 
-def ba_private_workspace(dev, E, U_max, N):
+def ba_private_workspace(dev, E, U_max, N, label="private BA workspace"):
     """a bundle-adjustment workspace of the caller's own (the per-device one above is re-allocated when somebody asks for
-    more): initialised, bound to the device's event counters"""
+    more): initialised, with an event block of its own -- `ws.events` (ops.EventBlock)"""
     lib = _lib.load()
     ws = torch.empty(int(lib.cdv_ba_workspace_bytes(E, U_max, max(N, 1))) + 4096, dtype=torch.uint8, device=dev)
     _lib.check(lib.cdv_ba_workspace_init(_p(ws), _stream()), "cdv_ba_workspace_init")
-    cnt = _ba_counters.get(dev)
-    if cnt is None:
-        cnt = _ba_counters[dev] = torch.zeros(4, dtype=torch.int32).pin_memory()
-        _ba_seen[dev] = [0, 0, 0, 0]
-    _lib.check(lib.cdv_ba_bind_status_counters(_p(ws), ctypes.c_void_p(cnt.data_ptr())), "cdv_ba_bind_status_counters")
+    _ba_bound.pop(ws.data_ptr(), None)
+    ws.events = EventBlock(dev, label)
+    ws.events.bind(ws)
     return ws
 
 
 def ba_event_counts(device=None):
-    """Failure events the BA kernels have counted on `device` since start-up, WITHOUT synchronising: a list of four
-    ints in the order of BA_EVENTS.  (The counters live in pinned host memory the kernels write to.)"""
+    """Failure events the BA kernels have counted on `device` since start-up, over ALL workspaces, WITHOUT synchronising: a
+    list of four ints in the order of BA_EVENTS.  (Per path: GraphIndex.events.counts(), ws.events.counts().)"""
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    cnt = _ba_counters.get(dev)
-    return [0, 0, 0, 0] if cnt is None else [int(v) for v in cnt.tolist()]
+    tot = [0, 0, 0, 0]
+    for d, row in EventBlock._all:
+        if d == dev:
+            for i, v in enumerate(row.tolist()):
+                tot[i] += int(v)
+    return tot
 
 
 def ba_status(device=None, raise_on_error=True):
@@ -997,20 +1049,6 @@ def ba_status(device=None, raise_on_error=True):
     if rc != 0 and raise_on_error:
         _lib.check(rc, "bundle adjustment")
     return tuple(int(v) for v in info)
-
-
-def _ba_report_events(dev):
-    """non-blocking: warn about failure events counted since the last look (the update they belong to is an earlier one)"""
-    cnt = _ba_counters.get(dev)
-    if cnt is None:
-        return
-    now, seen = cnt.tolist(), _ba_seen[dev]
-    for i in range(4):
-        if now[i] > seen[i]:
-            import warnings
-            warnings.warn("cdv_slam_amd BA on %s: %s -- %d new event(s); ops.ba_status() / CDV_CHECK=1 raise at the call"
-                          % (dev, BA_EVENTS[i], now[i] - seen[i]), RuntimeWarning, stacklevel=3)
-            seen[i] = now[i]
 
 
 def ba_forward(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, PPF, t0, t1, iterations,
@@ -1041,14 +1079,15 @@ def ba_forward(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, PP
         lmbda = lmbda.reshape(-1).float().contiguous().to(dev)
     ii, jj, kk = ii.contiguous(), jj.contiguous(), kk.contiguous()
     g = graph if graph is not None else _device_graph(dev)
-    _table_still_fits(g, dev)
+    _table_still_fits(g)
     g.index_for_ba(jj, kk, ii, N)
-    _ba_report_events(dev)
+    g.events.report()
     if U_max is None:
         U_max = min(E, patches.numel() // (3 * P * P))
     if g.is_table:
         U_max = max(U_max, g.table_capacity)      # the slab kernels work through every slot of the table
     ws = _ba_workspace(dev, E, U_max, N)
+    g.events.bind(ws)        # this call's failure events are this index's
     ppf = int(PPF) if (PPF is not None and int(PPF) > 0) else 0      # cuda_ba.forward's PPF: a hint for the 10 < N <= 32 path
     if _ba_ppf.get((dev, ws.data_ptr())) != ppf:
         _lib.check(lib.cdv_ba_set_patches_per_frame(_p(ws), ppf), "cdv_ba_set_patches_per_frame")

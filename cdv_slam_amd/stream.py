@@ -279,7 +279,8 @@ class DeviceStreamRunner:
         self.graph.bind_corr_stream(None, M * pmem, mem, pmem * M, mem)
         self.corr_out = torch.empty((1, ecap, 882), dtype=torch.float16, device=device)
         self.lmbda = torch.tensor([1e-4], **f32)
-        self.ba_ws = ops.ba_private_workspace(device, ecap, self.tcap, opt_window)
+        self.ba_ws = ops.ba_private_workspace(device, ecap, self.tcap, opt_window, label="DeviceStreamRunner")
+        self.events = self.ba_ws.events      # this stream's own failure events (ops.EventBlock; no synchronisation to read)
         self.frames = 0
         # the stubbed feature network: a pool of feature maps and, drawn ON THE DEVICE once, every frame's patch centres / depths
         g = torch.Generator(device=device).manual_seed(seed)
@@ -378,7 +379,7 @@ class DeviceStreamRunner:
         M = self.M
         self._stage = [(torch.empty_like(self.pool[0]), torch.empty(3, M, dtype=torch.float32, device=self.dev)) for _ in range(2)]
         for k in range(2):
-            self.stage_inputs(k, self.pool[k], *self._draws[self.frames + k])
+            self.stage_inputs(k, self.pool[k], *self._draws[(self.frames + k) % self.N])
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         frames0 = self.frames
@@ -413,7 +414,7 @@ class DeviceStreamRunner:
         f = self.frames
         if inputs is None:
             fmap = self._pool_ptrs[f % len(self._pool_ptrs)]
-            cx, cy, d = self._draw_ptrs[f]
+            cx, cy, d = self._draw_ptrs[f % self.N]      # (the stub's draws repeat after buffer_size frames)
         else:
             self._hold = tuple(t.contiguous() for t in inputs)           # alive until the launches that read them are enqueued
             fmap, cx, cy, d = (self._p(t) for t in self._hold)

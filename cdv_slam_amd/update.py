@@ -95,7 +95,8 @@ class UpdatePath:
         out = {}
         main = torch.cuda.current_stream()
         if (self.has_features and ingest and rebuild_graph and not self.overlap and self.fused_prologue and self.corr_stream
-                and ops.prefer_table() and self.n - self.t0 <= 32):
+                and ops.prefer_table() and self.graph.table_capacity and self.n - self.t0 <= 32):
+            # (graph.table_capacity == 0: this index has given its table up -- ops._table_still_fits -- and goes on ranked)
             # everything in front of the correlation in TWO launches: ring / tile ingest + the table's fill pass, then slot
             # sort + 3. neighbors (net_cdv.py:102 -> ba.cpp:59-97) + 1. reproject (slam.py:325-329) + the correlation's order
             # and packed input stream

@@ -1352,8 +1352,7 @@ def test_ba_never_dereferences_unwritten_index_slots():
         ws = ops._ba_workspace(dev, st.E, max(min(st.E, len(st.patches)), cap or 0), st.n - st.t0)   # the one ba_forward picks up
         ws.fill_(0x7F)
         ops._lib.check(lib.cdv_ba_workspace_init(ops._p(ws), ops._stream()), "init")   # as after a fresh allocation
-        import ctypes
-        ops._lib.check(lib.cdv_ba_bind_status_counters(ops._p(ws), ctypes.c_void_p(ops._ba_counters[dev].data_ptr())), "bind")
+        ops._ba_bound.pop(ws.data_ptr(), None)      # ... and binds its event counters (ba_forward does, for the index it is given)
         poses, patches = T(st.poses).clone(), T(st.patches).clone()
         ops.ba_forward(poses, patches, T(st.intrinsics), T(st.target), T(st.weight), torch.tensor([st.lmbda], device=DEV),
                        T(st.ii), T(st.jj), T(st.kk), st.cfg.M, st.t0, st.n, 2, False, graph=g)
@@ -1391,7 +1390,7 @@ def test_ba_window_irregular_graph(variant):
     ba_checks.check_end_state("small", st, poses, patches, p64, x64)
 
 
-@pytest.mark.parametrize("name,mode", [("default", 1), ("default", 2), ("stress", 1), ("stress", 2), ("global", 1), ("global", 3)])
+@pytest.mark.parametrize("name,mode", [("default", 1), ("default", 2), ("stress", 1), ("stress", 2), ("global", 1), ("global", 2), ("global", 3)])
 def test_ba_handoff_is_all_or_nothing(name, mode):
     """The solve -> retract hand-off inside a finish launch, with faults injected (cdv_ba_test_handoff): mode 1 -- the solver
     stalls before its commit (N <= 32: the retract workgroups run out of patience, decide ABANDONED, the solver publishes
@@ -1487,6 +1486,86 @@ def test_ba_status_is_reported():
         assert ops.ba_status(dev, raise_on_error=False)[3] == 1
         with pytest.raises(_lib.CdvError, match="range"):
             ops.ba_status(dev)
+    finally:
+        os.environ["CDV_CHECK"] = "1"
+
+
+@pytest.mark.parametrize("M", [8, 12, 16, 20])
+def test_ba_mid_path_on_a_table_with_few_patches_per_frame(M):
+    """10 < N <= 32 on a patch TABLE whose capacity is a multiple of the patches per frame, with cuda_ba.forward's PPF passed
+    on: frames of 8 and 12 patches must NOT be cut per frame (a frame would be a workgroup and a slab of its own: more slabs
+    than the workspace holds -- the round-4 advisor's out-of-bounds write), 16 and 20 may.  Either way: the ranked index's
+    result to rounding, the float64 oracle's within the stated bounds, clean status, and the bytes behind the workspace's
+    slab area untouched."""
+    st = synth.make_state("small", features=False, opt_window=15, M=M)
+    dev = torch.device(DEV)
+    N = st.n - st.t0
+    assert 10 < N <= 32
+    cap = (st.cfg.removal_window + 2) * M
+    gt = ops.GraphIndex(dev, E_cap=st.E, k_range=st.cfg.buffer_size * M, table_capacity=cap)
+    gr = ops.GraphIndex(dev, E_cap=st.E, k_range=st.cfg.buffer_size * M)
+    pt, xt, _ = _run_ba_on(st, gt)
+    assert gt.is_table
+    assert ops.ba_status(dev) == (0, 0, 0, 0)
+    pr, xr, _ = _run_ba_on(st, gr)
+    assert not gr.is_table
+    assert np.abs(pt - pr).max() <= 5e-6 and np.abs(xt - xr).max() <= 5e-5
+    p64, x64, _ = O.fastba(st.poses, st.patches, st.intrinsics[0], st.target, st.weight, st.lmbda, st.ii, st.jj, st.kk,
+                           st.t0, st.n, 2, np.float64)
+    ba_checks.check_end_state("small", st, pt, xt, p64, x64)
+    assert gt.events.counts() == [0, 0, 0, 0]
+
+
+def test_events_are_counted_per_index_and_cost_nobody_else_their_table():
+    """Failure events belong to the index the bundle adjustment ran over (GraphIndex.events), not to the device: an index whose
+    table is too small for its ids counts graph-range events on ITS block, gives ITS table up at its next call and goes on
+    ranked -- while an UpdatePath on the same device keeps its table and keeps stepping.  (Round 4: per-device counters; the
+    stream runner's events took the headline path's table away.)  And an UpdatePath whose OWN table fails falls back to the
+    ranked prologue instead of asking for a table of capacity 0."""
+    from cdv_slam_amd.update import UpdatePath
+    st = synth.make_state("small")
+    dev = torch.device(DEV)
+    up = UpdatePath(st, dev)
+    up.step()
+    torch.cuda.synchronize()
+    cap = up.graph.table_capacity
+    assert up.graph.is_table and cap > 0
+    call = lambda g: ops.ba_forward(T(st.poses).clone(), T(st.patches).clone(), T(st.intrinsics), T(st.target), T(st.weight),
+                                    torch.tensor([st.lmbda], device=DEV), T(st.ii), T(st.jj), T(st.kk), st.cfg.M, st.t0, st.n,
+                                    2, False, graph=g)
+    other = ops.GraphIndex(dev, E_cap=st.E, k_range=st.cfg.buffer_size * st.cfg.M, table_capacity=8)
+    os.environ["CDV_CHECK"] = "0"
+    try:
+        call(other)
+        torch.cuda.synchronize()
+        assert other.is_table and other.events.counts()[3] == 2          # one per iteration, on ITS block
+        assert up.graph.events.counts() == [0, 0, 0, 0]
+        before = up.poses.clone()
+        out = up.step()
+        torch.cuda.synchronize()
+        assert up.graph.table_capacity == cap and up.graph.is_table      # untouched by the neighbour's trouble
+        assert not torch.equal(up.poses, before) and bool((out["ix"] >= -1).all())
+        with pytest.warns(RuntimeWarning, match="falling back to the ranked index"):
+            call(other)
+        torch.cuda.synchronize()
+        assert other.table_capacity == 0 and not other.is_table
+        assert other.events.counts()[3] == 2                             # the ranked index holds the ids: no new event
+        # an UpdatePath whose own table is too small: first update skipped and counted, then on with the ranked index
+        up2 = UpdatePath(st, dev)
+        up2.graph.table_capacity = 8
+        start = up2.poses.clone()
+        up2.step()
+        torch.cuda.synchronize()
+        assert torch.equal(up2.poses, start) and up2.graph.events.counts()[3] == 2
+        with pytest.warns(RuntimeWarning, match="falling back to the ranked index"):
+            up2.step()
+        out2 = up2.step()
+        torch.cuda.synchronize()
+        assert up2.graph.table_capacity == 0 and not up2.graph.is_table
+        assert not torch.equal(up2.poses, start) and up2.graph.events.counts()[3] == 2      # no event since the fallback
+        ix_o, jx_o = O.neighbors(st.kk, st.jj)
+        assert np.array_equal(out2["ix"].cpu().numpy(), ix_o) and np.array_equal(out2["jx"].cpu().numpy(), jx_o)
+        assert ops.ba_event_counts(dev)[3] >= 4                          # the device total is the sum over the blocks
     finally:
         os.environ["CDV_CHECK"] = "1"
 

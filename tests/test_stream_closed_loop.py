@@ -141,10 +141,14 @@ def test_device_stream_equals_the_host_sized_stream_and_does_not_synchronise():
 def test_device_stream_two_frames_as_a_hipgraph():
     """With every size on the device a frame's launches do not depend on the host: two frames (24 launches: the edge lists are
     back in their first twin after two) captured as ONE hipGraph and replayed give the eager runner's bits -- edge lists,
-    keyframe count, poses, depths -- over 40 frames with the reference's keyframe test deciding on the device"""
+    keyframe count, poses, depths -- with the reference's keyframe test deciding on the device, for AS LONG AS the graph is
+    replayed: 90 pairs, over which the kept keyframes advance by more than the patch table's capacity (30 frames of ids), so
+    that every slot of the table is met again by a new id under a replayed launch.  (Round 4 froze the table build's
+    generation into the captured launches: from the first wrap on one of the two frames ran with its index in the error
+    state and its BA skipped.)  No failure event may be counted on either runner."""
     from cdv_slam_amd.stream import DeviceStreamRunner
     dev = torch.device(DEV)
-    kw = dict(buffer_size=160, pose_step=0.1)
+    kw = dict(buffer_size=256, pose_step=0.1)
     a, b = DeviceStreamRunner(dev, **kw), DeviceStreamRunner(dev, **kw)
     for f in range(20):
         a.frame(drop=None)
@@ -152,20 +156,42 @@ def test_device_stream_two_frames_as_a_hipgraph():
     while a.cur != 0:          # capture needs the lists in their first twin
         a.frame(drop=None)
         b.frame(drop=None)
+    n_cap = a.counts()[0]
     replay = a.capture_pair()
-    for pair in range(20):
+    for pair in range(90):
         f = a.frames
         for k in range(2):
-            dr = a._draws[f + k]
+            dr = a._draws[(f + k) % a.N]
             a.stage_inputs(k, a.pool[(f + k) % 4], dr[0], dr[1], dr[2])
             b.frame(drop=None, inputs=(b.pool[(f + k) % 4], dr[0], dr[1], dr[2]))
         replay()
     n, E = a.counts()
     assert (n, E) == b.counts() and a.frames == b.frames and n < a.frames          # keyframes were dropped on the way
+    assert n - n_cap > a.tcap // a.M, (n, n_cap)                                   # ... and the ids went round the table
     ea, eb = a.edges, b.edges
     assert torch.equal(ea.ii, eb.ii) and torch.equal(ea.jj, eb.jj) and torch.equal(ea.kk, eb.kk)
     assert torch.equal(a.poses[:n], b.poses[:n]) and torch.equal(a.patches[:n * a.M], b.patches[:n * a.M])
     assert a.E_inac == b.E_inac
+    assert a.events.counts() == [0, 0, 0, 0] and b.events.counts() == [0, 0, 0, 0]
+
+
+def test_device_stream_outlives_its_frame_buffer_when_keyframes_are_dropped():
+    """what is bounded is the number of KEYFRAMES (slam.py bounds n, not the frames seen): a stream that drops two frames in
+    three runs for several times buffer_size frames -- eagerly and as hipGraph replays alike -- and stops with the device's
+    capacity word, not a host-side count of frames, once the keyframes really fill the buffers"""
+    from cdv_slam_amd.stream import DeviceStreamRunner
+    run = DeviceStreamRunner(torch.device(DEV), M=24, ht=192, wd=256, buffer_size=48)
+    for f in range(12):
+        run.frame(drop=False)
+    for f in range(90):        # 102 frames through a 48-frame buffer: two in three are dropped, n ends at 12 + 30
+        run.frame(drop=(f % 3 != 0))
+    n, E = run.counts()
+    assert run.frames == 102 and n == 42 and E > 0
+    assert run.events.counts() == [0, 0, 0, 0]
+    for f in range(60):        # now keep everything: the buffers fill up, the device says so
+        run.frame(drop=False)
+    with pytest.raises(RuntimeError, match="capacity exceeded"):
+        run.counts()
 
 
 def test_device_stream_reports_a_capacity_error_instead_of_writing_past_it():
