@@ -261,6 +261,15 @@ __global__ __launch_bounds__(64) void ba_patch_kernel(PatchArgs A) {
   }
 }
 
+// what a workspace's first call zeroes (accumulators, status words, hand-off words), as a kernel
+__global__ __launch_bounds__(256) void ba_zero_kernel(uint32_t* __restrict__ p, int64_t n4) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const int64_t nv = n4 >> 2;
+  u32x4* p4 = reinterpret_cast<u32x4*>(p);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) p4[i] = u32x4{0u, 0u, 0u, 0u};
+  if (blockIdx.x == 0 && threadIdx.x < (n4 & 3)) p[4 * nv + threadIdx.x] = 0u;
+}
+
 // q = 1 / (C + lambda) of every patch (ba_cuda.cu:548): the structure-only call, whose retract kernel reads it
 __global__ __launch_bounds__(256) void ba_q_kernel(const float* __restrict__ lmbda, const int32_t* __restrict__ gmeta,
                                                    const float* __restrict__ Cg, float* __restrict__ qg,
@@ -273,8 +282,12 @@ __global__ __launch_bounds__(256) void ba_q_kernel(const float* __restrict__ lmb
 
 // ---- the frame-pair index ------------------------------------------------------------------------------------------
 // key of an edge: its two poses as free-pose numbers + 1 (0: a fixed pose), smaller first
+// ... and the (a, b) -> pair table goes back to zero here, two launches ahead of ba_pair_table_kernel: the library enqueues
+// kernels only -- no memset node ends up in a captured hipGraph
 __global__ __launch_bounds__(256) void ba_pair_key_kernel(const int64_t* __restrict__ ii, const int64_t* __restrict__ jj,
-                                                          int32_t E, int t0, int N, int64_t* __restrict__ keys) {
+                                                          int32_t E, int t0, int N, int64_t* __restrict__ keys,
+                                                          int32_t* __restrict__ ptab, int64_t pair_range) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < pair_range; i += (int64_t)gridDim.x * blockDim.x) ptab[i] = 0;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < E; e += gridDim.x * blockDim.x) {
     const int a = (int)ii[e] - t0, b = (int)jj[e] - t0;
     const int ra = (a >= 0 && a < N) ? a + 1 : 0, rb = (b >= 0 && b < N) ? b + 1 : 0;
@@ -1274,11 +1287,17 @@ static int ba_forward_impl(float* poses, float* patches, const float* intrinsics
   CDV_REQUIRE(!table || window, CDV_ERR_UNSUPPORTED,
               "cdv_ba_forward: graph_ws holds a patch table (cdv_graph_build_table), which serves 1 .. 32 free poses; build "
               "the ranked index (cdv_graph_build_edges) for the global bundle adjustment");
-  if (fresh) {
-    if (!window) CDV_HIP_CHECK(hipMemsetAsync(b + L.sy, 0, L.zero_bytes, s));   // the window path keeps no accumulators
-    CDV_HIP_CHECK(hipMemsetAsync(info, 0, sizeof(int32_t) * 16 + sizeof(uint64_t) * MID_GRAN, s));
-    if (window) CDV_HIP_CHECK(hipMemsetAsync(b + L.hand, 0, sizeof(int32_t) * HAND_WORDS, s));   // token 0, no flag set
-    if (big) CDV_HIP_CHECK(hipMemsetAsync(b + L.xgran, 0, sizeof(uint64_t) * (size_t)L.npad, s));   // no granule carries a token
+  if (fresh) {   // (zeroing KERNELS, not hipMemsetAsync: a first call made under stream capture leaves kernel nodes only)
+    const auto zero = [&](void* p, size_t bytes) {   // every area starts 256-byte aligned (ba_layout) and is a multiple of 4 bytes
+      const size_t n4 = bytes / 4;
+      if (n4 == 0) return;
+      const int grid = (int)(cdv_div_up((int64_t)n4, 1024) < 4096 ? cdv_div_up((int64_t)n4, 1024) : 4096);
+      hipLaunchKernelGGL(ba_zero_kernel, dim3(grid), dim3(256), 0, s, (uint32_t*)p, (int64_t)n4);
+    };
+    if (!window) zero(b + L.sy, L.zero_bytes);   // the window path keeps no accumulators
+    zero(info, sizeof(int32_t) * 16 + sizeof(uint64_t) * MID_GRAN);
+    if (window) zero(b + L.hand, sizeof(int32_t) * HAND_WORDS);   // token 0, no flag set
+    if (big) zero(b + L.xgran, sizeof(uint64_t) * (size_t)L.npad);   // no granule carries a token
   }
   if (window) {
     BaWinArgs wa;
@@ -1326,8 +1345,6 @@ static int ba_forward_impl(float* poses, float* patches, const float* intrinsics
   const int rb = cdv_div_up(L.U_max > N ? L.U_max : N, 64);
   const int npad = (int)L.npad, nbk = npad / CNB;
   static const bool block_steps = []() { const char* e = getenv("CDV_BA_BLOCK_STEPS"); return e && e[0] == '1'; }();
-  static const int diag_stop = []() { const char* e = getenv("CDV_BA_DIAG_STOP"); return e ? atoi(e) : 0; }();   // DIAG (temporary)
-#define CDV_DIAG(k) if (diag_stop == (k)) return CDV_OK;
   if (big) {
     // the frame-pair index of this call's edges (both iterations use it): keys, an ordinary index build over them, the
     // (a, b) -> pair table
@@ -1338,46 +1355,36 @@ static int ba_forward_impl(float* poses, float* patches, const float* intrinsics
       if (rc0 != CDV_OK) return rc0;
     }
     cdv_graph_no_corr_order(pws);   // (idempotent; the flag goes when the workspace is forgotten)
+    int32_t* ptab = (int32_t*)(b + L.ptab);
     hipLaunchKernelGGL(ba_pair_key_kernel, dim3(cdv_div_up(E, 256) < 2048 ? (int)cdv_div_up(E, 256) : 2048), dim3(256), 0, s, ii, jj,
-                       (int32_t)E, t0, N, pkeys);
-    CDV_DIAG(1)
+                       (int32_t)E, t0, N, pkeys, ptab, (int64_t)L.pair_range);
     const int rc1 = cdv_graph_build_edges(ii, jj, pkeys, E, pws, L.pgraph_bytes, L.E_max, L.pair_range, nullptr, nullptr, stream);
     if (rc1 != CDV_OK) return rc1;
-    CDV_DIAG(2)
     const GraphView pv = graph_view(pws, graph_layout(L.E_max, L.pair_range));
-    int32_t* ptab = (int32_t*)(b + L.ptab);
-    CDV_HIP_CHECK(hipMemsetAsync(ptab, 0, sizeof(int32_t) * (size_t)L.pair_range, s));
     hipLaunchKernelGGL(ba_pair_table_kernel, dim3(256), dim3(256), 0, s, pv.meta, pv.kx, ptab);
-    CDV_DIAG(3)
   }
   for (int itr = 0; itr < iterations; itr++) {
     float* d = (dbg && itr == 0) ? dbg : nullptr;
     const PatchArgs pa{poses, patches, intrinsics, target, weight, ii, P, t0, N, gv.meta, gv.prec, gv.koff_u, gv.kx, Cg, ug, Edg,
                        (int)L.U_stride, (int)L.U_max, info, cmask, counters, itr == 0 ? 1 : 0};
     hipLaunchKernelGGL(ba_patch_kernel, dim3(n_chunks), dim3(64), 0, s, pa);
-    CDV_DIAG(4)
     if (big) {
       const GraphView pv = graph_view(b + L.pgraph, graph_layout(L.E_max, L.pair_range));
       const PairArgs qa{poses, patches, intrinsics, target, weight, ii, kk, P, t0, N, gv.meta, pv.meta, pv.prec, pv.koff_u, pv.kx,
                         sy, (float*)(b + L.pdiag), (int32_t)L.pair_cap, info};
       const int pgrid = (int)(L.pair_cap < 16384 ? L.pair_cap : 16384);
       hipLaunchKernelGGL(ba_pair_kernel, dim3(pgrid), dim3(64), 0, s, qa);
-      CDV_DIAG(5)
       hipLaunchKernelGGL(ba_diag_kernel, dim3(N), dim3(64), 0, s, gv.meta, pv.meta, (const int32_t*)(b + L.ptab),
                          (const float*)(b + L.pdiag), N, sy, info);
-      CDV_DIAG(6)
       const int npan = cdv_div_up(N, BIG_PP);
       hipLaunchKernelGGL(ba_schur_kernel, dim3(npan * (npan + 1) / 2), dim3(256), 0, s, lmbda, N, gv.meta, sy, Cg, ug, Edg,
                          (int)L.U_stride, cmask, n_chunks, info);
-      CDV_DIAG(7)
       hipLaunchKernelGGL(ba_big_fold_kernel, dim3(1024), dim3(256), 0, s, sy, (int)L.sy_stride, n6i, npad, Abig, gv.meta,
                          d, info, (uint64_t*)(b + L.xgran), (int32_t*)(b + L.fctl), fac_ctl_words(nbk));
-      CDV_DIAG(8)
       if (!block_steps) {
         // the factorisation as one launch of block work items (ba_factor.hip)
         const int rcf = cdv_ba_big_factor(Abig, npad, (int32_t*)(b + L.fctl), (float*)(b + L.ltg), gv.meta, info, g_handoff_test.load(), s);
         if (rcf != CDV_OK) return rcf;
-        CDV_DIAG(9)
       } else {
         // (rounds 1-3, kept for comparison: CDV_BA_BLOCK_STEPS=1) one launch per block column.  Block step 0: the panel alone;
         // block step kb >= 1: the panel together with what step kb - 1 owes the matrix
@@ -1390,7 +1397,6 @@ static int ba_forward_impl(float* poses, float* patches, const float* intrinsics
       }
       hipLaunchKernelGGL(ba_big_backsolve_kernel, dim3(cdv_div_up(npad, 256)), dim3(256), 0, s, Abig, npad, n6i, dXg,
                          (uint64_t*)(b + L.xgran), token_base + 1 + itr, gv.meta, d, info, g_handoff_test.load());
-      CDV_DIAG(10)
     } else {
       // only N = 0 gets here (no free pose: depths alone are refined): q = 1 / (C + lambda)
       hipLaunchKernelGGL(ba_q_kernel, dim3(cdv_div_up(L.U_max, 256) < 1024 ? (int)cdv_div_up(L.U_max, 256) : 1024), dim3(256), 0, s,

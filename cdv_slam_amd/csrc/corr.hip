@@ -55,6 +55,9 @@ constexpr int NQ_MAX = 8;                       // 16-pixel groups of the densel
 // conflicted: 112 of 296 LDS cycles per edge)
 constexpr int RAW_MSH = RAW_ROWS * 16 + 12;
 constexpr int RAW_HALFS = 9 * RAW_MSH;          // 1836
+#ifndef CDV_CORR_OUT_POLICY
+#define CDV_CORR_OUT_POLICY 16   // cache policy of the product kernel's output stores: 0 plain, 16 sc1 (write-through), 2 nt
+#endif
 constexpr int OUT_HALFS = 896;                  // the staged output row: 882 halfs, linear (the copy-out needs no index math)
 constexpr int WAVE_LDS_BYTES = RAW_HALFS * 2 + OUT_HALFS * 2;  // wide kernel: raw volume + staged row
 // product kernel: the staged row re-uses the raw volume (written after the last blend has read it); the D-tile lanes
@@ -729,6 +732,20 @@ __device__ __forceinline__ void corr_edge(const CorrArgs2& a, int p, int e, cons
       typedef uint32_t cdv_u32x4 __attribute__((ext_vector_type(4)));
       typedef uint32_t cdv_u32x4u __attribute__((ext_vector_type(4), aligned(4)));
       const cdv_u32x4 v0 = *reinterpret_cast<const cdv_u32x4*>(src + 4 * lane);
+#if CDV_CORR_OUT_POLICY
+      // the output row leaves written through (sc1: the line is dropped from this XCD's L2 instead of staying there -- 84 MB of
+      // output per launch that nobody of this launch reads again pushed the feature maps out of the 4 MB L2s; round 5, measured
+      // back to back on the default / stress workloads: 38.4-38.9 -> 37.6 us, 70.5-71.2 -> 69.2-69.4 us; nt (2): the same)
+      typedef int cdv_i32x4s __attribute__((ext_vector_type(4)));
+      const auto rso = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(dst), (short)0, 1768, 0x00020000);
+      __builtin_amdgcn_raw_buffer_store_b128((cdv_i32x4s)v0, rso, 16 * lane, 0, CDV_CORR_OUT_POLICY);
+      if (lane < 46) {
+        const cdv_u32x4 v1 = *reinterpret_cast<const cdv_u32x4*>(src + 256 + 4 * lane);
+        __builtin_amdgcn_raw_buffer_store_b128((cdv_i32x4s)v1, rso, 1024 + 16 * lane, 0, CDV_CORR_OUT_POLICY);
+      }
+      if (lane == 63) __builtin_amdgcn_raw_buffer_store_b32((int)src[440], rso, 1760, 0, CDV_CORR_OUT_POLICY);
+      if (lane == 62 && SPLIT) __builtin_amdgcn_raw_buffer_store_b32((int)src[441], rso, 1764, 0, CDV_CORR_OUT_POLICY);
+#else
       *reinterpret_cast<cdv_u32x4u*>(dst + 4 * lane) = v0;
       if (lane < 46) {
         const cdv_u32x4 v1 = *reinterpret_cast<const cdv_u32x4*>(src + 256 + 4 * lane);
@@ -736,6 +753,7 @@ __device__ __forceinline__ void corr_edge(const CorrArgs2& a, int p, int e, cons
       }
       if (lane == 63) dst[440] = src[440];
       if (lane == 62 && SPLIT) dst[441] = src[441];
+#endif
     } else {
       _Float16* dst = a.out + (size_t)e * a.out_pitch + a.out_off;
 #pragma unroll

@@ -1752,6 +1752,57 @@ def test_update_captured_as_a_hipgraph_replays_bit_for_bit(iterations):
     assert ops.ba_status(dev) == (0, 0, 0, 0)
 
 
+def test_global_ba_captured_as_a_hipgraph_replays_bit_for_bit():
+    """cdv_ba_forward on the GLOBAL path (79 free poses: pair index, Schur products, one-launch factorisation, back
+    substitution with in-launch hand-offs) captured into a hipGraph and replayed: the eager calls' bits, replay after replay,
+    status clean.  Round 4's replays died with a GPU memory fault at the second replay: the call enqueued a hipMemsetAsync
+    (the (a, b) -> pair table), which becomes a memset NODE whose replay is not the eager memset's (found by replaying
+    prefixes of the call: the fault appears with the first kernel that reads the table, and goes when a kernel does the
+    zeroing).  The library now enqueues kernels only.  Also captured here: a FIRST call on a fresh workspace (its one-time
+    initialisation is part of the graph then, and harmless to replay)."""
+    st = synth.make_state("global", features=False)
+    dev = torch.device(DEV)
+    assert st.n - st.t0 > 32
+    args = (T(st.intrinsics), T(st.target), T(st.weight), torch.tensor([st.lmbda], device=DEV), T(st.ii), T(st.jj), T(st.kk))
+
+    def run(stepper, poses, patches, n):
+        outs = []
+        for _ in range(n):
+            poses.copy_(T(st.poses)); patches.copy_(T(st.patches))
+            stepper()
+            torch.cuda.synchronize()
+            outs.append((poses.clone(), patches.clone()))
+        return outs
+
+    g = ops.GraphIndex(dev, E_cap=st.E, k_range=st.cfg.buffer_size * st.cfg.M)
+    pe, xe = T(st.poses).clone(), T(st.patches).clone()
+    want = run(lambda: ops.ba_forward(pe, xe, *args, st.cfg.M, st.t0, st.n, 2, True, graph=g), pe, xe, 2)
+    assert torch.equal(want[0][0], want[1][0]) and not torch.equal(want[0][0], T(st.poses))
+    os.environ["CDV_CHECK"] = "0"      # (CDV_CHECK=1 reads the status words back after every BA: not capturable)
+    try:
+        for warm in (2, 0):            # captured after two eager calls / as the very first call on a fresh BA workspace
+            if warm == 0:
+                ops._ba_ws.pop(dev, None)
+            pc, xc = T(st.poses).clone(), T(st.patches).clone()
+            gi = ops.GraphIndex(dev, E_cap=st.E, k_range=st.cfg.buffer_size * st.cfg.M)
+            gi.build(args[5], args[6], ii=args[4])
+            call = lambda: ops.ba_forward(pc, xc, *args, st.cfg.M, st.t0, st.n, 2, True, graph=gi)
+            for _ in range(warm):
+                call()
+            torch.cuda.synchronize()
+            cg = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(cg):
+                call()
+            torch.cuda.synchronize()
+            got = run(cg.replay, pc, xc, 4)
+            for a, b in got:
+                assert torch.equal(a, want[0][0]) and torch.equal(b, want[0][1]), warm
+            assert ops.ba_status(dev) == (0, 0, 0, 0)
+            assert gi.events.counts() == [0, 0, 0, 0]
+    finally:
+        os.environ["CDV_CHECK"] = "1"
+
+
 def test_global_path_just_above_the_mid_path():
     """35 free poses -- the smallest systems the global path serves (the mid path ends at 32): five 8-pose panels with a
     ragged last one, a 210-unknown system padded to four 64-blocks.  Intermediates against the float64 oracle, the solve's
