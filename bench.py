@@ -467,6 +467,33 @@ def main():
                                            "shift, frame-buffer shift and removal-window pruning it triggers (slam.py:415-458); stub "
                                            "feature / update networks; device RNG drawn once; Python glue included"}
             del run
+            # BASELINE.json configs[4] as a stream: 196 patches per frame, OPTIMIZATION_WINDOW 22 -- the bundle adjustment on the
+            # 10 < N <= 32 path with its window on the device (cdv_ba_forward_dyn); same frame sequence, fewer frames
+            try:
+                run2 = DeviceStreamRunner(dev, M=196, opt_window=22, buffer_size=256, keyframe_thresh=12.5, pose_step=0.1)
+                for _ in range(45):
+                    run2.frame(drop=False)
+                for _ in range(20):
+                    run2.frame(drop=None)
+                torch.cuda.synchronize()
+                n_a2, _ = run2.counts()
+                nf2 = 240
+                ev_w0 = run2.events.counts()
+                tw = time.perf_counter()
+                for _ in range(nf2):
+                    run2.frame(drop=None)
+                torch.cuda.synchronize()
+                tw = time.perf_counter() - tw
+                n_k2, E_w = run2.counts()
+                ev_w = events_since(run2.events, ev_w0)
+                extra["stream_fps"]["stress"] = {"value": (nf2 / tw) if not any(ev_w) else None, "unit": "frames/s",
+                                                 "ms_per_frame": 1e3 * tw / nf2, "frames": nf2, "ba_events": ev_w, "edges": int(E_w),
+                                                 "keyframes": int(n_k2), "keyframes_dropped_in_the_timed_frames": int(nf2 - (n_k2 - n_a2)),
+                                                 "what": "the same device-resident stream at BASELINE.json configs[4]: 196 patches per "
+                                                         "frame, OPTIMIZATION_WINDOW 22 (bundle adjustment on the 10 < N <= 32 path)"}
+                del run2
+            except Exception as ex:
+                extra["stream_fps"]["stress"] = {"error": repr(ex)}
         except Exception as ex:
             extra["stream_fps"] = {"error": repr(ex)}
 

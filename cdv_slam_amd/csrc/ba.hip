@@ -1218,14 +1218,16 @@ extern "C" int cdv_ba_forward(float* poses, float* patches, const float* intrins
 }
 
 // cdv_ba_forward with the window on the device: the free poses are [dyn[CDV_DYN_T0], + dyn[CDV_DYN_NFREE]) with
-// dyn[CDV_DYN_NFREE] <= N_max <= 10 (the optimisation window of a frame stream, slam.py:512-513: known to the device only
-// when the keyframe decision stays there); E_bound sizes the workspace, the index in graph_ws must be a patch table.
+// dyn[CDV_DYN_NFREE] <= N_max <= 32 (the optimisation window of a frame stream, slam.py:512-513: known to the device only
+// when the keyframe decision stays there; N_max picks the path -- <= 10 the window kernels, <= 32 ba_mid.hip's -- and the
+// kernels then work on whatever the block says, e.g. the 7 free poses of a stream's first update inside launches laid out
+// for 22); E_bound sizes the workspace, the index in graph_ws must be a patch table.
 extern "C" int cdv_ba_forward_dyn(float* poses, float* patches, const float* intrinsics, const float* target, const float* weight,
                                   const float* lmbda, const int64_t* ii, const int64_t* jj, const int64_t* kk, int64_t E_bound,
                                   int P, int N_max, const int32_t* dyn, int iterations, const void* graph_ws, void* ba_ws,
                                   size_t ba_ws_bytes, int64_t U_max, void* stream) {
   CDV_REQUIRE(dyn != nullptr, CDV_ERR_ARG, "cdv_ba_forward_dyn: NULL dynamic block");
-  CDV_REQUIRE(N_max >= 1 && N_max <= WIN_N, CDV_ERR_UNSUPPORTED, "cdv_ba_forward_dyn: 1 <= N_max <= 10 free poses");
+  CDV_REQUIRE(N_max >= 1 && N_max <= MID_N, CDV_ERR_UNSUPPORTED, "cdv_ba_forward_dyn: 1 <= N_max <= 32 free poses");
   CDV_REQUIRE(cdv_graph_is_table(graph_ws), CDV_ERR_UNSUPPORTED, "cdv_ba_forward_dyn: graph_ws must hold a patch table");
   return ba_forward_impl(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, E_bound, P, 0, N_max, iterations, graph_ws,
                          ba_ws, ba_ws_bytes, U_max, nullptr, stream, dyn);

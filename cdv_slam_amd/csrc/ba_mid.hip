@@ -110,7 +110,8 @@ __device__ __forceinline__ int wide_count(const BaWinArgs& A, int U) {
 }
 
 template <bool HAS_II, int MKW, bool TABLE>
-__global__ __launch_bounds__(64 * MKW) CDV_MID_OCC void ba_mid_chunk_kernel(BaWinArgs A) {
+__global__ __launch_bounds__(64 * MKW) CDV_MID_OCC void ba_mid_chunk_kernel(BaWinArgs A_in) {
+  const BaWinArgs A = with_dyn(A_in);   // (a frame stream's window lives on the device: every layout below follows ITS N)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int N = A.N, t0 = A.t0, P = A.P;
   const int n6 = 6 * N;
@@ -940,7 +941,8 @@ __device__ __forceinline__ void mid_solve(const BaWinArgs& A, float* smem) {
 // further ones in separate rows whose partials meet in LDS.  W and every summation order depend on the number of slabs
 // only: the sum is the same whatever the launch geometry.
 template <bool TABLE>
-__global__ __launch_bounds__(256) void ba_mid_reduce_kernel(BaWinArgs A) {
+__global__ __launch_bounds__(256) void ba_mid_reduce_kernel(BaWinArgs A_in) {
+  const BaWinArgs A = with_dyn(A_in);
   const int32_t* __restrict__ gmeta = A.gmeta;
   const PatchSpan sp = patch_span<TABLE>(A);
   const int U = sp.U;
@@ -1026,7 +1028,8 @@ __global__ __launch_bounds__(256) void ba_mid_reduce_kernel(BaWinArgs A) {
 
 // SNP: the E column a retract thread keeps in registers (>= 6 N)
 template <int SNP, bool TABLE>
-__global__ __launch_bounds__(FT) void ba_mid_finish_kernel(BaWinArgs A) {
+__global__ __launch_bounds__(FT) void ba_mid_finish_kernel(BaWinArgs A_in) {
+  const BaWinArgs A = with_dyn(A_in);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int32_t* __restrict__ gmeta = A.gmeta;
   const PatchSpan sp = patch_span<TABLE>(A);

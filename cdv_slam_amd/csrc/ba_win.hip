@@ -298,17 +298,6 @@ __device__ __forceinline__ void solve_wave(const BaWinArgs& A, int RW) {
   CDV_STAMP_RT(baw, sslot, 15);
 }
 
-// sizes on the device: the window [t0, t0 + N) of this update comes from the dynamic block (two scalar loads that travel
-// with the first load level)
-__device__ __forceinline__ BaWinArgs with_dyn(const BaWinArgs& a) {
-  BaWinArgs A = a;
-  if (a.dyn) {
-    A.t0 = a.dyn[CDV_DYN_T0];
-    A.N = min(a.dyn[CDV_DYN_NFREE], a.N);
-  }
-  return A;
-}
-
 template <bool HAS_II, bool TABLE>
 __global__ __launch_bounds__(64 * CKW) void ba_chunk_kernel(BaWinArgs A_in) {
   const BaWinArgs A = with_dyn(A_in);

@@ -160,6 +160,17 @@ struct BaWinArgs {
   int has_ii;                        // the graph's records carry the source frames (it was built with ii)
 };
 
+// sizes on the device: the window [t0, t0 + N) of this update comes from the dynamic block (two scalar loads that travel
+// with the first load level); the N of the arguments bounds it (it dimensioned the launches and the workspace)
+__device__ __forceinline__ BaWinArgs with_dyn(const BaWinArgs& a) {
+  BaWinArgs A = a;
+  if (a.dyn) {
+    A.t0 = a.dyn[CDV_DYN_T0];
+    A.N = min(a.dyn[CDV_DYN_NFREE], a.N);
+  }
+  return A;
+}
+
 // the blocked Cholesky factorisation of the global path as one launch (ba_factor.hip): A [(npad + 1)][npad] in place; ctl
 // (fac_ctl_words(npad / CNB) words) must be zero when the launch starts; ltg: npad * CNB floats of scratch (the diagonal blocks'
 // factors in the layout the item workgroups solve against)

@@ -671,7 +671,7 @@ extern "C" int cdv_stream_frame(cdv_stream_desc* D, const void* fmap_chw, const 
   // (no host-side capacity check: what is bounded is the number of KEYFRAMES n, which only the device knows -- frames the
   // keyframe test drops do not use up the buffers (slam.py bounds n the same way); the begin launch refuses a frame that does
   // not fit and raises CDV_DYN_ERR, and a replayed hipGraph goes through exactly the same check)
-  CDV_REQUIRE(D->opt_window >= 1 && D->opt_window <= 10, CDV_ERR_UNSUPPORTED, "cdv_stream_frame: OPTIMIZATION_WINDOW 1 .. 10");
+  CDV_REQUIRE(D->opt_window >= 1 && D->opt_window <= 32, CDV_ERR_UNSUPPORTED, "cdv_stream_frame: OPTIMIZATION_WINDOW 1 .. 32");
   const int M = D->M;
   const int ring = D->ring_blocks > 0 ? D->ring_blocks : 8;
   CDV_REQUIRE(ring == 2 || ring == 4 || ring == 8, CDV_ERR_ARG, "cdv_stream_frame: ring_blocks must be 0 (8), 2, 4 or 8");

@@ -236,15 +236,17 @@ class DeviceStreamRunner:
     n, E, the decision live in a ring of "dynamic blocks"; the host only keeps an upper bound of E (from a pinned word the
     last launch of a frame writes) to dimension the launches.  Anything the host wants to KNOW (counts(), n, edges, poses of
     the keyframes) synchronises -- tests and the end of a run do, the frame loop does not.  Configurations: 3 x 3 patches,
-    OPTIMIZATION_WINDOW <= 10 (the window solver), no loop closure (StreamRunner serves those)."""
+    OPTIMIZATION_WINDOW <= 32 (<= 10: the window solver; beyond: the 10 < N <= 32 path, e.g. default_cdvo++.yaml's 22), no
+    loop closure (StreamRunner serves that: its proximity search and greedy edge selection are host logic in the reference
+    too, patchgraph.py:71-97)."""
 
     def __init__(self, device, M=96, ht=384, wd=512, C=24, mem=36, pmem=36, buffer_size=512, patch_lifetime=13,
                  removal_window=22, opt_window=10, keyframe_index=4, seed=1234, keyframe_thresh=12.5, gain=0.01, pose_step=0.05):
         import ctypes
         from . import _lib
         self.pose_step = pose_step
-        if opt_window > 10:
-            raise NotImplementedError("DeviceStreamRunner: OPTIMIZATION_WINDOW <= 10 (cdv_ba_forward_dyn)")
+        if opt_window > 32:
+            raise NotImplementedError("DeviceStreamRunner: OPTIMIZATION_WINDOW <= 32 (cdv_ba_forward_dyn)")
         self.lib = lib = _lib.load()
         self.dev = device
         self.M, self.C, self.mem, self.pmem, self.N = M, C, mem, pmem, buffer_size
@@ -281,6 +283,10 @@ class DeviceStreamRunner:
         self.lmbda = torch.tensor([1e-4], **f32)
         self.ba_ws = ops.ba_private_workspace(device, ecap, self.tcap, opt_window, label="DeviceStreamRunner")
         self.events = self.ba_ws.events      # this stream's own failure events (ops.EventBlock; no synchronisation to read)
+        if opt_window > 10 and M % 4 == 0 and M >= 16:
+            # a frame's patches are M consecutive slots of the table (its capacity is a multiple of M): the 10 < N <= 32 path may
+            # cut its workgroups per frame (cuda_ba.forward's PPF argument does the same for the drop-in caller)
+            _lib.check(lib.cdv_ba_set_patches_per_frame(ctypes.c_void_p(self.ba_ws.data_ptr()), M), "cdv_ba_set_patches_per_frame")
         self.frames = 0
         # the stubbed feature network: a pool of feature maps and, drawn ON THE DEVICE once, every frame's patch centres / depths
         g = torch.Generator(device=device).manual_seed(seed)

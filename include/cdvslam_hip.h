@@ -551,8 +551,9 @@ int cdv_corr_fused_stream_dyn(const void* gmap, const void* fmap0_nhwc, const vo
                               int64_t E_bound, const int32_t* dyn, int64_t Ng, int64_t slots, int C, int H0, int W0, int H1, int W1,
                               float scale0, float scale1, int gmap_pixel_major, void* stream);
 
-/* cdv_ba_forward over the window [dyn[CDV_DYN_T0], + dyn[CDV_DYN_NFREE]) (slam.py:512-513), NFREE <= N_max <= 10; graph_ws must
- * hold a patch table; E_bound / U_max size the workspace (cdv_ba_workspace_bytes(E_bound, U_max, N_max)). */
+/* cdv_ba_forward over the window [dyn[CDV_DYN_T0], + dyn[CDV_DYN_NFREE]) (slam.py:512-513), NFREE <= N_max <= 32 (N_max <= 10:
+ * the window kernels; 11 .. 32: the three-launch path of the wider OPTIMIZATION_WINDOW configurations, default_cdvo++.yaml);
+ * graph_ws must hold a patch table; E_bound / U_max size the workspace (cdv_ba_workspace_bytes(E_bound, U_max, N_max)). */
 int cdv_ba_forward_dyn(float* poses, float* patches, const float* intrinsics, const float* target, const float* weight,
                        const float* lmbda, const int64_t* ii, const int64_t* jj, const int64_t* kk, int64_t E_bound, int P,
                        int N_max, const int32_t* dyn, int iterations, const void* graph_ws, void* ba_ws, size_t ba_ws_bytes,

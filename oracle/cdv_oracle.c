@@ -176,6 +176,16 @@ LIE_DISPATCH(double, f64)
     return fb_ba_##S(poses, patches, intr, target, weight, lmbda, ii, jj, kk, kx, ku, E, U, P, t0, t1,   \
                      iterations, dbg);                                                                   \
   }                                                                                                      \
+  /* the per-edge factor of reprojection_residuals_and_hessian (ba_cuda.cu:262-342) on its own: residual rows r [E][2],  \
+     masked weights w [E][2], Jz [E][2], Ji / Jj [E][2][6] -- what the block-sparse E of block_e.cu is filled from     \
+     (oracle/block_e_py.py) */                                                                             \
+  void orc_fastba_edges_##S(const T *poses, const T *patches, const T *intr, const T *target, const T *weight, \
+                            const long *ii, const long *jj, const long *kk, long E, int P, T *r, T *w, T *Jz, \
+                            T *Ji, T *Jj) {                                                              \
+    for (long n = 0; n < E; n++)                                                                         \
+      fb_edge_##S(poses, patches, intr, target, weight, ii[n], jj[n], kk[n], P, n, r + 2 * n, w + 2 * n, \
+                  Jz + 2 * n, Ji + 12 * n, Jj + 12 * n);                                                 \
+  }                                                                                                      \
   /* fastba `reproject` kernel, ba_cuda.cu:408-458: intrinsics row 0, no depth clamp -> [E][2][P][P] */  \
   void orc_fastba_reproject_##S(const T *poses, const T *patches, const T *intr, const long *ii,         \
                                 const long *jj, const long *kk, long E, int P, T *coords) {              \

@@ -184,6 +184,23 @@ def fastba(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, t0, t1
     return poses, patches, info, out
 
 
+def fastba_edges(poses, patches, intrinsics, target, weight, ii, jj, kk, dtype=np.float64):
+    """the per-edge factor of ba_cuda.cu:262-342 on its own: (r [E,2], w [E,2] masked, Jz [E,2], Ji [E,2,6], Jj [E,2,6])"""
+    poses = _c(poses, dtype).reshape(-1, 7)
+    P = patches.shape[-1]
+    patches = _c(patches, dtype).reshape(-1, 3, P, P)
+    intrinsics = _c(intrinsics, dtype).reshape(-1, 4)
+    target, weight = _c(target, dtype).reshape(-1, 2), _c(weight, dtype).reshape(-1, 2)
+    ii, jj, kk = _c(ii, np.int64), _c(jj, np.int64), _c(kk, np.int64)
+    E = len(ii)
+    r, w, Jz = (np.zeros((E, 2), dtype) for _ in range(3))
+    Ji, Jj = np.zeros((E, 2, 6), dtype), np.zeros((E, 2, 6), dtype)
+    getattr(lib(), "orc_fastba_edges_" + _suffix(dtype))(_p(poses), _p(patches), _p(intrinsics), _p(target), _p(weight), _p(ii),
+                                                         _p(jj), _p(kk), ctypes.c_long(E), ctypes.c_int(P), _p(r), _p(w), _p(Jz),
+                                                         _p(Ji), _p(Jj))
+    return r, w, Jz, Ji, Jj
+
+
 # ------------------------------------------------------------------------------------------
 # altcorr (correlation_kernel.cu, correlation.py)
 # ------------------------------------------------------------------------------------------

@@ -229,3 +229,45 @@ def test_corr_oracle_vs_reference_run_pin(golden_dir):
                        z["ii"], z["jj"], 3, "truth")
     want = np.stack([z["corr0"], z["corr1"]], -1).reshape(len(z["ii"]), -1)      # slam.py:323
     assert np.abs(both - want).max() <= 2e-7 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("window", [None, 10])
+def test_block_sparse_E_of_the_reference_equals_its_dense_branch(window):
+    """Row a12: cuda_ba.forward has two branches for the Schur solve -- dense E (ba_cuda.cu:583-592) and, with eff_impl, the
+    block-sparse `EfficentE` (block_e.cu:38-300; ba_cuda.cu:380-383, 567-580).  The product computes the dense quantities and
+    does not reproduce EfficentE's index structures; here the two branches are restated side by side (oracle/fastba_impl.h,
+    oracle/block_e_py.py) and give the same damped S, y, dX, dZ on a graph with 25 free poses (the global BA's shape) and on a
+    windowed one (poses below t0 fixed: their rows are dropped at product time, block_e.cu:171-184) -- so the float64 oracle
+    the HIP global path is held against IS the eff_impl branch's result too.  A wrong reading of the two block roles
+    (ba_cuda.cu:382-383: the self block takes -w Jz Ji, the (i, j) block +w Jz Jj) is far off."""
+    from cdv_slam_amd import synth
+    from oracle.block_e_py import EfficentE, solve_eff_impl
+    kw = dict(frames=26, opt_window=10 ** 6, removal_window=10 ** 6) if window is None else dict(frames=26, opt_window=window)
+    st = synth.make_state("small", features=False, **kw)
+    N = st.n - st.t0
+    assert N == (25 if window is None else window)
+    _, _, info, o = O.fastba(st.poses, st.patches, st.intrinsics[0], st.target, st.weight, st.lmbda, st.ii, st.jj, st.kk,
+                             st.t0, st.n, 1, np.float64, debug=True)
+    assert info == 0
+    r, w, Jz, Ji, Jj = O.fastba_edges(st.poses, st.patches, st.intrinsics[0], st.target, st.weight, st.ii, st.jj, st.kk)
+    assert (st.kk // st.cfg.M == st.ii).all()                       # EfficentE's assumption: a patch's frame is its source frame
+    be = EfficentE(st.ii, st.jj, o["kx"], st.cfg.M, st.t0)
+    # ij_xself as torch::_unique(cat(ii n + jj, ii n + ii)) gives it (block_e.cu:45-50): bit-exact integer bookkeeping
+    nf = int(max(st.ii.max(), st.jj.max())) + 1
+    uq = np.unique(np.concatenate([st.ii * nf + st.jj, st.ii * nf + st.ii]))
+    assert np.array_equal(uq[be.ij_xself[0]], st.ii * nf + st.jj) and np.array_equal(uq[be.ij_xself[1]], st.ii * nf + st.ii)
+    deg = [len(np.unique(np.concatenate([st.jj[st.ii == i], [i]]))) for i in np.unique(st.ii)]
+    assert len(be.index_tensor) == sum(d * d for d in deg)          # block_e.cu:100-103
+    be.fill(st.kk, w, Jz, Ji, Jj)
+    S, y, dX, dZ = solve_eff_impl(o["B"], o["v"], o["C"], o["u"], st.lmbda, be, N)
+    for key, got, want in (("S", S, o["S"]), ("y", y, o["y"]), ("dX", dX, o["dX"].reshape(-1)), ("dZ", dZ, o["dZ"])):
+        assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max(), key
+    # the products one by one against the dense E
+    Q = 1.0 / (o["C"] + st.lmbda)
+    assert np.abs(be.computeEQEt(N, Q) - (o["E"] * Q) @ o["E"].T).max() <= 1e-12 * np.abs(o["B"]).max()
+    assert np.abs(be.computeEv(N, Q * o["u"]) - o["E"] @ (Q * o["u"])).max() <= 1e-12 * np.abs(o["v"]).max()
+    assert np.abs(be.computeEtv(len(Q), dX) - o["E"].T @ dX).max() <= 1e-12 * np.abs(o["u"]).max()
+    # negative control: the two block roles swapped
+    be.ij_xself = be.ij_xself[::-1].copy()
+    be.fill(st.kk, w, Jz, Ji, Jj)
+    assert np.abs(be.computeEQEt(N, Q) - (o["E"] * Q) @ o["E"].T).max() > 1e-2 * np.abs((o["E"] * Q) @ o["E"].T).max()

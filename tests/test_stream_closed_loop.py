@@ -109,6 +109,29 @@ def test_device_stream_with_the_reference_keyframe_test():
     assert ate <= ATE_TOL
 
 
+@pytest.mark.parametrize("drop", ["pattern", "flow"])
+def test_device_stream_with_the_wide_optimisation_window(drop):
+    """OPTIMIZATION_WINDOW 22 (default_cdvo++.yaml, BASELINE configs[4]) with every size on the device: the bundle adjustment
+    runs on the 10 < N <= 32 path (ba_mid.hip) with its window read from the dynamic block -- 7 free poses at the stream's first
+    update, growing to 22, inside launches laid out for 22.  Against the oracle-driven runner: edge lists bit-identical at
+    every frame, the same keyframe decisions, ATE within BASELINE.json's tolerance, no failure event."""
+    kw = dict(opt_window=22, keyframe_thresh=2.5) if drop == "flow" else dict(opt_window=22)
+    run, so = _pair_dev(0.01, **kw)
+    res = closed_loop(run, so, frames=110, drop=drop)
+    if drop == "flow":
+        assert not res["decisions_differ"], res["decisions_differ"]
+        assert res["motion_maxdiff"] <= 1e-3
+    assert res["edges_identical"], res.get("first_mismatch")
+    assert res["frames"] == 110 and res["keyframes"] >= 40 and res["dropped"] >= 10
+    ate = metrics.ate_rmse(res["poses_oracle"], res["poses_gpu"])
+    _log("device_stream_window22", drop, {"ate": ate, "frames": res["frames"], "keyframes": res["keyframes"],
+                                          "dropped": res["dropped"]}, {"ate": ATE_TOL})
+    assert ate <= ATE_TOL
+    rel = np.abs(res["patches_gpu"] - res["patches_oracle"]) / np.abs(res["patches_oracle"])
+    assert np.median(rel) <= 1e-4
+    assert run.events.counts() == [0, 0, 0, 0]
+
+
 def test_device_stream_equals_the_host_sized_stream_and_does_not_synchronise():
     """DeviceStreamRunner against StreamRunner (one read-back per removal) on the benchmark frame size, same frames, same
     forced drops: edge lists and keyframe count identical, poses equal to rounding (the tiles' blend and the operator stub are
