@@ -184,32 +184,39 @@ __device__ __forceinline__ void solve_wave(const BaWinArgs& A, int RW) {
       if (64 * i + lane < SLAB / 2) dst[64 * i + lane] = v[i];
   }
   wave_lds_sync();
+  // S += I (1e-4 S + 1.0)  (ba_cuda.cu:589 semantics; rows >= 6 N: identity) on the packed triangle in LDS, lane r its own
+  // diagonal entry -- as a select per column while the row is read (`if (c == row)`) it was 60 compares on hoisted lane masks
+  if (lane < SN) {
+    float* dp = Lt + tri_index(lane, lane);
+    float v = *dp;
+    v += 1e-4f * v + 1.0f;
+    *dp = v;
+  }
+  wave_lds_sync();
   const int row = min(lane, SN);
   const float* rp = Lt + ((row < SN) ? tri_index(row, 0) : TRI);
   cdv_float2 a2[SN / 2];     // the row as 30 float2 registers: rank-1 updates run two columns per v_pk_fma_f32
 #pragma unroll
-  for (int c = 0; c < SN; c++) {
-    float v = rp[c];
-    if (c == row) v += 1e-4f * v + 1.0f;             // S += I (1e-4 S + 1.0)  (ba_cuda.cu:589 semantics); rows >= 6 N: identity
-    a2[c >> 1][c & 1] = v;
-  }
-  wave_lds_sync();   // Lt is reused for L below
-  if (A.dbg && lane <= SN) {                          // damped S (both triangles) and y of iteration 0
-#pragma unroll
-    for (int c = 0; c < SN; c++) {
-      const float v = a2[c >> 1][c & 1];
-      if (lane < n && c <= lane) { A.dbg[(size_t)lane * n + c] = v; A.dbg[(size_t)c * n + lane] = v; }
-      if (lane == SN && c < n) A.dbg[(size_t)n * n + c] = v;
+  for (int c = 0; c < SN; c++) a2[c >> 1][c & 1] = rp[c];
+  if (A.dbg && (lane < n || lane == SN)) {            // damped S (both triangles) and y of iteration 0: a rolled loop over the
+    const int cmax = lane < n ? lane : n - 1;         // row in LDS (unrolled over the registers it was 120 hoisted lane masks)
+#pragma unroll 1
+    for (int c = 0; c <= cmax; c++) {
+      const float v = rp[c];
+      if (lane < n) { A.dbg[(size_t)lane * n + c] = v; A.dbg[(size_t)c * n + lane] = v; }
+      else A.dbg[(size_t)n * n + c] = v;
     }
   }
+  wave_lds_sync();   // Lt is reused for L below
   CDV_IF_STAMPS(asm volatile("v_nop" :: "v"(a2[29][1] + a2[0][0]));)
   CDV_STAMP(baw, sslot, 2);
   // ---- right-looking Cholesky, column k broadcast through LDS one column ahead of its rank-1 update ----
-  int badk = 0;
+  // (no pivot test inside the chain: a pivot that is not positive leaves a NaN on L's diagonal -- piv * rsq(piv) -- and is
+  // found there afterwards.  Tested per column, the compiler kept all 60 pivots in spilled scalar registers and evaluated the
+  // tests after the loop: 60 x (v_readlane of a spill lane, compare, or) at the END of the critical path.)
   float Lk;
   {
     const float piv = readlane_f(a2[0][0], 0);
-    if (!(piv > 0.f)) badk = 1;
     Lk = a2[0][0] * __builtin_amdgcn_rsqf(piv);
     a2[0][0] = Lk;
     colb[lane] = Lk;
@@ -230,7 +237,6 @@ __device__ __forceinline__ void solve_wave(const BaWinArgs& A, int RW) {
       // pivot -> scale -> next pivot never waits for an LDS round trip)
       float an = fmaf(-Lk, readlane_f(Lk, k + 1), a2[(k + 1) >> 1][(k + 1) & 1]);
       const float piv = readlane_f(an, k + 1);
-      if (!(piv > 0.f) && badk == 0) badk = (k + 1) / 6 + 1;        // wave-uniform
       Ln = an * __builtin_amdgcn_rsqf(piv);
       a2[(k + 1) >> 1][(k + 1) & 1] = Ln;
       colb[lane] = Ln;      // in-order LDS: the reads of column k were issued before this write
@@ -270,14 +276,25 @@ __device__ __forceinline__ void solve_wave(const BaWinArgs& A, int RW) {
 #pragma unroll
   for (int r = 0; r < SN; r++) col[r] = Lt[r * 68 + kc];
   float z = Lt[SN * 68 + kc];                       // z = L^-1 y
-  const float invd = 1.0f / Lt[kc * 68 + kc];
-  // back substitution L^T x = z: x_r = z_r / L[r][r] once every x_j, j > r, has been folded into z
+  const float dgk = Lt[kc * 68 + kc];
+  const float invd = 1.0f / dgk;
+  // the first pivot that was not positive (ba_cuda.cu:576,590 ignore cholesky_ex's info; here it is reported): block index + 1
+  const unsigned long long badm = __ballot(lane < SN && !(dgk > 0.f));
+  const int badk = badm ? (__ffsll((long long)badm) - 1) / 6 + 1 : 0;
+  // back substitution L^T x = z: x_r = z_r / L[r][r] once every x_j, j > r, has been folded into z.  x_r is wave-uniform when
+  // it is known (a scalar register) and goes into lane r of x with ONE v_writelane -- `x = (lane == r) ? xr : x` cost a
+  // hoisted 64-bit lane mask per step, 60 of them spilled and read back with v_readlane at the end of the kernel's critical path
+  // The sweep runs on the SCALED unknown zs_k = z_k / L[k][k] with columns scaled alike, so that a step's chain is
+  // v_readlane -> v_fma (the multiply by 1 / L[k][k] sat between them: 50 cycles a step, 3.0k of the solver's 24k)
   float x = 0.f;
 #pragma unroll
+  for (int r = 0; r < SN; r++) col[r] *= invd;
+  float zs = z * invd;
+#pragma unroll
   for (int r = SN - 1; r >= 0; r--) {
-    const float xr = readlane_f(z * invd, r);
-    x = (lane == r) ? xr : x;
-    z = fmaf(-col[r], xr, z);
+    const float xr = readlane_f(zs, r);
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(x) : "s"(xr), "n"(r));   // (x_r is a data operand here, not the lane select: no hazard wait)
+    zs = fmaf(-col[r], xr, zs);
   }
   CDV_STAMP(baw, sslot, 4);
   if (A.test == HO_TEST_STALL_AFTER) ho_test_stall();
@@ -574,8 +591,11 @@ __global__ __launch_bounds__(64 * CKW) void ba_chunk_kernel(BaWinArgs A_in) {
 }
 
 
+// (waves_per_eu 1..2: one workgroup per CU matters here, not occupancy -- left to itself the scheduler sinks the solver's
+// look-ahead broadcast reads to reach a smaller register bucket and the factorisation runs 50 % longer: 18.8k against 12.6k
+// cycles, measured when the kernel dropped from 180 to 140 registers)
 template <bool TABLE>
-__global__ __launch_bounds__(256) void ba_finish_kernel(BaWinArgs A_in) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void ba_finish_kernel(BaWinArgs A_in) {
   const BaWinArgs A = with_dyn(A_in);
   const int32_t* __restrict__ gmeta = A.gmeta;
   const PatchSpan sp = patch_span<TABLE>(A);
