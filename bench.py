@@ -400,11 +400,19 @@ def main():
             ev_s = events_since(up2.graph.events, ev_s0)
             ms2 = corr_event_ms(up2, 30)
             b2 = corr_algorithmic_bytes(st2)
+            tr2, tr2_src = None, None
+            try:      # counter traffic of the same kernel on this workload, collected in separate --pmc passes (profiles/)
+                pm2 = json.load(open(os.path.join(ROOT, "profiles", "corr_traffic.json"))).get("stress", {})
+                tr2 = pm2.get("hbm_bytes_per_launch")
+                tr2_src = None if tr2 is None else ("NOT measured in this run: profiles/%s_corr_pmc_stress.txt, 2 x FETCH_SIZE + WRITE_SIZE "
+                                                   "per launch (scripts/pmc_r2.sh)" % pm2.get("round", "r5"))
+            except Exception:
+                pass
             extra["stress"] = {"value": (n2 / t2) if not any(ev_s) else None, "unit": "frames/s", "ms_per_step": 1e3 * t2 / n2, "steps": n2,
                                "ba_events": ev_s,
                                "roofline": {"bound": "hbm", "achieved": b2 / (ms2 * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                             "frac": b2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel": "corr_fused2_kernel<24, 2, stream>",
-                                            "avg_launch_ms": ms2, "algorithmic_bytes": b2, "traffic": None},
+                                            "avg_launch_ms": ms2, "algorithmic_bytes": b2, "traffic": tr2, "traffic_source": tr2_src},
                                "what": "BASELINE.json configs[4]: the same update path, M=%d patches/frame, window %d, E=%d edges, "
                                        "%d free poses" % (st2.cfg.M, st2.cfg.opt_window, st2.E, st2.n - st2.t0)}
             del up2, st2
