@@ -383,3 +383,52 @@ def test_dropin_table_gives_way_to_the_ranked_index_when_the_ids_do_not_fit():
     finally:
         os.environ["CDV_CHECK"] = "1"
         ops.configure_table(None)
+
+
+def test_table_build_captured_as_a_hipgraph_serves_ids_that_move_round_the_table():
+    """The two launches of a table build carry nothing of the host but pointers and sizes (the build's generation is a device
+    word): captured ONCE into a hipGraph and replayed over edge lists whose patch ids move on by a quarter of the table's
+    capacity per replay -- every slot meets new ids under the very same launches, several times round -- every replay gives
+    the oracle's neighbors, bit for bit.  In between a replay whose ids do NOT fit the table (two live ids per slot): the
+    error state, neighbors -1; the replay after it is clean again -- the error word belongs to one build and is cleared by
+    the build before.  (Round 4 froze a host-side generation into the launches: the first wrap put every later replay into
+    the error state.)"""
+    import os
+    os.environ["CDV_CHECK"] = "0"      # (CDV_CHECK=1 reads the index's status back after every build: not capturable)
+    dev = torch.device(DEV)
+    rng = np.random.default_rng(3)
+    cap, E = 64, 900
+    g = ops.GraphIndex(dev, E_cap=E, k_range=4096, table_capacity=cap)
+    jj_d = torch.zeros(E, dtype=torch.int64, device=dev)
+    kk_d = torch.zeros(E, dtype=torch.int64, device=dev)
+
+    def edges(lo, span):
+        kk = lo + rng.integers(0, span, E)
+        jj = rng.integers(0, 30, E)
+        return kk.astype(np.int64), jj.astype(np.int64)
+
+    kk, jj = edges(100, cap)
+    kk_d.copy_(T(kk)); jj_d.copy_(T(jj))
+    g.build_table(jj_d, kk_d, with_neighbors=True, force=True)          # warm-up (one-time initialisation outside the capture)
+    torch.cuda.synchronize()
+    cg = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(cg):
+        g.build_table(jj_d, kk_d, with_neighbors=True, force=True)
+        ix, jx = g.neighbors()
+    torch.cuda.synchronize()
+    for rep in range(14):
+        bad = rep in (5, 9)
+        kk, jj = edges(100 + 16 * rep, 2 * cap if bad else cap)
+        if bad:
+            assert len(np.unique(kk % cap)) < len(np.unique(kk))         # two live ids in one slot
+        kk_d.copy_(T(kk)); jj_d.copy_(T(jj))
+        cg.replay()
+        torch.cuda.synchronize()
+        if bad:
+            assert bool((ix == -1).all()) and bool((jx == -1).all()), rep
+            with pytest.raises(ops._lib.CdvError, match="range"):
+                g.meta()
+        else:
+            ix_o, jx_o = O.neighbors(kk, jj)
+            assert np.array_equal(ix.cpu().numpy(), ix_o) and np.array_equal(jx.cpu().numpy(), jx_o), rep
+            assert g.meta()[6] == 0
