@@ -9,7 +9,7 @@ from cdv_slam_amd.stream import DeviceStreamRunner
 
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 step = float(sys.argv[2]) if len(sys.argv) > 2 else 0.1
-run = DeviceStreamRunner(torch.device("cuda:0"), buffer_size=1024, pose_step=step)
+run = DeviceStreamRunner(torch.device("cuda:0"), buffer_size=512, pose_step=step)
 for f in range(45):   # reach the steady state (E = 47,712 at the default window)
     run.frame(drop=False)
 for f in range(30):

@@ -1,0 +1,27 @@
+#!/bin/bash
+# round 5 evidence in one call: the GPU test suite, the bench line, kernel traces (default / stress / stream), in-kernel
+# stamps of the window BA (diagnostic build), the captured-memset micro check.  Copies into profiles/ are made afterwards.
+tag=${1:-r5final}
+out=gpurun_out; mkdir -p $out; export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+rm -f $out/${tag}_ba_errors.jsonl
+export CDV_TEST_LOG=$PWD/$out/${tag}_ba_errors.jsonl
+timeout -k 10 1100 python -m pytest tests -m gpu -v --timeout 600 -p no:cacheprovider > $out/${tag}_pytest.log 2>&1
+rc=$?; echo "pytest rc=$rc"; grep -E "FAILED|ERROR|passed|failed" $out/${tag}_pytest.log | tail -n 12
+if [ $rc -gt 1 ]; then echo "pytest was killed or errored out: no further GPU step"; exit $rc; fi
+unset CDV_TEST_LOG
+timeout -k 10 600 python bench.py --steps 200 --warmup 20 > $out/${tag}_bench.json 2> $out/${tag}_bench.err
+brc=$?; echo "bench rc=$brc"; tail -n 4 $out/${tag}_bench.err
+if [ $brc -ne 0 ]; then exit $brc; fi
+python scripts/micro/memset_node.py > $out/${tag}_memset_node.log 2>&1
+(cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/${tag}_prof -- python3 $R/bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-dropin --no-extra > $R/$out/${tag}_prof.log 2>&1); echo "rocprof default rc=$?"
+python scripts/kstats.py $out/${tag}_prof > $out/${tag}_kernel_stats_default.txt 2>&1; head -8 $out/${tag}_kernel_stats_default.txt
+timeout -k 10 300 python bench.py --config stress --no-cpu-baseline --no-dropin --no-extra --windows 3 > $out/${tag}_bench_stress.json 2> $out/${tag}_bench_stress.err || exit 1
+(cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/${tag}_prof_stress -- python3 $R/bench.py --config stress --steps 60 --warmup 10 --no-cpu-baseline --no-dropin --no-extra --windows 1 > $R/$out/${tag}_prof_stress.log 2>&1); echo "rocprof stress rc=$?"
+python scripts/kstats.py $out/${tag}_prof_stress 10 > $out/${tag}_kernel_stats_stress.txt 2>&1; head -8 $out/${tag}_kernel_stats_stress.txt
+python scripts/bench_stream.py 600 > $out/${tag}_stream.log 2>&1; tail -2 $out/${tag}_stream.log
+(cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/${tag}_stream_prof -- python3 $R/scripts/bench_stream.py 300 > $R/$out/${tag}_stream_prof.log 2>&1); echo "rocprof stream rc=$?"
+python scripts/kstats.py $out/${tag}_stream_prof 30 > $out/${tag}_kernel_stats_stream.txt 2>&1; head -12 $out/${tag}_kernel_stats_stream.txt
+CDV_LIB=$PWD/cdv_slam_amd/libcdvslam_hip_stamps.so timeout -k 10 200 python scripts/stamps_baw.py default 2 > $out/${tag}_stamps_default.log 2>&1
+CDV_LIB=$PWD/cdv_slam_amd/libcdvslam_hip_stamps.so timeout -k 10 200 python scripts/stamps_bam.py stress 2 > $out/${tag}_stamps_stress.log 2>&1
+echo "stamps done"; grep -A6 "solver wave" $out/${tag}_stamps_default.log
