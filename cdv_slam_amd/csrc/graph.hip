@@ -34,6 +34,8 @@
 
 using namespace cdv;
 
+CDV_STAMP_TU(graph)
+
 namespace {
 
 struct RegEntry {
@@ -511,6 +513,8 @@ __global__ __launch_bounds__(256) void graph_tsort_kernel(const TSortArgs A_in) 
   TSortArgs A = A_in;
   if (A.dyn) A.E = min(A.dyn[CDV_DYN_E], A_in.E);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  CDV_IF_STAMPS(const int sslot = (int)blockIdx.x;)
+  if (tid < 64) { CDV_STAMP_RT(graph, sslot, 0); CDV_STAMP(graph, sslot, 1); }
   // this build's generation and its error word, as the fill launch left them (nothing in this launch depends on host state
   // that a captured hipGraph would freeze)
   const int gen = A.meta[GM_GEN], par = gen & 1;
@@ -522,13 +526,57 @@ __global__ __launch_bounds__(256) void graph_tsort_kernel(const TSortArgs A_in) 
     __shared__ int s_pos[ORD_BINS];
     __shared__ int s_tot[32][ORD_BINS + 1], s_pre[32][ORD_BINS + 1];
     __shared__ __attribute__((aligned(16))) float s_xy[256 * 18];
+    // Three things this workgroup needs before it can write anything, none of which depends on another: the count table of
+    // the fill launch (-> its first position per target bin), its first tile's edges (kk, jj, ii), and -- behind those --
+    // the poses / intrinsics / patch of every edge.  They are requested in THAT order and waited for in the order of use:
+    // the table's 16-byte loads and the edge loads go out together, the reprojection (loads of its own, ~2.5k cycles of
+    // arithmetic) runs while the table is in flight, the table is summed afterwards.  (Round 5, stamps: the edge workgroups
+    // are this launch's long pole -- they ended at 8.4 us, the per-slot workgroups at 2.9 -- and spent 4.3k cycles on the
+    // table before their first edge load went out.)
+    const int bq = tid & 7, part = tid >> 3;
+    const cdv_i4* tab = reinterpret_cast<const cdv_i4*>(A.ocnt);
+    cdv_i4 c0[8];      // the first 256 rows of the table (all of it up to 256 fill workgroups)
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int b = part + 32 * u;
+      c0[u] = (b < nblk) ? tab[b * (ORD_BINS / 4) + bq] : cdv_i4{0, 0, 0, 0};
+    }
+    // the first tile
+    const auto load_edge = [&](int e, bool in, float (&cx)[9], float (&cy)[9], int64_t& k64, int64_t& j64) {
+      k64 = 0; j64 = 0;
+      if (in) {
+        k64 = A.kk[e]; j64 = A.jj[e];
+        if (A.poses) {
+          reproject_edge(A, A.ii[e], j64, k64, cx, cy);
+#pragma unroll
+          for (int a = 0; a < 9; a++) { s_xy[tid * 18 + a] = cx[a]; s_xy[tid * 18 + 9 + a] = cy[a]; }
+        } else if (A.cs.coords && A.crec) {
+          const float2* c2 = reinterpret_cast<const float2*>(A.cs.coords + (size_t)e * 18);
+#pragma unroll
+          for (int a = 0; a < 9; a++) {
+            const float2 v = c2[a];
+            if (2 * a < 9) cx[2 * a] = v.x; else cy[2 * a - 9] = v.x;
+            if (2 * a + 1 < 9) cx[2 * a + 1] = v.y; else cy[2 * a + 1 - 9] = v.y;
+          }
+        }
+        if (terr && A.ix) { A.ix[e] = -1; A.jx[e] = -1; }         // no index: "none", not uninitialised memory
+      }
+    };
+    float cx[9], cy[9];
+    int64_t k64 = 0, j64 = 0;
+    const int e_first = bid * 256;
+    load_edge(e_first + tid, e_first + tid < A.E, cx, cy, k64, j64);
     // this workgroup's first position per target bin: (edges of the bins before) + (edges of this bin in the workgroups
     // before it), summed from the per-workgroup counts the fill launch left
     {
-      const int bq = tid & 7, part = tid >> 3;
       int tot[4] = {0, 0, 0, 0}, pre[4] = {0, 0, 0, 0};
-      const cdv_i4* tab = reinterpret_cast<const cdv_i4*>(A.ocnt);
-      for (int b0 = part; b0 < nblk; b0 += 32 * 8) {   // eight 16-byte loads in flight: 256 rows per memory round trip
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const bool before = part + 32 * u < bid;
+#pragma unroll
+        for (int q = 0; q < 4; q++) { tot[q] += c0[u][q]; pre[q] += before ? c0[u][q] : 0; }
+      }
+      for (int b0 = part + 32 * 8; b0 < nblk; b0 += 32 * 8) {   // beyond 256 fill workgroups: eight 16-byte loads in flight per trip
         cdv_i4 c[8];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
@@ -559,28 +607,11 @@ __global__ __launch_bounds__(256) void graph_tsort_kernel(const TSortArgs A_in) 
       }
       __syncthreads();
     }
-    for (int e0 = bid * 256; e0 < A.E; e0 += nblk * 256) {      // workgroup-uniform trip count
+    if (tid < 64) { CDV_STAMP(graph, sslot, 2); }
+    for (int e0 = e_first; e0 < A.E; e0 += nblk * 256) {      // workgroup-uniform trip count
       const int e = e0 + tid;
       const bool in = e < A.E;
-      float cx[9], cy[9];
-      int64_t k64 = 0, j64 = 0;
-      if (in) {
-        k64 = A.kk[e]; j64 = A.jj[e];
-        if (A.poses) {
-          reproject_edge(A, A.ii[e], j64, k64, cx, cy);
-#pragma unroll
-          for (int a = 0; a < 9; a++) { s_xy[tid * 18 + a] = cx[a]; s_xy[tid * 18 + 9 + a] = cy[a]; }
-        } else if (A.cs.coords && A.crec) {
-          const float2* c2 = reinterpret_cast<const float2*>(A.cs.coords + (size_t)e * 18);
-#pragma unroll
-          for (int a = 0; a < 9; a++) {
-            const float2 v = c2[a];
-            if (2 * a < 9) cx[2 * a] = v.x; else cy[2 * a - 9] = v.x;
-            if (2 * a + 1 < 9) cx[2 * a + 1] = v.y; else cy[2 * a + 1 - 9] = v.y;
-          }
-        }
-        if (terr && A.ix) { A.ix[e] = -1; A.jx[e] = -1; }         // no index: "none", not uninitialised memory
-      }
+      if (e0 != e_first) load_edge(e, in, cx, cy, k64, j64);   // (the first tile is in hand; further trips only beyond 262 k edges)
       if (A.poses) {
         // the tile's coordinates leave as one contiguous block: 256 edges x 72 bytes, 16 bytes per lane
         __syncthreads();
@@ -623,6 +654,7 @@ __global__ __launch_bounds__(256) void graph_tsort_kernel(const TSortArgs A_in) 
       }
       if (A.poses) __syncthreads();                              // the tile is reused by the next trip
     }
+    if (tid < 64) { CDV_STAMP(graph, sslot, 3); CDV_STAMP_RT(graph, sslot, 15); }
     return;
   }
   // =================================== patch workgroups: 8 slots each, a half-wave per slot ===================================
@@ -660,6 +692,7 @@ __global__ __launch_bounds__(256) void graph_tsort_kernel(const TSortArgs A_in) 
   } else if (hl == 0) {
     s_flag[h] = 0;
   }
+  if (tid < 64) { CDV_STAMP(graph, sslot, 2); }
   if (deg > 0 && deg <= ELL_SLOTS) {
     const uint64_t key = hl < deg ? rec_key(rec) : ~0ull;
     s_key[h][hl] = key;
@@ -691,6 +724,7 @@ __global__ __launch_bounds__(256) void graph_tsort_kernel(const TSortArgs A_in) 
   __shared__ int s_deg8[8];
   if (hl == 0) s_deg8[h] = deg;
   __syncthreads();
+  if (tid < 64) { CDV_STAMP(graph, sslot, 3); CDV_STAMP_RT(graph, sslot, 15); }
   if (wave != 0) return;
   bool any_ovf = false;
 #pragma unroll
