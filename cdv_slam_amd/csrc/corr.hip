@@ -780,8 +780,15 @@ __device__ __forceinline__ bool ring_index(int64_t v64, uint32_t mod, uint32_t m
   return small && q < limit;
 }
 
+// The four leading arguments are what a wave needs to find its edge and request its record: one scalar load, and no second
+// one for the grid size (gridDim.x lives in the hidden arguments; `eighth` = gridDim.x / 8 comes from the host).  (Round 5:
+// with -amdgpu-kernarg-preload-count=4 these arguments arrive in scalar registers at wave launch and the record request
+// goes out with no kernel-argument load in front of it at all -- measured next to this build and to the one before it
+// (two dependent scalar round trips): 36.3-37.6 us back to back for all three, no difference.  The kernel is not bound by
+// the length of one wave's chain of round trips; the preload flag is not used.)
 template <int CC, int NLEV, bool SPLIT = false, bool REC = false>
-__global__ __launch_bounds__(256) void corr_fused2_kernel(const CorrArgs2 a) {
+__global__ __launch_bounds__(256) void corr_fused2_kernel(const uint32_t* __restrict__ rec_h, const int32_t* __restrict__ dynE_h,
+                                                          int E_h, int eighth_h, const CorrArgs2 a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -790,9 +797,9 @@ __global__ __launch_bounds__(256) void corr_fused2_kernel(const CorrArgs2 a) {
   // workgroup b runs on XCD b % 8 and takes 4 consecutive edges of the b % 8-th contiguous eighth of the list.  (Two or
   // three edges per wave, the next edge's coordinates and indices prefetched under the one in progress: measured
   // 10 % slower -- fewer, longer waves.)
-  int E = a.E, eighth = (int)gridDim.x >> 3;
-  if (REC && a.dynE) {    // sizes on the device: the contiguous eighths are those of the ACTUAL list, not of the launch
-    E = min(__builtin_amdgcn_readfirstlane(*a.dynE), a.E);
+  int E = E_h, eighth = eighth_h;
+  if (REC && dynE_h) {    // sizes on the device: the contiguous eighths are those of the ACTUAL list, not of the launch
+    E = min(__builtin_amdgcn_readfirstlane(*dynE_h), E_h);
     eighth = (E + 31) >> 5;
     if (((int)blockIdx.x >> 3) >= eighth) return;
   }
@@ -802,7 +809,7 @@ __global__ __launch_bounds__(256) void corr_fused2_kernel(const CorrArgs2 a) {
     // ---- ONE round trip: record p0 of the packed input stream the index build wrote in processing order -- the 18
     // coordinates as one vector load, edge id and ring indices as scalar loads of the same line (no order[] -> coords /
     // kk / jj indirection: one dependent memory round trip less per wave, no index arithmetic)
-    const uint32_t* r = a.rec + (size_t)p0 * cdv::CORR_REC_WORDS;
+    const uint32_t* r = rec_h + (size_t)p0 * cdv::CORR_REC_WORDS;
     const int bm = min(lane / 7, 8);
     EdgeCoords ec;
     ec.cval = 0;
@@ -1264,20 +1271,20 @@ static int corr_fused_impl(const void* gmap, const void* fmap0_nhwc, const void*
     const int blocks = 8 * (int)cdv_div_up(E, 32);   // a multiple of 8: the kernel deals contiguous eighths to the XCDs
     if (rec) {   // packed input stream in processing order (cdv_corr_fused_stream)
       CDV_REQUIRE(nlev == 2 && !split && coords_ref == nullptr, CDV_ERR_UNSUPPORTED, "cdv_corr_fused_stream: two fused levels only");
-      if (C == 24) hipLaunchKernelGGL((corr_fused2_kernel<24, 2, false, true>), dim3(blocks), dim3(256), smem, s, a);
-      else hipLaunchKernelGGL((corr_fused2_kernel<0, 2, false, true>), dim3(blocks), dim3(256), smem, s, a);
+      if (C == 24) hipLaunchKernelGGL((corr_fused2_kernel<24, 2, false, true>), dim3(blocks), dim3(256), smem, s, rec, dynE, (int)E, blocks >> 3, a);
+      else hipLaunchKernelGGL((corr_fused2_kernel<0, 2, false, true>), dim3(blocks), dim3(256), smem, s, rec, dynE, (int)E, blocks >> 3, a);
     } else if (nlev == 2 && split) {   // levels kept apart (cdv_corr_fused_split): a variant of its own, so that the main kernel
                               // keeps its 72 VGPRs (74 with the choice at run time: 6 instead of 7 waves per SIMD, +7 %)
-      if (C == 24) hipLaunchKernelGGL((corr_fused2_kernel<24, 2, true>), dim3(blocks), dim3(256), smem, s, a);
-      else hipLaunchKernelGGL((corr_fused2_kernel<0, 2, true>), dim3(blocks), dim3(256), smem, s, a);
+      if (C == 24) hipLaunchKernelGGL((corr_fused2_kernel<24, 2, true>), dim3(blocks), dim3(256), smem, s, rec, dynE, (int)E, blocks >> 3, a);
+      else hipLaunchKernelGGL((corr_fused2_kernel<0, 2, true>), dim3(blocks), dim3(256), smem, s, rec, dynE, (int)E, blocks >> 3, a);
     } else if (nlev == 2 && C == 24)
-      hipLaunchKernelGGL((corr_fused2_kernel<24, 2>), dim3(blocks), dim3(256), smem, s, a);
+      hipLaunchKernelGGL((corr_fused2_kernel<24, 2>), dim3(blocks), dim3(256), smem, s, rec, dynE, (int)E, blocks >> 3, a);
     else if (nlev == 2)
-      hipLaunchKernelGGL((corr_fused2_kernel<0, 2>), dim3(blocks), dim3(256), smem, s, a);
+      hipLaunchKernelGGL((corr_fused2_kernel<0, 2>), dim3(blocks), dim3(256), smem, s, rec, dynE, (int)E, blocks >> 3, a);
     else if (C == 24)   // one level per call: what an unchanged slam.py issues (slam.py:316-323), twice per update
-      hipLaunchKernelGGL((corr_fused2_kernel<24, 1>), dim3(blocks), dim3(256), smem, s, a);
+      hipLaunchKernelGGL((corr_fused2_kernel<24, 1>), dim3(blocks), dim3(256), smem, s, rec, dynE, (int)E, blocks >> 3, a);
     else
-      hipLaunchKernelGGL((corr_fused2_kernel<0, 1>), dim3(blocks), dim3(256), smem, s, a);
+      hipLaunchKernelGGL((corr_fused2_kernel<0, 1>), dim3(blocks), dim3(256), smem, s, rec, dynE, (int)E, blocks >> 3, a);
   } else {
     CDV_REQUIRE(out_stride == 1 && out_off == 0 && coords_ref == nullptr && !split, CDV_ERR_UNSUPPORTED,
                 "cdv_corr_fused: split levels / checked calls need C <= 32");
