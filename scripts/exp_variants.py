@@ -10,7 +10,8 @@ from cdv_slam_amd.update import UpdatePath
 dev = torch.device("cuda:0")
 cfgs = sys.argv[1:] or ["default"]
 for cfg in cfgs:
-    st = synth.make_state(cfg)
+    kw = {"C": int(os.environ["CDV_EXP_C"])} if os.environ.get("CDV_EXP_C") else {}     # experiment: another feature width
+    st = synth.make_state(cfg, **kw)
     up = UpdatePath(st, dev)
     coords = up.step()["coords"]
     out = up.corr_only(coords)
