@@ -55,6 +55,12 @@ constexpr int NQ_MAX = 8;                       // 16-pixel groups of the densel
 // conflicted: 112 of 296 LDS cycles per edge)
 constexpr int RAW_MSH = RAW_ROWS * 16 + 12;
 constexpr int RAW_HALFS = 9 * RAW_MSH;          // 1836
+#ifndef CDV_CORR_WAVES
+#define CDV_CORR_WAVES 4        // waves (= edges) per workgroup of the product kernel; the waves are independent (no barrier)
+#endif
+#ifndef CDV_CORR_EPW
+#define CDV_CORR_EPW 1          // edges per wave (packed-stream instance only): > 1 requests the next record under the current edge
+#endif
 #ifndef CDV_CORR_OUT_POLICY
 #define CDV_CORR_OUT_POLICY 16   // cache policy of the product kernel's output stores: 0 plain, 16 sc1 (write-through), 2 nt
 #endif
@@ -507,9 +513,17 @@ struct EdgeCoords {
   int ixmin, ixmax, iymin, iymax;
 };
 
+// the wave's NEXT record, requested inside corr_edge behind the level-0 window loads (experiment builds with more than one
+// edge per wave, CDV_CORR_EPW): two gathers for this lane's blend coordinates, the record's scalar words as scalar loads
+struct NextRec {
+  float xb, yb;
+  uint32_t w18, w19, w20, w21, w22;
+};
+
 template <int CC, int NLEV, bool SPLIT, bool REC>
 __device__ __forceinline__ void corr_edge(const CorrArgs2& a, int p, int e, const EdgeCoords& ec, uint32_t kq, uint32_t jq,
-                                          bool idx_ok, int lane, _Float16* __restrict__ raw, _Float16* __restrict__ outT) {
+                                          bool idx_ok, int lane, _Float16* __restrict__ raw, _Float16* __restrict__ outT,
+                                          const uint32_t* __restrict__ rnext = nullptr, NextRec* nx = nullptr) {
   CDV_STAMP(corr, p, 0);
   const int C = CC ? CC : a.C;
 #ifdef CDV_STAMPS
@@ -662,6 +676,11 @@ __device__ __forceinline__ void corr_edge(const CorrArgs2& a, int p, int e, cons
     }                                                                                              \
   }
   if (do0 && !CDV_EXP(1)) CDV2_LOAD_FIXED(b0, r0, pitch0, NQF0, nq0)
+  if (rnext) {   // (wave-uniform) behind the window request: the waits for the window data leave these in flight
+    nx->xb = __int_as_float((int)rnext[bm]);
+    nx->yb = __int_as_float((int)rnext[9 + bm]);
+    nx->w18 = rnext[18]; nx->w19 = rnext[19]; nx->w20 = rnext[20]; nx->w21 = rnext[21]; nx->w22 = rnext[22];
+  }
   const BlendGeo g0 = blend_geo(xb, yb, bm, bxo, L0, b0, !b0.fast);
   const BlendGeo g1 = blend_geo(xb, yb, bm, bxo, L1, b1, !b1.fast);
   CDV_STAMP(corr, p, 2);
@@ -786,25 +805,60 @@ __device__ __forceinline__ bool ring_index(int64_t v64, uint32_t mod, uint32_t m
 // goes out with no kernel-argument load in front of it at all -- measured next to this build and to the one before it
 // (two dependent scalar round trips): 36.3-37.6 us back to back for all three, no difference.  The kernel is not bound by
 // the length of one wave's chain of round trips; the preload flag is not used.)
+constexpr int CW = CDV_CORR_WAVES;
+constexpr int EPW = CDV_CORR_EPW;
 template <int CC, int NLEV, bool SPLIT = false, bool REC = false>
-__global__ __launch_bounds__(256) void corr_fused2_kernel(const uint32_t* __restrict__ rec_h, const int32_t* __restrict__ dynE_h,
+__global__ __launch_bounds__(64 * CW) void corr_fused2_kernel(const uint32_t* __restrict__ rec_h, const int32_t* __restrict__ dynE_h,
                                                           int E_h, int eighth_h, const CorrArgs2 a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   _Float16* raw = reinterpret_cast<_Float16*>(smem_raw + (size_t)wave * WAVE_LDS2_BYTES);
   _Float16* outT = raw;   // the staged output row takes the place of the raw volume once both blends are done
-  // workgroup b runs on XCD b % 8 and takes 4 consecutive edges of the b % 8-th contiguous eighth of the list.  (Two or
-  // three edges per wave, the next edge's coordinates and indices prefetched under the one in progress: measured
-  // 10 % slower -- fewer, longer waves.)
+  // workgroup b runs on XCD b % 8 and takes CW consecutive edges of the b % 8-th contiguous eighth of the list.  (Round 5,
+  // CDV_CORR_EPW = 2 / 3 edges per wave with the next record requested behind the current edge's window loads: 77 registers
+  // instead of 62, six waves per SIMD instead of eight -- and only 7 % slower, 40.5 against 37.7 us back to back: the hidden
+  // round trip is worth more than the two lost waves cost, but the body has to fit 64 registers to cash it in; forced to 64
+  // it spills 43 values: 79 us.  Workgroups of 8 / 16 waves instead of 4: 1 % / 5 % slower.  Kept as build switches.)
+  constexpr int KE = REC ? EPW : 1;
   int E = E_h, eighth = eighth_h;
   if (REC && dynE_h) {    // sizes on the device: the contiguous eighths are those of the ACTUAL list, not of the launch
     E = min(__builtin_amdgcn_readfirstlane(*dynE_h), E_h);
-    eighth = (E + 31) >> 5;
+    eighth = (E + 8 * CW * KE - 1) / (8 * CW * KE);
     if (((int)blockIdx.x >> 3) >= eighth) return;
   }
-  const int p0 = (((int)blockIdx.x & 7) * eighth + ((int)blockIdx.x >> 3)) * 4 + wave;
+  const int p0 = (((int)blockIdx.x & 7) * eighth + ((int)blockIdx.x >> 3)) * (CW * KE) + wave;
   if (p0 >= E) return;  // no block-wide barriers below: waves are independent
+  if (REC && KE > 1) {
+    // several edges per wave: positions p0, p0 + CW, ...; the next record is requested under the current edge
+    const int bm = min(lane / 7, 8);
+    const uint32_t* r = rec_h + (size_t)p0 * cdv::CORR_REC_WORDS;
+    EdgeCoords ec;
+    ec.cval = 0;
+    ec.xb = __int_as_float((int)r[bm]);
+    ec.yb = __int_as_float((int)r[9 + bm]);
+    uint32_t w18 = r[18], w19 = r[19], w20 = r[20], w21 = r[21], w22 = r[22];
+    int p = p0;
+#pragma unroll 1
+    for (int k = 0; k < KE; k++) {
+      const int pn = p + CW;
+      const bool has_next = k + 1 < KE && pn < E;      // wave-uniform
+      ec.ixmin = (int)(short)(w21 & 0xffff); ec.ixmax = (int)w21 >> 16;
+      ec.iymin = (int)(short)(w22 & 0xffff); ec.iymax = (int)w22 >> 16;
+      NextRec nx;
+      int lane_it = lane;      // opaque per trip: what the edge derives from the lane index is recomputed, not kept across the loop
+      asm volatile("" : "+v"(lane_it));
+      corr_edge<CC, NLEV, SPLIT, true>(a, p, (int)w18, ec, w19, w20, w20 != 0xFFFFFFFFu, lane_it, raw, outT,
+                                       has_next ? rec_h + (size_t)pn * cdv::CORR_REC_WORDS : nullptr, &nx);
+      if (!has_next) break;
+      ec.xb = nx.xb; ec.yb = nx.yb;
+      w18 = __builtin_amdgcn_readfirstlane(nx.w18); w19 = __builtin_amdgcn_readfirstlane(nx.w19);
+      w20 = __builtin_amdgcn_readfirstlane(nx.w20); w21 = __builtin_amdgcn_readfirstlane(nx.w21);
+      w22 = __builtin_amdgcn_readfirstlane(nx.w22);
+      p = pn;
+    }
+    return;
+  }
   if (REC) {
     // ---- ONE round trip: record p0 of the packed input stream the index build wrote in processing order -- the 18
     // coordinates as one vector load, edge id and ring indices as scalar loads of the same line (no order[] -> coords /
@@ -1268,23 +1322,35 @@ static int corr_fused_impl(const void* gmap, const void* fmap0_nhwc, const void*
                       (uint32_t)slots, (const char*)gmap, (_Float16*)out, A0,
                       nlev == 2 ? level(fmap1_nhwc, H1, W1, scale1, ex1 - ex0) : A0, C, gmap_pixel_major, exp,
                       out_stride, out_off, out_pitch, coords_ref, ref_mul, split, rec, dynE};
-    const int blocks = 8 * (int)cdv_div_up(E, 32);   // a multiple of 8: the kernel deals contiguous eighths to the XCDs
+    const int blocks = 8 * (int)cdv_div_up(E, 8 * CW * (rec ? EPW : 1));   // a multiple of 8: the kernel deals contiguous eighths to the XCDs
+    const size_t smem2 = (size_t)CW * WAVE_LDS2_BYTES;
+    if (smem2 > 48 * 1024) {   // (experiment builds with more than 11 waves per workgroup)
+      static const hipError_t attr = [&] {
+        hipError_t e = hipSuccess, x;
+#define CDV_CATTR(...) if ((x = hipFuncSetAttribute((const void*)corr_fused2_kernel<__VA_ARGS__>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2)) != hipSuccess) e = x;
+        CDV_CATTR(24, 2, false, true) CDV_CATTR(0, 2, false, true) CDV_CATTR(24, 2, true) CDV_CATTR(0, 2, true)
+        CDV_CATTR(24, 2) CDV_CATTR(0, 2) CDV_CATTR(24, 1) CDV_CATTR(0, 1)
+#undef CDV_CATTR
+        return e;
+      }();
+      CDV_HIP_CHECK(attr);
+    }
     if (rec) {   // packed input stream in processing order (cdv_corr_fused_stream)
       CDV_REQUIRE(nlev == 2 && !split && coords_ref == nullptr, CDV_ERR_UNSUPPORTED, "cdv_corr_fused_stream: two fused levels only");
-      if (C == 24) hipLaunchKernelGGL((corr_fused2_kernel<24, 2, false, true>), dim3(blocks), dim3(256), smem, s, rec, dynE, (int)E, blocks >> 3, a);
-      else hipLaunchKernelGGL((corr_fused2_kernel<0, 2, false, true>), dim3(blocks), dim3(256), smem, s, rec, dynE, (int)E, blocks >> 3, a);
+      if (C == 24) hipLaunchKernelGGL((corr_fused2_kernel<24, 2, false, true>), dim3(blocks), dim3(64 * CW), smem2, s, rec, dynE, (int)E, blocks >> 3, a);
+      else hipLaunchKernelGGL((corr_fused2_kernel<0, 2, false, true>), dim3(blocks), dim3(64 * CW), smem2, s, rec, dynE, (int)E, blocks >> 3, a);
     } else if (nlev == 2 && split) {   // levels kept apart (cdv_corr_fused_split): a variant of its own, so that the main kernel
                               // keeps its 72 VGPRs (74 with the choice at run time: 6 instead of 7 waves per SIMD, +7 %)
-      if (C == 24) hipLaunchKernelGGL((corr_fused2_kernel<24, 2, true>), dim3(blocks), dim3(256), smem, s, rec, dynE, (int)E, blocks >> 3, a);
-      else hipLaunchKernelGGL((corr_fused2_kernel<0, 2, true>), dim3(blocks), dim3(256), smem, s, rec, dynE, (int)E, blocks >> 3, a);
+      if (C == 24) hipLaunchKernelGGL((corr_fused2_kernel<24, 2, true>), dim3(blocks), dim3(64 * CW), smem2, s, rec, dynE, (int)E, blocks >> 3, a);
+      else hipLaunchKernelGGL((corr_fused2_kernel<0, 2, true>), dim3(blocks), dim3(64 * CW), smem2, s, rec, dynE, (int)E, blocks >> 3, a);
     } else if (nlev == 2 && C == 24)
-      hipLaunchKernelGGL((corr_fused2_kernel<24, 2>), dim3(blocks), dim3(256), smem, s, rec, dynE, (int)E, blocks >> 3, a);
+      hipLaunchKernelGGL((corr_fused2_kernel<24, 2>), dim3(blocks), dim3(64 * CW), smem2, s, rec, dynE, (int)E, blocks >> 3, a);
     else if (nlev == 2)
-      hipLaunchKernelGGL((corr_fused2_kernel<0, 2>), dim3(blocks), dim3(256), smem, s, rec, dynE, (int)E, blocks >> 3, a);
+      hipLaunchKernelGGL((corr_fused2_kernel<0, 2>), dim3(blocks), dim3(64 * CW), smem2, s, rec, dynE, (int)E, blocks >> 3, a);
     else if (C == 24)   // one level per call: what an unchanged slam.py issues (slam.py:316-323), twice per update
-      hipLaunchKernelGGL((corr_fused2_kernel<24, 1>), dim3(blocks), dim3(256), smem, s, rec, dynE, (int)E, blocks >> 3, a);
+      hipLaunchKernelGGL((corr_fused2_kernel<24, 1>), dim3(blocks), dim3(64 * CW), smem2, s, rec, dynE, (int)E, blocks >> 3, a);
     else
-      hipLaunchKernelGGL((corr_fused2_kernel<0, 1>), dim3(blocks), dim3(256), smem, s, rec, dynE, (int)E, blocks >> 3, a);
+      hipLaunchKernelGGL((corr_fused2_kernel<0, 1>), dim3(blocks), dim3(64 * CW), smem2, s, rec, dynE, (int)E, blocks >> 3, a);
   } else {
     CDV_REQUIRE(out_stride == 1 && out_off == 0 && coords_ref == nullptr && !split, CDV_ERR_UNSUPPORTED,
                 "cdv_corr_fused: split levels / checked calls need C <= 32");
