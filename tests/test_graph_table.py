@@ -432,3 +432,47 @@ def test_table_build_captured_as_a_hipgraph_serves_ids_that_move_round_the_table
             ix_o, jx_o = O.neighbors(kk, jj)
             assert np.array_equal(ix.cpu().numpy(), ix_o) and np.array_equal(jx.cpu().numpy(), jx_o), rep
             assert g.meta()[6] == 0
+
+
+@pytest.mark.parametrize("n_max", [10, 22, 32])
+def test_ba_forward_dyn_equals_the_static_call_for_every_window_inside_its_bound(n_max):
+    """cdv_ba_forward_dyn lays its launches out for N_max free poses and takes the window [t0, t0 + N) from a dynamic block on
+    the device: for N_max = 10 (window kernels) and 22 / 32 (the 10 < N <= 32 kernels) and several actual windows -- the full
+    one, a smaller one, the 7 free poses of a stream's first update -- poses and patches come out BIT FOR BIT as from
+    cdv_ba_forward(t0, t0 + N) on the same table, whenever the static call takes the same kernels (N > 10 on the wide
+    bounds), and within the BA's rounding bounds where it takes the window kernels instead (N <= 10 inside a bound of 22)."""
+    import ctypes
+    os_environ = __import__("os").environ
+    os_environ["CDV_CHECK"] = "0"
+    from cdv_slam_amd import _lib
+    lib = _lib.load()
+    dev = torch.device(DEV)
+    frames = n_max + 4
+    st = synth.make_state("small", features=False, frames=frames, opt_window=n_max, removal_window=frames + 2, buffer_size=frames + 8)
+    M = st.cfg.M
+    cap = (st.cfg.removal_window + 2) * M
+    g = ops.GraphIndex(dev, E_cap=st.E, k_range=st.cfg.buffer_size * M, table_capacity=cap)
+    ii, jj, kk = T(st.ii), T(st.jj), T(st.kk)
+    g.build_table(jj, kk, ii=ii, force=True)
+    tgt, wgt, intr, lm = T(st.target), T(st.weight), T(st.intrinsics), torch.tensor([st.lmbda], device=DEV)
+    ws = ops.ba_private_workspace(dev, st.E, cap, n_max)
+    assert lib.cdv_ba_set_patches_per_frame(ctypes.c_void_p(ws.data_ptr()), M) == 0     # as ops.ba_forward tells its workspace (PPF)
+    dyn = torch.zeros(16, dtype=torch.int32, device=dev)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    for N in sorted({n_max, max(n_max - 5, 1), 7}):
+        t0 = st.n - N
+        dyn[4], dyn[5], dyn[0], dyn[1] = t0, N, st.n, st.E
+        pd, xd = T(st.poses).clone(), T(st.patches).clone()
+        rc = lib.cdv_ba_forward_dyn(P(pd), P(xd), P(intr), P(tgt), P(wgt), P(lm), P(ii), P(jj), P(kk), st.E, 3, n_max, P(dyn), 2,
+                                    P(g.ws), P(ws), ws.numel(), cap, ops._stream())
+        assert rc == 0, lib.cdv_last_error()
+        ps, xs = T(st.poses).clone(), T(st.patches).clone()
+        ops.ba_forward(ps, xs, intr, tgt, wgt, lm, ii, jj, kk, M, t0, st.n, 2, False, U_max=cap, graph=g)
+        torch.cuda.synchronize()
+        assert not torch.equal(pd, T(st.poses))
+        same_kernels = (N <= 10) == (n_max <= 10)
+        if same_kernels:
+            assert torch.equal(pd, ps) and torch.equal(xd, xs), (n_max, N)
+        else:
+            assert float((pd - ps).abs().max()) < 2e-6 and float((xd - xs).abs().max()) < 2e-5, (n_max, N)
+        assert ws.events.counts() == [0, 0, 0, 0]
