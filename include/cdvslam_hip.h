@@ -16,10 +16,13 @@
  *     current HIP device unless the parameter name ends in _host.
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).  Every call only ENQUEUES
  *     work on that stream; no call synchronises or allocates (hipGraph-capturable), except
- *     cdv_graph_read_meta_host / cdv_ba_status, which are explicit device->host read-backs.  A captured sequence is valid
- *     for the shapes AND the edge list it was captured with (launch geometry, the table build's generation and the bundle
- *     adjustment's hand-off tokens are fixed when a call is enqueued; the hand-off words are re-armed by each iteration's
- *     first launch, so replays do not meet their own tags) -- capture again when the edge list changes.
+ *     cdv_graph_read_meta_host / cdv_ba_status, which are explicit device->host read-backs.  Only KERNELS are enqueued
+ *     (no hipMemsetAsync: a captured memset is not replayed like the eager one on ROCm 7.2), and nothing of the host but
+ *     pointers, sizes and the bundle adjustment's hand-off tokens is fixed into a launch when a call is enqueued -- the
+ *     hand-off words are re-armed by each iteration's first launch, so replays do not meet their own tags, and the table
+ *     build's generation is a device word.  A captured sequence of the static entry points is valid for the SHAPES it was
+ *     captured with (launch geometry follows the number of edges) and may be replayed over other edge lists of that shape;
+ *     the *_dyn entry points take even the sizes from the device, so a captured frame pair is good for a whole stream.
  *   - return value: 0 = success, < 0 = error (CDV_ERR_*); cdv_last_error() gives the message.
  *     Never calls exit() (the reference does, block_e.cu:20-27, ba.cpp:151-152).
  *   - index tensors are int64 (torch.long) exactly as the reference passes them.
