@@ -502,6 +502,40 @@ def main():
                 del run2
             except Exception as ex:
                 extra["stream_fps"]["stress"] = {"error": repr(ex)}
+            # BASELINE.json configs[2]'s mechanics (LOOP_CLOSURE): the host-sized StreamRunner -- the reference decides on the host
+            # whether an update sees long-range edges (slam.py:507) and selects its loop edges on the CPU (patchgraph.py:71-97), and
+            # so does this runner: one read-back per update, edges_loop every GLOBAL_OPT_FREQ frames, the GLOBAL bundle adjustment
+            # over inactive + active edges when loop edges exist.  A camera on a closed circle so that loops really close.
+            try:
+                import math
+                from cdv_slam_amd.stream import StreamRunner
+                circle = lambda t: [-0.5 * math.cos(2 * math.pi * t / 60.0), -0.5 * math.sin(2 * math.pi * t / 60.0), 0.0, 0.0, 0.0, 0.0, 1.0]
+                run3 = StreamRunner(dev, buffer_size=256, loop_closure=True, max_edge_age=1000, global_opt_freq=15, backend_thresh=64.0,
+                                    pose_init=circle)
+                for _ in range(70):
+                    run3.frame(drop=False)
+                torch.cuda.synchronize()
+                g0, ev_l0 = run3.n_global, run3.graph.events.counts()
+                nf3 = 90
+                tl = time.perf_counter()
+                for _ in range(nf3):
+                    run3.frame(drop=False)
+                torch.cuda.synchronize()
+                tl = time.perf_counter() - tl
+                ev_l = events_since(run3.graph.events, ev_l0)
+                if run3.graph_full is not None:
+                    ev_l = [a + b for a, b in zip(ev_l, run3.graph_full.events.counts())]
+                extra["stream_fps"]["loop_closure"] = {
+                    "value": (nf3 / tl) if not any(ev_l) else None, "unit": "frames/s", "ms_per_frame": 1e3 * tl / nf3, "frames": nf3,
+                    "ba_events": ev_l, "global_bundle_adjustments_in_the_timed_frames": int(run3.n_global - g0),
+                    "keyframes": int(run3.n), "edges": int(run3.edges.E), "inactive_edges": int(run3.edges.E_inac),
+                    "what": "configs[2]'s mechanics on a synthetic closed path: patch ring of MAX_EDGE_AGE = 1000 frames, proximity loop "
+                            "edges every GLOBAL_OPT_FREQ = 15 frames, global BA over inactive + active edges (hundreds of free poses) when "
+                            "an update sees long-range edges; host-sized runner (cdv_slam_amd.stream.StreamRunner) with the reference's own "
+                            "host decisions and read-backs, NOT the device-resident stream"}
+                del run3
+            except Exception as ex:
+                extra["stream_fps"]["loop_closure"] = {"error": repr(ex)}
         except Exception as ex:
             extra["stream_fps"] = {"error": repr(ex)}
 
