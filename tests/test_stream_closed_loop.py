@@ -198,6 +198,39 @@ def test_device_stream_two_frames_as_a_hipgraph():
     assert a.events.counts() == [0, 0, 0, 0] and b.events.counts() == [0, 0, 0, 0]
 
 
+def test_device_stream_hipgraph_soak():
+    """3,000 replays of ONE captured frame pair (6,000 frames; the reference's BUFFER_SIZE of 4096 keyframes) against the eager
+    runner: the patch ids go round the table some sixty times, the patch and feature rings wrap a hundred times, the dynamic
+    blocks alternate 3,000 times -- the same edge lists, keyframe count, poses and depths at the end, bit for bit, and not one
+    failure event on either side."""
+    from cdv_slam_amd.stream import DeviceStreamRunner
+    dev = torch.device(DEV)
+    kw = dict(buffer_size=4096, pose_step=0.1)
+    a, b = DeviceStreamRunner(dev, **kw), DeviceStreamRunner(dev, **kw)
+    for f in range(20):
+        a.frame(drop=None)
+        b.frame(drop=None)
+    while a.cur != 0:
+        a.frame(drop=None)
+        b.frame(drop=None)
+    replay = a.capture_pair()
+    for pair in range(3000):
+        f = a.frames
+        for k in range(2):
+            dr = a._draws[(f + k) % a.N]
+            a.stage_inputs(k, a.pool[(f + k) % 4], dr[0], dr[1], dr[2])
+            b.frame(drop=None, inputs=(b.pool[(f + k) % 4], dr[0], dr[1], dr[2]))
+        replay()
+    n, E = a.counts()
+    assert (n, E) == b.counts() and a.frames == b.frames and a.frames > 6000 and n > 1500
+    ea, eb = a.edges, b.edges
+    assert torch.equal(ea.ii, eb.ii) and torch.equal(ea.jj, eb.jj) and torch.equal(ea.kk, eb.kk)
+    assert torch.equal(a.poses[:n], b.poses[:n]) and torch.equal(a.patches[:n * a.M], b.patches[:n * a.M])
+    assert a.E_inac == b.E_inac
+    assert bool(torch.isfinite(a.poses[:n]).all())
+    assert a.events.counts() == [0, 0, 0, 0] and b.events.counts() == [0, 0, 0, 0]
+
+
 def test_device_stream_outlives_its_frame_buffer_when_keyframes_are_dropped():
     """what is bounded is the number of KEYFRAMES (slam.py bounds n, not the frames seen): a stream that drops two frames in
     three runs for several times buffer_size frames -- eagerly and as hipGraph replays alike -- and stops with the device's
