@@ -817,9 +817,9 @@ __global__ __launch_bounds__(64 * CW) void corr_fused2_kernel(const uint32_t* __
   _Float16* outT = raw;   // the staged output row takes the place of the raw volume once both blends are done
   // workgroup b runs on XCD b % 8 and takes CW consecutive edges of the b % 8-th contiguous eighth of the list.  (Round 5,
   // CDV_CORR_EPW = 2 / 3 edges per wave with the next record requested behind the current edge's window loads: 77 registers
-  // instead of 62, six waves per SIMD instead of eight -- and only 7 % slower, 40.5 against 37.7 us back to back: the hidden
-  // round trip is worth more than the two lost waves cost, but the body has to fit 64 registers to cash it in; forced to 64
-  // it spills 43 values: 79 us.  Workgroups of 8 / 16 waves instead of 4: 1 % / 5 % slower.  Kept as build switches.)
+  // instead of 62 (70 without machine LICM), six (seven) waves per SIMD instead of eight: 40.5 (39.3) against 37.7 us back to
+  // back -- the hidden round trip buys what the lost waves cost, no more; forced to 64 registers it spills 43 values: 79 us.
+  // Workgroups of 8 / 16 waves instead of 4: 1 % / 5 % slower.  Kept as build switches)
   constexpr int KE = REC ? EPW : 1;
   int E = E_h, eighth = eighth_h;
   if (REC && dynE_h) {    // sizes on the device: the contiguous eighths are those of the ACTUAL list, not of the launch
