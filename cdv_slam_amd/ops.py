@@ -91,6 +91,81 @@ def version():
 
 
 # ---------------------------------------------------------------------------------------------------
+# the compiled steady state of the drop-in modules (csrc/dropin_fast.cpp -> cdv_slam_amd/_dropin_fast.so)
+# ---------------------------------------------------------------------------------------------------
+# The reference binds its kernels with a torch extension (correlation.cpp:57-63, ba.cpp:183-188); the drop-in modules here
+# are Python over the C ABI, and the caches below that make an unchanged slam.py fast cost 15-55 us of Python per call.  For
+# the steady state -- the same call sequence on tensors that look like those of the update before -- the same bookkeeping
+# runs compiled: the code below HANDS the state over ("arms") once it has served a complete pair / a complete neighbors +
+# BA itself, asks the extension first at the next call, and TAKES the state back ("disarms") before any Python code touches
+# the shared shadows or workspaces again.  Whatever the extension does not recognise it declines (None) and the Python code
+# -- the authority on semantics -- serves the call.  CDV_DROPIN_FAST=0 (read at every call) switches the lane off.
+_FAST_SYMS = ("cdv_fmap_sync_nhwc", "cdv_gmap_to_pixel_major", "cdv_corr_fused", "cdv_corr_level_checked_interleaved",
+              "cdv_graph_build_table", "cdv_ba_workspace_bytes", "cdv_ba_forward", "cdv_transform")
+_fast = None           # the bound extension module; False: not available (warned once)
+_armed_pair = None     # (the _LevelPairing, ring entry A, ring entry B, the TileCache) whose state the extension holds
+_armed_graph = None    # (token, the GraphIndex) whose workspace the extension builds in and runs the BA over
+
+
+def _fast_mod():
+    global _fast
+    if _fast is None:
+        try:
+            from . import _dropin_fast as m
+            lib = _lib.load()
+            m.bind({n: ctypes.cast(getattr(lib, n), ctypes.c_void_p).value for n in _FAST_SYMS})
+            _fast = m
+        except ImportError as e:
+            import warnings
+            warnings.warn("cdv_slam_amd: the compiled drop-in bookkeeping (_dropin_fast.so, `make -C cdv_slam_amd/csrc`) is not "
+                          "available (%s); the Python bookkeeping serves every call" % e, RuntimeWarning)
+            _fast = False
+    return _fast
+
+
+def fast_lane_enabled():
+    return _env("CDV_DROPIN_FAST", "1") != "0" and bool(_fast_mod())
+
+
+def _disarm_pair():
+    """take the ring / tile shadows' state back from the extension (before Python code syncs or converts them itself)"""
+    global _armed_pair
+    if _armed_pair is None:
+        return
+    pairing, ea, eb, tiles = _armed_pair
+    _armed_pair = None
+    st = _fast.disarm_pair()
+    pairing.fast_token = 0
+    ea.pop("fast", None)
+    eb.pop("fast", None)
+    tiles.fast = False
+    if st is not None:
+        ea["version"], ea["parity"] = st["A_version"], st["A_parity"]
+        eb["version"], eb["parity"] = st["B_version"], st["B_parity"]
+        src = st["tiles_src"]
+        tiles.src, tiles.ident = src, (src.data_ptr(), st["tiles_version"], src.shape, src.stride(), src.dtype)
+
+
+def _disarm_graph(g=None):
+    """take the per-device index workspace back (g given: only if it is the armed one), with the record of what it holds"""
+    global _armed_graph
+    if _armed_graph is None or (g is not None and _armed_graph[1] is not g):
+        return
+    g = _armed_graph[1]
+    _armed_graph = None
+    st = _fast.disarm_graph()
+    g._key = g._nbr = None
+    if st is not None and st["has_key"]:      # the index the extension left in the workspace, as build_table() would record it
+        idn = lambda t, v: (t.data_ptr(), v, t.shape, t.stride(), t.dtype)
+        jj, kk, ii = st["jj"], st["kk"], st["ii"]
+        g._key = (idn(jj, st["jj_version"]), idn(kk, st["kk_version"]), None if ii is None else idn(ii, st["ii_version"]),
+                  (jj, kk, ii), "table")
+        g.E, g.is_table = kk.numel(), True
+        if st["ix"] is not None:
+            g._nbr = (st["ix"], st["jx"])
+
+
+# ---------------------------------------------------------------------------------------------------
 # patch-graph index
 # ---------------------------------------------------------------------------------------------------
 
@@ -125,6 +200,7 @@ class GraphIndex:
     def _reserve(self, E):
         if self.ws is not None and E <= self.E_cap:
             return
+        _disarm_graph(self)
         self.E_cap = max(E, int(self.E_cap * 1.5), 1024)
         nbytes = self.lib.cdv_graph_workspace_bytes(self.E_cap, self.k_range)
         self.ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
@@ -184,6 +260,7 @@ class GraphIndex:
         tensor objects (neighbors() and BA() of one update share one build).  with_neighbors: the build also
         produces fastba.neighbors(kk, jj) (picked up by neighbors() without another launch).  ii (optional): the
         source frames, copied into the per-patch edge records the bundle adjustment walks."""
+        _disarm_graph(self)
         _need_cuda(jj, kk)
         if jj.dtype != torch.int64 or kk.dtype != torch.int64:
             raise TypeError("index tensors must be int64")
@@ -222,6 +299,7 @@ class GraphIndex:
         """make sure the workspace holds an index of (ii, jj, kk) the bundle adjustment with N free poses can use: either
         form for N <= 32 (whatever is there and current is kept; otherwise the preferred one is built, CDV_INDEX), the ranked
         one for the global bundle adjustment"""
+        _disarm_graph(self)
         if N > 32 or N < 1:      # global bundle adjustment, and the structure-only call (no free pose): ranked index
             return self.build(jj, kk, ii=ii)
         key = self._make_key(jj, kk, ii)
@@ -234,6 +312,7 @@ class GraphIndex:
         neighbors(), the window / mid bundle adjustment (N <= 32) and the correlation's order + packed stream; not
         unique() (no ranks) and not the global bundle adjustment -- build() is there for those.  Same caching rule as
         build(): identity + version of the tensors."""
+        _disarm_graph(self)
         _need_cuda(jj, kk)
         if not self.table_capacity:
             raise RuntimeError("GraphIndex.build_table: this workspace was created without a table capacity")
@@ -290,6 +369,7 @@ class GraphIndex:
         return m
 
     def neighbors(self):
+        _disarm_graph(self)
         if getattr(self, "_nbr", None) is not None:
             return self._nbr
         ix = torch.empty(self.E, dtype=torch.int64, device=self.device)
@@ -300,6 +380,7 @@ class GraphIndex:
 
     def unique(self):
         """(kx, ku) == torch._unique(kk, sorted=True, return_inverse=True); one host sync for U."""
+        _disarm_graph(self)
         if self.is_table:      # a table has no ranks: rebuild as the ranked index from the tensors it was built from
             jj, kk, ii = self._key[3]
             self.build(jj, kk, force=True, ii=ii)
@@ -323,6 +404,7 @@ def update_prologue(graph, fmap_chw, fmap1_nhwc, fmap2_nhwc, slot, gmap, gmap_pm
     if P != 3 or poses.dtype != torch.float32:
         raise TypeError("update_prologue: float32 state, 3x3 patches")
     dev = poses.device
+    _disarm_graph(graph)
     graph._reserve(E)
     shape = (1, E, 2, P, P) if layout_e2pp else (1, E, P, P, 2)
     if coords_out is not None:      # a caller-owned buffer (the one bound with GraphIndex.bind_corr_stream)
@@ -358,6 +440,7 @@ def update_prologue_table(graph, fmap_chw, fmap1_nhwc, fmap2_nhwc, slot, gmap, g
     if P != 3 or poses.dtype != torch.float32:
         raise TypeError("update_prologue_table: float32 state, 3x3 patches")
     dev = poses.device
+    _disarm_graph(graph)
     graph._reserve(E)
     if coords_out is not None:
         coords = coords_out.view(-1)[: E * 18].view(1, E, 2, P, P)
@@ -398,6 +481,7 @@ def configure_table(capacity):
     (no assumption about the ids).  install_dropin(table_capacity=...) calls this; CDV_TABLE_CAPACITY sets the default."""
     global _table_capacity
     _table_capacity = int(capacity) if capacity else None
+    _disarm_graph()
     _graphs.clear()
 
 
@@ -413,6 +497,7 @@ def set_patch_capacity(n_patches):
     the ranked index of the per-device workspaces created from now on by neighbors() / BA()"""
     global DEFAULT_K_RANGE
     DEFAULT_K_RANGE = int(n_patches)
+    _disarm_graph()
     _graphs.clear()
 
 
@@ -445,6 +530,7 @@ def _table_still_fits(g, dev=None):
 def graph_for(jj, kk, ii=None, **kw):
     """Per-device shared GraphIndex, (re)built for (jj, kk) in the preferred form."""
     g = _device_graph(kk.device, **kw)
+    _disarm_graph(g)
     _table_still_fits(g)
     key = g._make_key(jj.contiguous(), kk.contiguous(), None if ii is None else ii.contiguous())
     if g._key is not None and g._same_key(key):
@@ -459,6 +545,14 @@ def neighbors(kk, jj):
     if kk.numel() == 0:
         e = torch.empty(0, dtype=torch.int64, device=kk.device)
         return e, e.clone()
+    ag = _armed_graph
+    if ag is not None and _env("CDV_DROPIN_FAST", "1") != "0" and prefer_table() and not _sync_check():
+        r = _fast.neighbors(ag[0], kk, jj, _stream())
+        if r is not None:
+            if type(r) is int:
+                _lib.check(r, "cdv_graph_build_table")
+            ag[1].n_builds += r[2]
+            return r[0], r[1]
     return graph_for(jj, kk).neighbors()
 
 
@@ -540,6 +634,8 @@ class NhwcCache:
         place = _place(fmap)
         for ent in self.entries:
             if ent["place"] == place:      # the same memory, through whichever view object (ent["src"] pins the storage)
+                if "fast" in ent:
+                    _disarm_pair()         # the extension kept this shadow in step meanwhile: its version / parity come back
                 if ent["version"] != fmap._version:
                     self._sync(ent)
                 return ent["shadow"]
@@ -553,8 +649,18 @@ class NhwcCache:
         self._sync(ent)
         self.entries.append(ent)
         if len(self.entries) > self.max_entries:
+            if "fast" in self.entries[0]:
+                _disarm_pair()
             self.entries.pop(0)
         return ent["shadow"]
+
+    def entry(self, fmap):
+        """the shadow entry of this ring, or None"""
+        place = _place(fmap)
+        for ent in self.entries:
+            if ent["place"] == place:
+                return ent
+        return None
 
     @staticmethod
     def _sync(ent):
@@ -586,10 +692,13 @@ class TileCache:
     def __init__(self):
         self.src, self.ident, self.shadow = None, None, None
         self.n_converted = 0
+        self.fast = False          # the extension holds (and keeps converting into) the shadow
 
     def get(self, gmap):
         """keyed on the memory + version (_ident), not on the Python object: slam.py's `gmap` property is a fresh view of
         gmap_ at every access (slam.py:249-251) and SLAM.corr reads it twice (:321-322)"""
+        if self.fast:
+            _disarm_pair()
         idn = _ident(gmap)
         if self.ident != idn or self.shadow is None:
             g = gmap[0] if gmap.dim() == 5 else gmap
@@ -754,6 +863,7 @@ class _LevelPairing:
         self.pending = None
         self.n_fused = 0
         self.n_stacked = 0
+        self.fast_token = 0    # != 0: the extension holds this pairing's rings and tiles (_arm / _disarm_pair)
 
     @staticmethod
     def _same(held, now):
@@ -773,9 +883,31 @@ class _LevelPairing:
               and rb.shape[3] * ratio == ringA.shape[3] and rb.shape[4] * ratio == ringA.shape[4])
         return (rb, ratio) if ok else (None, 0)
 
+    def _arm(self, tiles, ringA, ringB, ratio):
+        """a complete pair has just been served from here: from the next call on the extension serves this pattern"""
+        global _armed_pair
+        if not fast_lane_enabled() or tiles.dim() != 5 or not tiles.is_contiguous() or _tiles.shadow is None:
+            return
+        ea, eb = _nhwc.entry(ringA), _nhwc.entry(ringB)
+        if ea is None or eb is None or _tiles.ident != _ident(tiles):
+            return
+        _disarm_pair()
+        ring = lambda e: {"src": e["src"], "shadow": e["shadow"], "ws": e["ws"], "version": e["version"], "parity": e["parity"]}
+        try:
+            self.fast_token = _fast.arm_pair({"A": ring(ea), "B": ring(eb), "ratio": int(ratio), "tiles_src": tiles,
+                                              "tiles_pm": _tiles.shadow, "tiles_version": _tiles.ident[1]})
+        except RuntimeError:      # shapes the extension does not serve (a ring with a batch, ...): Python goes on serving them
+            self.fast_token = 0
+            return
+        ea["fast"] = eb["fast"] = True
+        _tiles.fast = True
+        _armed_pair = (self, ea, eb, _tiles)
+
     def call(self, fmap1, fmap2, coords, ii, jj):
         lib = _lib.load()
         E = coords.shape[1]
+        if self.fast_token:
+            _fast.drop_pending()
         pend, self.pending = self.pending, None
         last, self.last = self.last, None
         if not pair_levels_enabled():
@@ -791,6 +923,8 @@ class _LevelPairing:
                                                         1.0, 0, 0, 0, _stream())
             _lib.check(rc, "cdv_corr_level_checked_interleaved")
             self.n_fused += 1
+            if not self.fast_token and g is fmap1:
+                self._arm(fmap1, pend["ringA"], fmap2, pend["ratio"])
             return PairedLevel.wrap(pend["buf"][..., 1], pend["buf"], 1)
         # ---- a first call whose second is expected: both levels now, interleaved as the stack will want them
         ringB, ratio = self._partner(fmap2)
@@ -798,7 +932,8 @@ class _LevelPairing:
             sa, sb = _nhwc.get(fmap2), _nhwc.get(ringB)
             buf = torch.empty((1, E, 7, 7, 3, 3, 2), dtype=torch.float16, device=fmap1.device)
             corr_fused(_tiles.get(fmap1), sa[0], sb[0], coords, ii, jj, scales=(1.0, float(ratio)), out=buf, pixel_major=True)
-            self.pending = {"held": self._hold(fmap1, ii, jj, ringB), "E": E, "coords": coords, "ratio": ratio, "buf": buf}
+            self.pending = {"held": self._hold(fmap1, ii, jj, ringB), "E": E, "coords": coords, "ratio": ratio, "buf": buf,
+                            "ringA": fmap2}
             return PairedLevel.wrap(buf[..., 0], buf, 0)
         # ---- an ordinary call: remember it, and learn the pairing from two in a row on the same tiles and indices
         if last is not None and E == last["E"] and self._same(last["held"], (fmap1, ii, jj)):
@@ -821,6 +956,16 @@ _pairing = _LevelPairing()
 def corr_forward(fmap1, fmap2, coords, ii, jj, radius):
     """cuda_corr.forward (cdvslam/altcorr/correlation.cpp:35-42): fmap1 [B,N1,C,P,P], fmap2
     [B,N2,C,H2,W2], coords [B,M,2,P,P] f32 -> [B,M,2r+1 (x),2r+1 (y),P,P]."""
+    pr = _pairing
+    if pr.fast_token and _env("CDV_DROPIN_FAST", "1") != "0" and pair_levels_enabled():
+        r = _fast.corr(pr.fast_token, fmap1, fmap2, coords, ii, jj, radius, _stream())
+        if r is not None:
+            if type(r) is int:
+                _lib.check(r, "cuda_corr.forward")
+            if r[3] & 4:
+                _tiles.n_converted += 1
+            pr.n_fused += r[2]
+            return PairedLevel.wrap(r[0], r[1], r[2])
     lib = _lib.load()
     _need_cuda(fmap1, fmap2, coords, ii, jj)
     if fmap1.dtype != fmap2.dtype or fmap1.dtype not in (torch.float16, torch.float32):
@@ -1009,6 +1154,24 @@ class EventBlock:
 _ba_need = {}         # (E, U_max, N) -> cdv_ba_workspace_bytes: asked once per shape, not once per call
 
 
+def _arm_graph(g, ba_ws, ppf):
+    """the per-device table index has just served a complete BA from here: from the next call on the extension serves
+    cuda_ba.neighbors / cuda_ba.forward on it (same workspaces, same event block, same PPF hint) until something it does
+    not recognise comes along"""
+    global _armed_graph
+    k = g._key      # (ident jj, ident kk, ident ii | None, (jj, kk, ii), "table")
+    jj, kk, ii = k[3]
+    nbr = getattr(g, "_nbr", None)
+    ev = g.events
+    _disarm_graph()
+    tok = _fast.arm_graph({"ws": g.ws, "ba_ws": ba_ws, "ws_bytes": g.ws_bytes, "E_cap": g.E_cap, "k_range": g.k_range,
+                           "table_capacity": g.table_capacity, "ppf": ppf, "events_ptr": ev.cnt.data_ptr(), "events_seen": list(ev.seen),
+                           "jj": jj, "kk": kk, "ii": ii, "jj_version": k[0][1], "kk_version": k[1][1],
+                           "ii_version": None if k[2] is None else k[2][1],
+                           "ix": None if nbr is None else nbr[0], "jx": None if nbr is None else nbr[1]})
+    _armed_graph = (tok, g)
+
+
 def _ba_workspace(dev, E, U_max, N):
     lib = _lib.load()
     need = _ba_need.get((E, U_max, N))
@@ -1067,6 +1230,17 @@ def ba_status(device=None, raise_on_error=True):
 def ba_forward(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, PPF, t0, t1, iterations,
                eff_impl=False, debug=False, U_max=None, graph=None):
     """cuda_ba.forward (cdvslam/fastba/ba.cpp:31-45): in place on poses / patches, returns []."""
+    ag = _armed_graph
+    if (ag is not None and graph is None and not debug and torch.is_tensor(lmbda) and _env("CDV_DROPIN_FAST", "1") != "0"
+            and prefer_table() and not _sync_check()):
+        r = _fast.ba(ag[0], poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, int(PPF) if PPF else 0, int(t0), int(t1),
+                     int(iterations), _stream())
+        if r is not None:
+            if type(r) is int:
+                _lib.check(r, "cdv_ba_forward")
+            ag[1].n_builds += r[0]
+            return []
+    _disarm_graph()        # whoever runs a BA from here may re-bind, grow or re-index what the extension was working on
     lib = _lib.load()
     _need_cuda(poses, patches, intrinsics, target, weight, ii, jj, kk)
     for t in (poses, patches, intrinsics):
@@ -1115,6 +1289,8 @@ def ba_forward(poses, patches, intrinsics, target, weight, lmbda, ii, jj, kk, PP
     _lib.check(rc, "cdv_ba_forward")
     if _sync_check() and iterations > 0:
         ba_status(dev)        # raises CdvError: not positive definite / U_max exceeded / hand-off lost / graph range
+    if graph is None and not debug and g.is_table and 1 <= N <= 32 and g._key is not None and fast_lane_enabled():
+        _arm_graph(g, ws, ppf)
     if debug:
         n6, Us = 6 * N, (U_max + 63) // 64 * 64
         o = 0

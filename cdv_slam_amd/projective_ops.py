@@ -58,6 +58,15 @@ def transform(poses, patches, intrinsics, ii, jj, kk, depth=False, valid=False, 
     (coords, (Z > 0.2) at the centre [1,E], (Ji [1,E,2,6], Jj [1,E,2,6], Jz [1,E,2,1]))."""
     if depth:
         raise NotImplementedError("transform(depth=True) is not on the update path")
+    if not (valid or jacobian or tonly) and ops._fast and ops._env("CDV_DROPIN_FAST", "1") != "0":
+        # the compiled lane (csrc/dropin_fast.cpp): the same checks, allocation and launch as below without the Python around them
+        data = poses.data if isinstance(poses, LieGroup) else poses
+        if torch.is_tensor(data) and not (isinstance(poses, LieGroup) and poses.group_id != 3):
+            r = ops._fast.transform(data, patches, intrinsics, ii, jj, kk, ops._stream())
+            if r is not None:
+                if type(r) is int:
+                    ops._lib.check(r, "cdv_transform")
+                return r.permute(0, 1, 3, 4, 2)
     if not (valid or jacobian):
         # every inference caller turns the result into [1,E,2,P,P] at once (`.permute(0, 1, 4, 2, 3).contiguous()`,
         # slam.py:328-329, loop_closure/long_term.py:118-129): the kernel writes THAT layout and the [1,E,P,P,2] tensor handed

@@ -131,3 +131,34 @@ def test_stream_descriptor_layout_matches_the_header(tmp_path):
     got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
     D = _lib.StreamDesc
     assert got == [ctypes.sizeof(D), D.slot.offset, D.edge_capacity.offset, D.ii.offset, D.mirror_host.offset, D.bufs.offset]
+
+
+def test_compiled_dropin_bookkeeping_loads_binds_and_declines_unarmed():
+    """cdv_slam_amd/_dropin_fast.so (csrc/dropin_fast.cpp: the steady state of the drop-in modules' per-call bookkeeping,
+    compiled against torch's C++ API as the reference's own bindings are, correlation.cpp:57-63 / ba.cpp:183-188): it
+    imports without a GPU, binds every C-ABI entry point it calls from the library _lib.load() opened, and -- nothing armed --
+    declines every call, so that the Python code serves it."""
+    import torch
+    from cdv_slam_amd import _lib, ops
+    m = ops._fast_mod()
+    assert m, "the extension was not built (make -C cdv_slam_amd/csrc)"
+    for n in ("bind", "arm_pair", "disarm_pair", "drop_pending", "corr", "arm_graph", "disarm_graph", "neighbors", "ba", "transform"):
+        assert callable(getattr(m, n)), n
+    assert set(ops._FAST_SYMS) <= set(_lib.SIGNATURES)
+    assert ops.fast_lane_enabled()
+    os.environ["CDV_DROPIN_FAST"] = "0"
+    try:
+        assert not ops.fast_lane_enabled()          # read at every call
+    finally:
+        del os.environ["CDV_DROPIN_FAST"]
+    x, i = torch.zeros(4), torch.zeros(4, dtype=torch.int64)
+    assert m.disarm_pair() is None and m.disarm_graph() is None
+    assert m.corr(1, x, x, x, i, i, 3, 0) is None
+    assert m.neighbors(1, i, i, 0) is None
+    assert m.ba(1, x, x, x, x, x, x, i, i, i, 96, 0, 10, 2, 0) is None
+    assert m.transform(x.view(1, 1, 4), x, x, i, i, i, 0) is None      # host tensors: not served (and nothing is launched)
+    # handing over state that is not what the lane serves is refused at the hand-over, not at the next call
+    with pytest.raises(RuntimeError):
+        m.arm_pair({"A": {"src": x, "shadow": x, "ws": x, "version": 0, "parity": 0}, "B": {"src": x, "shadow": x, "ws": x, "version": 0, "parity": 0},
+                    "ratio": 4, "tiles_src": x, "tiles_pm": x, "tiles_version": 0})
+    assert m.disarm_pair() is None

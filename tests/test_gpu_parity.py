@@ -582,6 +582,85 @@ def test_dropin_fast_path_under_the_unchanged_caller():
     ops._pairing, ops._tiles = ops._LevelPairing(), ops.TileCache()
 
 
+def test_dropin_compiled_bookkeeping_equals_the_python_bookkeeping():
+    """The steady state of the drop-in modules runs compiled (csrc/dropin_fast.cpp, armed by ops.py after it has served a
+    complete pair and a complete neighbors + BA itself).  The same updates with the lane on and off (CDV_DROPIN_FAST) from
+    the same state: correlation, coordinates and neighbors bit for bit, the state after the bundle adjustment bit for bit
+    (the same launches with the same arguments).  The lane is really the one that runs: armed after the second update, the
+    counters the Python side keeps (pairs served, tiles converted, index builds) move as they do without it; what it does
+    not recognise it hands back -- rings written through a batch view, another E, a call in between -- and is armed again
+    by the next complete update."""
+    from cdv_slam_amd.update import DropinPath
+    st = synth.make_state("default")
+    dev = torch.device(DEV)
+    assert ops.fast_lane_enabled()
+
+    def run(fast, n=5):
+        os.environ["CDV_DROPIN_FAST"] = "1" if fast else "0"
+        ops._disarm_pair(); ops._disarm_graph()
+        ops._pairing, ops._tiles, ops._nhwc = ops._LevelPairing(), ops.TileCache(), ops.NhwcCache()
+        dp = DropinPath(st, dev)
+        g = ops._device_graph(dev)
+        outs, used = [], []
+        for it in range(n):
+            dp.new_frame = (dp.new_frame.float() * 0.75 + 0.03125 * it).half()
+            dp.new_tiles = (dp.new_tiles.float() * 0.5 + 0.0625 * it).half()
+            c0, b0, f0 = ops._tiles.n_converted, g.n_builds, ops._pairing.n_fused
+            o = dp.step()
+            torch.cuda.synchronize()
+            paired = 1 if it > 0 else 0          # update 0: two ordinary calls on planar tiles, which teach the pairing
+            assert ops._tiles.n_converted == c0 + paired and g.n_builds == b0 + 1 and ops._pairing.n_fused == f0 + paired, it
+            outs.append([o["corr"].clone(), o["coords"].clone(), o["ix"].clone(), o["jx"].clone(), dp.poses_.clone(), dp.patches_.clone()])
+            used.append((ops._armed_pair is not None, ops._armed_graph is not None))
+        return dp, outs, used
+
+    try:
+        _, want, used0 = run(False)
+        assert not any(a or b for a, b in used0)
+        dp, got, used1 = run(True)
+        assert used1[0] == (False, True) and all(u == (True, True) for u in used1[1:])     # update 0 taught the pairing
+        for it, (w, g_) in enumerate(zip(want, got)):
+            for a, b in zip(w, g_):
+                assert torch.equal(a, b), it
+        # ---- what the lane does not recognise goes back to Python, which serves it and arms the lane again
+        g = ops._device_graph(dev)
+        # (a) shorter edge lists: another E is fine for the lane (buffers are per call) -- still armed, same results as Python
+        keep = dp.ii.numel() - 96
+        dp.ii, dp.jj, dp.kk = dp.ii[:keep].clone(), dp.jj[:keep].clone(), dp.kk[:keep].clone()
+        dp.target, dp.weight = dp.target[:, :keep].contiguous(), dp.weight[:, :keep].contiguous()
+        dp.n_new = min(dp.n_new, keep // 2)
+        o = dp.step()
+        assert ops._armed_pair is not None and ops._armed_graph is not None and o["corr"].shape[1] == keep
+        # (b) the level-0 ring written through ANOTHER tensor on the same memory: the version counter moves, the lane re-syncs
+        before = ops._nhwc.converted_slots(dp.fmap1_)
+        dp.fmap1_.view(-1)[:8] += 1.0
+        dp.step(ingest=False)
+        assert ops._armed_pair is not None and ops._nhwc.converted_slots(dp.fmap1_) == before + 1
+        # (c) a float32 BA state is not the lane's: Python serves (and raises what it raises)
+        with pytest.raises(TypeError):
+            ops.ba_forward(dp.poses.data.double(), dp.patches, dp.intrinsics, dp.target, dp.weight, torch.as_tensor([1e-4], device=dev),
+                           dp.ii, dp.jj, dp.kk, dp.M, dp.t0, dp.n, 2)
+        assert ops._armed_graph is None              # the Python path took the workspace back ...
+        dp.step()
+        assert ops._armed_graph is not None          # ... and the next complete update hands it over again
+        # (d) the documented switch, read at every call
+        os.environ["CDV_DROPIN_FAST"] = "0"
+        b0 = g.n_builds
+        o2 = dp.step(ingest=False)
+        assert ops._armed_pair is None and ops._armed_graph is None and g.n_builds == b0      # same tensors: the index is kept
+        os.environ["CDV_DROPIN_FAST"] = "1"
+        dp.reset()
+        a = dp.step(ingest=False)
+        dp.reset()
+        os.environ["CDV_DROPIN_FAST"] = "0"
+        b = dp.step(ingest=False)
+        assert torch.equal(a["corr"], b["corr"]) and torch.equal(a["ix"], b["ix"])
+    finally:
+        os.environ.pop("CDV_DROPIN_FAST", None)
+        ops._disarm_pair(); ops._disarm_graph()
+        ops._pairing, ops._tiles, ops._nhwc = ops._LevelPairing(), ops.TileCache(), ops.NhwcCache()
+
+
 def test_corr_pixel_major_tiles_bit_identical():
     """the [Ng,9,C] operand layout (cdv_gmap_to_pixel_major / cdv_frame_ingest) changes loads, not results"""
     from cdv_slam_amd.update import UpdatePath
