@@ -372,6 +372,8 @@ def main():
         ev_d = events_since(dg.events, ev_d0)
         dropin = {"value": (nd / td) if not any(ev_d) else None, "unit": "frames/s", "ms_per_step": 1e3 * td / nd, "steps": nd,
                   "ba_events": ev_d,
+                  # the per-call bookkeeping ran compiled (cdv_slam_amd/_dropin_fast.so) if it was armed when the timed region ended
+                  "compiled_bookkeeping": bool(_ops._armed_pair is not None and _ops._armed_graph is not None),
                   "what": "the reference's own call sequence through the install_dropin() names on the reference's state layouts, handed over "
                           "the way slam.py hands it over: gmap / poses / patches / intrinsics as FRESH views per access, edge tensors "
                           "re-created by torch.cat every step, the two per-level correlations through an autograd.Function under "

@@ -21,6 +21,7 @@ SIGNATURES = {
     "cdv_fmap_to_nhwc": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i64, _i64, _vp]),
     "cdv_fmap_sync_workspace_bytes": (_sz, [_i64]),
     "cdv_fmap_sync_nhwc": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _i32, _vp]),
+    "cdv_shadows_sync": (_i32, [_vp, _i32, _vp, _vp, _i64, _i32, _vp]),
     "cdv_fmap_ingest": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "cdv_corr_fused": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32,
                               _f32, _f32, _i32, _i64, _i64, _i32, _vp]),
@@ -121,6 +122,12 @@ def _stream_desc_fields():
 class StreamDesc(ctypes.Structure):
     """cdv_stream_desc (include/cdvslam_hip.h): the buffers and sizes of a device-resident frame stream, field for field"""
     _fields_ = _stream_desc_fields()
+
+
+class ShadowRing(ctypes.Structure):
+    """cdv_shadow_ring (include/cdvslam_hip.h): one planar ring and its channels-last shadow for cdv_shadows_sync"""
+    _fields_ = [("src_nchw", ctypes.c_void_p), ("dst_nhwc", ctypes.c_void_p), ("ws", ctypes.c_void_p), ("N", ctypes.c_int64),
+                ("C", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("parity", ctypes.c_int32)]
 
 
 class PatchifyJob(ctypes.Structure):

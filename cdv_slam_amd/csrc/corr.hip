@@ -968,9 +968,9 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const _Float16* __res
 // the one taken at the previous sync (normally ONE).  Fingerprint = FP_PARTS position-keyed 64-bit sums per slot.
 constexpr int FP_PARTS = 16;      // workgroups (and partial sums) per slot
 
-__global__ __launch_bounds__(256) void fmap_fingerprint_kernel(const uint32_t* __restrict__ src, int64_t words_per_slot,
-                                                               uint64_t* __restrict__ fp) {
-  const int slot = (int)blockIdx.x / FP_PARTS, part = (int)blockIdx.x % FP_PARTS;
+__device__ __forceinline__ void fingerprint_body(const uint32_t* __restrict__ src, int64_t words_per_slot,
+                                                 uint64_t* __restrict__ fp, int bid) {
+  const int slot = bid / FP_PARTS, part = bid % FP_PARTS;
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   const u32x4* p = reinterpret_cast<const u32x4*>(src + (size_t)slot * words_per_slot);
   const int64_t n4 = words_per_slot / 4;        // slots are multiples of 16 bytes (C % 8 == 0)
@@ -989,13 +989,16 @@ __global__ __launch_bounds__(256) void fmap_fingerprint_kernel(const uint32_t* _
   if (threadIdx.x == 0) fp[(size_t)slot * FP_PARTS + part] = (sw[0] + sw[1]) + (sw[2] + sw[3]) + 1ull;   // never 0 = "no fingerprint yet"
 }
 
-__global__ __launch_bounds__(256) void nchw_to_nhwc_dirty_kernel(const _Float16* __restrict__ src,
-                                                                 _Float16* __restrict__ dst, int C, int H, int W,
-                                                                 const uint64_t* __restrict__ fp_new,
-                                                                 const uint64_t* __restrict__ fp_old, int wg_per_slot,
-                                                                 int32_t* __restrict__ n_dirty) {
-  const int64_t nslot = (int)blockIdx.x / wg_per_slot;
-  const int wg = (int)blockIdx.x % wg_per_slot;
+__global__ __launch_bounds__(256) void fmap_fingerprint_kernel(const uint32_t* __restrict__ src, int64_t words_per_slot,
+                                                               uint64_t* __restrict__ fp) {
+  fingerprint_body(src, words_per_slot, fp, (int)blockIdx.x);
+}
+
+__device__ __forceinline__ void dirty_body(const _Float16* __restrict__ src, _Float16* __restrict__ dst, int C, int H, int W,
+                                           const uint64_t* __restrict__ fp_new, const uint64_t* __restrict__ fp_old,
+                                           int wg_per_slot, int32_t* __restrict__ n_dirty, int bid) {
+  const int64_t nslot = bid / wg_per_slot;
+  const int wg = bid % wg_per_slot;
   bool same = true;
 #pragma unroll
   for (int i = 0; i < FP_PARTS; i++) same = same && fp_new[nslot * FP_PARTS + i] == fp_old[nslot * FP_PARTS + i];
@@ -1014,6 +1017,56 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_dirty_kernel(const _Float16*
     *reinterpret_cast<cdv_half8*>(dst + ((nslot * (H + 2 * PADY) + yh + PADY) * (W + 2 * PADX) + xw + PADX) * C +
                                   8 * gq) = v;
   }
+}
+
+__global__ __launch_bounds__(256) void nchw_to_nhwc_dirty_kernel(const _Float16* __restrict__ src,
+                                                                 _Float16* __restrict__ dst, int C, int H, int W,
+                                                                 const uint64_t* __restrict__ fp_new,
+                                                                 const uint64_t* __restrict__ fp_old, int wg_per_slot,
+                                                                 int32_t* __restrict__ n_dirty) {
+  dirty_body(src, dst, C, H, W, fp_new, fp_old, wg_per_slot, n_dirty, (int)blockIdx.x);
+}
+
+// ---- the same two passes for SEVERAL rings at once, the tiles' conversion riding the second (cdv_shadows_sync): what an
+// unchanged slam.py needs in front of its correlation -- both pyramid levels' shadows and the tile shadow in step -- is five
+// launches through the single-ring entry points and two here.  Same bodies, same bytes.
+struct ShadowJob {
+  const _Float16* src; _Float16* dst;
+  uint64_t *fp_new; const uint64_t* fp_old;
+  int32_t* n_dirty;
+  int64_t words_per_slot;
+  int C, H, W, wg_per_slot, fp_blocks, cv_blocks;
+};
+struct ShadowJobs {
+  ShadowJob j[2];
+  int n;
+  const _Float16* g_src; _Float16* g_dst;     // tiles (NULL: none)
+  int64_t g_count;
+  int g_C, g_blocks;
+};
+
+__global__ __launch_bounds__(256) void shadows_fingerprint_kernel(const ShadowJobs J) {
+  int b = (int)blockIdx.x;
+  for (int q = 0; q < J.n; q++) {               // workgroup-uniform
+    if (b < J.j[q].fp_blocks) {
+      fingerprint_body(reinterpret_cast<const uint32_t*>(J.j[q].src), J.j[q].words_per_slot, J.j[q].fp_new, b);
+      return;
+    }
+    b -= J.j[q].fp_blocks;
+  }
+}
+
+__global__ __launch_bounds__(256) void shadows_convert_kernel(const ShadowJobs J) {
+  int b = (int)blockIdx.x;
+  for (int q = 0; q < J.n; q++) {
+    const ShadowJob& s = J.j[q];
+    if (b < s.cv_blocks) {
+      dirty_body(s.src, s.dst, s.C, s.H, s.W, s.fp_new, s.fp_old, s.wg_per_slot, s.n_dirty, b);
+      return;
+    }
+    b -= s.cv_blocks;
+  }
+  if (J.g_src) cdv::gmap_pm_convert(J.g_src, J.g_dst, 0, J.g_count, J.g_C, (int64_t)b * 256 + threadIdx.x, (int64_t)J.g_blocks * 256);
 }
 
 __global__ __launch_bounds__(256) void gmap_pm_kernel(const _Float16* __restrict__ src, _Float16* __restrict__ dst,
@@ -1242,6 +1295,47 @@ extern "C" int cdv_fmap_sync_nhwc(const void* src_nchw, void* dst_nhwc, int64_t 
   const int wg_per_slot = (int)(cdv_div_up((int64_t)H * W * (C / 8), 256) < 64 ? cdv_div_up((int64_t)H * W * (C / 8), 256) : 64);
   hipLaunchKernelGGL(nchw_to_nhwc_dirty_kernel, dim3((unsigned)(N * wg_per_slot)), dim3(256), 0, s, (const _Float16*)src_nchw,
                      (_Float16*)dst_nhwc, C, H, W, fp_new, fp_old, wg_per_slot, n_dirty);
+  CDV_LAUNCH_CHECK();
+  return CDV_OK;
+}
+
+extern "C" int cdv_shadows_sync(const cdv_shadow_ring* rings, int n_rings, const void* gmap_planar, void* gmap_pm, int64_t Ng,
+                                int C_tiles, void* stream) {
+  CDV_REQUIRE(n_rings >= 0 && n_rings <= 2 && (n_rings == 0 || rings != nullptr), CDV_ERR_ARG, "cdv_shadows_sync: 0 to 2 rings");
+  const bool do_g = gmap_planar != nullptr && gmap_pm != nullptr && Ng > 0;
+  CDV_REQUIRE(!do_g || (C_tiles % 8 == 0 && C_tiles > 0), CDV_ERR_ARG, "cdv_shadows_sync: C of the tiles must be a multiple of 8");
+  ShadowJobs J;
+  J.n = 0;
+  int fp_total = 0, cv_total = 0;
+  for (int q = 0; q < n_rings; q++) {
+    const cdv_shadow_ring& r = rings[q];
+    CDV_REQUIRE(r.C % 8 == 0 && r.C > 0 && r.src_nchw && r.dst_nhwc && r.ws && r.N >= 0 && r.H > 0 && r.W > 0, CDV_ERR_ARG,
+                "cdv_shadows_sync: bad ring");
+    if (r.N == 0) continue;
+    ShadowJob& s = J.j[J.n++];
+    uint64_t* fp = (uint64_t*)r.ws;
+    s.src = (const _Float16*)r.src_nchw; s.dst = (_Float16*)r.dst_nhwc;
+    s.fp_new = fp + (size_t)(r.parity & 1) * r.N * FP_PARTS;
+    s.fp_old = fp + (size_t)((r.parity & 1) ^ 1) * r.N * FP_PARTS;
+    s.n_dirty = (int32_t*)(fp + 2 * (size_t)r.N * FP_PARTS);
+    s.words_per_slot = (int64_t)r.C * r.H * r.W / 2;
+    s.C = r.C; s.H = r.H; s.W = r.W;
+    const int64_t per = cdv_div_up((int64_t)r.H * r.W * (r.C / 8), 256);
+    s.wg_per_slot = (int)(per < 64 ? per : 64);
+    s.fp_blocks = (int)(r.N * FP_PARTS);
+    s.cv_blocks = (int)(r.N * s.wg_per_slot);
+    fp_total += s.fp_blocks; cv_total += s.cv_blocks;
+  }
+  J.g_src = do_g ? (const _Float16*)gmap_planar : nullptr;
+  J.g_dst = (_Float16*)gmap_pm;
+  J.g_count = Ng; J.g_C = C_tiles;
+  const int64_t gtotal = do_g ? Ng * 9 * (C_tiles / 8) : 0;
+  J.g_blocks = (int)(cdv_div_up(gtotal, 256) < 16384 ? cdv_div_up(gtotal, 256) : 16384);
+  if (!do_g) J.g_blocks = 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (fp_total > 0) hipLaunchKernelGGL(shadows_fingerprint_kernel, dim3((unsigned)fp_total), dim3(256), 0, s, J);
+  if (cv_total + J.g_blocks > 0)
+    hipLaunchKernelGGL(shadows_convert_kernel, dim3((unsigned)(cv_total + J.g_blocks)), dim3(256), 0, s, J);
   CDV_LAUNCH_CHECK();
   return CDV_OK;
 }

@@ -29,9 +29,14 @@ using at::Tensor;
 
 namespace {
 
+struct ShadowRing {   // cdv_shadow_ring (include/cdvslam_hip.h)
+  const void* src_nchw; void* dst_nhwc; void* ws;
+  int64_t N;
+  int32_t C, H, W, parity;
+};
+
 struct Abi {   // include/cdvslam_hip.h, by address
-  int (*fmap_sync_nhwc)(const void*, void*, int64_t, int, int, int, void*, int, void*) = nullptr;
-  int (*gmap_to_pixel_major)(const void*, void*, int64_t, int, int64_t, int64_t, void*) = nullptr;
+  int (*shadows_sync)(const ShadowRing*, int, const void*, void*, int64_t, int, void*) = nullptr;
   int (*corr_fused)(const void*, const void*, const void*, const float*, const int64_t*, const int64_t*, const int32_t*, void*,
                     int64_t, int64_t, int64_t, int, int, int, int, int, float, float, int, int64_t, int64_t, int, void*) = nullptr;
   int (*corr_level_checked_interleaved)(const void*, const void*, const float*, const float*, float, const int64_t*,
@@ -54,8 +59,7 @@ void take(const py::dict& d, const char* name, F& f) {
 }
 
 void bind(const py::dict& d) {
-  take(d, "cdv_fmap_sync_nhwc", abi.fmap_sync_nhwc);
-  take(d, "cdv_gmap_to_pixel_major", abi.gmap_to_pixel_major);
+  take(d, "cdv_shadows_sync", abi.shadows_sync);
   take(d, "cdv_corr_fused", abi.corr_fused);
   take(d, "cdv_corr_level_checked_interleaved", abi.corr_level_checked_interleaved);
   take(d, "cdv_graph_build_table", abi.graph_build_table);
@@ -162,11 +166,8 @@ void drop_pending() {
   pr.p_coords = Tensor(); pr.p_buf = Tensor(); pr.p_ii = Tensor(); pr.p_jj = Tensor();
 }
 
-inline int sync_ring(Ring& r, int64_t now, void* stream) {
-  const int rc = abi.fmap_sync_nhwc(r.ptr, r.shadow.data_ptr(), r.N, r.C, r.H, r.W, r.ws.data_ptr(), r.parity, stream);
-  r.parity ^= 1;
-  r.version = now;
-  return rc;
+inline ShadowRing shadow_job(const Ring& r) {
+  return ShadowRing{r.ptr, r.shadow.data_ptr(), r.ws.data_ptr(), r.N, r.C, r.H, r.W, r.parity};
 }
 
 // -> None (not served: ops.corr_forward goes on) | int (a C-ABI error code) | (view, buffer, level, what was re-synchronised)
@@ -204,13 +205,19 @@ py::object corr(int64_t token, const Tensor& fmap1, const Tensor& fmap2, const T
   // the first call: bring the shadows in step (only what somebody wrote since), both levels in one launch
   int what = 0, rc = 0;
   const int64_t va = (int64_t)fmap2._version(), vb = (int64_t)pr.B.src._version();
-  if (va != pr.A.version) { rc = sync_ring(pr.A, va, stream); what |= 1; if (rc != 0) return py::int_(rc); }
-  if (vb != pr.B.version) { rc = sync_ring(pr.B, vb, stream); what |= 2; if (rc != 0) return py::int_(rc); }
-  if (tv != pr.tiles_version) {
-    rc = abi.gmap_to_pixel_major(fmap1.data_ptr(), pr.tiles_pm.data_ptr(), pr.Ng, C, 0, pr.Ng, stream);
+  if (va != pr.A.version) what |= 1;
+  if (vb != pr.B.version) what |= 2;
+  if (tv != pr.tiles_version) what |= 4;
+  if (what) {                                            // whatever has to be brought in step: one call, two launches
+    ShadowRing jobs[2];
+    int n = 0;
+    if (what & 1) jobs[n++] = shadow_job(pr.A);
+    if (what & 2) jobs[n++] = shadow_job(pr.B);
+    rc = abi.shadows_sync(jobs, n, (what & 4) ? fmap1.data_ptr() : nullptr, pr.tiles_pm.data_ptr(), pr.Ng, C, stream);
     if (rc != 0) return py::int_(rc);
-    pr.tiles_version = tv;
-    what |= 4;
+    if (what & 1) { pr.A.parity ^= 1; pr.A.version = va; }
+    if (what & 2) { pr.B.parity ^= 1; pr.B.version = vb; }
+    if (what & 4) pr.tiles_version = tv;
   }
   pr.tiles_src = fmap1;                                  // the view in hand pins the storage the version speaks of
   Tensor buf = at::empty({1, E, 7, 7, 3, 3, 2}, fmap1.options());

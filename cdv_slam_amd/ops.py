@@ -100,7 +100,7 @@ def version():
 # BA itself, asks the extension first at the next call, and TAKES the state back ("disarms") before any Python code touches
 # the shared shadows or workspaces again.  Whatever the extension does not recognise it declines (None) and the Python code
 # -- the authority on semantics -- serves the call.  CDV_DROPIN_FAST=0 (read at every call) switches the lane off.
-_FAST_SYMS = ("cdv_fmap_sync_nhwc", "cdv_gmap_to_pixel_major", "cdv_corr_fused", "cdv_corr_level_checked_interleaved",
+_FAST_SYMS = ("cdv_shadows_sync", "cdv_corr_fused", "cdv_corr_level_checked_interleaved",
               "cdv_graph_build_table", "cdv_ba_workspace_bytes", "cdv_ba_forward", "cdv_transform")
 _fast = None           # the bound extension module; False: not available (warned once)
 _armed_pair = None     # (the _LevelPairing, ring entry A, ring entry B, the TileCache) whose state the extension holds

@@ -121,6 +121,24 @@ int cdv_fmap_sync_nhwc(const void* src_nchw, void* dst_nhwc, int64_t N, int C, i
                        void* stream);
 
 /*
+ * What an unchanged slam.py needs in step in front of SLAM.corr (slam.py:316-323) -- the shadows of BOTH pyramid levels
+ * (slam.py:679-682 writes one slot of each per frame) and the pixel-major shadow of the patch tiles (slam.py:676) -- in TWO
+ * launches instead of the five of 2 x cdv_fmap_sync_nhwc + cdv_gmap_to_pixel_major: launch 1 fingerprints every slot of every
+ * ring given, launch 2 converts the slots that differ and, next to them, all Ng tiles.  Per ring exactly what
+ * cdv_fmap_sync_nhwc does with the same (ws, parity); the caller flips each ring's parity after the call as it does there.
+ *   rings [n_rings], n_rings 0 .. 2 (read during the call); gmap_planar [Ng][C][3][3] f16 -> gmap_pm [Ng][9][C], or NULL.
+ */
+typedef struct cdv_shadow_ring {
+  const void* src_nchw;   /* [N][C][H][W] f16, written by somebody else */
+  void* dst_nhwc;         /* its padded channels-last shadow (cdv_fmap_padded_elems) */
+  void* ws;               /* cdv_fmap_sync_workspace_bytes(N) */
+  int64_t N;
+  int32_t C, H, W, parity;
+} cdv_shadow_ring;
+int cdv_shadows_sync(const cdv_shadow_ring* rings, int n_rings, const void* gmap_planar, void* gmap_pm, int64_t Ng, int C_tiles,
+                     void* stream);
+
+/*
  * Per-frame ingest of one new feature frame (slam.py:681-682): fmap [C][H][W] f16 (planar) is
  * written into ring slot `slot` of the padded channels-last ring fmap1_nhwc (H x W interior) and its
  * 4x4 average pool into fmap2_nhwc (H/4 x W/4 interior); optionally also into the planar rings the

@@ -582,6 +582,67 @@ def test_dropin_fast_path_under_the_unchanged_caller():
     ops._pairing, ops._tiles = ops._LevelPairing(), ops.TileCache()
 
 
+def test_shadows_sync_equals_the_single_ring_calls():
+    """cdv_shadows_sync (both pyramid levels' shadows and the tile shadow brought in step in two launches) against
+    2 x cdv_fmap_sync_nhwc + cdv_gmap_to_pixel_major on the same planar rings: the same shadows byte for byte, the same slots
+    converted (first sync: all; then only the slots somebody wrote), for two rings, one ring, tiles only."""
+    import ctypes
+    from cdv_slam_amd import _lib
+    lib = _lib.load()
+    dev = torch.device(DEV)
+    g = torch.Generator(device="cpu").manual_seed(11)
+    mem, C, H, W, Ng = 12, 24, 32, 48, 300
+    ra = torch.randn((1, mem, C, H, W), generator=g).half().to(dev)
+    rb = torch.randn((1, mem, C, H // 4, W // 4), generator=g).half().to(dev)
+    tiles = torch.randn((Ng, C, 3, 3), generator=g).half().to(dev)
+    stream = ops._stream()
+
+    def fresh(r):
+        return {"shadow": torch.zeros((mem, r.shape[3] + 2 * ops.FMAP_PADY, r.shape[4] + 2 * ops.FMAP_PADX, C), dtype=torch.float16, device=dev),
+                "ws": torch.zeros(lib.cdv_fmap_sync_workspace_bytes(mem), dtype=torch.uint8, device=dev), "parity": 0}
+
+    def single(r, e):
+        _lib.check(lib.cdv_fmap_sync_nhwc(r.data_ptr(), e["shadow"].data_ptr(), mem, C, r.shape[3], r.shape[4], e["ws"].data_ptr(),
+                                          e["parity"], stream), "cdv_fmap_sync_nhwc")
+        e["parity"] ^= 1
+
+    def fused(pairs, tiles_in, pm):
+        jobs = (_lib.ShadowRing * 2)()
+        for q, (r, e) in enumerate(pairs):
+            jobs[q] = _lib.ShadowRing(r.data_ptr(), e["shadow"].data_ptr(), e["ws"].data_ptr(), mem, C, r.shape[3], r.shape[4], e["parity"])
+        _lib.check(lib.cdv_shadows_sync(ctypes.cast(jobs, ctypes.c_void_p), len(pairs), None if tiles_in is None else tiles_in.data_ptr(),
+                                        None if pm is None else pm.data_ptr(), Ng, C, stream), "cdv_shadows_sync")
+        for _, e in pairs:
+            e["parity"] ^= 1
+
+    dirty = lambda e: int(e["ws"][-64:-60].view(torch.int32).item())
+    sa, sb, fa, fb = fresh(ra), fresh(rb), fresh(ra), fresh(rb)
+    pm_f = torch.zeros((Ng, 9, C), dtype=torch.float16, device=dev)
+    for step in range(4):
+        if step == 1:                      # one slot of each ring written, as a frame does; tiles too
+            ra[0, 5] += 0.5; rb[0, 5] -= 0.25; tiles[17] *= 2
+        if step == 2:                      # nothing written
+            pass
+        if step == 3:                      # two slots of A, none of B
+            ra[0, 0, 3, 2, 1] += 1.0; ra[0, 11] *= 0.5
+        single(ra, sa); single(rb, sb)
+        pm_s = ops.gmap_to_pixel_major(tiles)
+        fused([(ra, fa), (rb, fb)], tiles, pm_f)
+        torch.cuda.synchronize()
+        assert torch.equal(sa["shadow"], fa["shadow"]) and torch.equal(sb["shadow"], fb["shadow"]) and torch.equal(pm_s, pm_f), step
+        assert dirty(sa) == dirty(fa) == (mem, mem + 1, mem + 1, mem + 3)[step] and dirty(sb) == dirty(fb) == (mem, mem + 1, mem + 1, mem + 1)[step]
+    # one ring only / tiles only / nothing at all
+    rb[0, 2] += 1.0
+    single(rb, sb); fused([(rb, fb)], None, None)
+    tiles[3] += 1.0
+    pm_f2 = pm_f.clone()
+    fused([], tiles, pm_f2)
+    fused([], None, None)
+    torch.cuda.synchronize()
+    assert torch.equal(sb["shadow"], fb["shadow"]) and dirty(fb) == mem + 2 and torch.equal(pm_f2, ops.gmap_to_pixel_major(tiles))
+    assert lib.cdv_shadows_sync(None, 3, None, None, 0, C, stream) == -2
+
+
 def test_dropin_compiled_bookkeeping_equals_the_python_bookkeeping():
     """The steady state of the drop-in modules runs compiled (csrc/dropin_fast.cpp, armed by ops.py after it has served a
     complete pair and a complete neighbors + BA itself).  The same updates with the lane on and off (CDV_DROPIN_FAST) from
