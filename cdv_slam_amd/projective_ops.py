@@ -61,7 +61,7 @@ def transform(poses, patches, intrinsics, ii, jj, kk, depth=False, valid=False, 
     if not (valid or jacobian or tonly) and ops._fast and ops._env("CDV_DROPIN_FAST", "1") != "0":
         # the compiled lane (csrc/dropin_fast.cpp): the same checks, allocation and launch as below without the Python around them
         data = poses.data if isinstance(poses, LieGroup) else poses
-        if torch.is_tensor(data) and not (isinstance(poses, LieGroup) and poses.group_id != 3):
+        if torch.is_tensor(data) and data.is_cuda and not (isinstance(poses, LieGroup) and poses.group_id != 3):
             r = ops._fast.transform(data, patches, intrinsics, ii, jj, kk, ops._stream())
             if r is not None:
                 if type(r) is int:

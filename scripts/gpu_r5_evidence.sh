@@ -26,8 +26,8 @@ CDV_LIB=$PWD/cdv_slam_amd/libcdvslam_hip_stamps.so timeout -k 10 200 python scri
 CDV_LIB=$PWD/cdv_slam_amd/libcdvslam_hip_stamps.so timeout -k 10 200 python scripts/stamps_bam.py stress 2 > $out/${tag}_stamps_stress.log 2>&1
 echo "stamps done"; grep -A6 "solver wave" $out/${tag}_stamps_default.log
 # the reference's call sequence through the drop-in names: host time per call (compiled bookkeeping on / off) and its kernels
-python scripts/prof_dropin.py default 400 2>&1 | grep -v amdgpu.ids > $out/${tag}_dropin_host.log
-CDV_DROPIN_FAST=0 python scripts/prof_dropin.py default 400 2>&1 | grep -v amdgpu.ids > $out/${tag}_dropin_host_python.log
+python scripts/profile_dropin_host.py default 400 2>&1 | grep -v amdgpu.ids > $out/${tag}_dropin_host.log
+CDV_DROPIN_FAST=0 python scripts/profile_dropin_host.py default 400 2>&1 | grep -v amdgpu.ids > $out/${tag}_dropin_host_python.log
 (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/${tag}_prof_dropin -- python3 $R/scripts/run_dropin.py default 300 > $R/$out/${tag}_prof_dropin.log 2>&1); echo "rocprof dropin rc=$?"
 python scripts/kstats.py $out/${tag}_prof_dropin 24 > $out/${tag}_kernel_stats_dropin.txt 2>&1
 head -1 $out/${tag}_dropin_host.log; head -1 $out/${tag}_dropin_host_python.log
