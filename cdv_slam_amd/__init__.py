@@ -15,19 +15,26 @@ Layout (only what the path needs):
 __all__ = ["ops", "altcorr", "fastba", "lietorch", "projective_ops", "ba", "synth", "install_dropin"]
 
 
-def install_dropin(table_capacity=None):
+def install_dropin(table_capacity=None, package=None):
     """Register cuda_corr, cuda_ba and lietorch_backends in sys.modules (reference import names:
     cdvslam/altcorr/correlation.py:2, cdvslam/fastba/ba.py:2, cdvslam/lietorch/group_ops.py:1).
     table_capacity (optional): the number of patch ids that can be live at once, (REMOVAL_WINDOW + 2) * PATCHES_PER_FRAME of
     the configuration the SLAM object runs (2,304 for default_cdvo.yaml): cuda_ba.neighbors / forward then use the
     two-launch table form of the patch-graph index (ops.configure_table); without it the ranked index, which assumes
-    nothing about the ids."""
+    nothing about the ids.
+    package (optional, e.g. "cdvslam"; call BEFORE importing it): also answer `<package>.projective_ops` with
+    cdv_slam_amd.projective_ops, so that `from . import projective_ops as pops` in the package's slam.py (slam.py:7) gets the
+    one-launch transform / flow_mag / point_cloud instead of composing ~15 lietorch and torch launches per call
+    (projective_ops.py:53-130) over lietorch_backends.  The pose argument may be the package's own SE3 object: anything with
+    a `.data` tensor and group_id 3 is read (projective_ops._kernel_pose_rows)."""
     import sys
-    from . import ops
+    from . import ops, projective_ops
     from .dropin import cuda_ba, cuda_corr, lietorch_backends
     if table_capacity is not None:
         ops.configure_table(table_capacity)
     sys.modules.setdefault("cuda_corr", cuda_corr)
     sys.modules.setdefault("cuda_ba", cuda_ba)
     sys.modules.setdefault("lietorch_backends", lietorch_backends)
+    if package:
+        sys.modules.setdefault(package + ".projective_ops", projective_ops)
     return cuda_corr, cuda_ba, lietorch_backends

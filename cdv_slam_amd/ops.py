@@ -115,12 +115,21 @@ def _fast_mod():
             lib = _lib.load()
             m.bind({n: ctypes.cast(getattr(lib, n), ctypes.c_void_p).value for n in _FAST_SYMS})
             _fast = m
+            import atexit
+            atexit.register(_fast_release)      # the extension holds tensors: they go before the interpreter tears torch down
         except ImportError as e:
             import warnings
             warnings.warn("cdv_slam_amd: the compiled drop-in bookkeeping (_dropin_fast.so, `make -C cdv_slam_amd/csrc`) is not "
                           "available (%s); the Python bookkeeping serves every call" % e, RuntimeWarning)
             _fast = False
     return _fast
+
+
+def _fast_release():
+    if _fast:
+        _fast.drop_pending()
+        _fast.disarm_pair()
+        _fast.disarm_graph()
 
 
 def fast_lane_enabled():

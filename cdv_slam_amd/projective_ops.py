@@ -9,7 +9,6 @@ plain tensor expressions for callers that want them on their own.
 import torch
 
 from . import ops
-from .lietorch import LieGroup
 
 MIN_DEPTH = 0.2
 
@@ -40,8 +39,11 @@ def proj(X, intrinsics, depth=False):
 
 def _kernel_pose_rows(poses, what):
     """the [1,n,7] float32 tensor the kernels read, or an error naming what is not served"""
-    data = poses.data if isinstance(poses, LieGroup) else poses
-    if isinstance(poses, LieGroup) and poses.group_id != 3:
+    # a tensor, this package's LieGroup, or the caller's own group object (the reference's lietorch.SE3 when only
+    # projective_ops is substituted, install_dropin(package=)): anything that carries its rows in `.data` and names its group
+    group = not torch.is_tensor(poses)
+    data = getattr(poses, "data", None) if group else poses
+    if group and getattr(poses, "group_id", None) != 3:
         raise NotImplementedError("%s: SE3 poses only (Sim3 belongs to loop closure, out of scope)" % what)
     if not torch.is_tensor(data):
         raise TypeError("%s: poses must be an SE3 or a tensor" % what)
@@ -60,8 +62,9 @@ def transform(poses, patches, intrinsics, ii, jj, kk, depth=False, valid=False, 
         raise NotImplementedError("transform(depth=True) is not on the update path")
     if not (valid or jacobian or tonly) and ops._fast and ops._env("CDV_DROPIN_FAST", "1") != "0":
         # the compiled lane (csrc/dropin_fast.cpp): the same checks, allocation and launch as below without the Python around them
-        data = poses.data if isinstance(poses, LieGroup) else poses
-        if torch.is_tensor(data) and data.is_cuda and not (isinstance(poses, LieGroup) and poses.group_id != 3):
+        group = not torch.is_tensor(poses)
+        data = getattr(poses, "data", None) if group else poses
+        if torch.is_tensor(data) and data.is_cuda and not (group and getattr(poses, "group_id", None) != 3):
             r = ops._fast.transform(data, patches, intrinsics, ii, jj, kk, ops._stream())
             if r is not None:
                 if type(r) is int:

@@ -162,3 +162,40 @@ def test_compiled_dropin_bookkeeping_loads_binds_and_declines_unarmed():
         m.arm_pair({"A": {"src": x, "shadow": x, "ws": x, "version": 0, "parity": 0}, "B": {"src": x, "shadow": x, "ws": x, "version": 0, "parity": 0},
                     "ratio": 4, "tiles_src": x, "tiles_pm": x, "tiles_version": 0})
     assert m.disarm_pair() is None
+
+
+def test_install_dropin_can_answer_the_packages_projective_ops(tmp_path, monkeypatch):
+    """install_dropin(package=...): `from . import projective_ops as pops` inside the package's slam.py (cdvslam/slam.py:7)
+    resolves to cdv_slam_amd.projective_ops, and the fused transform accepts the package's OWN pose objects (anything with a
+    `.data` tensor and group_id 3).  Shown on a stand-in package with the same import line and no projective_ops.py of its own
+    that could be picked up instead."""
+    import sys
+    import torch
+    import cdv_slam_amd
+    from cdv_slam_amd import projective_ops as ours
+    pkg = tmp_path / "standin_slam"
+    pkg.mkdir()
+    (pkg / "__init__.py").write_text("")
+    (pkg / "slam.py").write_text("from . import projective_ops as pops\n")
+    monkeypatch.syspath_prepend(str(tmp_path))
+    cdv_slam_amd.install_dropin(package="standin_slam")
+    try:
+        import importlib
+        slam = importlib.import_module("standin_slam.slam")
+        assert slam.pops is ours
+        assert sys.modules["cuda_corr"].forward and sys.modules["cuda_ba"].neighbors and sys.modules["lietorch_backends"]
+
+        class TheirSE3:                 # the reference's lietorch.SE3 carries its rows in .data and names its group (groups.py:268)
+            group_id = 3
+            def __init__(self, data):
+                self.data = data
+        rows = ours._kernel_pose_rows(TheirSE3(torch.zeros(1, 4, 7)), "transform")
+        assert rows.shape == (1, 4, 7)
+        TheirSE3.group_id = 4           # Sim3: not served
+        with pytest.raises(NotImplementedError):
+            ours._kernel_pose_rows(TheirSE3(torch.zeros(1, 4, 7)), "transform")
+        with pytest.raises(TypeError):
+            ours._kernel_pose_rows(type("NoRows", (), {"group_id": 3})(), "transform")
+    finally:
+        for n in ("standin_slam", "standin_slam.slam", "standin_slam.projective_ops"):
+            sys.modules.pop(n, None)
