@@ -722,6 +722,77 @@ def test_dropin_compiled_bookkeeping_equals_the_python_bookkeeping():
         ops._pairing, ops._tiles, ops._nhwc = ops._LevelPairing(), ops.TileCache(), ops.NhwcCache()
 
 
+def test_dropin_compiled_bookkeeping_randomised_against_the_python_bookkeeping():
+    """A seeded random walk of what a caller can do between and inside updates -- plain updates, updates without a new
+    frame, a ring slot or the tiles written through another view, edge lists that shrink and grow, neighbors asked twice, a
+    BA with another iteration count, a third caller's correlation between the two calls of a pair, the pairing switched off
+    for an update, another path's bundle adjustment on the shared workspace -- run once with the compiled lane and once with
+    the Python bookkeeping: every output of every step bit for bit the same, and the lane is the one that ran most steps."""
+    from cdv_slam_amd.update import DropinPath, UpdatePath
+    st = synth.make_state("small")
+    dev = torch.device(DEV)
+    other = UpdatePath(st, dev)                      # another path: its own index, the SHARED per-device BA workspace
+
+    def walk(fast, steps=70):
+        os.environ["CDV_DROPIN_FAST"] = "1" if fast else "0"
+        ops._disarm_pair(); ops._disarm_graph()
+        ops._pairing, ops._tiles, ops._nhwc = ops._LevelPairing(), ops.TileCache(), ops.NhwcCache()
+        rng = np.random.default_rng(77)
+        dp = DropinPath(st, dev)
+        full = (dp.ii.clone(), dp.jj.clone(), dp.kk.clone(), dp.target.clone(), dp.weight.clone())
+        outs, armed = [], 0
+        for it in range(steps):
+            act = int(rng.integers(0, 10)) if it >= 3 else 0
+            dp.reset()
+            if act == 1:                             # a ring slot and a tile written through other views of the same memory
+                dp.fmap1_.view(-1, dp.fmap1_.shape[-1])[int(rng.integers(0, 50))] += 0.25
+                dp.gmap_.view(-1)[int(rng.integers(0, 1000))] += 0.5
+            if act == 2:                             # other edge lists: a random prefix
+                keep = int(rng.integers(full[0].numel() // 2, full[0].numel()))
+                dp.ii, dp.jj, dp.kk = full[0][:keep].clone(), full[1][:keep].clone(), full[2][:keep].clone()
+                dp.target, dp.weight = full[3][:, :keep].contiguous(), full[4][:, :keep].contiguous()
+                dp.n_new = min(dp.n_new, keep // 2)
+            if act == 3:                             # all of them again
+                dp.ii, dp.jj, dp.kk, dp.target, dp.weight = (t.clone() for t in full)
+            if act == 4:
+                os.environ["CDV_PAIR_LEVELS"] = "0"
+            if act == 5:                             # somebody else's bundle adjustment on the shared workspace
+                other.step()
+            if act == 6:                             # a third caller between the two calls of a pair
+                coords = dp.reproject()
+                ii1, jj1 = dp.kk % (dp.M * dp.pmem), dp.jj % dp.mem
+                a, = dp.cuda_corr.forward(dp.gmap, dp.pyramid[0], coords / 1, ii1, jj1, 3)
+                x, = dp.cuda_corr.forward(dp.gmap, dp.pyramid[0], coords[:, :64].contiguous() + 0.5, ii1[:64].contiguous(), jj1[:64].contiguous(), 3)
+                b, = dp.cuda_corr.forward(dp.gmap, dp.pyramid[1], coords / 4, ii1, jj1, 3)
+                outs.append([a.clone(), x.clone(), b.clone()])
+            o = dp.step(ingest=act != 7, iterations=3 if act == 8 else 2)
+            rec = [o["corr"].clone(), o["coords"].clone(), o["ix"].clone(), o["jx"].clone(), dp.poses_.clone(), dp.patches_.clone()]
+            if act == 9:                             # neighbors asked again, of the same and of other tensors
+                ix2, jx2 = dp.cuda_ba.neighbors(dp.kk, dp.jj)
+                ix3, jx3 = dp.cuda_ba.neighbors(dp.kk.clone(), dp.jj.clone())
+                rec += [ix2.clone(), jx2.clone(), ix3.clone(), jx3.clone()]
+            os.environ.pop("CDV_PAIR_LEVELS", None)
+            outs.append(rec)
+            armed += int(ops._armed_pair is not None and ops._armed_graph is not None)
+        torch.cuda.synchronize()
+        return outs, armed
+
+    try:
+        want, a0 = walk(False)
+        got, a1 = walk(True)
+        assert a0 == 0 and a1 >= 35, (a0, a1)
+        assert len(want) == len(got)
+        for it, (w, g_) in enumerate(zip(want, got)):
+            assert len(w) == len(g_)
+            for q, (x, y) in enumerate(zip(w, g_)):
+                assert x.shape == y.shape and torch.equal(x, y), (it, q)
+    finally:
+        os.environ.pop("CDV_DROPIN_FAST", None)
+        os.environ.pop("CDV_PAIR_LEVELS", None)
+        ops._disarm_pair(); ops._disarm_graph()
+        ops._pairing, ops._tiles, ops._nhwc = ops._LevelPairing(), ops.TileCache(), ops.NhwcCache()
+
+
 def test_corr_pixel_major_tiles_bit_identical():
     """the [Ng,9,C] operand layout (cdv_gmap_to_pixel_major / cdv_frame_ingest) changes loads, not results"""
     from cdv_slam_amd.update import UpdatePath
