@@ -955,126 +955,121 @@ __global__ __launch_bounds__(STEP_T) void ba_big_step_kernel(float* __restrict__
     *reinterpret_cast<cdv_float4*>(rowp + 4 * c4) = cdv_float4{x[4 * c4], x[4 * c4 + 1], x[4 * c4 + 2], x[4 * c4 + 3]};
 }
 
-// L^T x = z as ONE launch: workgroup w owns columns 256 w .. 256 w + 255 of z, one per thread, IN REGISTERS for the whole
-// sweep.  Step kb (from the bottom): the wave whose 64 columns are block kb solves its 64 unknowns (lane k holds column k of
-// L_kk: one v_readlane + FMA per unknown) and publishes them as {launch token, value} granules, written through; every
-// workgroup picks them up (the poll is the load) and folds them into its columns left of the block -- all 64 row loads
-// of a thread in flight together.  The next block's L_kk is fetched before the wait.  29 launches of 8.7 us became one
-// chain of ~5 us steps.  Bounded polls: a lost hand-off raises the hand-off word; dX is then incomplete and the retract launch
-// that follows applies NOTHING of it (it only re-zeroes the accumulators): the update is all-or-nothing.
-__global__ __launch_bounds__(256) void ba_big_backsolve_kernel(float* __restrict__ A, int npad, int n,
-                                                               float* __restrict__ dXg, uint64_t* __restrict__ xg, int token,
-                                                               const int32_t* __restrict__ gmeta, float* __restrict__ dbg,
-                                                               int32_t* __restrict__ info, int test) {
+// L^T x = z as ONE launch of one-wave workgroups, one per 64-column block (round 5; until then 256-column workgroups with four
+// barriers and an LDS exchange per step: 12.8k cycles a step, of which 5.0k went into ISSUING 64 four-byte row loads per
+// thread -- a wave cannot have more than 64 vector loads outstanding -- in front of the block solve instead of under it).
+// The wave of block b keeps its 64 entries of z (lane = column) and the column `lane` of its own diagonal block L_bb, scaled by
+// 1 / L[lane][lane], in registers for the whole sweep.  Step kb > b: it picks up x_kb -- published by block kb's wave as {launch
+// token, value} granules, written through; the poll is the load -- and folds it into its z: the 64 x 64 tile L[kb rows][my
+// columns] travels as sixteen 16-byte loads per lane (lane group g = rows 16 g .., lane q = columns 4 q ..), requested one step
+// ahead; the four row groups' sums meet through lane shuffles, in a fixed order.  Step kb == b: the 64-step chain (one
+// v_readlane + one FMA per unknown on the scaled columns), publish, done.  No barrier, no LDS hand-off between waves; a wave
+// only ever waits for blocks to its RIGHT, whose waves wait for nobody to their left, so the launch cannot lock up; the polls
+// are bounded all the same: a lost hand-off raises the hand-off word, dX is then incomplete and the retract launch that
+// follows applies NOTHING of it (it only re-zeroes the accumulators): the update is all-or-nothing.
+__global__ __launch_bounds__(64) void ba_big_backsolve_kernel(float* __restrict__ A, int npad, int n,
+                                                              float* __restrict__ dXg, uint64_t* __restrict__ xg, int token,
+                                                              const int32_t* __restrict__ gmeta, float* __restrict__ dbg,
+                                                              int32_t* __restrict__ info, int test) {
   if (gmeta[GM_ERROR] || info[1]) return;
   if (info[BI_HANDOFF]) return;   // the factorisation in front gave up on a hand-off: nothing of this iteration is applied
-  __shared__ __attribute__((aligned(16))) float Lb[CNB * CLD];
-  __shared__ float xs[CNB];
-  __shared__ int s_ok;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  __shared__ __attribute__((aligned(16))) float xs[CNB];
+  const int lane = threadIdx.x;
   const size_t lda = (size_t)npad;
   const int nb = npad / CNB;
-  const int cc = (int)blockIdx.x * 256 + t;        // this thread's column of z
-  const float* zrow = A + (size_t)npad * lda;
-  float z = cc < npad ? zrow[cc] : 0.f;
-  // L_kk of the first block this workgroup solves, if it is the very first step's (no step before it to hide the load in)
-  {
-    const int c0 = CNB * (nb - 1);
-    if ((c0 >> 8) == (int)blockIdx.x)
-      for (int i = t; i < CNB * CNB; i += 256) {
-        const int r = i >> 6, c = i & 63;
-        Lb[r * CLD + c] = (c <= r) ? A[(size_t)(c0 + r) * lda + c0 + c] : 0.f;
-      }
-  }
-  for (int kb = nb - 1; kb >= 0; kb--) {
-    CDV_IF_STAMPS(const int sslot = 2000 + 64 * (int)blockIdx.x + kb;)
-    if (threadIdx.x < 64) { CDV_STAMP(ba, sslot, 0); }
-    const int c0 = CNB * kb;
-    if (c0 + CNB <= (int)blockIdx.x * 256) break;   // this block and all that follow lie left of my columns: nothing of
-                                                     // them folds into mine (workgroup-uniform)
-    const bool owner = (c0 >> 8) == (int)blockIdx.x;   // block kb lies inside this workgroup's columns
-    const bool owner_next = kb > 0 && ((c0 - CNB) >> 8) == (int)blockIdx.x;
-    // requested BEFORE the wait, neither depends on x: the rows of L this thread folds with, and (the next step's owner) the
-    // next diagonal block
-    float l[CNB];
+  const int me = (int)blockIdx.x, c0m = CNB * me;     // my block and its first column
+  CDV_IF_STAMPS(const int sbase = 2000 + 64 * me;)
+  CDV_STAMP(ba, sbase + 63, 0);
+  CDV_STAMP_RT(ba, sbase + 63, 5);
+  float z = A[(size_t)npad * lda + c0m + lane];
+  // my diagonal block: column `lane`, L[c0m + r][c0m + lane] (zero above the diagonal), 64 coalesced row loads -- in flight while
+  // the blocks to my right are folded
+  float col[CNB];
 #pragma unroll
-    for (int r = 0; r < CNB; r++) l[r] = (cc < c0) ? A[(size_t)(c0 + r) * lda + cc] : 0.f;
-    float pre[CNB * CNB / 256];
-    if (owner_next) {
+  for (int r = 0; r < CNB; r++) col[r] = A[(size_t)(c0m + r) * lda + c0m + lane];
+  const int g = lane >> 4, q = lane & 15;
+  const auto tile_rows = [&](int kb, cdv_float4 (&dst)[16]) {
 #pragma unroll
-      for (int u = 0; u < CNB * CNB / 256; u++) {
-        const int i = t + 256 * u, r = i >> 6, c = i & 63;
-        pre[u] = (c <= r) ? A[(size_t)(c0 - CNB + r) * lda + c0 - CNB + c] : 0.f;
+    for (int u = 0; u < 16; u++)
+      dst[u] = *reinterpret_cast<const cdv_float4*>(A + (size_t)(CNB * kb + 16 * g + u) * lda + c0m + 4 * q);
+  };
+  cdv_float4 cur[16], nxt[16];
+  if (me < nb - 1) tile_rows(nb - 1, cur);
+  for (int kb = nb - 1; kb > me; kb--) {
+    CDV_IF_STAMPS(const int sslot = sbase + kb;)
+    CDV_STAMP(ba, sslot, 0);
+    if (kb - 1 > me) tile_rows(kb - 1, nxt);          // requested now, consumed a step later
+    float xv = 0.f;
+    bool ok = false;
+    for (int spins = 0; spins < (test == HO_TEST_STALL_BEFORE ? (1 << 10) : (1 << 20)); spins++) {
+      if (!ok) {
+        const uint64_t gr = __hip_atomic_load(&xg[CNB * kb + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)(gr >> 32) == (uint32_t)token) { xv = __int_as_float((int)(uint32_t)gr); ok = true; }
       }
+      if (__all(ok)) break;
+      __builtin_amdgcn_s_sleep(1);
     }
-    if (t == 0) s_ok = 1;
-    lds_barrier();   // Lb holds L_kk (written a step ago, or above).  (LDS only, here and below: __syncthreads() would also wait for
-                     // the 64 row loads just requested -- their round trip then sat on the chain of every step: 130 us for the sweep)
-    if (threadIdx.x < 64) { CDV_STAMP(ba, sslot, 1); }
-    if (owner) {
-      if (wave == ((c0 & 255) >> 6)) {   // this wave's z IS block kb's: x_r = z_r / L[r][r] once every x_j, j > r, is folded in
-        float col[CNB];
-#pragma unroll
-        for (int r = 0; r < CNB; r++) col[r] = Lb[r * CLD + lane];   // column `lane` of L_kk: L[r][lane], zero for r < lane
-        const float invd = 1.0f / Lb[lane * CLD + lane];
-        float zz = z, x = 0.f;
-#pragma unroll
-        for (int r = CNB - 1; r >= 0; r--) {
-          const float xr = readlane_f(zz * invd, r);
-          x = (lane == r) ? xr : x;
-          zz = fmaf(-col[r], xr, zz);
-        }
-        xs[lane] = x;
-        if (!(test == HO_TEST_STALL_BEFORE && kb == nb - 2))   // fault injection (tests, mode 1 only): the second block's solution never leaves its owner
-          __hip_atomic_store(&xg[c0 + lane], ((uint64_t)(uint32_t)token << 32) | (uint64_t)(uint32_t)__float_as_int(x),
-                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (c0 + lane < n) {
-          dXg[c0 + lane] = x;
-          if (dbg) dbg[(size_t)n * n + n + c0 + lane] = x;
-        }
-      }
-    } else if (wave == 0) {
-      float xv = 0.f;
-      bool ok = false;
-      for (int spins = 0; spins < (test == HO_TEST_STALL_BEFORE ? (1 << 10) : (1 << 20)); spins++) {
-        if (!ok) {
-          const uint64_t g = __hip_atomic_load(&xg[c0 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if ((uint32_t)(g >> 32) == (uint32_t)token) { xv = __int_as_float((int)(uint32_t)g); ok = true; }
-        }
-        if (__all(ok)) break;
-        __builtin_amdgcn_s_sleep(1);
-      }
-      xs[lane] = xv;
-      if (!ok) s_ok = 0;
-    }
-    if (threadIdx.x < 64) { CDV_STAMP(ba, sslot, 2); }
-    lds_barrier();
-    if (threadIdx.x < 64) { CDV_STAMP(ba, sslot, 3); }
-    if (!s_ok) {
-      if (t == 0) ba_flag(info, BI_HANDOFF, 1);
+    CDV_STAMP(ba, sslot, 1);
+    CDV_STAMP_RT(ba, sslot, 6);
+    if (!__all(ok)) {
+      if (lane == 0) ba_flag(info, BI_HANDOFF, 1);
       return;
     }
-    // z[cc] -= sum_r L[c0 + r][cc] x_r (zero rows for a column that is not left of the block)
-    {
-      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    xs[lane] = xv;
+    wave_lds_sync();
+    // z[c] -= sum_r L[64 kb + r][c] x_r: my 16 rows of my four columns ...
+    cdv_float4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < CNB; r += 4) {
-        s0 = fmaf(l[r], xs[r], s0); s1 = fmaf(l[r + 1], xs[r + 1], s1);
-        s2 = fmaf(l[r + 2], xs[r + 2], s2); s3 = fmaf(l[r + 3], xs[r + 3], s3);
-      }
-      z -= (s0 + s1) + (s2 + s3);
+    for (int u4 = 0; u4 < 4; u4++) {
+      const cdv_float4 x4 = *reinterpret_cast<const cdv_float4*>(&xs[16 * g + 4 * u4]);
+      s0 += cur[4 * u4] * x4[0];
+      s1 += cur[4 * u4 + 1] * x4[1];
+      s0 += cur[4 * u4 + 2] * x4[2];
+      s1 += cur[4 * u4 + 3] * x4[3];
     }
-    if (threadIdx.x < 64) { CDV_STAMP(ba, sslot, 4); }
-    lds_barrier();   // xs and Lb are rewritten
-    if (threadIdx.x < 64) { CDV_STAMP(ba, sslot, 5); }
-    if (owner_next) {
+    cdv_float4 sm = s0 + s1;
+    // ... the four row groups together (lanes 16 apart), then column c's sum from lane c >> 2, element c & 3
+    float pick = 0.f;
 #pragma unroll
-      for (int u = 0; u < CNB * CNB / 256; u++) {
-        const int i = t + 256 * u, r = i >> 6, c = i & 63;
-        Lb[r * CLD + c] = pre[u];
-      }
+    for (int e = 0; e < 4; e++) {
+      float v = sm[e];
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      const float w = __shfl(v, lane >> 2);
+      pick = ((lane & 3) == e) ? w : pick;
     }
+    z -= pick;
+    wave_lds_sync();                                  // xs is rewritten by the next step
+    CDV_STAMP(ba, sslot, 2);
+#pragma unroll
+    for (int u = 0; u < 16; u++) cur[u] = nxt[u];
   }
+  // my own block: x_r = z_r / L[r][r] once every x_j, j > r, is folded in.  On columns scaled by the lane's own 1 / L[lane][lane]:
+  // zs = (z - folded part) / L[lane][lane] is what lane r hands out as x_r, so a step of the chain is one v_readlane and one
+  // FMA (as in the window solver, ba_win.hip solve_wave); x_r lands in lane r with a v_writelane, off the chain
+  CDV_STAMP(ba, sbase + me, 0);
+  float dg = 0.f;
+#pragma unroll
+  for (int r = 0; r < CNB; r++) dg = (lane == r) ? col[r] : dg;   // L[lane][lane]
+  const float inv = 1.0f / dg;
+#pragma unroll
+  for (int r = 0; r < CNB; r++) col[r] = (r >= lane) ? col[r] * inv : 0.f;
+  float zs = z * inv, x = 0.f;
+#pragma unroll
+  for (int r = CNB - 1; r >= 0; r--) {
+    const float xr = readlane_f(zs, r);
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(x) : "s"(xr), "n"(r));
+    zs = fmaf(-col[r], xr, zs);
+  }
+  if (!(test == HO_TEST_STALL_BEFORE && me == nb - 2))   // fault injection (tests, mode 1 only): the second block's solution never leaves its owner
+    __hip_atomic_store(&xg[c0m + lane], ((uint64_t)(uint32_t)token << 32) | (uint64_t)(uint32_t)__float_as_int(x),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (c0m + lane < n) {
+    dXg[c0m + lane] = x;
+    if (dbg) dbg[(size_t)n * n + n + c0m + lane] = x;
+  }
+  CDV_STAMP(ba, sbase + me, 1);
+  CDV_STAMP_RT(ba, sbase + me, 5);
 }
 
 // dZ = Q (u - E^T dX), inverse-depth update, and re-zeroing of this patch's E column / C / u so that the
@@ -1397,7 +1392,7 @@ static int ba_forward_impl(float* poses, float* patches, const float* intrinsics
                              info);
         }
       }
-      hipLaunchKernelGGL(ba_big_backsolve_kernel, dim3(cdv_div_up(npad, 256)), dim3(256), 0, s, Abig, npad, n6i, dXg,
+      hipLaunchKernelGGL(ba_big_backsolve_kernel, dim3(npad / CNB), dim3(64), 0, s, Abig, npad, n6i, dXg,
                          (uint64_t*)(b + L.xgran), token_base + 1 + itr, gv.meta, d, info, g_handoff_test.load());
     } else {
       // only N = 0 gets here (no free pose: depths alone are refined): q = 1 / (C + lambda)

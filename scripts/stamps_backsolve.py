@@ -15,11 +15,21 @@ fn = lib.cdv_set_stamps_ba; fn.argtypes = [ctypes.c_void_p]; assert fn(ctypes.c_
 ops.ba_forward(poses0.clone(), patches0.clone(), *args, U_max=U, graph=g); torch.cuda.synchronize()
 b = buf.cpu().numpy().astype(np.float64)
 nb = 29
-for wg in (0, 3, 7):
-    rows = b[2000 + 64 * wg: 2000 + 64 * wg + nb]; rows = rows[rows[:, 5] > 0]
-    if not len(rows): continue
-    print("workgroup %d: %d steps" % (wg, len(rows)))
-    for i0, i1, nme in [(0, 1, "row loads issued + barrier"), (1, 2, "solve (owner) / poll (others)"), (2, 3, "barrier"), (3, 4, "fold"), (4, 5, "barrier")]:
-        x = rows[:, i1] - rows[:, i0]
-        print("  %-32s median %7.0f min %7.0f max %7.0f" % (nme, np.median(x), x.min(), x.max()))
-    o = np.sort(rows[:, 0]); print("  step to step median %.0f cycles" % np.median(np.diff(o)))
+# one wave per block `me`: row 2000 + 64 me + kb holds, for the fold of block kb > me, {0: step start, 1: x_kb in hand, 2: folded};
+# row 2000 + 64 me + me holds {0: own solve starts, 1: published}; row 2000 + 64 me + 63 holds {0: wave start}
+row = lambda me, kb: b[2000 + 64 * me + kb]
+# (cycle stamps -- s_memtime -- are per XCD: only differences inside one wave mean anything; across waves the 100 MHz real-time
+# stamps 5 (published / wave start) and 6 (x in hand) are compared)
+beg = np.array([row(me, me)[0] for me in range(nb)])
+end = np.array([row(me, me)[1] for me in range(nb)])
+print("per block, inside its wave (cycles):")
+print("  own solve (chain + publish)        median %7.0f" % np.median(end - beg))
+print("  fold of the block before it        median %7.0f" % np.median([row(me, me + 1)[2] - row(me, me + 1)[1] for me in range(nb - 1)]))
+print("  folded -> own solve starts         median %7.0f" % np.median([beg[me] - row(me, me + 1)[2] for me in range(nb - 1)]))
+pub = np.array([row(me, me)[5] for me in range(nb)])
+start = min(row(me, 63)[5] for me in range(nb))
+seen = np.array([row(me, me + 1)[6] - pub[me + 1] for me in range(nb - 1)])
+d = pub[:-1] - pub[1:]
+print("across waves (us): launch's first wave -> x_0 published %.2f" % ((pub[0] - start) / 100))
+print("  x_k+1 published -> x_k published   median %.2f min %.2f max %.2f" % (np.median(d) / 100, d.min() / 100, d.max() / 100))
+print("  published -> in the next block's hand  median %.2f min %.2f max %.2f" % (np.median(seen) / 100, seen.min() / 100, seen.max() / 100))
