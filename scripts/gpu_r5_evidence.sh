@@ -22,8 +22,11 @@ python scripts/kstats.py $out/${tag}_prof_stress 10 > $out/${tag}_kernel_stats_s
 python scripts/bench_stream.py 600 > $out/${tag}_stream.log 2>&1; tail -2 $out/${tag}_stream.log
 (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/${tag}_stream_prof -- python3 $R/scripts/bench_stream.py 300 > $R/$out/${tag}_stream_prof.log 2>&1); echo "rocprof stream rc=$?"
 python scripts/kstats.py $out/${tag}_stream_prof 30 > $out/${tag}_kernel_stats_stream.txt 2>&1; head -12 $out/${tag}_kernel_stats_stream.txt
+[ cdv_slam_amd/libcdvslam_hip_stamps.so -nt cdv_slam_amd/csrc/ba.hip ] || echo "WARNING: libcdvslam_hip_stamps.so is older than the sources (make -C cdv_slam_amd/csrc STAMPS=1)"
 CDV_LIB=$PWD/cdv_slam_amd/libcdvslam_hip_stamps.so timeout -k 10 200 python scripts/stamps_baw.py default 2 > $out/${tag}_stamps_default.log 2>&1
 CDV_LIB=$PWD/cdv_slam_amd/libcdvslam_hip_stamps.so timeout -k 10 200 python scripts/stamps_bam.py stress 2 > $out/${tag}_stamps_stress.log 2>&1
+CDV_LIB=$PWD/cdv_slam_amd/libcdvslam_hip_stamps.so timeout -k 10 200 python scripts/stamps_backsolve.py > $out/${tag}_stamps_backsolve.log 2>&1
+python scripts/bench_global_ba.py > $out/${tag}_global_time.log 2>&1
 echo "stamps done"; grep -A6 "solver wave" $out/${tag}_stamps_default.log
 # the reference's call sequence through the drop-in names: host time per call (compiled bookkeeping on / off) and its kernels
 python scripts/profile_dropin_host.py default 400 2>&1 | grep -v amdgpu.ids > $out/${tag}_dropin_host.log
