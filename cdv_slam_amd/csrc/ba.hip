@@ -529,10 +529,12 @@ __global__ __launch_bounds__(256) void ba_schur_kernel(const float* __restrict__
       }
       __syncthreads();
       if (i + 1 < total) fetch(lst[i + 1]);   // in flight during the products
+      // nine 16 x 16 tiles on four waves: tiles 0 .. 7 two per wave, the ninth -- (2, 2) -- cut along k, wave w taking the k
+      // steps 4 w .. 4 w + 3 of every lane group (round 5: as a whole tile of wave 0 it made that wave's 48 MFMAs the chunk's
+      // critical path, 36 now); its four parts meet once, behind the loop
 #pragma unroll
-      for (int u = 0; u < 3; u++) {
-        const int tix = wave + 4 * u;   // tiles 0 .. 8: (ti, tj) = (tix / 3, tix % 3)
-        if (tix >= 9) continue;
+      for (int u = 0; u < 2; u++) {
+        const int tix = wave + 4 * u;   // tiles 0 .. 7: (ti, tj) = (tix / 3, tix % 3)
         const int ti = tix / 3, tj = tix - 3 * ti;
         if (pa == pb && tj > ti) continue;
         const float* pra = Ea + (size_t)(16 * ti + c16) * ELD;
@@ -553,6 +555,20 @@ __global__ __launch_bounds__(256) void ba_schur_kernel(const float* __restrict__
         }
         acc[u] += t0 + t1;
       }
+      {
+        const float* pra = Ea + (size_t)(32 + c16) * ELD;
+        const float* prb = Ebp + (size_t)(32 + c16) * ELD;
+        const int k = 16 * g4 + 4 * wave;
+        const cdv_float4 av = *reinterpret_cast<const cdv_float4*>(pra + k);
+        const cdv_float4 bv = *reinterpret_cast<const cdv_float4*>(prb + k);
+        const cdv_float4 qv = *reinterpret_cast<const cdv_float4*>(qs + k);
+        cdv_float4 t0 = {0.f, 0.f, 0.f, 0.f}, t1 = {0.f, 0.f, 0.f, 0.f};
+        t0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], qv[0] * bv[0], t0, 0, 0, 0);
+        t1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], qv[1] * bv[1], t1, 0, 0, 0);
+        t0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], qv[2] * bv[2], t0, 0, 0, 0);
+        t1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], qv[3] * bv[3], t1, 0, 0, 0);
+        acc[2] += t0 + t1;
+      }
       if (pa == pb && tid < SPR) {
         float sacc = 0.f;
         const float* pr = Ea + (size_t)tid * ELD;
@@ -562,6 +578,14 @@ __global__ __launch_bounds__(256) void ba_schur_kernel(const float* __restrict__
       }
       __syncthreads();   // the next chunk overwrites the panels
     }
+  }
+  // the four k parts of tile (2, 2), in wave order, into wave 0 (the panels' LDS is free now)
+  {
+    cdv_float4* part = reinterpret_cast<cdv_float4*>(Ea);
+    __syncthreads();
+    part[tid] = acc[2];
+    __syncthreads();
+    if (wave == 0) acc[2] = (part[lane] + part[64 + lane]) + (part[128 + lane] + part[192 + lane]);
   }
   float* S = sy;
   float* y = S + (size_t)n6 * n6;
